@@ -1,0 +1,179 @@
+"""Pins the oracle (oracle/oi_oracle.py) against golden vectors produced by the reference itself
+(oracle/gen_golden.py, fixtures F1-F8 of SURVEY.md section 8c).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import oi_oracle as O
+from conftest import load_golden, maxdiff, sub_sd
+
+TOL = 2e-5
+
+
+def test_f1_film_siren(sdf_sd):
+    g = load_golden("f1_film_siren")
+    w = O.style_mlp(sdf_sd, g["z"])
+    assert maxdiff(w, g["w"]) < 1e-6
+    sdf, feat, grad = O.sdf_forward(sdf_sd, g["pts"], g["w"], want_grad=True)
+    assert maxdiff(sdf, g["sdf"]) < TOL
+    assert maxdiff(feat, g["feat"]) < TOL
+    assert maxdiff(grad, g["grad"]) < 1e-4 * max(1.0, float(g["grad"].abs().max()))
+    ga = O.sdf_gradient_autograd(sdf_sd, g["pts"], g["w"])
+    assert maxdiff(ga, g["grad"]) < 1e-4
+
+
+def test_f1_fp64_agrees(sdf_sd):
+    """fp64 evaluation of the restatement bounds the fp32 evaluation error of the reference."""
+    g = load_golden("f1_film_siren")
+    sd64 = {k: v.double() for k, v in sdf_sd.items()}
+    sdf, feat, grad = O.sdf_forward(sd64, g["pts"].double(), g["w"].double(), want_grad=True)
+    assert maxdiff(sdf, g["sdf"]) < 1e-4
+    assert maxdiff(grad, g["grad"]) < 2e-4
+
+
+def test_f2_color(col_sd):
+    g = load_golden("f2_color")
+    rgb = O.color_head(col_sd, g["feat"], g["grad"], g["w"])
+    assert maxdiff(rgb, g["rgb"]) < TOL
+
+
+def test_f3_upsample(sdf_sd):
+    g = load_golden("f3_upsample")
+    wts = O.up_sample_weights(g["rays_o"], g["rays_d"], g["z_coarse"], g["sdf_coarse"], 64.0)
+    z_new = O.sample_pdf_det(g["z_coarse"], wts, 16)
+    assert maxdiff(z_new, g["z_new_k1"]) < TOL
+    for K in (1, 4):
+        z = O.hierarchical_z(sdf_sd, g["rays_o"], g["rays_d"], g["near"], g["far"], g["w"], 16, 16, K)
+        assert z.shape == g[f"z_merged_k{K}"].shape
+        assert (z[:, 1:] >= z[:, :-1]).all()
+        assert maxdiff(z, g[f"z_merged_k{K}"]) < 5e-5, K
+
+
+@pytest.mark.parametrize("tag,car", [("c0p0", 0.0), ("c0p5", 0.5), ("c1p0", 1.0)])
+def test_f4_render(sdf_sd, col_sd, tag, car):
+    g = load_golden("f4_render")
+    out = O.render(sdf_sd, col_sd, g["variance"], g["rays_o"], g["rays_d"], g["near"], g["far"],
+                   g["w"], 16, 16, 1, car)
+    for k in ("s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error",
+              "inside_sphere", "mid_z_vals", "surface_loss", "sdf", "pts_norm", "pts", "color_fine", "raw_color"):
+        ref = g[f"{tag}_{k}"]
+        assert out[k].shape == ref.shape, k
+        assert maxdiff(out[k], ref) < 1e-4, (k, maxdiff(out[k], ref))
+
+
+def test_f4_render_two_elements_jitter(sdf_sd, col_sd):
+    g = load_golden("f4_render")
+    out = O.render(sdf_sd, col_sd, g["variance"], g["rays_o"], g["rays_d"], g["near"], g["far"],
+                   g["b2_w"], 16, 16, 1, 0.3, jitter=g["b2_jitter"])
+    for k in ("weights", "color_fine", "gradients", "sdf", "mid_z_vals", "gradient_error"):
+        assert maxdiff(out[k], g[f"b2_{k}"]) < 1e-4, k
+
+
+def test_f5_generator(sdf_sd):
+    g = load_golden("f5_generator")
+    R = int(g["resolution"])
+    K, K_inv, c2w, w2c = O.camera_matrices(float(g["cam_dist"]), float(g["scene_fov"]), int(g["scene_resolution"]))
+    assert maxdiff(K_inv, g["intrinsics_inv"]) < 1e-7 and maxdiff(c2w, g["c2w"]) < 1e-7
+    ro, rd, c2b, w2b = O.gen_rays(g["b2w"], K_inv, c2w, w2c, float(g["cam_dist"]), R, int(g["scene_resolution"]))
+    assert maxdiff(c2b, g["c2b"]) < 1e-5
+    assert maxdiff(ro, g["rays_o"]) < 1e-5 and maxdiff(rd, g["rays_d"]) < 1e-6
+    w = O.style_mlp(sdf_sd, g["z"])
+    assert maxdiff(w, g["w"]) < 1e-6
+    csd, lsd = sub_sd(g, "color."), sub_sd(g, "light.")
+    ro_f, rd_f = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    near, far = O.near_far_from_sphere(ro_f, rd_f)
+    car = min(1.0, float(g["it"]) / float(g["anneal_end"]))
+    out = O.render(sdf_sd, csd, torch.tensor(0.3), ro_f, rd_f, near, far, w, 16, 16, 1, car)
+    assert maxdiff(out["weights"], g["raw_weights"]) < 1e-4
+    maps = O.render_maps(out, ro_f, lsd, w2b, g["bg"], 2, R, R, return_raw=True)
+    for k, v in maps.items():
+        ref = g["map_" + k]
+        assert v.shape == ref.shape, k
+        assert maxdiff(v, ref) < 1e-4, (k, maxdiff(v, ref))
+    assert maxdiff(out["gradient_error"], g["eikonal"]) < 1e-4
+
+
+def test_f6_grads(sdf_sd):
+    """First-order parameter gradients of a loss that needs second-order terms (eikonal, normals)."""
+    g = load_golden("f6_grads")
+    p = sub_sd(g, "p.")
+    sd = {k: v.clone().requires_grad_(True) for k, v in sub_sd(p, "sdf_network.").items()}
+    csd = {k: v.clone().requires_grad_(True) for k, v in sub_sd(p, "color_network.").items()}
+    lsd = {k: v.clone().requires_grad_(True) for k, v in sub_sd(p, "light.").items()}
+    var = p["deviation_network.variance"].clone().requires_grad_(True)
+    ro, rd = g["rays_o"], g["rays_d"]
+    near, far = O.near_far_from_sphere(ro, rd)
+    w = O.style_mlp(sd, g["z"])
+    out = O.render(sd, csd, var, ro, rd, near, far, w, 8, 8, 1, float(g["cos_anneal_ratio"]), jitter=g["jitter"])
+    w2b = O.invert_rot_t(g["b2w"])
+    maps = O.render_maps(out, ro, lsd, w2b, g["bg"], 1, 8, 8)
+    loss = maps["image"].sum() + 10.0 * out["gradient_error"] + maps["shading_map"].sum() + 0.5 * maps["mask"].sum()
+    assert maxdiff(loss, g["loss"]) < 1e-3
+    names, tensors = [], []
+    for pre, d in (("sdf_network.", sd), ("color_network.", csd), ("light.", lsd)):
+        for k, v in d.items():
+            names.append(pre + k)
+            tensors.append(v)
+    names.append("deviation_network.variance")
+    tensors.append(var)
+    grads = torch.autograd.grad(loss, tensors, allow_unused=True)
+    checked = 0
+    for n, gr in zip(names, grads):
+        key = "g." + n
+        if key not in g:
+            assert gr is None or float(gr.abs().max()) == 0.0, n
+            continue
+        ref = g[key]
+        scale = max(1.0, float(ref.abs().max()))
+        assert maxdiff(gr, ref) < 2e-3 * scale, (n, maxdiff(gr, ref), scale)
+        checked += 1
+    assert checked > 60
+
+
+@pytest.mark.parametrize("tag", ["r16c3_", "r64c3_", "r64c1_"])
+def test_f7_discriminator(tag):
+    g = load_golden("f7_discriminator")
+    dsd = {k: v.clone().requires_grad_(True) for k, v in sub_sd(g, tag + "w.").items()}
+    x = g[tag + "x"].clone().requires_grad_(True)
+    d = O.dc_discriminator(dsd, x)
+    assert maxdiff(d, g[tag + "d"]) < 1e-5
+    d1 = d[:, :1]
+    reg = O.r1_penalty(d1, x)
+    assert maxdiff(reg, g[tag + "reg"]) < 1e-5 * max(1.0, float(g[tag + "reg"]))
+    loss = O.bce_logits_const(d1, 1) + 10.0 * reg
+    gw = torch.autograd.grad(loss, list(dsd.values()), retain_graph=True)
+    for (k, _), gr in zip(dsd.items(), gw):
+        ref = g[tag + "g." + k]
+        assert maxdiff(gr, ref) < 1e-4 * max(1.0, float(ref.abs().max())), k
+    (gx,) = torch.autograd.grad(d1.sum(), x)
+    assert maxdiff(gx, g[tag + "gx"]) < 1e-6
+
+
+def test_f8_augment():
+    g = load_golden("f8_augment")
+    assert maxdiff(O.hz_geom(), g["Hz_geom"]) < 1e-7
+    for pct, tag in ((0.1, "0p1"), (0.5, "0p5"), (0.9, "0p9")):
+        p = torch.tensor(pct)
+        for key, x in (("32", g["x32"]), ("64", g["x64"])):
+            B, C, H, W = x.shape
+            t = ((p * 2 - 1) * 0.125).expand(B, 2)
+            s = torch.exp2(torch.erfinv(p * 2 - 1) * 0.2).expand(B)
+            G = O.ada_G_inv(B, W, H, t, s)
+            y, _ = O.ada_geometric(x, G)
+            ref = g[f"y{key}_{tag}"]
+            assert y.shape == ref.shape
+            assert maxdiff(y, ref) < 2e-5, (pct, key, maxdiff(y, ref))
+
+
+def test_f8_upfirdn2d():
+    g = load_golden("f8_augment")
+    f1 = g["Hz_geom"]
+    x = g["ufd_x"].clone().requires_grad_(True)
+    up = O.upsample2d(x, f1, up=2)
+    assert maxdiff(up, g["ufd_up"]) < 1e-5
+    dn = O.downsample2d(up, f1, down=2, padding=-2, flip=True)
+    assert maxdiff(dn, g["ufd_down"]) < 1e-5
+    (gx,) = torch.autograd.grad((dn * dn).sum(), x)
+    assert maxdiff(gx, g["ufd_gx"]) < 1e-4
+    y = O.upfirdn2d(g["ufd_x"], g["ufd_f2d"], up=(2, 1), down=(1, 3), pad=(1, 2, 0, 3), flip=False, gain=1.7)
+    assert maxdiff(y, g["ufd_general"]) < 1e-5
