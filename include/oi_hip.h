@@ -1,0 +1,223 @@
+/*
+ * oi_hip.h -- C ABI of liboi_hip.so: the MI355X (gfx950 / CDNA4) implementation of the
+ * object-intrinsics volumetric-render + GAN-discriminator hot path.
+ *
+ * This is the drop-in boundary.  The reference binds its native ops as
+ * pybind/torch-extension modules built with torch.utils.cpp_extension.load
+ *   - fused.fused_bias_act(...)          src/third_party/stylesdf/op/fused_bias_act.cpp:11-20
+ *   - upfirdn2d_plugin.upfirdn2d(...)    src/third_party/ada/torch_utils/ops/upfirdn2d.cpp:16-94
+ * and everything else on the path is ATen/cuBLAS/cuDNN called from Python
+ * (renderer.py, fields.py, generator.py, discriminator.py, augment.py).  This library replaces
+ * both groups by hand-written HIP kernels behind plain-C entry points: raw device pointers,
+ * sizes and scalars only -- no torch types.  All buffers are owned by the caller (PyTorch
+ * allocates them); the library allocates nothing user visible.  Every call is asynchronous and
+ * strictly ordered on the hipStream_t passed as `stream` (an opaque void* here so that C
+ * callers need no HIP headers); no call synchronises the device or touches the null stream.
+ * Calls are re-entrant and thread safe (they may come from autograd worker threads).
+ *
+ * Return value: 0 (OI_OK) or a negative oi_status; oi_last_error() gives a thread-local message.
+ * Tensors are dense row-major fp32 unless stated.  "element" = batch element of the generator;
+ * point/ray rows are element-major: row r belongs to element r / (rows / B)  (fields.py:55).
+ */
+#ifndef OI_HIP_H_
+#define OI_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* oi_stream_t; /* hipStream_t */
+
+enum oi_status {
+  OI_OK = 0,
+  OI_ERR_INVALID_ARG = -1,
+  OI_ERR_LAUNCH = -2,
+  OI_ERR_UNSUPPORTED = -3,
+};
+
+/* MFMA operand precision of the MLP contractions (accumulation is always fp32, FiLM phase and
+ * sin/cos always fp32).  F32 = v_mfma_f32_32x32x2_f32 (exact fp32, the 1e-4 parity path);
+ * BF16X3 = three bf16 MFMAs on hi/lo splits of both operands (fp32-class accuracy at 3/16 of the
+ * fp32 matrix cost); BF16 = one bf16 MFMA (throughput path, tolerance stated in DESIGN.md). */
+enum oi_precision { OI_PREC_F32 = 0, OI_PREC_BF16X3 = 1, OI_PREC_BF16 = 2 };
+
+int oi_version(void);
+const char* oi_arch(void);       /* "gfx950" */
+const char* oi_last_error(void); /* thread local */
+
+/* ---------------------------------------------------------------------------------------------
+ * a1 + a2: style MLP and FiLM parameters.
+ * Replaces ShapeNetwork.style (src/models/fields.py:15-21; MappingLinear stylesdf/model.py:49-54 ->
+ * fused_bias_act) and the gamma/beta LinearLayers evaluated inside every FiLMSiren.forward
+ * (stylesdf/volume_renderer.py:27-30, 47-48, 56-57) -- computed ONCE per render here.
+ *   style_w [3][64][64], style_b [3][64]; z [B][64] -> w_out [B][64]   (skipped when z == NULL:
+ *   w_out is then an input).  gw/bw [NL][128][64], gb/bb [NL][128]  ->  gamma, beta [B][NL][128]
+ *   with gamma = 15*(w Wg^T + bg) + 30, beta = 0.25*(w Wb^T + bb).  NL = 9 (8 sdf layers + colour).
+ */
+int oi_film_params(const float* style_w, const float* style_b, const float* z, float* w_out,
+                   const float* gw, const float* gb, const float* bw, const float* bb,
+                   float* gamma, float* beta, int B, int NL, oi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight pre-pack for the MFMA kernels (run when weights change; a few microseconds).
+ * Reorders the FiLM-SIREN matrices into the lane-linear A-operand images the MLP kernel streams
+ * through LDS (DESIGN.md "MLP kernel").  Inputs carry the reference's shapes
+ * (SURVEY.md 8b state_dict): w0 [128][3], b0 [128]; wh [7][128][128], bh [7][128] (layers 1..7);
+ * wsig [128], bsig [1]; wv [128][131], bv [128]; wrgb [3][128], brgb [3].
+ * `packed` must hold oi_mlp_packed_bytes(prec) bytes.
+ */
+size_t oi_mlp_packed_bytes(int prec);
+int oi_mlp_pack_weights(const float* w0, const float* b0, const float* wh, const float* bh,
+                        const float* wsig, const float* bsig, const float* wv, const float* bv,
+                        const float* wrgb, const float* brgb, void* packed, int prec,
+                        oi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a3-a6: FiLM-SIREN SDF network (+ analytic d sdf/dx + colour head) at n points per element.
+ * Replaces ShapeNetwork.forward/.sdf/.gradient and ColorNetwork.forward (src/models/fields.py:49-77,
+ * 89-101, 104-122) and the F.linear/sin chains of FiLMSiren.forward (volume_renderer.py:50-61).
+ *   pts [B*n][3]; gamma/beta from oi_film_params ([B][9][128]).
+ *   sdf [B*n] (always).  If grad != NULL: grad [B*n][3] (raw d sdf/dx) and, if rgb != NULL,
+ *   rgb [B*n][3] = colour head on [feat, grad].  feat [B*n][128] optional (NULL to skip).
+ *   scratch: oi_mlp_scratch_bytes(B, n) bytes, needed when grad != NULL (stores the per-layer
+ *   gamma*cos(phase) for the reverse sweep, and is what the backward kernels re-read).
+ */
+size_t oi_mlp_scratch_bytes(int B, long long n_per_elem);
+int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, const float* beta,
+                   float* sdf, float* grad, float* rgb, float* feat, void* scratch,
+                   int B, long long n_per_elem, int prec, int fast_trig, oi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a13 + a14: crop rays.  Replaces Generator.gen_rays_at + build_rays + near_far_from_sphere
+ * (src/models/generator.py:255-279, 317-333, 336-342).
+ *   c2b [B][4][4] (camera->box), kinv [3][3] (row-major 3x3 of intrinsics_inv), offs [B][2]
+ *   (x_offset, y_offset in scene pixels), R = crop resolution  ->
+ *   rays_o, rays_d [B][R][R][3], near, far [B*R*R].
+ */
+int oi_gen_rays(const float* c2b, const float* kinv, const float* offs, int B, int R,
+                float* rays_o, float* rays_d, float* near, float* far, oi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a8: coarse samples.  z[r][i] = near + (far-near) i/(S-1) (+ (jitter[r]-0.5)*2/S if jitter),
+ * pts[r][i] = o + d z.   NeuSRenderer.render, renderer.py:359-373, 391.
+ */
+int oi_coarse_samples(const float* rays_o, const float* rays_d, const float* near, const float* far,
+                      const float* jitter, long long N, int S, float* z, float* pts,
+                      oi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a9 + a10 (+ a11): SDF-guided importance resampling, one wavefront per ray.
+ * Replaces NeuSRenderer.up_sample + sample_pdf(det=True) + cat_z_vals
+ * (src/third_party/neus/models/renderer.py:137-181, 44-74, 183-197).
+ *   z, sdf [N][Sc] (sorted z) -> z_new [N][n_new] and pts_new [N][n_new][3] (for the next SDF pass).
+ *   If z_merged != NULL also writes the ascending merge of z and z_new ([N][Sc+n_new]).
+ */
+int oi_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf,
+                long long N, int Sc, int n_new, float inv_s, float* z_new, float* pts_new,
+                float* z_merged, oi_stream_t stream);
+
+/* a11 when more up-sampling steps follow: merge (z, sdf) with (z_new, sdf_new), ascending in z. */
+int oi_merge_sorted(const float* z, const float* sdf, const float* z_new, const float* sdf_new,
+                    long long N, int Sc, int n_new, float* z_out, float* sdf_out, oi_stream_t stream);
+
+/* Section mid-points of the merged z: dists (last = 2/S), mid_z, pts = o + d*mid_z.
+ * renderer.py:219-228. */
+int oi_midpoints(const float* rays_o, const float* rays_d, const float* z, long long N, int T,
+                 float last_dist, float* dists, float* mid_z, float* pts, oi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a12 (tail) + a15: NeuS alpha compositing with a wavefront transmittance scan, fused with the
+ * Phong shading and the weighted sums to image-space maps.
+ * Replaces NeuSRenderer.render_core after the network calls (renderer.py:266-311, 338) and
+ * Generator.render_maps + lighting.diffuse/specular (generator.py:80-174; lighting.py:126-225).
+ */
+typedef struct oi_composite_params {
+  /* per sample [N][T] / [N][T][3] */
+  const float* sdf;
+  const float* grad;
+  const float* rgb;
+  const float* dists;
+  const float* mid_z;
+  /* per ray [N][3] */
+  const float* rays_o;
+  const float* rays_d;
+  /* per element */
+  const float* light_dir; /* [B][3] light direction in the box frame (not normalised) */
+  const float* bg;        /* [B][3] background colour, may be NULL (then image == image_no_bg) */
+  /* scalars */
+  const float* variance;  /* device pointer to the SingleVarianceNetwork parameter */
+  float cos_anneal_ratio;
+  float ambient, diffuse, specular, shininess; /* sigmoid(param_ambient), 1-that, max(spec,0), shininess */
+  long long N; /* rays = B*H*W */
+  int T;       /* samples per ray */
+  int B;       /* elements; N % B == 0 */
+  /* per-sample outputs (any may be NULL): weights, cdf (prev_cdf), alpha, inside (<1.0), pts_norm */
+  float* weights;
+  float* cdf;
+  float* alpha;
+  float* inside_sphere;
+  float* pts_norm;
+  /* per-ray outputs [N] / [N][3] (any may be NULL) */
+  float* weight_sum;
+  float* weight_max;
+  float* color_fine;   /* sum w*rgb */
+  float* image_no_bg;  /* sum w*(shade*rgb + spec) */
+  float* image;        /* + bg*(1-weight_sum) */
+  float* shading;      /* sum w*shade (1 channel; the reference's 3 channels are identical) */
+  float* normal;       /* sum w*grad (raw) */
+  float* mask;         /* clamp(weight_sum, 1e-3, 1-1e-3) */
+  float* z_map;        /* sum w*mid_z */
+  float* specular_map; /* sum w*spec (1 channel) */
+  float* diffuse_map;  /* sum w*diff (1 channel) */
+  /* global reductions, accumulated with atomics; caller zeroes them: [0]=sum m*(|g|-1)^2,
+   * [1]=sum m, [2]=sum exp(-100|sdf|), [3]=min mid_z is NOT here (see z_min) */
+  float* reduce4;
+} oi_composite_params;
+
+int oi_composite_fwd(const oi_composite_params* p, oi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a16: DC discriminator convolutions.  Replaces nn.Conv2d(4,2,1,bias=False)+LeakyReLU(0.2) blocks
+ * and the 4x4 valid head of DCDiscriminator.forward (src/models/discriminator.py:63-85) (cuDNN in the
+ * reference).  NCHW fp32; w [Cout][Cin][4][4].  stride/pad: (2,1) for blocks, (1,0) for the head.
+ * y = lrelu_slope(conv(x)) when slope != 1 (slope == 1: linear).
+ */
+int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin,
+                   int H, int W, int Cout, int stride, int pad, float slope, oi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a18: upfirdn2d.  Same contract as the reference plugin entry
+ * upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)
+ * (src/third_party/ada/torch_utils/ops/upfirdn2d.cpp:16-94): x [B*C][H][W], f [fh][fw] fp32,
+ * y [B*C][Ho][Wo] with Ho = (H*upy + pady0 + pady1 - fh + downy) / downy (idem Wo).
+ */
+int oi_upfirdn2d(const float* x, const float* f, float* y, int BC, int H, int W, int fh, int fw,
+                 int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1,
+                 int flip, float gain, oi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a17/a19: affine_grid + bilinear grid_sample (zeros padding, align_corners=False) fused; the grid
+ * is never materialised.  Replaces F.affine_grid + grid_sample_gradfix.grid_sample
+ * (src/third_party/ada/augment.py:297-298; grid_sample_gradfix.py:33-66).
+ *   x [B][C][Hi][Wi], theta [B][2][3] -> y [B][C][Ho][Wo].
+ * The backward wrt x (aten::grid_sampler_2d_backward, grid_sample_gradfix.py:69-85) is the adjoint
+ * scatter oi_affine_grid_sample_bwd; its own backward is oi_affine_grid_sample_fwd again.
+ */
+int oi_affine_grid_sample_fwd(const float* x, const float* theta, float* y, int B, int C, int Hi,
+                              int Wi, int Ho, int Wo, oi_stream_t stream);
+int oi_affine_grid_sample_bwd(const float* gy, const float* theta, float* gx, int B, int C, int Hi,
+                              int Wi, int Ho, int Wo, oi_stream_t stream);
+
+/* Reflect padding (torch.nn.functional.pad(mode='reflect'), augment.py:286) and its adjoint. */
+int oi_reflect_pad_fwd(const float* x, float* y, int BC, int H, int W, int px0, int px1, int py0,
+                       int py1, oi_stream_t stream);
+int oi_reflect_pad_bwd(const float* gy, float* gx, int BC, int H, int W, int px0, int px1, int py0,
+                       int py1, oi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OI_HIP_H_ */

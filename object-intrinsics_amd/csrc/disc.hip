@@ -1,0 +1,333 @@
+// ADA-augmented DC discriminator kernels for gfx950.
+//
+// Replaces:
+//   DCDiscriminator.forward: nn.Conv2d(4,2,1,bias=False)+LeakyReLU(0.2) blocks and the 4x4 valid
+//     head (reference src/models/discriminator.py:63-85; cuDNN there)
+//   upfirdn2d plugin (src/third_party/ada/torch_utils/ops/upfirdn2d.cu:29-200, upfirdn2d.cpp:16-94)
+//   F.affine_grid + grid_sample (ada/augment.py:297-298, grid_sample_gradfix.py:33-97), reflect pad
+//     (augment.py:286)
+#include "oi_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------
+// 4x4 convolution as an implicit GEMM on the fp32 matrix cores.
+//   D[n][m] = sum_k W[n][k] * im2col[m][k],  k = (cin, ky, kx), m = (b, oy, ox)
+// One wavefront = one 32(channel) x 32(pixel) tile of v_mfma_f32_32x32x2_f32 over one K split.
+// The output pixel sits on the MFMA column (lane & 31): coalesced stores, and each lane gathers its
+// own input window.  K is consumed one 4-tap kernel row per lane-half per 4 MFMAs (the A and B
+// fragments use the same (half, tap) -> k map, so any K order is valid).
+// Small-M layers (late blocks at batch 1-4) are weight-bandwidth bound: K is split across
+// wavefronts (grid) and partial tiles are combined with fp32 atomics, activation in a second pass.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+conv4x4_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                   float* __restrict__ y, int B, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride,
+                   int pad, float slope, int m_tiles, int n_tiles, int k_splits, int rows_per_split) {
+  const int lane = threadIdx.x & 63;
+  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long n_items = (long long)m_tiles * n_tiles * k_splits;
+  if (item >= n_items) return;
+  const int ks = item % k_splits;
+  const int nt = (item / k_splits) % n_tiles;
+  const int mt = item / ((long long)k_splits * n_tiles);
+
+  const int h = lane >> 5, j = lane & 31;
+  const int M = B * Ho * Wo;
+  // B-operand side: this lane's output pixel
+  const int m = mt * 32 + j;
+  const bool m_ok = m < M;
+  const int mm = m_ok ? m : 0;
+  const int ox = mm % Wo, oy = (mm / Wo) % Ho, b = mm / (Wo * Ho);
+  const int ix0 = ox * stride - pad, iy0 = oy * stride - pad;
+  // A-operand side: this lane's output channel
+  const int n = nt * 32 + j;
+  const bool n_ok = n < Cout;
+  const float* wrow = w + (size_t)(n_ok ? n : 0) * Cin * 16;
+  const float* xb = x + (size_t)b * Cin * H * W;
+
+  f32x16 acc = {0};
+  const int krows = Cin * 4;  // kernel rows (cin, ky)
+  const int r_begin = ks * rows_per_split;
+  const int r_end = min(krows, r_begin + rows_per_split);
+  for (int r0 = r_begin; r0 < r_end; r0 += 2) {
+    const int r = r0 + h;  // this lane-half's kernel row
+    const bool r_ok = r < r_end;
+    const int cin = r >> 2, ky = r & 3;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (r_ok && n_ok) {
+      const float4 wv = *reinterpret_cast<const float4*>(wrow + r * 4);
+      a0 = wv.x; a1 = wv.y; a2 = wv.z; a3 = wv.w;
+    }
+    const int iy = iy0 + ky;
+    if (r_ok && m_ok && iy >= 0 && iy < H) {
+      const float* xr = xb + ((size_t)cin * H + iy) * W;
+      if (ix0 + 0 >= 0 && ix0 + 0 < W) b0 = xr[ix0 + 0];
+      if (ix0 + 1 >= 0 && ix0 + 1 < W) b1 = xr[ix0 + 1];
+      if (ix0 + 2 >= 0 && ix0 + 2 < W) b2 = xr[ix0 + 2];
+      if (ix0 + 3 >= 0 && ix0 + 3 < W) b3 = xr[ix0 + 3];
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc, 0, 0, 0);
+  }
+  // D layout: column = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * h (channel)
+  if (!m_ok) return;
+#pragma unroll
+  for (int rg = 0; rg < 16; ++rg) {
+    const int nn = nt * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * h;
+    if (nn >= Cout) continue;
+    float* dst = y + (((size_t)b * Cout + nn) * Ho + oy) * Wo + ox;
+    float v = acc[rg];
+    if (k_splits == 1) {
+      if (bias != nullptr) v += bias[nn];
+      *dst = v > 0.f ? v : v * slope;
+    } else {
+      atomicAdd(dst, v);
+    }
+  }
+}
+
+__global__ void bias_lrelu_kernel(float* __restrict__ y, const float* __restrict__ bias, long long n, int Cout,
+                                  int hw, float slope) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = y[i];
+  if (bias != nullptr) v += bias[(i / hw) % Cout];
+  y[i] = v > 0.f ? v : v * slope;
+}
+
+// ------------------------------------------------------------------------------------------
+// upfirdn2d: zero-insert upsample -> pad/crop -> FIR -> decimate, direct form.
+// ------------------------------------------------------------------------------------------
+__global__ void upfirdn2d_kernel(const float* __restrict__ x, const float* __restrict__ f, float* __restrict__ y,
+                                 int BC, int H, int W, int Ho, int Wo, int fh, int fw, int upx, int upy, int downx,
+                                 int downy, int padx0, int pady0, int flip, float gain) {
+  extern __shared__ float fs[];
+  for (int i = threadIdx.x; i < fh * fw; i += blockDim.x) {
+    const int fy = i / fw, fx = i % fw;
+    // correlation taps: the op is a convolution unless flip_filter (upfirdn2d.py:194-196)
+    fs[i] = (flip ? f[fy * fw + fx] : f[(fh - 1 - fy) * fw + (fw - 1 - fx)]) * gain;
+  }
+  __syncthreads();
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)BC * Ho * Wo;
+  if (idx >= n) return;
+  const int ox = idx % Wo, oy = (idx / Wo) % Ho;
+  const long long bc = idx / ((long long)Wo * Ho);
+  const float* xp = x + bc * H * W;
+  float acc = 0.f;
+  for (int fy = 0; fy < fh; ++fy) {
+    const int uy = oy * downy + fy - pady0;
+    if (uy < 0 || uy % upy != 0) continue;
+    const int iy = uy / upy;
+    if (iy >= H) continue;
+    for (int fx = 0; fx < fw; ++fx) {
+      const int ux = ox * downx + fx - padx0;
+      if (ux < 0 || ux % upx != 0) continue;
+      const int ix = ux / upx;
+      if (ix >= W) continue;
+      acc = fmaf(xp[iy * W + ix], fs[fy * fw + fx], acc);
+    }
+  }
+  y[idx] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// affine_grid + bilinear grid_sample (zeros padding, align_corners=False), fused
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void affine_src(const float* th, int ox, int oy, int Wo, int Ho, int Wi, int Hi, float& ix,
+                                           float& iy) {
+  const float xn = (2.0f * ox + 1.0f) / Wo - 1.0f;  // affine_grid base grid, align_corners=False
+  const float yn = (2.0f * oy + 1.0f) / Ho - 1.0f;
+  const float gx = th[0] * xn + th[1] * yn + th[2];
+  const float gy = th[3] * xn + th[4] * yn + th[5];
+  ix = ((gx + 1.0f) * Wi - 1.0f) * 0.5f;  // grid_sampler unnormalize, align_corners=False
+  iy = ((gy + 1.0f) * Hi - 1.0f) * 0.5f;
+}
+
+__global__ void affine_grid_sample_fwd_kernel(const float* __restrict__ x, const float* __restrict__ theta,
+                                              float* __restrict__ y, int B, int C, int Hi, int Wi, int Ho, int Wo) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)B * C * Ho * Wo;
+  if (idx >= n) return;
+  const int ox = idx % Wo, oy = (idx / Wo) % Ho, c = (idx / ((long long)Wo * Ho)) % C;
+  const int b = idx / ((long long)Wo * Ho * C);
+  float ix, iy;
+  affine_src(theta + b * 6, ox, oy, Wo, Ho, Wi, Hi, ix, iy);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float tx = ix - fx, ty = iy - fy;
+  const float* xp = x + ((size_t)b * C + c) * Hi * Wi;
+  float v = 0.f;
+  if (y0 >= 0 && y0 < Hi) {
+    if (x0 >= 0 && x0 < Wi) v += xp[y0 * Wi + x0] * (1.f - tx) * (1.f - ty);
+    if (x0 + 1 >= 0 && x0 + 1 < Wi) v += xp[y0 * Wi + x0 + 1] * tx * (1.f - ty);
+  }
+  if (y0 + 1 >= 0 && y0 + 1 < Hi) {
+    if (x0 >= 0 && x0 < Wi) v += xp[(y0 + 1) * Wi + x0] * (1.f - tx) * ty;
+    if (x0 + 1 >= 0 && x0 + 1 < Wi) v += xp[(y0 + 1) * Wi + x0 + 1] * tx * ty;
+  }
+  y[idx] = v;
+}
+
+__global__ void affine_grid_sample_bwd_kernel(const float* __restrict__ gy_, const float* __restrict__ theta,
+                                              float* __restrict__ gx_, int B, int C, int Hi, int Wi, int Ho, int Wo) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)B * C * Ho * Wo;
+  if (idx >= n) return;
+  const int ox = idx % Wo, oy = (idx / Wo) % Ho, c = (idx / ((long long)Wo * Ho)) % C;
+  const int b = idx / ((long long)Wo * Ho * C);
+  float ix, iy;
+  affine_src(theta + b * 6, ox, oy, Wo, Ho, Wi, Hi, ix, iy);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float tx = ix - fx, ty = iy - fy;
+  float* gp = gx_ + ((size_t)b * C + c) * Hi * Wi;
+  const float g = gy_[idx];
+  if (y0 >= 0 && y0 < Hi) {
+    if (x0 >= 0 && x0 < Wi) atomicAdd(gp + y0 * Wi + x0, g * (1.f - tx) * (1.f - ty));
+    if (x0 + 1 >= 0 && x0 + 1 < Wi) atomicAdd(gp + y0 * Wi + x0 + 1, g * tx * (1.f - ty));
+  }
+  if (y0 + 1 >= 0 && y0 + 1 < Hi) {
+    if (x0 >= 0 && x0 < Wi) atomicAdd(gp + (y0 + 1) * Wi + x0, g * (1.f - tx) * ty);
+    if (x0 + 1 >= 0 && x0 + 1 < Wi) atomicAdd(gp + (y0 + 1) * Wi + x0 + 1, g * tx * ty);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// reflect padding and its adjoint
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+template <bool BWD>
+__global__ void reflect_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, int BC, int H, int W,
+                                   int px0, int py0, int Ho, int Wo) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)BC * Ho * Wo;
+  if (idx >= n) return;
+  const int ox = idx % Wo, oy = (idx / Wo) % Ho;
+  const long long bc = idx / ((long long)Wo * Ho);
+  const int ix = reflect_idx(ox - px0, W), iy = reflect_idx(oy - py0, H);
+  if (BWD) atomicAdd(dst + (bc * H + iy) * W + ix, src[idx]);
+  else dst[idx] = src[(bc * H + iy) * W + ix];
+}
+
+}  // namespace
+
+extern "C" {
+
+int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
+                   int stride, int pad, float slope, oi_stream_t stream) {
+  OI_REQUIRE(x && w && y, "oi_conv4x4_fwd: null pointer");
+  OI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && stride > 0 && pad >= 0, "oi_conv4x4_fwd: bad shape");
+  const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
+  OI_REQUIRE(Ho > 0 && Wo > 0, "oi_conv4x4_fwd: input %dx%d too small", H, W);
+  const long long M = (long long)B * Ho * Wo;
+  const int m_tiles = oi::cdiv(M, 32), n_tiles = oi::cdiv(Cout, 32);
+  const int krows = Cin * 4;
+  // split K until ~2 waves per SIMD are in flight, at least 16 kernel rows (64 taps) per split
+  int k_splits = 1;
+  const long long tiles = (long long)m_tiles * n_tiles;
+  while (tiles * k_splits < 2048 && krows / (k_splits * 2) >= 16) k_splits *= 2;
+  int rows_per_split = oi::cdiv(krows, k_splits);
+  rows_per_split += rows_per_split & 1;  // whole lane-half pairs
+  k_splits = oi::cdiv(krows, rows_per_split);
+  hipStream_t st = oi::as_stream(stream);
+  const long long total = (long long)B * Cout * Ho * Wo;
+  if (k_splits > 1) {
+    hipError_t e = hipMemsetAsync(y, 0, total * sizeof(float), st);
+    if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_fwd: memset: %s", hipGetErrorString(e));
+  }
+  const long long items = tiles * k_splits;
+  hipLaunchKernelGGL(conv4x4_fwd_kernel, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, x, w, bias, y, B, Cin, H, W,
+                     Cout, Ho, Wo, stride, pad, slope, m_tiles, n_tiles, k_splits, rows_per_split);
+  int rc = oi::check_launch("oi_conv4x4_fwd");
+  if (rc != OI_OK) return rc;
+  if (k_splits > 1 && (slope != 1.0f || bias != nullptr)) {
+    hipLaunchKernelGGL(bias_lrelu_kernel, dim3(oi::cdiv(total, 256)), dim3(256), 0, st, y, bias, total, Cout, Ho * Wo,
+                       slope);
+    rc = oi::check_launch("oi_conv4x4_fwd(bias_lrelu)");
+  }
+  return rc;
+}
+
+int oi_upfirdn2d(const float* x, const float* f, float* y, int BC, int H, int W, int fh, int fw, int upx, int upy,
+                 int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
+                 oi_stream_t stream) {
+  OI_REQUIRE(x && f && y, "oi_upfirdn2d: null pointer");
+  OI_REQUIRE(upx >= 1 && upy >= 1 && downx >= 1 && downy >= 1, "oi_upfirdn2d: up/down must be >= 1");
+  OI_REQUIRE(BC > 0 && H > 0 && W > 0 && fh > 0 && fw > 0, "oi_upfirdn2d: bad shape");
+  // upfirdn2d.cpp:38-40
+  const int Wo = (W * upx + padx0 + padx1 - fw + downx) / downx;
+  const int Ho = (H * upy + pady0 + pady1 - fh + downy) / downy;
+  OI_REQUIRE(Wo >= 1 && Ho >= 1, "oi_upfirdn2d: output size %dx%d", Ho, Wo);
+  const long long n = (long long)BC * Ho * Wo;
+  hipLaunchKernelGGL(upfirdn2d_kernel, dim3(oi::cdiv(n, 256)), dim3(256), fh * fw * sizeof(float),
+                     oi::as_stream(stream), x, f, y, BC, H, W, Ho, Wo, fh, fw, upx, upy, downx, downy, padx0, pady0,
+                     flip, gain);
+  return oi::check_launch("oi_upfirdn2d");
+}
+
+int oi_affine_grid_sample_fwd(const float* x, const float* theta, float* y, int B, int C, int Hi, int Wi, int Ho,
+                              int Wo, oi_stream_t stream) {
+  OI_REQUIRE(x && theta && y, "oi_affine_grid_sample_fwd: null pointer");
+  OI_REQUIRE(B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "oi_affine_grid_sample_fwd: bad shape");
+  const long long n = (long long)B * C * Ho * Wo;
+  hipLaunchKernelGGL(affine_grid_sample_fwd_kernel, dim3(oi::cdiv(n, 256)), dim3(256), 0, oi::as_stream(stream), x,
+                     theta, y, B, C, Hi, Wi, Ho, Wo);
+  return oi::check_launch("oi_affine_grid_sample_fwd");
+}
+
+int oi_affine_grid_sample_bwd(const float* gy, const float* theta, float* gx, int B, int C, int Hi, int Wi, int Ho,
+                              int Wo, oi_stream_t stream) {
+  OI_REQUIRE(gy && theta && gx, "oi_affine_grid_sample_bwd: null pointer");
+  OI_REQUIRE(B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "oi_affine_grid_sample_bwd: bad shape");
+  hipStream_t st = oi::as_stream(stream);
+  hipError_t e = hipMemsetAsync(gx, 0, (size_t)B * C * Hi * Wi * sizeof(float), st);
+  if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_affine_grid_sample_bwd: memset: %s", hipGetErrorString(e));
+  const long long n = (long long)B * C * Ho * Wo;
+  hipLaunchKernelGGL(affine_grid_sample_bwd_kernel, dim3(oi::cdiv(n, 256)), dim3(256), 0, st, gy, theta, gx, B, C, Hi,
+                     Wi, Ho, Wo);
+  return oi::check_launch("oi_affine_grid_sample_bwd");
+}
+
+int oi_reflect_pad_fwd(const float* x, float* y, int BC, int H, int W, int px0, int px1, int py0, int py1,
+                       oi_stream_t stream) {
+  OI_REQUIRE(x && y, "oi_reflect_pad_fwd: null pointer");
+  OI_REQUIRE(px0 >= 0 && px1 >= 0 && py0 >= 0 && py1 >= 0 && px0 < W && px1 < W && py0 < H && py1 < H,
+             "oi_reflect_pad_fwd: padding must be in [0, size)");
+  const int Ho = H + py0 + py1, Wo = W + px0 + px1;
+  const long long n = (long long)BC * Ho * Wo;
+  hipLaunchKernelGGL(reflect_pad_kernel<false>, dim3(oi::cdiv(n, 256)), dim3(256), 0, oi::as_stream(stream), x, y, BC,
+                     H, W, px0, py0, Ho, Wo);
+  return oi::check_launch("oi_reflect_pad_fwd");
+}
+
+int oi_reflect_pad_bwd(const float* gy, float* gx, int BC, int H, int W, int px0, int px1, int py0, int py1,
+                       oi_stream_t stream) {
+  OI_REQUIRE(gy && gx, "oi_reflect_pad_bwd: null pointer");
+  OI_REQUIRE(px0 >= 0 && px1 >= 0 && py0 >= 0 && py1 >= 0 && px0 < W && px1 < W && py0 < H && py1 < H,
+             "oi_reflect_pad_bwd: padding must be in [0, size)");
+  hipStream_t st = oi::as_stream(stream);
+  hipError_t e = hipMemsetAsync(gx, 0, (size_t)BC * H * W * sizeof(float), st);
+  if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_reflect_pad_bwd: memset: %s", hipGetErrorString(e));
+  const int Ho = H + py0 + py1, Wo = W + px0 + px1;
+  const long long n = (long long)BC * Ho * Wo;
+  hipLaunchKernelGGL(reflect_pad_kernel<true>, dim3(oi::cdiv(n, 256)), dim3(256), 0, st, gy, gx, BC, H, W, px0, py0,
+                     Ho, Wo);
+  return oi::check_launch("oi_reflect_pad_bwd");
+}
+
+int oi_version(void) { return 1; }
+const char* oi_arch(void) { return "gfx950"; }
+const char* oi_last_error(void) { return oi::err_buf(); }
+
+}  // extern "C"

@@ -1,0 +1,488 @@
+// Ray generation, hierarchical importance resampling and NeuS alpha compositing for gfx950.
+//
+// Replaces: the per-ray tensor programs of
+//   NeuSRenderer.render / up_sample / sample_pdf / cat_z_vals / render_core
+//     (reference src/third_party/neus/models/renderer.py:44-74, 137-197, 199-349, 351-473)
+//   Generator.gen_rays_at / build_rays / near_far_from_sphere / render_maps
+//     (src/models/generator.py:80-174, 255-279, 317-342) and lighting.diffuse / specular
+//     (src/models/lighting.py:126-225)
+// which the reference runs as ~150 separate elementwise/scan/sort/gather kernels.
+//
+// These are HBM-streaming kernels: one 64-lane wavefront owns one ray, samples are strided over
+// lanes (coalesced), the transmittance product and the CDF are wavefront shuffle scans, the
+// searchsorted / sort of the reference become binary searches over LDS-resident per-ray arrays.
+#include "oi_common.h"
+
+namespace {
+
+using oi::sigmoidf_;
+using oi::wave_max;
+using oi::wave_scan_add;
+using oi::wave_scan_mul;
+using oi::wave_sum;
+
+constexpr int RAYS_PER_BLOCK = 4;  // 256 threads
+constexpr int MAX_SC = 1024;       // max samples per ray held in LDS by the resampling kernels
+
+// torch.linspace(start, end, n)[i] in fp32: start + i*step below the midpoint, end - (n-1-i)*step above.
+__device__ __forceinline__ float linspace_at(float start, float end, int n, int i) {
+  if (n == 1) return start;
+  const float step = (end - start) / (float)(n - 1);
+  return i < n / 2 ? start + step * (float)i : end - step * (float)(n - 1 - i);
+}
+
+// ------------------------------------------------------------------------------------------
+// a13 + a14: rays of the object crop
+// ------------------------------------------------------------------------------------------
+__global__ void gen_rays_kernel(const float* __restrict__ c2b, const float* __restrict__ kinv,
+                                const float* __restrict__ offs, int B, int R, float* __restrict__ rays_o,
+                                float* __restrict__ rays_d, float* __restrict__ near_, float* __restrict__ far_) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)B * R * R;
+  if (idx >= n) return;
+  const int x = idx % R, y = (idx / R) % R, b = idx / ((long long)R * R);
+  // build_rays: pixels = linspace(0,1,R) * recp_size + offset   (generator.py:325-329)
+  const float px = linspace_at(0.f, 1.f, R, x) * (float)R + offs[b * 2 + 0];
+  const float py = linspace_at(0.f, 1.f, R, y) * (float)R + offs[b * 2 + 1];
+  float p[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) p[i] = kinv[i * 3 + 0] * px + kinv[i * 3 + 1] * py + kinv[i * 3 + 2];
+  const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+  p[0] /= nrm;
+  p[1] /= nrm;
+  p[2] /= nrm;
+  const float* M = c2b + b * 16;
+  float d[3], o[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    d[i] = M[i * 4 + 0] * p[0] + M[i * 4 + 1] * p[1] + M[i * 4 + 2] * p[2];
+    o[i] = M[i * 4 + 3];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    rays_d[idx * 3 + i] = d[i];
+    rays_o[idx * 3 + i] = o[i];
+  }
+  // near_far_from_sphere (generator.py:336-342)
+  const float a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  const float bb = 2.0f * (o[0] * d[0] + o[1] * d[1] + o[2] * d[2]);
+  const float mid = 0.5f * (-bb) / a;
+  near_[idx] = mid - 1.0f;
+  far_[idx] = mid + 1.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// a8: coarse samples + their points
+// ------------------------------------------------------------------------------------------
+__global__ void coarse_samples_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                      const float* __restrict__ near_, const float* __restrict__ far_,
+                                      const float* __restrict__ jitter, long long N, int S,
+                                      float* __restrict__ z, float* __restrict__ pts) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * S) return;
+  const long long r = idx / S;
+  const int i = idx % S;
+  const float nr = near_[r], fr = far_[r];
+  float zv = nr + (fr - nr) * linspace_at(0.f, 1.f, S, i);                   // renderer.py:359-360
+  if (jitter != nullptr) zv = zv + (jitter[r] - 0.5f) * 2.0f / (float)S;     // renderer.py:372-373
+  z[idx] = zv;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) pts[idx * 3 + k] = rays_o[r * 3 + k] + rays_d[r * 3 + k] * zv;
+}
+
+// ------------------------------------------------------------------------------------------
+// section mid-points of the merged z
+// ------------------------------------------------------------------------------------------
+__global__ void midpoints_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                 const float* __restrict__ z, long long N, int T, float last_dist,
+                                 float* __restrict__ dists, float* __restrict__ mid_z, float* __restrict__ pts) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * T) return;
+  const long long r = idx / T;
+  const int i = idx % T;
+  const float zi = z[idx];
+  const float d = i + 1 < T ? z[idx + 1] - zi : last_dist;  // renderer.py:219-225
+  const float m = zi + d * 0.5f;
+  dists[idx] = d;
+  mid_z[idx] = m;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) pts[idx * 3 + k] = rays_o[r * 3 + k] + rays_d[r * 3 + k] * m;
+}
+
+// ------------------------------------------------------------------------------------------
+// a9 + a10 (+ a11): importance resampling, one wavefront per ray
+// ------------------------------------------------------------------------------------------
+// number of elements of ascending a[0..n) that are <= v  (searchsorted right=True)
+__device__ __forceinline__ int count_le(const float* a, int n, float v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] <= v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// number of elements strictly < v
+__device__ __forceinline__ int count_lt(const float* a, int n, float v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// alpha of section i of (zs, ss): renderer.py:143-173
+__device__ __forceinline__ float upsample_alpha(const float* zs, const float* ss, int i, float ox, float oy,
+                                                float oz, float dx, float dy, float dz, float inv_s) {
+  const float z0 = zs[i], z1 = zs[i + 1], s0 = ss[i], s1 = ss[i + 1];
+  const float ax = ox + dx * z0, ay = oy + dy * z0, az = oz + dz * z0;
+  const float bx = ox + dx * z1, by = oy + dy * z1, bz = oz + dz * z1;
+  const float r0 = sqrtf(ax * ax + ay * ay + az * az), r1 = sqrtf(bx * bx + by * by + bz * bz);
+  const float inside = (r0 < 1.0f || r1 < 1.0f) ? 1.0f : 0.0f;
+  const float cosv = (s1 - s0) / (z1 - z0 + 1e-5f);
+  float prev_cos = 0.0f;
+  if (i > 0) prev_cos = (s0 - ss[i - 1]) / (z0 - zs[i - 1] + 1e-5f);
+  float c = fminf(prev_cos, cosv);
+  c = fminf(fmaxf(c, -1e3f), 0.0f) * inside;
+  const float dist = z1 - z0;
+  const float mid = (s0 + s1) * 0.5f;
+  const float prev_cdf = sigmoidf_((mid - c * dist * 0.5f) * inv_s);
+  const float next_cdf = sigmoidf_((mid + c * dist * 0.5f) * inv_s);
+  return (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);
+}
+
+__global__ void __launch_bounds__(256)
+upsample_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ z,
+                const float* __restrict__ sdf, long long N, int Sc, int n_new, float inv_s,
+                float* __restrict__ z_new, float* __restrict__ pts_new, float* __restrict__ z_merged) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long r = (long long)blockIdx.x * RAYS_PER_BLOCK + wave;
+  const bool live = r < N;
+  if (!live) r = N - 1;  // keep every wave in the block-wide barriers; stores are masked
+  float* zs = smem + wave * (3 * Sc + n_new);
+  float* ss = zs + Sc;
+  float* cdf = ss + Sc;  // Sc entries: cdf[0] = 0, cdf[i+1] = cumsum(pdf)[i]
+  float* zn = cdf + Sc;  // n_new
+
+  const float ox = rays_o[r * 3 + 0], oy = rays_o[r * 3 + 1], oz = rays_o[r * 3 + 2];
+  const float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
+  for (int i = lane; i < Sc; i += 64) {
+    zs[i] = z[r * Sc + i];
+    ss[i] = sdf[r * Sc + i];
+  }
+  __syncthreads();
+
+  // weights = alpha * exclusive-product(1 - alpha + 1e-7), then + 1e-5  (renderer.py:174-175, 47)
+  const int nsec = Sc - 1;
+  float carry = 1.0f, total = 0.0f;
+  for (int c0 = 0; c0 < nsec; c0 += 64) {
+    const int i = c0 + lane;
+    const bool on = i < nsec;
+    const float alpha = on ? upsample_alpha(zs, ss, i, ox, oy, oz, dx, dy, dz, inv_s) : 0.0f;
+    const float incl = wave_scan_mul(on ? 1.0f - alpha + 1e-7f : 1.0f, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.0f;
+    const float w5 = alpha * (excl * carry) + 1e-5f;
+    if (on) cdf[i + 1] = w5;
+    total += wave_sum(on ? w5 : 0.0f);
+    carry *= __shfl(incl, 63, 64);
+  }
+  __syncthreads();
+  float run = 0.0f;
+  for (int c0 = 0; c0 < nsec; c0 += 64) {
+    const int i = c0 + lane;
+    const bool on = i < nsec;
+    const float pdf = on ? cdf[i + 1] / total : 0.0f;
+    const float incl = wave_scan_add(pdf, lane);
+    if (on) cdf[i + 1] = incl + run;
+    run += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) cdf[0] = 0.0f;
+  __syncthreads();
+
+  // inverse CDF at u_j = linspace(0.5/n, 1 - 0.5/n, n)   (renderer.py:52-72)
+  float zmaxrun = -3.0e38f;
+  for (int c0 = 0; c0 < n_new; c0 += 64) {
+    const int jn = c0 + lane;
+    const bool on = jn < n_new;
+    float s = -3.0e38f;
+    if (on) {
+      const float u = linspace_at(0.5f / (float)n_new, 1.0f - 0.5f / (float)n_new, n_new, jn);
+      const int ind = count_le(cdf, Sc, u);
+      const int below = max(ind - 1, 0), above = min(ind, Sc - 1);
+      const float cb = cdf[below], ca = cdf[above], zb = zs[below], za = zs[above];
+      float den = ca - cb;
+      if (den < 1e-5f) den = 1.0f;
+      s = zb + (u - cb) / den * (za - zb);
+    }
+    // keep the list non-decreasing (the reference sorts afterwards; this only matters at the ulp level)
+    float m = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float t = __shfl_up(m, o, 64);
+      if (lane >= o) m = fmaxf(m, t);
+    }
+    m = fmaxf(m, zmaxrun);
+    zmaxrun = __shfl(m, 63, 64);
+    if (on) {
+      zn[jn] = m;
+      if (live) {
+        z_new[r * n_new + jn] = m;
+        pts_new[(r * n_new + jn) * 3 + 0] = ox + dx * m;
+        pts_new[(r * n_new + jn) * 3 + 1] = oy + dy * m;
+        pts_new[(r * n_new + jn) * 3 + 2] = oz + dz * m;
+      }
+    }
+  }
+  if (z_merged == nullptr) return;
+  __syncthreads();
+  // a11: rank merge of the two ascending lists (== cat + sort, renderer.py:187-188)
+  const int Tm = Sc + n_new;
+  if (live) {
+    for (int i = lane; i < Sc; i += 64) z_merged[r * Tm + i + count_lt(zn, n_new, zs[i])] = zs[i];
+    for (int jn = lane; jn < n_new; jn += 64) z_merged[r * Tm + jn + count_le(zs, Sc, zn[jn])] = zn[jn];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+merge_sorted_kernel(const float* __restrict__ z, const float* __restrict__ sdf, const float* __restrict__ z_new,
+                    const float* __restrict__ sdf_new, long long N, int Sc, int n_new, float* __restrict__ z_out,
+                    float* __restrict__ sdf_out) {
+  extern __shared__ float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long r = (long long)blockIdx.x * RAYS_PER_BLOCK + wave;
+  const bool live = r < N;
+  if (!live) r = N - 1;
+  float* zs = smem + wave * (Sc + n_new);
+  float* zn = zs + Sc;
+  for (int i = lane; i < Sc; i += 64) zs[i] = z[r * Sc + i];
+  for (int i = lane; i < n_new; i += 64) zn[i] = z_new[r * n_new + i];
+  __syncthreads();
+  const int Tm = Sc + n_new;
+  if (!live) return;
+  for (int i = lane; i < Sc; i += 64) {
+    const int pos = i + count_lt(zn, n_new, zs[i]);
+    z_out[r * Tm + pos] = zs[i];
+    sdf_out[r * Tm + pos] = sdf[r * Sc + i];
+  }
+  for (int jn = lane; jn < n_new; jn += 64) {
+    const int pos = jn + count_le(zs, Sc, zn[jn]);
+    z_out[r * Tm + pos] = zn[jn];
+    sdf_out[r * Tm + pos] = sdf_new[r * n_new + jn];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a12 (tail) + a15: alpha compositing + Phong shading + maps, one wavefront per ray
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z, float eps) {
+  // F.normalize(v, eps): v / max(|v|, eps)
+  const float n = fmaxf(sqrtf(x * x + y * y + z * z), eps);
+  x /= n;
+  y /= n;
+  z /= n;
+}
+
+__global__ void __launch_bounds__(256)
+composite_fwd_kernel(const oi_composite_params p) {
+  __shared__ float red[RAYS_PER_BLOCK][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long r = (long long)blockIdx.x * RAYS_PER_BLOCK + wave;
+  const bool live = r < p.N;
+  if (!live) r = p.N - 1;
+  const int T = p.T;
+  const int e = (int)(r / (p.N / p.B));
+
+  const float ox = p.rays_o[r * 3 + 0], oy = p.rays_o[r * 3 + 1], oz = p.rays_o[r * 3 + 2];
+  const float dx = p.rays_d[r * 3 + 0], dy = p.rays_d[r * 3 + 1], dz = p.rays_d[r * 3 + 2];
+  float lx = p.light_dir[e * 3 + 0], ly = p.light_dir[e * 3 + 1], lz = p.light_dir[e * 3 + 2];
+  normalize3(lx, ly, lz, 1e-6f);
+  // SingleVarianceNetwork + clip (neus/models/fields.py:267-268; renderer.py:266)
+  const float inv_s = fminf(fmaxf(expf(p.variance[0] * 10.0f), 1e-6f), 1e6f);
+  const float car = p.cos_anneal_ratio;
+
+  float carry = 1.0f;
+  float a_wsum = 0.f, a_wmax = 0.f, a_c0 = 0.f, a_c1 = 0.f, a_c2 = 0.f, a_i0 = 0.f, a_i1 = 0.f, a_i2 = 0.f;
+  float a_sh = 0.f, a_n0 = 0.f, a_n1 = 0.f, a_n2 = 0.f, a_z = 0.f, a_sp = 0.f, a_df = 0.f;
+  float a_eik = 0.f, a_m = 0.f, a_surf = 0.f;
+
+  for (int c0 = 0; c0 < T; c0 += 64) {
+    const int i = c0 + lane;
+    const bool on = i < T;
+    const long long k = r * T + (on ? i : T - 1);
+    const float sdf = p.sdf[k], dist = p.dists[k], mz = p.mid_z[k];
+    const float gx = p.grad[k * 3 + 0], gy = p.grad[k * 3 + 1], gz = p.grad[k * 3 + 2];
+    const float c_r = p.rgb[k * 3 + 0], c_g = p.rgb[k * 3 + 1], c_b = p.rgb[k * 3 + 2];
+
+    // renderer.py:269-286
+    const float true_cos = dx * gx + dy * gy + dz * gz;
+    const float iter_cos = -(fmaxf(-true_cos * 0.5f + 0.5f, 0.f) * (1.0f - car) + fmaxf(-true_cos, 0.f) * car);
+    const float prev_cdf = sigmoidf_((sdf - iter_cos * dist * 0.5f) * inv_s);
+    const float next_cdf = sigmoidf_((sdf + iter_cos * dist * 0.5f) * inv_s);
+    float alpha = (prev_cdf - next_cdf + 1e-5f) / (prev_cdf + 1e-5f);
+    alpha = fminf(fmaxf(alpha, 0.f), 1.f);
+    if (!on) alpha = 0.f;
+
+    // weights = alpha * cumprod([1, 1 - alpha + 1e-7])[:-1]   (renderer.py:300): wavefront product scan
+    const float incl = wave_scan_mul(on ? 1.0f - alpha + 1e-7f : 1.0f, lane);
+    float excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1.0f;
+    const float w = alpha * (excl * carry);
+    carry *= __shfl(incl, 63, 64);
+
+    const float px = ox + dx * mz, py = oy + dy * mz, pz = oz + dz * mz;
+    const float pn = sqrtf(px * px + py * py + pz * pz);
+    const float gn = sqrtf(gx * gx + gy * gy + gz * gz);
+
+    // Phong terms (lighting.py:167-170, 212-225; generator.py:128-152)
+    const float gnc = fmaxf(gn, 1e-6f);
+    const float nx = gx / gnc, ny = gy / gnc, nz = gz / gnc;
+    const float ndl = nx * lx + ny * ly + nz * lz;
+    const float diff = p.diffuse * fmaxf(ndl, 0.f);
+    float vx = ox - px, vy = oy - py, vz = oz - pz;
+    normalize3(vx, vy, vz, 1e-6f);
+    const float rx = -lx + 2.0f * (ndl * nx), ry = -ly + 2.0f * (ndl * ny), rz = -lz + 2.0f * (ndl * nz);
+    const float al = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (ndl > 0.f ? 1.f : 0.f);
+    const float spec = p.specular * powf(al, p.shininess);
+    const float shade = p.ambient + diff;
+
+    if (on && live) {
+      if (p.weights) p.weights[k] = w;
+      if (p.cdf) p.cdf[k] = prev_cdf;
+      if (p.alpha) p.alpha[k] = alpha;
+      if (p.inside_sphere) p.inside_sphere[k] = pn < 1.0f ? 1.f : 0.f;
+      if (p.pts_norm) p.pts_norm[k] = pn;
+    }
+    if (on) {
+      a_wsum += w;
+      a_wmax = fmaxf(a_wmax, w);
+      a_c0 += w * c_r;
+      a_c1 += w * c_g;
+      a_c2 += w * c_b;
+      a_i0 += w * (shade * c_r + spec);
+      a_i1 += w * (shade * c_g + spec);
+      a_i2 += w * (shade * c_b + spec);
+      a_sh += w * shade;
+      a_n0 += w * gx;
+      a_n1 += w * gy;
+      a_n2 += w * gz;
+      a_z += w * mz;
+      a_sp += w * spec;
+      a_df += w * diff;
+      const float m = pn < 1.2f ? 1.f : 0.f;  // relax_inside_sphere (renderer.py:290)
+      a_eik += m * (gn - 1.0f) * (gn - 1.0f);
+      a_m += m;
+      a_surf += expf(-100.0f * fabsf(sdf));
+    }
+  }
+  a_wsum = wave_sum(a_wsum);
+  a_wmax = wave_max(a_wmax);
+  a_c0 = wave_sum(a_c0); a_c1 = wave_sum(a_c1); a_c2 = wave_sum(a_c2);
+  a_i0 = wave_sum(a_i0); a_i1 = wave_sum(a_i1); a_i2 = wave_sum(a_i2);
+  a_sh = wave_sum(a_sh);
+  a_n0 = wave_sum(a_n0); a_n1 = wave_sum(a_n1); a_n2 = wave_sum(a_n2);
+  a_z = wave_sum(a_z); a_sp = wave_sum(a_sp); a_df = wave_sum(a_df);
+  a_eik = wave_sum(a_eik); a_m = wave_sum(a_m); a_surf = wave_sum(a_surf);
+
+  if (lane == 0 && live) {
+    if (p.weight_sum) p.weight_sum[r] = a_wsum;
+    if (p.weight_max) p.weight_max[r] = a_wmax;
+    if (p.color_fine) { p.color_fine[r * 3] = a_c0; p.color_fine[r * 3 + 1] = a_c1; p.color_fine[r * 3 + 2] = a_c2; }
+    if (p.image_no_bg) { p.image_no_bg[r * 3] = a_i0; p.image_no_bg[r * 3 + 1] = a_i1; p.image_no_bg[r * 3 + 2] = a_i2; }
+    if (p.image) {
+      const float t = 1.0f - a_wsum;  // generator.py:159
+      const float b0 = p.bg ? p.bg[e * 3 + 0] : 0.f, b1 = p.bg ? p.bg[e * 3 + 1] : 0.f, b2 = p.bg ? p.bg[e * 3 + 2] : 0.f;
+      p.image[r * 3] = a_i0 + b0 * t;
+      p.image[r * 3 + 1] = a_i1 + b1 * t;
+      p.image[r * 3 + 2] = a_i2 + b2 * t;
+    }
+    if (p.shading) p.shading[r] = a_sh;
+    if (p.normal) { p.normal[r * 3] = a_n0; p.normal[r * 3 + 1] = a_n1; p.normal[r * 3 + 2] = a_n2; }
+    if (p.mask) p.mask[r] = fminf(fmaxf(a_wsum, 1e-3f), 1.0f - 1e-3f);
+    if (p.z_map) p.z_map[r] = a_z;
+    if (p.specular_map) p.specular_map[r] = a_sp;
+    if (p.diffuse_map) p.diffuse_map[r] = a_df;
+  }
+  if (p.reduce4 != nullptr) {
+    if (lane == 0) {
+      red[wave][0] = live ? a_eik : 0.f;
+      red[wave][1] = live ? a_m : 0.f;
+      red[wave][2] = live ? a_surf : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      float v = 0.f;
+      for (int w = 0; w < RAYS_PER_BLOCK; ++w) v += red[w][threadIdx.x];
+      atomicAdd(p.reduce4 + threadIdx.x, v);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int oi_gen_rays(const float* c2b, const float* kinv, const float* offs, int B, int R, float* rays_o, float* rays_d,
+                float* near_, float* far_, oi_stream_t stream) {
+  OI_REQUIRE(c2b && kinv && offs && rays_o && rays_d && near_ && far_, "oi_gen_rays: null pointer");
+  OI_REQUIRE(B > 0 && R > 0, "oi_gen_rays: B=%d R=%d", B, R);
+  const long long n = (long long)B * R * R;
+  hipLaunchKernelGGL(gen_rays_kernel, dim3(oi::cdiv(n, 256)), dim3(256), 0, oi::as_stream(stream), c2b, kinv, offs, B,
+                     R, rays_o, rays_d, near_, far_);
+  return oi::check_launch("oi_gen_rays");
+}
+
+int oi_coarse_samples(const float* rays_o, const float* rays_d, const float* near_, const float* far_,
+                      const float* jitter, long long N, int S, float* z, float* pts, oi_stream_t stream) {
+  OI_REQUIRE(rays_o && rays_d && near_ && far_ && z && pts, "oi_coarse_samples: null pointer");
+  OI_REQUIRE(N > 0 && S > 0, "oi_coarse_samples: N=%lld S=%d", N, S);
+  hipLaunchKernelGGL(coarse_samples_kernel, dim3(oi::cdiv(N * S, 256)), dim3(256), 0, oi::as_stream(stream), rays_o,
+                     rays_d, near_, far_, jitter, N, S, z, pts);
+  return oi::check_launch("oi_coarse_samples");
+}
+
+int oi_midpoints(const float* rays_o, const float* rays_d, const float* z, long long N, int T, float last_dist,
+                 float* dists, float* mid_z, float* pts, oi_stream_t stream) {
+  OI_REQUIRE(rays_o && rays_d && z && dists && mid_z && pts, "oi_midpoints: null pointer");
+  OI_REQUIRE(N > 0 && T > 0, "oi_midpoints: N=%lld T=%d", N, T);
+  hipLaunchKernelGGL(midpoints_kernel, dim3(oi::cdiv(N * T, 256)), dim3(256), 0, oi::as_stream(stream), rays_o,
+                     rays_d, z, N, T, last_dist, dists, mid_z, pts);
+  return oi::check_launch("oi_midpoints");
+}
+
+int oi_upsample(const float* rays_o, const float* rays_d, const float* z, const float* sdf, long long N, int Sc,
+                int n_new, float inv_s, float* z_new, float* pts_new, float* z_merged, oi_stream_t stream) {
+  OI_REQUIRE(rays_o && rays_d && z && sdf && z_new && pts_new, "oi_upsample: null pointer");
+  OI_REQUIRE(N > 0 && Sc >= 2 && n_new > 0, "oi_upsample: N=%lld Sc=%d n_new=%d", N, Sc, n_new);
+  OI_REQUIRE(Sc <= MAX_SC && n_new <= MAX_SC, "oi_upsample: at most %d samples per ray", MAX_SC);
+  const size_t sh = (size_t)RAYS_PER_BLOCK * (3 * Sc + n_new) * sizeof(float);
+  hipLaunchKernelGGL(upsample_kernel, dim3(oi::cdiv(N, RAYS_PER_BLOCK)), dim3(256), sh, oi::as_stream(stream), rays_o,
+                     rays_d, z, sdf, N, Sc, n_new, inv_s, z_new, pts_new, z_merged);
+  return oi::check_launch("oi_upsample");
+}
+
+int oi_merge_sorted(const float* z, const float* sdf, const float* z_new, const float* sdf_new, long long N, int Sc,
+                    int n_new, float* z_out, float* sdf_out, oi_stream_t stream) {
+  OI_REQUIRE(z && sdf && z_new && sdf_new && z_out && sdf_out, "oi_merge_sorted: null pointer");
+  OI_REQUIRE(N > 0 && Sc > 0 && n_new > 0, "oi_merge_sorted: N=%lld Sc=%d n_new=%d", N, Sc, n_new);
+  OI_REQUIRE(Sc <= MAX_SC && n_new <= MAX_SC, "oi_merge_sorted: at most %d samples per ray", MAX_SC);
+  const size_t sh = (size_t)RAYS_PER_BLOCK * (Sc + n_new) * sizeof(float);
+  hipLaunchKernelGGL(merge_sorted_kernel, dim3(oi::cdiv(N, RAYS_PER_BLOCK)), dim3(256), sh, oi::as_stream(stream), z,
+                     sdf, z_new, sdf_new, N, Sc, n_new, z_out, sdf_out);
+  return oi::check_launch("oi_merge_sorted");
+}
+
+int oi_composite_fwd(const oi_composite_params* p, oi_stream_t stream) {
+  OI_REQUIRE(p != nullptr, "oi_composite_fwd: null params");
+  OI_REQUIRE(p->sdf && p->grad && p->rgb && p->dists && p->mid_z && p->rays_o && p->rays_d && p->light_dir &&
+                 p->variance,
+             "oi_composite_fwd: null input pointer");
+  OI_REQUIRE(p->N > 0 && p->T > 0 && p->B > 0 && p->N % p->B == 0, "oi_composite_fwd: N=%lld T=%d B=%d", p->N, p->T,
+             p->B);
+  hipLaunchKernelGGL(composite_fwd_kernel, dim3(oi::cdiv(p->N, RAYS_PER_BLOCK)), dim3(256), 0, oi::as_stream(stream),
+                     *p);
+  return oi::check_launch("oi_composite_fwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+"""ctypes binding of liboi_hip.so (C ABI declared in include/oi_hip.h).
+
+The library handle is module-global (never stored on nn.Module instances, so modules stay
+deepcopy-able for the EMA copies the reference trainer makes, src/utils/ema.py:11-12).
+There is NO fallback: if the HIP library cannot be loaded every op raises."""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboi_hip.so")
+_lock = threading.Lock()
+_lib = None
+
+OI_PREC_F32, OI_PREC_BF16X3, OI_PREC_BF16 = 0, 1, 2
+PRECISIONS = {"f32": OI_PREC_F32, "fp32": OI_PREC_F32, "bf16x3": OI_PREC_BF16X3, "bf16": OI_PREC_BF16}
+
+_vp, _i, _ll, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t
+
+
+class CompositeParams(ctypes.Structure):
+    """Mirror of `oi_composite_params` (include/oi_hip.h)."""
+    _fields_ = ([(n, _vp) for n in ("sdf", "grad", "rgb", "dists", "mid_z", "rays_o", "rays_d", "light_dir", "bg",
+                                    "variance")] +
+                [("cos_anneal_ratio", _f), ("ambient", _f), ("diffuse", _f), ("specular", _f), ("shininess", _f),
+                 ("N", _ll), ("T", _i), ("B", _i)] +
+                [(n, _vp) for n in ("weights", "cdf", "alpha", "inside_sphere", "pts_norm", "weight_sum", "weight_max",
+                                    "color_fine", "image_no_bg", "image", "shading", "normal", "mask", "z_map",
+                                    "specular_map", "diffuse_map", "reduce4")])
+
+
+_SIGS = {
+    "oi_version": (_i, []),
+    "oi_arch": (ctypes.c_char_p, []),
+    "oi_last_error": (ctypes.c_char_p, []),
+    "oi_film_params": (_i, [_vp] * 10 + [_i, _i, _vp]),
+    "oi_mlp_packed_bytes": (_sz, [_i]),
+    "oi_mlp_pack_weights": (_i, [_vp] * 11 + [_i, _vp]),
+    "oi_mlp_scratch_bytes": (_sz, [_i, _ll]),
+    "oi_sdf_mlp_fwd": (_i, [_vp] * 9 + [_i, _ll, _i, _i, _vp]),
+    "oi_gen_rays": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "oi_coarse_samples": (_i, [_vp] * 5 + [_ll, _i, _vp, _vp, _vp]),
+    "oi_upsample": (_i, [_vp] * 4 + [_ll, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "oi_merge_sorted": (_i, [_vp] * 4 + [_ll, _i, _i, _vp, _vp, _vp]),
+    "oi_midpoints": (_i, [_vp] * 3 + [_ll, _i, _f, _vp, _vp, _vp, _vp]),
+    "oi_composite_fwd": (_i, [ctypes.POINTER(CompositeParams), _vp]),
+    "oi_conv4x4_fwd": (_i, [_vp] * 4 + [_i] * 7 + [_f, _vp]),
+    "oi_upfirdn2d": (_i, [_vp] * 3 + [_i] * 14 + [_f, _vp]),
+    "oi_affine_grid_sample_fwd": (_i, [_vp] * 3 + [_i] * 6 + [_vp]),
+    "oi_affine_grid_sample_bwd": (_i, [_vp] * 3 + [_i] * 6 + [_vp]),
+    "oi_reflect_pad_fwd": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
+    "oi_reflect_pad_bwd": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
+}
+
+# entry points added by later source files (backward kernels); bound when present in the .so
+_OPTIONAL_SIGS = {}
+
+
+class OiHipError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises OiHipError when the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise OiHipError(
+                f"{LIB_PATH} not found: build it with `python object-intrinsics_amd/build.py` (hipcc, gfx950). "
+                "oi_amd has no CPU or PyTorch fallback for its kernels.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in {**_SIGS, **_OPTIONAL_SIGS}.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                if name in _OPTIONAL_SIGS:
+                    continue
+                raise OiHipError(f"{LIB_PATH} does not export {name}; rebuild the library")
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().oi_last_error()
+        raise OiHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

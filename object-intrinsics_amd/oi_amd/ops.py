@@ -1,0 +1,246 @@
+"""Thin functional wrappers: torch tensors in/out, HIP kernels underneath (no autograd here).
+
+Every function allocates its outputs with the torch caching allocator, passes raw device
+pointers + the *current* HIP stream to liboi_hip.so, and returns immediately (stream ordered).
+Autograd structure lives in `oi_amd.autograd`."""
+import ctypes
+import math
+
+import torch
+
+from . import lib as _l
+
+_vp = ctypes.c_void_p
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _l.OiHipError("oi_amd ops need CUDA/HIP tensors (there is no CPU path)")
+    if t.dtype not in (torch.float32, torch.uint8):
+        raise _l.OiHipError(f"expected float32 tensor, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _l.OiHipError("expected a contiguous tensor")
+    return _vp(t.data_ptr())
+
+
+def _c(t):
+    return t.contiguous().float() if t is not None else None
+
+
+def _new(ref, *shape):
+    return torch.empty(shape, dtype=torch.float32, device=ref.device)
+
+
+# ------------------------------------------------------------------------------------------
+# MLP
+# ------------------------------------------------------------------------------------------
+
+def film_params(style_w, style_b, gw, gb, bw, bb, z=None, w=None):
+    """(w, gamma[B,NL,128], beta[B,NL,128]); give z (style MLP runs) or w."""
+    L = _l.load()
+    assert (z is None) != (w is None)
+    src = z if z is not None else w
+    B, NL = src.shape[0], gw.shape[0]
+    w_out = _new(src, B, 64) if w is None else _c(w)
+    gamma, beta = _new(src, B, NL, 128), _new(src, B, NL, 128)
+    z_ = _c(z)
+    args = [_c(style_w), _c(style_b), z_, w_out, _c(gw), _c(gb), _c(bw), _c(bb)]
+    _l.check(L.oi_film_params(*[_p(a) for a in args], _p(gamma), _p(beta), B, NL, _stream()), "oi_film_params")
+    return w_out, gamma, beta
+
+
+def mlp_pack_weights(w0, b0, wh, bh, wsig, bsig, wv, bv, wrgb, brgb, prec):
+    L = _l.load()
+    packed = torch.empty(L.oi_mlp_packed_bytes(prec), dtype=torch.uint8, device=w0.device)
+    args = [_c(t) for t in (w0, b0, wh, bh, wsig.reshape(-1), bsig.reshape(-1), wv, bv, wrgb, brgb)]
+    _l.check(L.oi_mlp_pack_weights(*[_p(a) for a in args], _p(packed), prec, _stream()), "oi_mlp_pack_weights")
+    return packed
+
+
+def mlp_scratch_bytes(B, n_per_elem):
+    return _l.load().oi_mlp_scratch_bytes(B, n_per_elem)
+
+
+def sdf_mlp_fwd(pts, packed, gamma, beta, B, prec, fast_trig=False, want_grad=False, want_rgb=False,
+                want_feat=False, scratch=None):
+    """pts (B*n, 3) -> sdf (B*n,), grad (B*n,3)|None, rgb (B*n,3)|None, feat (B*n,128)|None, scratch."""
+    L = _l.load()
+    pts = _c(pts)
+    n_tot = pts.shape[0]
+    assert n_tot % B == 0
+    n = n_tot // B
+    sdf = _new(pts, n_tot)
+    grad = _new(pts, n_tot, 3) if want_grad else None
+    rgb = _new(pts, n_tot, 3) if want_rgb else None
+    feat = _new(pts, n_tot, 128) if want_feat else None
+    if want_grad and scratch is None:
+        scratch = torch.empty(L.oi_mlp_scratch_bytes(B, n), dtype=torch.uint8, device=pts.device)
+    assert not want_rgb or want_grad
+    _l.check(L.oi_sdf_mlp_fwd(_p(pts), _p(packed), _p(gamma), _p(beta), _p(sdf), _p(grad), _p(rgb), _p(feat),
+                              _p(scratch) if want_grad else None, B, n, prec, int(bool(fast_trig)), _stream()),
+             "oi_sdf_mlp_fwd")
+    return sdf, grad, rgb, feat, scratch
+
+
+# ------------------------------------------------------------------------------------------
+# rays / sampling / compositing
+# ------------------------------------------------------------------------------------------
+
+def gen_rays(c2b, kinv3, offs, R):
+    L = _l.load()
+    B = c2b.shape[0]
+    ro, rd = _new(c2b, B, R, R, 3), _new(c2b, B, R, R, 3)
+    near, far = _new(c2b, B * R * R, 1), _new(c2b, B * R * R, 1)
+    _l.check(L.oi_gen_rays(_p(_c(c2b)), _p(_c(kinv3)), _p(_c(offs)), B, R, _p(ro), _p(rd), _p(near), _p(far),
+                           _stream()), "oi_gen_rays")
+    return ro, rd, near, far
+
+
+def coarse_samples(rays_o, rays_d, near, far, S, jitter=None):
+    L = _l.load()
+    N = rays_o.shape[0]
+    z, pts = _new(rays_o, N, S), _new(rays_o, N, S, 3)
+    _l.check(L.oi_coarse_samples(_p(_c(rays_o)), _p(_c(rays_d)), _p(_c(near)), _p(_c(far)), _p(_c(jitter)), N, S,
+                                 _p(z), _p(pts), _stream()), "oi_coarse_samples")
+    return z, pts
+
+
+def upsample(rays_o, rays_d, z, sdf, n_new, inv_s, merge=True):
+    L = _l.load()
+    N, Sc = z.shape
+    z_new, pts_new = _new(z, N, n_new), _new(z, N, n_new, 3)
+    z_merged = _new(z, N, Sc + n_new) if merge else None
+    _l.check(L.oi_upsample(_p(_c(rays_o)), _p(_c(rays_d)), _p(_c(z)), _p(_c(sdf)), N, Sc, n_new, float(inv_s),
+                           _p(z_new), _p(pts_new), _p(z_merged), _stream()), "oi_upsample")
+    return z_new, pts_new, z_merged
+
+
+def merge_sorted(z, sdf, z_new, sdf_new):
+    L = _l.load()
+    N, Sc = z.shape
+    n_new = z_new.shape[1]
+    zo, so = _new(z, N, Sc + n_new), _new(z, N, Sc + n_new)
+    _l.check(L.oi_merge_sorted(_p(_c(z)), _p(_c(sdf)), _p(_c(z_new)), _p(_c(sdf_new)), N, Sc, n_new, _p(zo), _p(so),
+                               _stream()), "oi_merge_sorted")
+    return zo, so
+
+
+def midpoints(rays_o, rays_d, z, last_dist):
+    L = _l.load()
+    N, T = z.shape
+    dists, mid_z, pts = _new(z, N, T), _new(z, N, T), _new(z, N, T, 3)
+    _l.check(L.oi_midpoints(_p(_c(rays_o)), _p(_c(rays_d)), _p(_c(z)), N, T, float(last_dist), _p(dists), _p(mid_z),
+                            _p(pts), _stream()), "oi_midpoints")
+    return dists, mid_z, pts
+
+
+PER_SAMPLE_OUT = ("weights", "cdf", "alpha", "inside_sphere", "pts_norm")
+PER_RAY_OUT = {"weight_sum": 1, "weight_max": 1, "color_fine": 3, "image_no_bg": 3, "image": 3, "shading": 1,
+               "normal": 3, "mask": 1, "z_map": 1, "specular_map": 1, "diffuse_map": 1}
+
+
+def composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, cos_anneal_ratio,
+                  ambient, diffuse, specular, shininess, B, outputs=None):
+    """Returns dict of requested outputs (default: all) + 'reduce4' = [sum m*(|g|-1)^2, sum m, sum exp(-100|sdf|), 0]."""
+    L = _l.load()
+    N, T = dists.shape
+    P = _l.CompositeParams()
+    keep = []
+    for name, t in (("sdf", sdf), ("grad", grad), ("rgb", rgb), ("dists", dists), ("mid_z", mid_z), ("rays_o", rays_o),
+                    ("rays_d", rays_d), ("light_dir", light_dir), ("bg", bg), ("variance", variance.reshape(1))):
+        t = _c(t)
+        keep.append(t)
+        setattr(P, name, _p(t))
+    P.cos_anneal_ratio, P.ambient, P.diffuse = float(cos_anneal_ratio), float(ambient), float(diffuse)
+    P.specular, P.shininess = float(specular), float(shininess)
+    P.N, P.T, P.B = N, T, B
+    want = set(outputs) if outputs is not None else set(PER_SAMPLE_OUT) | set(PER_RAY_OUT) | {"reduce4"}
+    out = {}
+    for name in PER_SAMPLE_OUT:
+        if name in want:
+            out[name] = _new(dists, N, T)
+        setattr(P, name, _p(out.get(name)))
+    for name, c in PER_RAY_OUT.items():
+        if name in want:
+            out[name] = _new(dists, N, c)
+        setattr(P, name, _p(out.get(name)))
+    if "reduce4" in want:
+        out["reduce4"] = torch.zeros(4, dtype=torch.float32, device=dists.device)
+    P.reduce4 = _p(out.get("reduce4"))
+    _l.check(L.oi_composite_fwd(ctypes.byref(P), _stream()), "oi_composite_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# discriminator side
+# ------------------------------------------------------------------------------------------
+
+def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2):
+    L = _l.load()
+    x, w = _c(x), _c(w)
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    assert w.shape[1:] == (Cin, 4, 4)
+    Ho, Wo = (H + 2 * pad - 4) // stride + 1, (W + 2 * pad - 4) // stride + 1
+    y = _new(x, B, Cout, Ho, Wo)
+    _l.check(L.oi_conv4x4_fwd(_p(x), _p(w), _p(_c(bias)), _p(y), B, Cin, H, W, Cout, stride, pad, float(slope),
+                              _stream()), "oi_conv4x4_fwd")
+    return y
+
+
+def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, pady1=0, flip=False, gain=1.0):
+    """Same contract as the reference plugin op (f is 2-D [fh, fw])."""
+    L = _l.load()
+    x, f = _c(x), _c(f)
+    B, C, H, W = x.shape
+    fh, fw = f.shape
+    Wo = (W * upx + padx0 + padx1 - fw + downx) // downx
+    Ho = (H * upy + pady0 + pady1 - fh + downy) // downy
+    y = _new(x, B, C, Ho, Wo)
+    _l.check(L.oi_upfirdn2d(_p(x), _p(f), _p(y), B * C, H, W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0,
+                            pady1, int(bool(flip)), float(gain), _stream()), "oi_upfirdn2d")
+    return y
+
+
+def affine_grid_sample_fwd(x, theta, Ho, Wo):
+    L = _l.load()
+    x, theta = _c(x), _c(theta)
+    B, C, Hi, Wi = x.shape
+    y = _new(x, B, C, Ho, Wo)
+    _l.check(L.oi_affine_grid_sample_fwd(_p(x), _p(theta), _p(y), B, C, Hi, Wi, Ho, Wo, _stream()),
+             "oi_affine_grid_sample_fwd")
+    return y
+
+
+def affine_grid_sample_bwd(gy, theta, Hi, Wi):
+    L = _l.load()
+    gy, theta = _c(gy), _c(theta)
+    B, C, Ho, Wo = gy.shape
+    gx = _new(gy, B, C, Hi, Wi)
+    _l.check(L.oi_affine_grid_sample_bwd(_p(gy), _p(theta), _p(gx), B, C, Hi, Wi, Ho, Wo, _stream()),
+             "oi_affine_grid_sample_bwd")
+    return gx
+
+
+def reflect_pad_fwd(x, px0, px1, py0, py1):
+    L = _l.load()
+    x = _c(x)
+    B, C, H, W = x.shape
+    y = _new(x, B, C, H + py0 + py1, W + px0 + px1)
+    _l.check(L.oi_reflect_pad_fwd(_p(x), _p(y), B * C, H, W, px0, px1, py0, py1, _stream()), "oi_reflect_pad_fwd")
+    return y
+
+
+def reflect_pad_bwd(gy, H, W, px0, px1, py0, py1):
+    L = _l.load()
+    gy = _c(gy)
+    B, C = gy.shape[:2]
+    gx = _new(gy, B, C, H, W)
+    _l.check(L.oi_reflect_pad_bwd(_p(gy), _p(gx), B * C, H, W, px0, px1, py0, py1, _stream()), "oi_reflect_pad_bwd")
+    return gx

@@ -1,0 +1,307 @@
+"""GPU parity tests: every HIP kernel of liboi_hip.so (called through the C ABI via oi_amd.ops)
+against the oracle on the same seeded inputs and against the committed golden fixtures.
+Tolerances: fp32 / bf16x3 paths 1e-4 (north_star); bf16 path stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oi_oracle as O
+from conftest import load_golden, maxdiff, sub_sd
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(d):
+    return {k: v.cuda() for k, v in d.items()}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from oi_amd import ops as _ops, lib
+    lib.load()
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def packed_all(ops, sdf_sd, col_sd):
+    from oi_amd.params import stack_field_params
+    P = stack_field_params(dev(sdf_sd), dev(col_sd))
+    packs = {}
+    for name, prec in (("f32", 0), ("bf16x3", 1), ("bf16", 2)):
+        packs[name] = ops.mlp_pack_weights(P["w0"], P["b0"], P["wh"], P["bh"], P["wsig"], P["bsig"], P["wv"], P["bv"],
+                                           P["wrgb"], P["brgb"], prec)
+    return P, packs
+
+
+def test_lib_identity(ops):
+    from oi_amd import lib
+    L = lib.load()
+    assert L.oi_arch() == b"gfx950" and L.oi_version() >= 1
+
+
+def test_film_params(ops, packed_all, sdf_sd, col_sd):
+    P, _ = packed_all
+    g1 = load_golden("f1_film_siren")
+    w, gamma, beta = ops.film_params(P["style_w"], P["style_b"], P["gw"], P["gb"], P["bw"], P["bb"], z=g1["z"].cuda())
+    assert maxdiff(w.cpu(), g1["w"]) < 1e-5
+    for l in range(8):
+        g, b = O.film_params(sdf_sd, f"pts_linears.{l}.", g1["w"])
+        assert maxdiff(gamma[:, l].cpu(), g) < 1e-4 and maxdiff(beta[:, l].cpu(), b) < 1e-5
+    g, b = O.film_params(col_sd, "views_linears.", g1["w"])
+    assert maxdiff(gamma[:, 8].cpu(), g) < 1e-4 and maxdiff(beta[:, 8].cpu(), b) < 1e-5
+    w2, gamma2, _ = ops.film_params(P["style_w"], P["style_b"], P["gw"], P["gb"], P["bw"], P["bb"], w=g1["w"].cuda())
+    assert maxdiff(gamma2, gamma) < 1e-4
+
+
+@pytest.mark.parametrize("mode,tol_sdf,tol_grad,tol_rgb", [("f32", 2e-5, 1e-4, 2e-5), ("bf16x3", 5e-5, 2e-4, 5e-5),
+                                                           ("bf16", 3e-2, 1.5e-1, 3e-2)])
+def test_sdf_mlp_golden(ops, packed_all, col_sd, mode, tol_sdf, tol_grad, tol_rgb):
+    """F1/F2: sdf, features, analytic gradient and colour head vs the reference's own outputs."""
+    P, packs = packed_all
+    g1, g2 = load_golden("f1_film_siren"), load_golden("f2_color")
+    prec = {"f32": 0, "bf16x3": 1, "bf16": 2}[mode]
+    w, gamma, beta = ops.film_params(P["style_w"], P["style_b"], P["gw"], P["gb"], P["bw"], P["bb"], w=g1["w"].cuda())
+    sdf, grad, rgb, feat, _ = ops.sdf_mlp_fwd(g1["pts"].cuda(), packs[mode], gamma, beta, 2, prec,
+                                              fast_trig=(mode == "bf16"), want_grad=True, want_rgb=True, want_feat=True)
+    torch.cuda.synchronize()
+    e_sdf, e_feat = maxdiff(sdf.cpu(), g1["sdf"].squeeze(-1)), maxdiff(feat.cpu(), g1["feat"])
+    e_grad, e_rgb = maxdiff(grad.cpu(), g1["grad"]), maxdiff(rgb.cpu(), g2["rgb"])
+    print(f"[{mode}] sdf {e_sdf:.2e} feat {e_feat:.2e} grad {e_grad:.2e} rgb {e_rgb:.2e}")
+    assert e_sdf < tol_sdf and e_grad < tol_grad and e_rgb < tol_rgb
+    assert e_feat < (5e-2 if mode == "bf16" else 1e-4)
+    # sdf-only variant agrees with the full variant
+    sdf2, _, _, _, _ = ops.sdf_mlp_fwd(g1["pts"].cuda(), packs[mode], gamma, beta, 2, prec, fast_trig=(mode == "bf16"))
+    assert maxdiff(sdf2, sdf) < 1e-6
+
+
+@pytest.mark.parametrize("n", [1, 37, 128, 1000])
+def test_sdf_mlp_ragged_tiles(ops, packed_all, sdf_sd, col_sd, n):
+    """Tile tails: n points per element not a multiple of the 128-point workgroup tile."""
+    P, packs = packed_all
+    g = torch.Generator().manual_seed(n)
+    B = 3
+    pts = torch.rand(B * n, 3, generator=g) * 2.4 - 1.2
+    z = torch.randn(B, 64, generator=g)
+    w = O.style_mlp(sdf_sd, z)
+    sdf_o, feat_o, grad_o = O.sdf_forward(sdf_sd, pts, w, want_grad=True)
+    rgb_o = O.color_head(col_sd, feat_o, grad_o, w)
+    _, gamma, beta = ops.film_params(P["style_w"], P["style_b"], P["gw"], P["gb"], P["bw"], P["bb"], w=w.cuda())
+    sdf, grad, rgb, _, _ = ops.sdf_mlp_fwd(pts.cuda(), packs["f32"], gamma, beta, B, 0, want_grad=True, want_rgb=True)
+    assert maxdiff(sdf.cpu(), sdf_o.squeeze(-1)) < 2e-5
+    assert maxdiff(grad.cpu(), grad_o) < 1e-4
+    assert maxdiff(rgb.cpu(), rgb_o) < 2e-5
+
+
+def test_gen_rays(ops):
+    g = load_golden("f5_generator")
+    R, SR = int(g["resolution"]), int(g["scene_resolution"])
+    K, K_inv, c2w, w2c = O.camera_matrices(float(g["cam_dist"]), float(g["scene_fov"]), SR)
+    b2w = g["b2w"]
+    b2c = w2c @ b2w
+    t = b2c[:, :3, 3]
+    cd = float(g["cam_dist"])
+    offs = torch.stack([cd / t[:, 2] * t[:, 0] * R / 2 + 0.5 * SR - R / 2, cd / t[:, 2] * t[:, 1] * R / 2 + 0.5 * SR - R / 2], -1)
+    ro, rd, near, far = ops.gen_rays(g["c2b"].cuda(), K_inv[:3, :3].contiguous().cuda(), offs.cuda(), R)
+    assert maxdiff(ro.cpu(), g["rays_o"]) < 1e-5 and maxdiff(rd.cpu(), g["rays_d"]) < 2e-6
+    n_o, f_o = O.near_far_from_sphere(g["rays_o"].reshape(-1, 3), g["rays_d"].reshape(-1, 3))
+    assert maxdiff(near.cpu(), n_o) < 1e-5 and maxdiff(far.cpu(), f_o) < 1e-5
+
+
+@pytest.mark.parametrize("S", [16, 64, 7])
+def test_coarse_samples_and_midpoints(ops, S):
+    g = load_golden("f3_upsample")
+    ro, rd, near, far = (g[k] for k in ("rays_o", "rays_d", "near", "far"))
+    jit = torch.rand(ro.shape[0], 1, generator=torch.Generator().manual_seed(S))
+    for j in (None, jit):
+        z_o = O.coarse_z(near, far, S, j)
+        z, pts = ops.coarse_samples(ro.cuda(), rd.cuda(), near.cuda(), far.cuda(), S, None if j is None else j.cuda())
+        assert maxdiff(z.cpu(), z_o) < 1e-6
+        assert maxdiff(pts.cpu(), ro[:, None] + rd[:, None] * z_o[..., None]) < 1e-6
+    dists, mid, pts = ops.midpoints(ro.cuda(), rd.cuda(), z, 2.0 / S)
+    d_o = torch.cat([z_o[:, 1:] - z_o[:, :-1], torch.full_like(z_o[:, :1], 2.0 / S)], -1)
+    assert maxdiff(dists.cpu(), d_o) < 1e-6 and maxdiff(mid.cpu(), z_o + d_o * 0.5) < 1e-6
+
+
+def test_upsample_golden(ops):
+    """F3: up_sample + sample_pdf + merge against the reference's outputs (K=1)."""
+    g = load_golden("f3_upsample")
+    ro, rd = g["rays_o"].cuda(), g["rays_d"].cuda()
+    z_new, pts_new, z_m = ops.upsample(ro, rd, g["z_coarse"].cuda(), g["sdf_coarse"].cuda(), 16, 64.0)
+    assert maxdiff(z_new.cpu(), g["z_new_k1"]) < 2e-5
+    assert maxdiff(z_m.cpu(), g["z_merged_k1"]) < 2e-5
+    assert (z_m[:, 1:] >= z_m[:, :-1]).all()
+    assert maxdiff(pts_new.cpu(), g["rays_o"][:, None] + g["rays_d"][:, None] * z_new.cpu()[..., None]) < 1e-6
+
+
+@pytest.mark.parametrize("Sc,n_new,inv_s", [(16, 4, 64.0), (64, 64, 64.0), (160, 32, 256.0), (128, 128, 512.0), (9, 70, 64.0)])
+def test_upsample_vs_oracle(ops, sdf_sd, Sc, n_new, inv_s):
+    g = torch.Generator().manual_seed(Sc + n_new)
+    N = 203
+    ro = torch.tensor([0.0, 0.0, -3.0]).expand(N, 3) + 0.05 * torch.randn(N, 3, generator=g)
+    rd = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + 0.2 * torch.randn(N, 3, generator=g), dim=-1)
+    near, far = O.near_far_from_sphere(ro, rd)
+    z = torch.sort(near + (far - near) * torch.rand(N, Sc, generator=g), -1).values
+    w = O.style_mlp(sdf_sd, torch.randn(1, 64, generator=g))
+    pts = ro[:, None] + rd[:, None] * z[..., None]
+    sdf = O.sdf_forward(sdf_sd, pts.reshape(-1, 3), w)[0].reshape(N, Sc)
+    wts = O.up_sample_weights(ro, rd, z, sdf, inv_s)
+    zn_o = O.sample_pdf_det(z, wts, n_new)
+    zm_o, _ = O.merge_sorted(z, zn_o)
+    z_new, _, z_m = ops.upsample(ro.cuda(), rd.cuda(), z.cuda(), sdf.cuda(), n_new, inv_s)
+    assert maxdiff(z_new.cpu(), zn_o) < 5e-5, maxdiff(z_new.cpu(), zn_o)
+    assert maxdiff(z_m.cpu(), zm_o) < 5e-5
+    # merge with payload
+    sdf_new = torch.randn(N, n_new, generator=g)
+    zo, so = ops.merge_sorted(z.cuda(), sdf.cuda(), z_new, sdf_new.cuda())
+    zr, sr = O.merge_sorted(z, z_new.cpu(), sdf, sdf_new)
+    assert maxdiff(zo.cpu(), zr) == 0.0
+    # payload follows its key (ties between equal keys may swap payloads of *equal* z only)
+    same = (so.cpu() == sr)
+    assert same.float().mean() > 0.999
+
+
+def _composite_inputs(tag, g):
+    return dict(sdf=g[f"{tag}_sdf"], grad=g[f"{tag}_gradients"], rgb=g[f"{tag}_raw_color"], mid_z=g[f"{tag}_mid_z_vals"])
+
+
+@pytest.mark.parametrize("tag,car", [("c0p0", 0.0), ("c0p5", 0.5), ("c1p0", 1.0)])
+def test_composite_golden_f4(ops, tag, car):
+    """F4: compositing tail of render_core on the reference's own per-sample network outputs."""
+    g = load_golden("f4_render")
+    ci = _composite_inputs(tag, g)
+    N, T = ci["sdf"].shape
+    z = g[f"{tag}_mid_z_vals"]
+    # dists are recovered from mid_z: mid = z + d/2 with the last d = 2/S
+    S = 16
+    dists = torch.empty_like(z)
+    dists[:, -1] = 2.0 / S
+    zz = torch.empty_like(z)
+    zz[:, -1] = z[:, -1] - dists[:, -1] * 0.5
+    for i in range(T - 2, -1, -1):
+        zz[:, i] = 2 * z[:, i] - zz[:, i + 1]
+        dists[:, i] = zz[:, i + 1] - zz[:, i]
+    out = ops.composite_fwd(ci["sdf"].cuda(), ci["grad"].cuda(), ci["rgb"].cuda(), dists.cuda(), ci["mid_z"].cuda(),
+                            g["rays_o"].cuda(), g["rays_d"].cuda(), torch.tensor([[0.0, 0.0, -1.0]]).cuda(), None,
+                            g["variance"].cuda(), car, 0.33, 0.67, 0.0, 10.0, 1)
+    torch.cuda.synchronize()
+    tol = 3e-4  # the recovered dists carry ~1e-6 error amplified by inv_s
+    assert maxdiff(out["weights"].cpu(), g[f"{tag}_weights"]) < tol
+    assert maxdiff(out["cdf"].cpu(), g[f"{tag}_cdf_fine"]) < tol
+    assert maxdiff(out["weight_sum"].cpu(), g[f"{tag}_weight_sum"]) < tol
+    assert maxdiff(out["weight_max"].cpu(), g[f"{tag}_weight_max"]) < tol
+    assert maxdiff(out["color_fine"].cpu(), g[f"{tag}_color_fine"]) < tol
+    assert maxdiff(out["inside_sphere"].cpu(), g[f"{tag}_inside_sphere"]) == 0
+    assert maxdiff(out["pts_norm"].cpu(), g[f"{tag}_pts_norm"]) < 1e-5
+    r4 = out["reduce4"].cpu()
+    assert abs(float(r4[0] / (r4[1] + 1e-5)) - float(g[f"{tag}_gradient_error"])) < 1e-4
+    assert abs(float(r4[2] / (N * T)) - float(g[f"{tag}_surface_loss"])) < 1e-5
+
+
+def test_composite_vs_oracle_maps(ops, sdf_sd, col_sd):
+    """Composite + Phong maps (specular on, 2 elements, T not a multiple of 64) vs oracle render_maps."""
+    g = torch.Generator().manual_seed(3)
+    B, H, W, S, I = 2, 5, 7, 40, 37
+    N = B * H * W
+    ro = torch.tensor([0.0, 0.0, -3.0]).expand(N, 3) + 0.05 * torch.randn(N, 3, generator=g)
+    rd = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + 0.2 * torch.randn(N, 3, generator=g), dim=-1)
+    near, far = O.near_far_from_sphere(ro, rd)
+    w = O.style_mlp(sdf_sd, torch.randn(B, 64, generator=g))
+    var = torch.tensor(0.3)
+    out_o = O.render(sdf_sd, col_sd, var, ro, rd, near, far, w, S, I, 1, 0.37)
+    lsd = {"param_direction": torch.tensor([0.3, -0.5, -0.8]), "param_ambient": torch.tensor(-0.4),
+           "param_specular": torch.tensor(0.35), "param_shininess": torch.tensor(6.0)}
+    w2b = torch.eye(4).repeat(B, 1, 1)
+    q = torch.linalg.qr(torch.randn(B, 3, 3, generator=g)).Q
+    w2b[:, :3, :3] = q
+    bg = torch.rand(B, 3, generator=g)
+    maps = O.render_maps(out_o, ro, lsd, w2b, bg, B, H, W, return_raw=True)
+    ldir, amb, cd, cs, sh = O.light_terms(lsd, w2b)
+    T = S + I
+    dists = torch.cat([out_o["mid_z_vals"][:, 1:] * 0, torch.zeros(N, 1)], -1)
+    # exact dists from the oracle's z: recompute
+    z = O.hierarchical_z(sdf_sd, ro, rd, near, far, w, S, I, 1)
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((N, 1), 2.0 / S)], -1)
+    out = ops.composite_fwd(out_o["sdf"].cuda(), out_o["gradients"].cuda(), out_o["raw_color"].cuda(), dists.cuda(),
+                            out_o["mid_z_vals"].cuda(), ro.cuda(), rd.cuda(), ldir.cuda(), bg.cuda(), var.cuda(), 0.37,
+                            float(amb), float(cd), float(cs), float(sh), B)
+    torch.cuda.synchronize()
+
+    def as_map(x):
+        return x.cpu().reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+    assert maxdiff(out["weights"].cpu(), out_o["weights"]) < 1e-5
+    assert maxdiff(out["alpha"].cpu(), out_o["alpha"]) < 1e-5
+    for name, key in (("image", "image"), ("image_no_bg", "image_no_bg"), ("mask", "mask"), ("normal", "normal_map"),
+                      ("z_map", "z_map"), ("color_fine", "color_map"), ("weight_sum", "weight_sum_map")):
+        assert maxdiff(as_map(out[name]), maps[key]) < 2e-5, name
+    assert maxdiff(as_map(out["shading"]), maps["shading_map"][:, :1]) < 2e-5
+    assert maxdiff(as_map(out["specular_map"]), maps["specular_map"][:, :1]) < 2e-5
+    assert maxdiff(as_map(out["diffuse_map"]), maps["diff_shading_map"][:, :1]) < 2e-5
+    r4 = out["reduce4"].cpu()
+    assert abs(float(r4[0] / (r4[1] + 1e-5)) - float(out_o["gradient_error"])) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["r16c3_", "r64c3_", "r64c1_"])
+def test_conv_discriminator_golden_f7(ops, tag):
+    g = load_golden("f7_discriminator")
+    dsd = sub_sd(g, tag + "w.")
+    x = g[tag + "x"].cuda()
+    n = len([k for k in dsd if k.startswith("blocks.")])
+    for i in range(n):
+        x = ops.conv4x4_fwd(x, dsd[f"blocks.{i}.weight"].cuda(), None, 2, 1, 0.2)
+    d = ops.conv4x4_fwd(x, dsd["conv_out.weight"].cuda(), None, 1, 0, 1.0).reshape(x.shape[0], -1)
+    assert maxdiff(d.cpu(), g[tag + "d"]) < 2e-5
+
+
+@pytest.mark.parametrize("B,Cin,H,Cout,stride,pad", [(1, 3, 64, 64, 2, 1), (1, 256, 8, 512, 2, 1), (3, 512, 4, 7, 1, 0),
+                                                      (2, 5, 10, 33, 2, 1), (4, 1, 128, 32, 2, 1)])
+def test_conv4x4_vs_torch(ops, B, Cin, H, Cout, stride, pad):
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) / math.sqrt(Cin * 16)
+    b = torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=pad), 0.2)
+    y = ops.conv4x4_fwd(x.cuda(), w.cuda(), b.cuda(), stride, pad, 0.2)
+    assert maxdiff(y.cpu(), ref) < 2e-5
+
+
+def test_upfirdn2d_golden_f8(ops):
+    g = load_golden("f8_augment")
+    f1 = g["Hz_geom"].cuda()
+    x = g["ufd_x"].cuda()
+    # upsample2d = two separable passes (upfirdn2d.py:239-241, 325-357)
+    up = ops.upfirdn2d(x, f1[None, :], upx=2, padx0=6, padx1=5, gain=2.0)
+    up = ops.upfirdn2d(up, f1[:, None], upy=2, pady0=6, pady1=5, gain=2.0)
+    assert maxdiff(up.cpu(), g["ufd_up"]) < 1e-5
+    dn = ops.upfirdn2d(up, f1[None, :], downx=2, padx0=-2 + 5, padx1=-2 + 5, flip=True)
+    dn = ops.upfirdn2d(dn, f1[:, None], downy=2, pady0=-2 + 5, pady1=-2 + 5, flip=True)
+    assert maxdiff(dn.cpu(), g["ufd_down"]) < 1e-5
+    y = ops.upfirdn2d(x, g["ufd_f2d"].cuda(), upx=2, upy=1, downx=1, downy=3, padx0=1, padx1=2, pady0=0, pady1=3, gain=1.7)
+    assert maxdiff(y.cpu(), g["ufd_general"]) < 1e-5
+
+
+def test_affine_grid_sample_and_pad(ops):
+    g = torch.Generator().manual_seed(0)
+    B, C, Hi, Wi, Ho, Wo = 3, 2, 37, 29, 24, 40
+    x = torch.randn(B, C, Hi, Wi, generator=g)
+    theta = torch.eye(2, 3).repeat(B, 1, 1) + 0.3 * torch.randn(B, 2, 3, generator=g)
+    grid = torch.nn.functional.affine_grid(theta, [B, C, Ho, Wo], align_corners=False)
+    ref = torch.nn.functional.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    y = ops.affine_grid_sample_fwd(x.cuda(), theta.cuda(), Ho, Wo)
+    assert maxdiff(y.cpu(), ref) < 2e-5
+    gy = torch.randn(B, C, Ho, Wo, generator=g)
+    xr = x.clone().requires_grad_(True)
+    torch.nn.functional.grid_sample(xr, grid, mode="bilinear", padding_mode="zeros", align_corners=False).backward(gy)
+    gx = ops.affine_grid_sample_bwd(gy.cuda(), theta.cuda(), Hi, Wi)
+    assert maxdiff(gx.cpu(), xr.grad) < 5e-5
+    p = (3, 5, 2, 7)
+    yp = ops.reflect_pad_fwd(x.cuda(), *p)
+    refp = torch.nn.functional.pad(x, list(p), mode="reflect")
+    assert maxdiff(yp.cpu(), refp) == 0
+    gp = torch.randn_like(refp)
+    xr2 = x.clone().requires_grad_(True)
+    torch.nn.functional.pad(xr2, list(p), mode="reflect").backward(gp)
+    gxp = ops.reflect_pad_bwd(gp.cuda(), Hi, Wi, *p)
+    assert maxdiff(gxp.cpu(), xr2.grad) < 1e-5
