@@ -149,8 +149,10 @@ typedef struct oi_composite_params {
   const float* bg;        /* [B][3] background colour, may be NULL (then image == image_no_bg) */
   /* scalars */
   const float* variance;  /* device pointer to the SingleVarianceNetwork parameter */
+  const float* light;     /* device pointer to [param_ambient (logit), param_specular, param_shininess] of
+                             DirectionalLightWithSpecularFixInit (lighting.py:33-52): ambient = sigmoid(l[0]),
+                             diffuse = 1 - ambient, specular = max(l[1], 0), shininess = l[2].  No host sync. */
   float cos_anneal_ratio;
-  float ambient, diffuse, specular, shininess; /* sigmoid(param_ambient), 1-that, max(spec,0), shininess */
   long long N; /* rays = B*H*W */
   int T;       /* samples per ray */
   int B;       /* elements; N % B == 0 */

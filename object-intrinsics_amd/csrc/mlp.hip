@@ -589,8 +589,8 @@ extern "C" {
 int oi_film_params(const float* style_w, const float* style_b, const float* z, float* w_out, const float* gw,
                    const float* gb, const float* bw, const float* bb, float* gamma, float* beta, int B, int NL,
                    oi_stream_t stream) {
-  OI_REQUIRE(B > 0 && NL > 0, "oi_film_params: B=%d NL=%d", B, NL);
-  OI_REQUIRE(w_out && gw && gb && bw && bb && gamma && beta, "oi_film_params: null pointer");
+  OI_REQUIRE(B > 0 && NL >= 0, "oi_film_params: B=%d NL=%d", B, NL);
+  OI_REQUIRE(w_out && (NL == 0 || (gw && gb && bw && bb && gamma && beta)), "oi_film_params: null pointer");
   OI_REQUIRE(z == nullptr || (style_w && style_b), "oi_film_params: z given without style weights");
   hipLaunchKernelGGL(film_params_kernel, dim3(B), dim3(C), 0, oi::as_stream(stream), style_w, style_b, z, w_out,
                      gw, gb, bw, bb, gamma, beta, NL);

@@ -301,6 +301,7 @@ composite_fwd_kernel(const oi_composite_params p) {
   // SingleVarianceNetwork + clip (neus/models/fields.py:267-268; renderer.py:266)
   const float inv_s = fminf(fmaxf(expf(p.variance[0] * 10.0f), 1e-6f), 1e6f);
   const float car = p.cos_anneal_ratio;
+  const float l_amb = sigmoidf_(p.light[0]), l_dif = 1.0f - l_amb, l_spec = fmaxf(p.light[1], 0.f), l_shin = p.light[2];
 
   float carry = 1.0f;
   float a_wsum = 0.f, a_wmax = 0.f, a_c0 = 0.f, a_c1 = 0.f, a_c2 = 0.f, a_i0 = 0.f, a_i1 = 0.f, a_i2 = 0.f;
@@ -339,13 +340,13 @@ composite_fwd_kernel(const oi_composite_params p) {
     const float gnc = fmaxf(gn, 1e-6f);
     const float nx = gx / gnc, ny = gy / gnc, nz = gz / gnc;
     const float ndl = nx * lx + ny * ly + nz * lz;
-    const float diff = p.diffuse * fmaxf(ndl, 0.f);
+    const float diff = l_dif * fmaxf(ndl, 0.f);
     float vx = ox - px, vy = oy - py, vz = oz - pz;
     normalize3(vx, vy, vz, 1e-6f);
     const float rx = -lx + 2.0f * (ndl * nx), ry = -ly + 2.0f * (ndl * ny), rz = -lz + 2.0f * (ndl * nz);
     const float al = fmaxf(vx * rx + vy * ry + vz * rz, 0.f) * (ndl > 0.f ? 1.f : 0.f);
-    const float spec = p.specular * powf(al, p.shininess);
-    const float shade = p.ambient + diff;
+    const float spec = l_spec * powf(al, l_shin);
+    const float shade = l_amb + diff;
 
     if (on && live) {
       if (p.weights) p.weights[k] = w;
@@ -476,7 +477,7 @@ int oi_merge_sorted(const float* z, const float* sdf, const float* z_new, const 
 int oi_composite_fwd(const oi_composite_params* p, oi_stream_t stream) {
   OI_REQUIRE(p != nullptr, "oi_composite_fwd: null params");
   OI_REQUIRE(p->sdf && p->grad && p->rgb && p->dists && p->mid_z && p->rays_o && p->rays_d && p->light_dir &&
-                 p->variance,
+                 p->variance && p->light,
              "oi_composite_fwd: null input pointer");
   OI_REQUIRE(p->N > 0 && p->T > 0 && p->B > 0 && p->N % p->B == 0, "oi_composite_fwd: N=%lld T=%d B=%d", p->N, p->T,
              p->B);

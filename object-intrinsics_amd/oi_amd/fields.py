@@ -1,0 +1,198 @@
+"""Latent-conditioned FiLM-SIREN SDF / albedo networks -- drop-ins for the reference classes
+    src.models.fields.ShapeNetwork / ColorNetwork            (src/models/fields.py:10-101)
+    src.third_party.neus.models.fields.SingleVarianceNetwork (neus/models/fields.py:262-268)
+with identical constructor kwargs, method names and state_dict keys:
+    style.{0,1,2}.{weight,bias}; pts_linears.{l}.{weight,bias,gamma.weight,gamma.bias,beta.weight,beta.bias};
+    sigma_linear.{weight,bias}; views_linears.{...}; rgb_linear.{weight,bias}; variance.
+The modules only *hold* parameters; evaluation happens in the HIP MLP kernel (csrc/mlp.hip) through
+`FieldPack`, which caches the MFMA weight images per parameter version."""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import lib as _l
+from . import ops
+from .params import stack_field_params
+
+
+class LinearLayer(nn.Module):
+    """std_init * (x W^T + b) + bias_init   (stylesdf/volume_renderer.py:12-30)."""
+
+    def __init__(self, in_dim, out_dim, bias_init=0, std_init=1, freq_init=False, is_first=False):
+        super().__init__()
+        if is_first:
+            w = torch.empty(out_dim, in_dim).uniform_(-1 / in_dim, 1 / in_dim)
+        elif freq_init:
+            a = np.sqrt(6 / in_dim) / 25
+            w = torch.empty(out_dim, in_dim).uniform_(-a, a)
+        else:
+            w = 0.25 * nn.init.kaiming_normal_(torch.randn(out_dim, in_dim), a=0.2, mode="fan_in",
+                                               nonlinearity="leaky_relu")
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.empty(out_dim).uniform_(-np.sqrt(1 / in_dim), np.sqrt(1 / in_dim)))
+        self.bias_init, self.std_init = bias_init, std_init
+
+
+class FiLMSiren(nn.Module):
+    """sin(gamma(w) * (x W^T + b) + beta(w))   (stylesdf/volume_renderer.py:33-61)."""
+
+    def __init__(self, in_channel, out_channel, style_dim, is_first=False):
+        super().__init__()
+        self.in_channel, self.out_channel = in_channel, out_channel
+        a = 1 / 3 if is_first else np.sqrt(6 / in_channel) / 25
+        self.weight = nn.Parameter(torch.empty(out_channel, in_channel).uniform_(-a, a))
+        self.bias = nn.Parameter(torch.empty(out_channel).uniform_(-np.sqrt(1 / in_channel), np.sqrt(1 / in_channel)))
+        self.gamma = LinearLayer(style_dim, out_channel, bias_init=30, std_init=15)
+        self.beta = LinearLayer(style_dim, out_channel, bias_init=0, std_init=0.25)
+
+
+class MappingLinear(nn.Module):
+    """linear + fused leaky-relu(0.2), scale 1   (stylesdf/model.py:32-56)."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.weight = nn.Parameter(nn.init.kaiming_normal_(torch.empty(out_dim, in_dim), a=0.2, mode="fan_in",
+                                                           nonlinearity="leaky_relu"))
+        self.bias = nn.Parameter(torch.empty(out_dim).uniform_(-np.sqrt(1 / in_dim), np.sqrt(1 / in_dim)))
+
+
+class StyleMLP(nn.Sequential):
+    """`ShapeNetwork.style`: three MappingLinear layers evaluated by one HIP launch (oi_film_params)."""
+
+    def forward(self, z):
+        from .autograd import style_mlp
+        return style_mlp(self, z)
+
+
+def _check_dims(D, W, input_ch, style_dim):
+    if (D, W, input_ch, style_dim) != (8, 128, 3, 64):
+        raise NotImplementedError(
+            f"the gfx950 MLP kernel is specialised for D=8, W=128, input_ch=3, style_dim=64 "
+            f"(configs/train.yaml:34-49); got D={D} W={W} input_ch={input_ch} style_dim={style_dim}")
+
+
+class ShapeNetwork(nn.Module):
+    def __init__(self, checkpoint_path, D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64, **_unused):
+        super().__init__()
+        _check_dims(D, W, input_ch, style_dim)
+        self.style = StyleMLP(*[MappingLinear(style_dim, style_dim) for _ in range(3)])
+        self.pts_linears = nn.ModuleList([FiLMSiren(input_ch, W, style_dim, is_first=True)] +
+                                         [FiLMSiren(W, W, style_dim) for _ in range(D - 1)])
+        self.sigma_linear = LinearLayer(W, 1, freq_init=True)
+        self._pack = None
+        if checkpoint_path is not None:
+            self.load_state_dict(load_sdf_checkpoint(checkpoint_path))
+
+    # -- reference API (fields.py:49-77); the renderer does not go through these -----------------
+    def _own_pack(self):
+        if self._pack is None:
+            object.__setattr__(self, "_pack", FieldPack(self, None))
+        return self._pack
+
+    def forward(self, x, z, w=None):
+        from .autograd import sdf_mlp
+        pk = self._own_pack()
+        w, gamma, beta = pk.film(z=z if w is None else None, w=w)
+        sdf, _, _, feat = sdf_mlp(pk, x, gamma, beta, w.shape[0], want_grad=False, want_rgb=False, want_feat=True)
+        return torch.cat([sdf[:, None], feat], -1)
+
+    def sdf(self, x, z, w=None):
+        from .autograd import sdf_mlp
+        pk = self._own_pack()
+        w, gamma, beta = pk.film(z=z if w is None else None, w=w)
+        return sdf_mlp(pk, x, gamma, beta, w.shape[0], want_grad=False, want_rgb=False, want_feat=False)[0][:, None]
+
+    def gradient(self, x, z, w=None, second_order=False):
+        from .autograd import sdf_mlp
+        if second_order:
+            raise NotImplementedError("second_order=True (hessian) is dead on the path (renderer.py:254)")
+        pk = self._own_pack()
+        w, gamma, beta = pk.film(z=z if w is None else None, w=w)
+        return sdf_mlp(pk, x, gamma, beta, w.shape[0], want_grad=True, want_rgb=False, want_feat=False)[1]
+
+    def __deepcopy__(self, memo):  # EMA copies (src/utils/ema.py:11-12): never share the cache
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            object.__setattr__(new, k, None if k == "_pack" else copy.deepcopy(v, memo))
+        return new
+
+
+class ColorNetwork(nn.Module):
+    def __init__(self, D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64, **_unused):
+        super().__init__()
+        _check_dims(D, W, input_ch, style_dim)
+        if input_ch_views != 3:
+            raise NotImplementedError("colour head consumes [feat(128), grad(3)] (fields.py:96)")
+        self.views_linears = FiLMSiren(input_ch_views + W, W, style_dim)
+        self.rgb_linear = LinearLayer(W, 3, freq_init=True)
+        self.style_dim, self.w_dim = style_dim, W
+
+
+class SingleVarianceNetwork(nn.Module):
+    def __init__(self, init_val):
+        super().__init__()
+        self.variance = nn.Parameter(torch.tensor(float(init_val)))
+
+    def forward(self, x):
+        return torch.ones([len(x), 1], device=self.variance.device) * torch.exp(self.variance * 10.0)
+
+
+def load_sdf_checkpoint(path):
+    """Reference checkpoints are torch pickles {'sdf_network': state_dict, 'cfg': ...}
+    (fields.py:25-38); the test fixture tests/golden/weights_sdf.npz holds the same tensors."""
+    if str(path).endswith(".npz"):
+        with np.load(path) as f:
+            return {k: torch.from_numpy(np.asarray(f[k])) for k in f.files}
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    return sd["sdf_network"] if "sdf_network" in sd else sd
+
+
+class FieldPack:
+    """Per (sdf_network, color_network) cache of what the kernels consume: stacked parameter views
+    (differentiable torch.stack) and the packed MFMA weight image, keyed by parameter versions."""
+
+    def __init__(self, sdf_network, color_network, precision="f32", fast_trig=None):
+        self.sdf_network, self.color_network = sdf_network, color_network
+        self.set_precision(precision, fast_trig)
+        self._key = None
+        self._packed = None
+
+    def set_precision(self, precision, fast_trig=None):
+        self.prec = _l.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+        self.fast_trig = (self.prec == _l.OI_PREC_BF16) if fast_trig is None else bool(fast_trig)
+        self._key = None
+
+    def _sds(self):
+        sd = dict(self.sdf_network.named_parameters())
+        if self.color_network is not None:
+            csd = dict(self.color_network.named_parameters())
+        else:
+            ref = sd["pts_linears.1.weight"]
+            z = lambda *s: torch.zeros(*s, device=ref.device)
+            csd = {"views_linears.weight": z(128, 131), "views_linears.bias": z(128), "rgb_linear.weight": z(3, 128),
+                   "rgb_linear.bias": z(3), "views_linears.gamma.weight": z(128, 64), "views_linears.gamma.bias": z(128),
+                   "views_linears.beta.weight": z(128, 64), "views_linears.beta.bias": z(128)}
+        return sd, csd
+
+    def stacked(self):
+        return stack_field_params(*self._sds())
+
+    def packed(self):
+        sd, csd = self._sds()
+        key = (self.prec,) + tuple((p.data_ptr(), p._version) for p in list(sd.values()) + list(csd.values()))
+        if key != self._key:
+            with torch.no_grad():
+                P = stack_field_params(sd, csd)
+                self._packed = ops.mlp_pack_weights(P["w0"], P["b0"], P["wh"], P["bh"], P["wsig"], P["bsig"], P["wv"],
+                                                    P["bv"], P["wrgb"], P["brgb"], self.prec)
+            self._key = key
+        return self._packed
+
+    def film(self, z=None, w=None):
+        from .autograd import film_params
+        return film_params(self, z=z, w=w)

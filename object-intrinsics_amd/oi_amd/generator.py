@@ -1,0 +1,174 @@
+"""Generator -- drop-in for src.models.generator.Generator (generator.py:19-314): same constructor
+(config dicts with `__target__`), same `forward(bs, it, data, return_raw)` contract and returned
+structure {'box': {'loss', 'stats', 'render_out', 'prior_info' [, 'latent_info', 'rays_info',
+'raw_render_out']}}.
+
+MI355X-first differences: the whole image is rendered by ~8 kernel launches
+with no host synchronisation -- `it` is mirrored on the host, the light scalars are read by the
+compositing kernel from device memory, stats stay on the device -- and the Phong maps come out of
+the same compositing launch instead of ~40 elementwise kernels over (N, T, 3) tensors."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import build_from_config
+from .renderer import assemble_render_dict
+
+MAX_RAY_BATCH_SIZE = 128 * 128 * 1
+
+
+def invert_rot_t(pose):
+    """src/utils/pose.py:143-154 (rigid inverse)."""
+    R = pose[..., :3, :3].transpose(-1, -2)
+    t = -(R @ pose[..., :3, 3:4])
+    out = torch.zeros_like(pose)
+    out[..., :3, :3] = R
+    out[..., :3, 3:4] = t
+    out[..., 3, 3] = 1.0
+    return out
+
+
+class Generator(nn.Module):
+    def __init__(self, color_network, sdf_network, deviation_network, light_network, camera, z_dim, resolution,
+                 scene_resolution, renderer, anneal_end, pose_prior):
+        super().__init__()
+        self.resolution = resolution
+        self.scene_resolution = scene_resolution
+        self.z_dim = z_dim
+        self.anneal_end = anneal_end
+        self.register_buffer("it", torch.tensor(-1, dtype=torch.long))
+        self._it_host = -1
+        self.camera = build_from_config(camera)
+        self.light = build_from_config(light_network)
+        self.pose_prior = build_from_config(pose_prior)
+        self.color_network = build_from_config(color_network)
+        self.sdf_network = build_from_config(sdf_network)
+        self.deviation_network = build_from_config(deviation_network)
+        self.renderer = build_from_config(renderer, nerf=None, sdf_network=self.sdf_network,
+                                          deviation_network=self.deviation_network, color_network=self.color_network)
+
+    # -- host-side sampling (generator.py:65-78, 176-184; prior.py:11-29) -------------------------
+    def bg_color(self, bs):
+        return torch.tensor(np.random.uniform(low=0, high=1, size=(bs, 3)), dtype=torch.float32)
+
+    def sample_prior(self, bs, data):
+        dev = self.it.device
+        if "b2w" in data:
+            assert not self.training
+            b2w = data["b2w"].to(dev)
+        else:
+            b2w = torch.tensor(self.pose_prior(bs), dtype=torch.float32, device=dev)
+        w2b = invert_rot_t(b2w)
+        c2b = torch.einsum("bij,jk->bik", w2b, self.camera.c2w)
+        return {"c2b": c2b, "b2w": b2w, "w2b": w2b, "light": self.light.batch_transform(w2b=w2b)}
+
+    def sample_latent(self, bs, data):
+        if "w" in data:
+            assert not self.training
+            return {"z": data["z"], "w": data["w"]}
+        if "z" in data:
+            assert not self.training
+            return {"z": data["z"]}
+        return {"z": torch.randn(bs, self.z_dim, device=self.it.device)}
+
+    def gen_rays_at(self, data, prior_info):
+        """generator.py:255-279 + build_rays :317-333 + near_far_from_sphere :336-342 (one kernel)."""
+        b2w, R = prior_info["b2w"], self.resolution
+        b2c_t = torch.einsum("ij,bjk->bik", self.camera.w2c, b2w)[..., :3, 3]
+        cx = self.camera.cam_dist / b2c_t[..., 2] * b2c_t[..., 0] * R / 2 + 0.5 * self.scene_resolution
+        cy = self.camera.cam_dist / b2c_t[..., 2] * b2c_t[..., 1] * R / 2 + 0.5 * self.scene_resolution
+        x_off, y_off = cx - R / 2, cy - R / 2
+        ro, rd, near, far = ops.gen_rays(prior_info["c2b"], self.camera.intrinsics_inv[:3, :3].contiguous(),
+                                         torch.stack([x_off, y_off], -1), R)
+        return {"rays_o": ro, "rays_d": rd, "x_offset": x_off, "y_offset": y_off, "near": near, "far": far}
+
+    # -- forward --------------------------------------------------------------------------------
+    def forward(self, bs, it, data, return_raw=False):
+        if it is None:
+            it = int(self.it)  # eval / inference callers only (one D2H read); training passes `it`
+        self._it_host = int(it)
+        self.it.fill_(int(it))
+        prior = self.sample_prior(bs, data)
+        latent = self.sample_latent(bs, data)
+        rays = self.gen_rays_at(data, prior)
+        h = w = self.resolution
+        n_rays = bs * h * w
+        cos_anneal_ratio = min(1.0, self._it_host / self.anneal_end)
+        bg = self.bg_color(bs).to(self.it.device)
+        ldir = prior["light"].direction()
+        lpk = self.light.packed()
+
+        ro_all, rd_all = rays["rays_o"].view(bs, h * w, 3), rays["rays_d"].view(bs, h * w, 3)
+        near_all, far_all = rays["near"].view(bs, h * w, 1), rays["far"].view(bs, h * w, 1)
+        chunk = int(MAX_RAY_BATCH_SIZE / bs)
+        n_chunks = math.ceil(h * w / chunk)
+        if n_chunks > 1:
+            assert not self.training, (n_rays, chunk)
+        if "w" not in latent:
+            latent["w"] = self.renderer.sdf_network.style(latent["z"])  # generator.py:235-238
+        outs = []
+        for ci in range(n_chunks):
+            sl = slice(ci * chunk, (ci + 1) * chunk)
+            flat = lambda t: t[:, sl].reshape(-1, t.shape[-1])
+            s, c = self.renderer.render_full(flat(ro_all), flat(rd_all), flat(near_all), flat(far_all),
+                                             perturb_overwrite=-1 if self.training else 0,
+                                             cos_anneal_ratio=cos_anneal_ratio, z=latent["z"], w=latent["w"],
+                                             light=lpk, light_dir=ldir, bg=bg)
+            outs.append((s, c))
+        if n_chunks == 1:
+            s, c = outs[0]
+        else:  # eval only: (bs, chunk, ...) pieces back to (bs*h*w, ...) rows (generator.py:298-305)
+            cat = lambda k, d: torch.cat([o[d][k].unflatten(0, (bs, -1)) for o in outs], 1).flatten(0, 1)
+            s = {k: cat(k, 0) for k in outs[0][0]}
+            c = {k: cat(k, 1) for k in outs[0][1] if k != "reduce4"}
+            c["reduce4"] = sum(o[1]["reduce4"] for o in outs)
+        render_out = assemble_render_dict(s, c, self.deviation_network.variance)
+        if n_chunks > 1:
+            render_out["gradient_error"] = None
+            render_out["surface_loss"] = None
+
+        def to_map(x):
+            return x.reshape(bs, h, w, -1).permute(0, 3, 1, 2)
+
+        new = {
+            "weight_sum_map": to_map(c["weight_sum"]),
+            "color_map": to_map(c["color_fine"]),
+            "shading_map": to_map(c["shading"]).expand(bs, 3, h, w),
+            "image_no_bg": to_map(c["image_no_bg"]),
+            "image": to_map(c["image"]),
+            "mask": to_map(c["mask"]),
+        }
+        if return_raw:
+            amb = torch.sigmoid(self.light.param_ambient)
+            new.update({
+                "amb_shading_map": (amb * to_map(c["weight_sum"])).expand(bs, 3, h, w),
+                "diff_shading_map": to_map(c["diffuse_map"]).expand(bs, 3, h, w),
+                "normal_map": to_map(c["normal"]),
+                "no_specular_map": to_map(c["image_no_bg"]) - to_map(c["specular_map"]),
+                "specular_map": to_map(c["specular_map"]).expand(bs, 3, h, w),
+                "z_map": to_map(c["z_map"]),
+                "z_min": s["mid_z_vals"].min(-1).values.reshape(bs, -1).min(-1).values,
+            })
+        blob = {
+            "loss": {"eikonal": render_out["gradient_error"]},
+            "stats": {
+                "surface": render_out["surface_loss"],
+                "s_val": render_out["s_val"].mean(),
+                "cdf": render_out["cdf_fine"][:, :1].mean(),
+                "weight_max": render_out["weight_max"].mean(),
+                "weight_sum": render_out["weight_sum"].mean(),
+                # device scalars (the reference calls .item() here: 4 host syncs per forward, generator.py:220-223)
+                "light/ambient": self.light.ambient_color.mean().detach(),
+                "light/diffuse": self.light.diffuse_color.mean().detach(),
+                "light/specular": self.light.specular_color.mean().detach(),
+                "material/shininess": self.light.shininess.detach(),
+            },
+            "render_out": new,
+            "prior_info": prior,
+        }
+        if return_raw:
+            blob.update({"latent_info": latent, "rays_info": rays, "raw_render_out": render_out})
+        return {"box": blob}

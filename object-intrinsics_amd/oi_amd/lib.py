@@ -21,9 +21,8 @@ _vp, _i, _ll, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes
 class CompositeParams(ctypes.Structure):
     """Mirror of `oi_composite_params` (include/oi_hip.h)."""
     _fields_ = ([(n, _vp) for n in ("sdf", "grad", "rgb", "dists", "mid_z", "rays_o", "rays_d", "light_dir", "bg",
-                                    "variance")] +
-                [("cos_anneal_ratio", _f), ("ambient", _f), ("diffuse", _f), ("specular", _f), ("shininess", _f),
-                 ("N", _ll), ("T", _i), ("B", _i)] +
+                                    "variance", "light")] +
+                [("cos_anneal_ratio", _f), ("N", _ll), ("T", _i), ("B", _i)] +
                 [(n, _vp) for n in ("weights", "cdf", "alpha", "inside_sphere", "pts_norm", "weight_sum", "weight_max",
                                     "color_fine", "image_no_bg", "image", "shading", "normal", "mask", "z_map",
                                     "specular_map", "diffuse_map", "reduce4")])

@@ -1,0 +1,75 @@
+"""Learnable directional Phong light.  Parameter names/shapes mirror
+DirectionalLightWithSpecularFixInit (src/models/lighting.py:6-76) so state_dicts interchange; the
+shading arithmetic itself runs inside the fused compositing kernel (csrc/render.hip), which reads
+`param_ambient/param_specular/param_shininess` straight from device memory (no .item() syncs)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .pose import look_at_rot
+
+
+class DirectionalLightWithSpecularFixInit(nn.Module):
+    def __init__(self, direction, ambient_color=0.33, diffuse_color=0.66, specular_color=0.01, shininess=10):
+        super().__init__()
+        ratio = ambient_color / (ambient_color + diffuse_color)
+        self.param_ambient = nn.Parameter(torch.tensor(ratio, dtype=torch.float32).logit())
+        self.param_direction = nn.Parameter(torch.as_tensor(np.asarray(direction), dtype=torch.float32))
+        self.param_shininess = nn.Parameter(torch.tensor(float(shininess)))
+        self.param_specular = nn.Parameter(torch.tensor(float(specular_color)))
+
+    @property
+    def specular_color(self):
+        return self.param_specular.expand(3).clamp(min=0)
+
+    @property
+    def ambient_color(self):
+        return torch.sigmoid(self.param_ambient).expand(3)
+
+    @property
+    def diffuse_color(self):
+        return (1 - torch.sigmoid(self.param_ambient)).expand(3)
+
+    @property
+    def shininess(self):
+        return self.param_shininess
+
+    @property
+    def direction(self):
+        return self.param_direction / torch.linalg.norm(self.param_direction)
+
+    def packed(self):
+        """[param_ambient, param_specular, param_shininess] as the kernel reads them."""
+        return torch.stack([self.param_ambient, self.param_specular, self.param_shininess])
+
+    def batch_direction(self, w2b):
+        """(B,3) light direction in each box frame (lighting.py:115-119)."""
+        return torch.einsum("bij,j->bi", w2b[:, :3, :3], self.direction)
+
+    def batch_transform(self, *, w2b):
+        return BatchLight(self, w2b)
+
+
+class BatchLight:
+    """Counterpart of BatchDirectionalLightWithSpecularFixInit (lighting.py:79-119): just carries w2b."""
+
+    def __init__(self, light, w2b):
+        self.light, self.w2b = light, w2b
+
+    @property
+    def ambient_color(self):
+        return self.light.ambient_color
+
+    def direction(self):
+        return self.light.batch_direction(self.w2b)
+
+
+def build_directional_light_optimizable(cam_loc, light_loc, ambient_color=0.33, diffuse_color=0.66,
+                                        specular_color=0, shininess=10):
+    """src/utils/prior.py:32-49."""
+    if cam_loc is None and light_loc is None:
+        cam_loc, light_loc = [0, 0, -1], [0, 0, -1]
+    dw = np.array(light_loc) / np.linalg.norm(light_loc)
+    dc = look_at_rot(cam_loc).T @ dw
+    return DirectionalLightWithSpecularFixInit(direction=dc, ambient_color=ambient_color, diffuse_color=diffuse_color,
+                                               specular_color=specular_color, shininess=shininess)

@@ -46,9 +46,9 @@ def film_params(style_w, style_b, gw, gb, bw, bb, z=None, w=None):
     L = _l.load()
     assert (z is None) != (w is None)
     src = z if z is not None else w
-    B, NL = src.shape[0], gw.shape[0]
+    B, NL = src.shape[0], (gw.shape[0] if gw is not None else 0)
     w_out = _new(src, B, 64) if w is None else _c(w)
-    gamma, beta = _new(src, B, NL, 128), _new(src, B, NL, 128)
+    gamma, beta = _new(src, B, max(NL, 1), 128), _new(src, B, max(NL, 1), 128)
     z_ = _c(z)
     args = [_c(style_w), _c(style_b), z_, w_out, _c(gw), _c(gb), _c(bw), _c(bb)]
     _l.check(L.oi_film_params(*[_p(a) for a in args], _p(gamma), _p(beta), B, NL, _stream()), "oi_film_params")
@@ -145,20 +145,20 @@ PER_RAY_OUT = {"weight_sum": 1, "weight_max": 1, "color_fine": 3, "image_no_bg":
                "normal": 3, "mask": 1, "z_map": 1, "specular_map": 1, "diffuse_map": 1}
 
 
-def composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, cos_anneal_ratio,
-                  ambient, diffuse, specular, shininess, B, outputs=None):
+def composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light, cos_anneal_ratio,
+                  B, outputs=None):
     """Returns dict of requested outputs (default: all) + 'reduce4' = [sum m*(|g|-1)^2, sum m, sum exp(-100|sdf|), 0]."""
     L = _l.load()
     N, T = dists.shape
     P = _l.CompositeParams()
     keep = []
     for name, t in (("sdf", sdf), ("grad", grad), ("rgb", rgb), ("dists", dists), ("mid_z", mid_z), ("rays_o", rays_o),
-                    ("rays_d", rays_d), ("light_dir", light_dir), ("bg", bg), ("variance", variance.reshape(1))):
+                    ("rays_d", rays_d), ("light_dir", light_dir), ("bg", bg), ("variance", variance.reshape(1)),
+                    ("light", light)):
         t = _c(t)
         keep.append(t)
         setattr(P, name, _p(t))
-    P.cos_anneal_ratio, P.ambient, P.diffuse = float(cos_anneal_ratio), float(ambient), float(diffuse)
-    P.specular, P.shininess = float(specular), float(shininess)
+    P.cos_anneal_ratio = float(cos_anneal_ratio)
     P.N, P.T, P.B = N, T, B
     want = set(outputs) if outputs is not None else set(PER_SAMPLE_OUT) | set(PER_RAY_OUT) | {"reduce4"}
     out = {}

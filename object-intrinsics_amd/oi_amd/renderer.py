@@ -1,0 +1,115 @@
+"""NeuS renderer -- drop-in for src.third_party.neus.models.renderer.NeuSRenderer
+(renderer.py:77-96 ctor, 351-473 render) with the same constructor kwargs and the same keys /
+shapes in the dict `render()` returns.  Every stage is a HIP kernel:
+
+    coarse z + points          oi_coarse_samples     (renderer.py:359-373, 391)
+    coarse SDF                 oi_sdf_mlp_fwd        (renderer.py:396; sdf-only variant)
+    K x importance resampling  oi_upsample [+ oi_sdf_mlp_fwd + oi_merge_sorted]  (:400-413)
+    mid-points                 oi_midpoints          (:219-235)
+    SDF + d sdf/dx + albedo    oi_sdf_mlp_fwd        (:241-261; ONE pass instead of the reference's three)
+    compositing (+ Phong maps) oi_composite_fwd      (:266-311, 338; generator.py:80-174)
+"""
+import torch
+
+from . import ops
+from .autograd import sdf_mlp
+from .fields import FieldPack
+
+
+class NeuSRenderer:
+    def __init__(self, nerf, sdf_network, deviation_network, color_network, n_samples, n_importance, n_outside,
+                 up_sample_steps, perturb, precision="f32", fast_trig=None):
+        if n_outside != 0:
+            raise NotImplementedError("n_outside > 0 (NeRF++ background) is dead on the path (train.yaml:73)")
+        self.nerf = nerf
+        self.sdf_network = sdf_network
+        self.deviation_network = deviation_network
+        self.color_network = color_network
+        self.n_samples = n_samples
+        self.n_importance = n_importance
+        self.n_outside = n_outside
+        self.up_sample_steps = up_sample_steps
+        self.perturb = perturb
+        self.pack = FieldPack(sdf_network, color_network, precision, fast_trig)
+
+    # -- stages -----------------------------------------------------------------------------
+    def sample_z(self, rays_o, rays_d, near, far, gamma, beta, B, perturb):
+        """Hierarchical sampling (no grad, as in the reference: renderer.py:390, 180).  -> z (N, S+I)."""
+        S, I, K = self.n_samples, self.n_importance, self.up_sample_steps
+        N = rays_o.shape[0]
+        with torch.no_grad():
+            jitter = torch.rand([N, 1], device=rays_o.device) if perturb > 0 else None  # renderer.py:372
+            z, pts = ops.coarse_samples(rays_o, rays_d, near, far, S, jitter)
+            if I > 0:
+                sdf = sdf_mlp(self.pack, pts.view(-1, 3), gamma, beta, B, False, False, False)[0].view(N, S)
+                for i in range(K):
+                    last = i + 1 == K
+                    z_new, pts_new, z_merged = ops.upsample(rays_o, rays_d, z, sdf, I // K, 64.0 * 2 ** i, merge=last)
+                    if last:
+                        z = z_merged
+                    else:
+                        sdf_new = sdf_mlp(self.pack, pts_new.view(-1, 3), gamma, beta, B, False, False, False)[0]
+                        z, sdf = ops.merge_sorted(z, sdf, z_new, sdf_new.view(N, -1))
+        return z
+
+    def render_full(self, rays_o, rays_d, near, far, perturb_overwrite=-1, cos_anneal_ratio=0.0, z=None, w=None,
+                    light=None, light_dir=None, bg=None, outputs=None):
+        """Shared implementation: returns (per-sample/per-ray dict, composite dict)."""
+        from .autograd import composite
+        rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
+        N = rays_o.shape[0]
+        w_, gamma, beta = self.pack.film(z=z if w is None else None, w=w)
+        B = w_.shape[0]
+        perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
+        zv = self.sample_z(rays_o, rays_d, near, far, gamma.detach(), beta.detach(), B, perturb)
+        T = zv.shape[1]
+        with torch.no_grad():
+            dists, mid_z, pts = ops.midpoints(rays_o, rays_d, zv, 2.0 / self.n_samples)
+        sdf, grad, rgb, _ = sdf_mlp(self.pack, pts.view(-1, 3), gamma, beta, B, True, True, False)
+        dev = rays_o.device
+        if light is None:
+            light = torch.tensor([0.0, 0.0, 1.0], device=dev)
+            light_dir = torch.tensor([[0.0, 0.0, -1.0]], device=dev).expand(B, 3)
+        comp = composite(sdf.view(N, T), grad.view(N, T, 3), rgb.view(N, T, 3), dists, mid_z, rays_o, rays_d,
+                         light_dir, bg, self.deviation_network.variance, light, cos_anneal_ratio, B, outputs)
+        samples = {"sdf": sdf.view(N, T), "gradients": grad.view(N, T, 3), "raw_color": rgb.view(N, T, 3),
+                   "mid_z_vals": mid_z, "pts": pts, "dists": dists, "z_vals": zv}
+        return samples, comp
+
+    # -- reference API ----------------------------------------------------------------------
+    def render(self, rays_o, rays_d, near, far, perturb_overwrite=-1, background_rgb=None, cos_anneal_ratio=0.0,
+               siren_network=None, z=None, w=None, second_order=None, compute_color=True, compute_sample_dist=False,
+               blend_background=False):
+        if siren_network is not None or second_order or compute_sample_dist or blend_background:
+            raise NotImplementedError("only the code path exercised by generator.py:245-252 is implemented")
+        s, c = self.render_full(rays_o, rays_d, near, far, perturb_overwrite, cos_anneal_ratio, z, w,
+                                outputs=("weights", "cdf", "inside_sphere", "pts_norm", "weight_sum", "weight_max",
+                                         "color_fine", "reduce4"))
+        return assemble_render_dict(s, c, self.deviation_network.variance, background_rgb)
+
+
+def assemble_render_dict(s, c, variance, background_rgb=None):
+    """Same keys/shapes as NeuSRenderer.render's return value (renderer.py:448-473)."""
+    N, T = s["sdf"].shape
+    r4 = c["reduce4"]
+    inv_s = torch.exp(variance * 10.0).clamp(1e-6, 1e6)
+    color = c["color_fine"]
+    if background_rgb is not None:
+        color = color + background_rgb * (1.0 - c["weight_sum"])
+    return {
+        "s_val": (1.0 / inv_s).expand(N, 1),
+        "cdf_fine": c["cdf"],
+        "weight_sum": c["weight_sum"],
+        "weight_max": c["weight_max"],
+        "gradients": s["gradients"],
+        "weights": c["weights"],
+        "gradient_error": r4[0] / (r4[1] + 1e-5),
+        "inside_sphere": c["inside_sphere"],
+        "mid_z_vals": s["mid_z_vals"],
+        "surface_loss": r4[2] / float(N * T),
+        "sdf": s["sdf"],
+        "pts_norm": c["pts_norm"],
+        "pts": s["pts"],
+        "color_fine": color,
+        "raw_color": s["raw_color"],
+    }

@@ -67,10 +67,12 @@ def test_sdf_mlp_golden(ops, packed_all, col_sd, mode, tol_sdf, tol_grad, tol_rg
                                               fast_trig=(mode == "bf16"), want_grad=True, want_rgb=True, want_feat=True)
     torch.cuda.synchronize()
     e_sdf, e_feat = maxdiff(sdf.cpu(), g1["sdf"].squeeze(-1)), maxdiff(feat.cpu(), g1["feat"])
-    e_grad, e_rgb = maxdiff(grad.cpu(), g1["grad"]), maxdiff(rgb.cpu(), g2["rgb"])
-    print(f"[{mode}] sdf {e_sdf:.2e} feat {e_feat:.2e} grad {e_grad:.2e} rgb {e_rgb:.2e}")
+    gscale = max(1.0, float(g1["grad"].abs().max()))  # |d sdf/dx| reaches O(10) for random latents
+    e_grad, e_rgb = maxdiff(grad.cpu(), g1["grad"]) / gscale, maxdiff(rgb.cpu(), g2["rgb"])
+    print(f"[{mode}] sdf {e_sdf:.2e} feat {e_feat:.2e} grad(rel {gscale:.1f}) {e_grad:.2e} rgb {e_rgb:.2e}")
     assert e_sdf < tol_sdf and e_grad < tol_grad and e_rgb < tol_rgb
-    assert e_feat < (5e-2 if mode == "bf16" else 1e-4)
+    # intermediate 128-d features (not a renderer output): bf16x3 drops the lo*lo product terms
+    assert e_feat < {"f32": 1e-4, "bf16x3": 3e-4, "bf16": 1e-1}[mode]
     # sdf-only variant agrees with the full variant
     sdf2, _, _, _, _ = ops.sdf_mlp_fwd(g1["pts"].cuda(), packs[mode], gamma, beta, 2, prec, fast_trig=(mode == "bf16"))
     assert maxdiff(sdf2, sdf) < 1e-6
@@ -90,7 +92,7 @@ def test_sdf_mlp_ragged_tiles(ops, packed_all, sdf_sd, col_sd, n):
     _, gamma, beta = ops.film_params(P["style_w"], P["style_b"], P["gw"], P["gb"], P["bw"], P["bb"], w=w.cuda())
     sdf, grad, rgb, _, _ = ops.sdf_mlp_fwd(pts.cuda(), packs["f32"], gamma, beta, B, 0, want_grad=True, want_rgb=True)
     assert maxdiff(sdf.cpu(), sdf_o.squeeze(-1)) < 2e-5
-    assert maxdiff(grad.cpu(), grad_o) < 1e-4
+    assert maxdiff(grad.cpu(), grad_o) < 1e-4 * max(1.0, float(grad_o.abs().max()))
     assert maxdiff(rgb.cpu(), rgb_o) < 2e-5
 
 
@@ -157,9 +159,13 @@ def test_upsample_vs_oracle(ops, sdf_sd, Sc, n_new, inv_s):
     zo, so = ops.merge_sorted(z.cuda(), sdf.cuda(), z_new, sdf_new.cuda())
     zr, sr = O.merge_sorted(z, z_new.cpu(), sdf, sdf_new)
     assert maxdiff(zo.cpu(), zr) == 0.0
-    # payload follows its key (ties between equal keys may swap payloads of *equal* z only)
-    same = (so.cpu() == sr)
-    assert same.float().mean() > 0.999
+    # payload follows its key: the (key, payload) pairs agree as multisets per ray (torch.sort is not
+    # stable, so payloads of *equal* keys may come out in a different order)
+    a = np.stack([zo.cpu().numpy(), so.cpu().numpy()], -1)
+    b = np.stack([zr.numpy(), sr.numpy()], -1)
+    for i in range(N):
+        ia, ib = np.lexsort((a[i, :, 1], a[i, :, 0])), np.lexsort((b[i, :, 1], b[i, :, 0]))
+        assert np.array_equal(a[i][ia], b[i][ib]), i
 
 
 def _composite_inputs(tag, g):
@@ -184,7 +190,7 @@ def test_composite_golden_f4(ops, tag, car):
         dists[:, i] = zz[:, i + 1] - zz[:, i]
     out = ops.composite_fwd(ci["sdf"].cuda(), ci["grad"].cuda(), ci["rgb"].cuda(), dists.cuda(), ci["mid_z"].cuda(),
                             g["rays_o"].cuda(), g["rays_d"].cuda(), torch.tensor([[0.0, 0.0, -1.0]]).cuda(), None,
-                            g["variance"].cuda(), car, 0.33, 0.67, 0.0, 10.0, 1)
+                            g["variance"].cuda(), torch.tensor([-0.7, 0.0, 10.0]).cuda(), car, 1)
     torch.cuda.synchronize()
     tol = 3e-4  # the recovered dists carry ~1e-6 error amplified by inv_s
     assert maxdiff(out["weights"].cpu(), g[f"{tag}_weights"]) < tol
@@ -224,8 +230,9 @@ def test_composite_vs_oracle_maps(ops, sdf_sd, col_sd):
     z = O.hierarchical_z(sdf_sd, ro, rd, near, far, w, S, I, 1)
     dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((N, 1), 2.0 / S)], -1)
     out = ops.composite_fwd(out_o["sdf"].cuda(), out_o["gradients"].cuda(), out_o["raw_color"].cuda(), dists.cuda(),
-                            out_o["mid_z_vals"].cuda(), ro.cuda(), rd.cuda(), ldir.cuda(), bg.cuda(), var.cuda(), 0.37,
-                            float(amb), float(cd), float(cs), float(sh), B)
+                            out_o["mid_z_vals"].cuda(), ro.cuda(), rd.cuda(), ldir.cuda(), bg.cuda(), var.cuda(),
+                            torch.stack([lsd["param_ambient"], lsd["param_specular"], lsd["param_shininess"]]).cuda(),
+                            0.37, B)
     torch.cuda.synchronize()
 
     def as_map(x):

@@ -1,0 +1,176 @@
+"""GPU parity of the drop-in modules (oi_amd.renderer / generator / fields) against the golden
+vectors produced by the reference itself (F1, F4, F5) and against the oracle on larger inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oi_oracle as O
+from conftest import GOLDEN, load_golden, maxdiff, sub_sd
+
+pytestmark = pytest.mark.gpu
+NET_KW = dict(D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64)
+SDF_NPZ = os.path.join(GOLDEN, "weights_sdf.npz")
+
+
+def make_renderer(col_sd, S, I, K, precision="f32", variance=0.3):
+    from oi_amd.fields import ShapeNetwork, ColorNetwork, SingleVarianceNetwork
+    from oi_amd.renderer import NeuSRenderer
+    sdf = ShapeNetwork(checkpoint_path=SDF_NPZ, **NET_KW).cuda()
+    col = ColorNetwork(**NET_KW)
+    col.load_state_dict(col_sd)
+    col = col.cuda()
+    dev = SingleVarianceNetwork(variance).cuda()
+    return NeuSRenderer(None, sdf, dev, col, n_samples=S, n_importance=I, n_outside=0, up_sample_steps=K, perturb=0,
+                        precision=precision)
+
+
+def test_state_dict_keys_match_reference(sdf_sd, col_sd):
+    from oi_amd.fields import ShapeNetwork, ColorNetwork
+    assert set(ShapeNetwork(None, **NET_KW).state_dict().keys()) == set(sdf_sd.keys())
+    assert set(ColorNetwork(**NET_KW).state_dict().keys()) == set(col_sd.keys())
+    for k, v in ShapeNetwork(None, **NET_KW).state_dict().items():
+        assert v.shape == sdf_sd[k].shape, k
+
+
+def test_shape_network_api(col_sd):
+    g = load_golden("f1_film_siren")
+    r = make_renderer(col_sd, 16, 16, 1)
+    net = r.sdf_network
+    with torch.no_grad():
+        w = net.style(g["z"].cuda())
+        assert maxdiff(w.cpu(), g["w"]) < 1e-5
+        out = net(g["pts"].cuda(), z=g["z"].cuda(), w=w)
+        assert out.shape == (1024, 129)
+        assert maxdiff(out[:, :1].cpu(), g["sdf"]) < 2e-5 and maxdiff(out[:, 1:].cpu(), g["feat"]) < 1e-4
+        assert maxdiff(net.sdf(g["pts"].cuda(), z=g["z"].cuda(), w=w).cpu(), g["sdf"]) < 2e-5
+        gr = net.gradient(g["pts"].cuda(), z=g["z"].cuda(), w=w)
+        assert maxdiff(gr.cpu(), g["grad"]) < 1e-4 * float(g["grad"].abs().max())
+
+
+KEYS = ("s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error", "inside_sphere",
+        "mid_z_vals", "surface_loss", "sdf", "pts_norm", "pts", "color_fine", "raw_color")
+
+
+# f32 = the 1e-4 parity path of the north star.  bf16x3 (hi/lo split operands on the bf16 matrix cores) carries
+# ~2^-16 relative error per product; amplified by the gamma~30 FiLM phases it reaches 3e-4 (relative) on
+# d sdf/dx and stays within 2e-4 on every other renderer output -- stated here and in DESIGN.md.
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("bf16x3", 2e-4)])
+@pytest.mark.parametrize("tag,car", [("c0p0", 0.0), ("c0p5", 0.5), ("c1p0", 1.0)])
+def test_render_golden_f4(col_sd, tag, car, precision, tol):
+    """NeuSRenderer.render on identical rays / weights: every key of the returned dict within 1e-4."""
+    g = load_golden("f4_render")
+    r = make_renderer(col_sd, 16, 16, 1, precision)
+    with torch.no_grad():
+        out = r.render(g["rays_o"].cuda(), g["rays_d"].cuda(), g["near"].cuda(), g["far"].cuda(), perturb_overwrite=0,
+                       cos_anneal_ratio=car, z=None, w=g["w"].cuda())
+    for k in KEYS:
+        ref = g[f"{tag}_{k}"]
+        assert tuple(out[k].shape) == tuple(ref.shape), (k, out[k].shape, ref.shape)
+        scale = max(1.0, float(ref.abs().max())) if k == "gradients" else 1.0
+        if precision == "bf16x3" and k == "gradients":
+            scale *= 2.5
+        assert maxdiff(out[k].cpu(), ref) < tol * scale, (k, maxdiff(out[k].cpu(), ref))
+
+
+@pytest.mark.parametrize("K,I", [(1, 64), (4, 64), (2, 32)])
+def test_render_vs_oracle_hierarchical(sdf_sd, col_sd, K, I):
+    """More rays, 2 elements, K up-sampling steps, vs the oracle."""
+    S = 64
+    g = torch.Generator().manual_seed(K)
+    N = 2 * 150
+    ro = torch.tensor([0.0, 0.0, -3.0]).expand(N, 3) + 0.05 * torch.randn(N, 3, generator=g)
+    rd = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + 0.2 * torch.randn(N, 3, generator=g), dim=-1)
+    near, far = O.near_far_from_sphere(ro, rd)
+    w = O.style_mlp(sdf_sd, torch.randn(2, 64, generator=g))
+    ref = O.render(sdf_sd, col_sd, torch.tensor(0.3), ro, rd, near, far, w, S, I, K, 0.25)
+    r = make_renderer(col_sd, S, I, K)
+    with torch.no_grad():
+        out = r.render(ro.cuda(), rd.cuda(), near.cuda(), far.cuda(), perturb_overwrite=0, cos_anneal_ratio=0.25,
+                       w=w.cuda())
+    # Importance sampling is discontinuous in its inputs (searchsorted bins, the `den < 1e-5` and
+    # `radius < 1` switches, inv_s up to 512): fp32 round-off differences between two correct
+    # implementations move a few samples of a few rays by more than 1e-4.  Per-stage exactness on
+    # identical inputs is pinned in test_gpu_kernels.py::test_upsample_*; here: >= 97 % of the rays agree
+    # sample-for-sample, and those rays agree in everything downstream.
+    dz = (out["mid_z_vals"].cpu() - ref["mid_z_vals"]).abs().max(-1).values
+    ok = dz < 1e-4
+    assert ok.float().mean() >= 0.97, float(ok.float().mean())
+    for k in ("weights", "color_fine", "weight_sum", "sdf", "raw_color"):
+        assert maxdiff(out[k].cpu()[ok], ref[k][ok]) < 2e-4, (k, maxdiff(out[k].cpu()[ok], ref[k][ok]))
+    assert abs(float(out["color_fine"].cpu().mean()) - float(ref["color_fine"].mean())) < 1e-4
+
+
+def example_cfg(R):
+    fov, img, img_scene = 10.0, 256, 1588
+    cam_dist = float(1 / np.tan(0.5 * fov * np.pi / 180))
+    scene_fov = float(2 * np.arctan(img_scene / img * np.tan(0.5 * fov * np.pi / 180)) * 180 / np.pi)
+    return cam_dist, scene_fov, int(R * img_scene / img)
+
+
+def build_generator(R, S, I, K, precision="f32"):
+    """Built from a config whose __target__ strings are the REFERENCE's (configs/train.yaml): the
+    oi_amd config seam redirects them."""
+    from oi_amd.config import build_from_config
+    cam_dist, scene_fov, scene_res = example_cfg(R)
+    net = lambda t, **kw: {"__target__": t, "kwargs": kw}
+    cfg = net("src.models.generator.Generator",
+              color_network=net("src.models.fields.ColorNetwork", **NET_KW),
+              sdf_network=net("src.models.fields.ShapeNetwork", checkpoint_path=SDF_NPZ, **NET_KW),
+              deviation_network=net("src.third_party.neus.models.fields.SingleVarianceNetwork", init_val=0.3),
+              light_network=net("src.utils.prior.build_directional_light_optimizable", cam_loc=None, light_loc=None,
+                                ambient_color=0.33, diffuse_color=0.66, specular_color=0, shininess=10),
+              camera=net("src.models.camera_network.Camera", cam_dist=cam_dist, resolution=scene_res, fov=scene_fov),
+              z_dim=64, resolution=R, scene_resolution=scene_res,
+              renderer=net("src.third_party.neus.models.renderer.NeuSRenderer", n_importance=I, n_outside=0,
+                           n_samples=S, perturb=1, up_sample_steps=K),
+              anneal_end=50000,
+              pose_prior=net("src.utils.pose_sampler.Plane", cam_loc=[0, -1, 0], rot_degree_range_scale=360,
+                             rot_roll_degree_range_scale=20, xy_range_scale=[6, 3.5]))
+    gen = build_from_config(cfg)
+    gen.renderer.pack.set_precision(precision)
+    return gen.cuda()
+
+
+def test_generator_golden_f5():
+    """Full Generator.forward(return_raw=True) vs the reference's own output (rays, maps, stats)."""
+    g = load_golden("f5_generator")
+    gen = build_generator(16, 16, 16, 1).eval()
+    gen.color_network.load_state_dict(sub_sd(g, "color."))
+    gen.light.load_state_dict(sub_sd(g, "light."))
+    gen.it.fill_(int(g["it"]))
+    np.random.seed(12)  # the background colour is the first numpy draw of the forward (prior.py:15)
+    with torch.no_grad():
+        blob = gen(bs=2, it=None, data={"z": g["z"].cuda(), "b2w": g["b2w"].cuda()}, return_raw=True)["box"]
+    assert maxdiff(blob["rays_info"]["rays_o"].cpu(), g["rays_o"]) < 1e-5
+    assert maxdiff(blob["rays_info"]["rays_d"].cpu(), g["rays_d"]) < 2e-6
+    assert maxdiff(blob["prior_info"]["c2b"].cpu(), g["c2b"]) < 1e-5
+    assert maxdiff(blob["latent_info"]["w"].cpu(), g["w"]) < 1e-5
+    for k, v in blob["render_out"].items():
+        ref = g["map_" + k]
+        assert tuple(v.shape) == tuple(ref.shape), (k, v.shape, ref.shape)
+        assert maxdiff(v.cpu(), ref) < 1e-4, (k, maxdiff(v.cpu(), ref))
+    for k in ("weights", "mid_z_vals", "weight_sum", "color_fine", "sdf"):
+        assert maxdiff(blob["raw_render_out"][k].cpu(), g["raw_" + k]) < 1e-4, k
+    assert maxdiff(blob["loss"]["eikonal"].cpu(), g["eikonal"]) < 1e-4
+    for k in ("surface", "s_val", "cdf", "weight_max", "weight_sum"):
+        assert abs(float(blob["stats"][k]) - float(g["stat_" + k])) < 1e-4, k
+    for k in ("light/ambient", "light/diffuse", "light/specular", "material/shininess"):
+        assert abs(float(blob["stats"][k]) - float(g["stat_" + k.replace("/", "_")])) < 1e-5, k
+
+
+def test_generator_multi_chunk_matches_single(monkeypatch):
+    """Eval-time ray chunking (generator.py:281-305) does not change the image."""
+    import oi_amd.generator as G
+    gen = build_generator(16, 8, 8, 1).eval()
+    g = load_golden("f5_generator")
+    data = {"z": g["z"].cuda(), "b2w": g["b2w"].cuda()}
+    np.random.seed(1)
+    with torch.no_grad():
+        a = gen(bs=2, it=0, data=dict(data))["box"]["render_out"]
+        monkeypatch.setattr(G, "MAX_RAY_BATCH_SIZE", 2 * 100)
+        np.random.seed(1)
+        b = gen(bs=2, it=0, data=dict(data))["box"]["render_out"]
+    for k in a:
+        assert maxdiff(a[k], b[k]) < 1e-6, k
