@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Benchmark of the object-intrinsics hot path on MI355X (contract: see the task statement).
+
+    python bench.py --gpus N --steps K --warmup W [--precision f32|bf16x3|bf16] [--batch B]
+
+Metric (BASELINE.json): rendered rays/sec at a 64x64 crop with 128 samples/ray (64 coarse + 64
+importance, 1 up-sampling step = BASELINE config C2), plus discriminator images/sec, whole job
+over N GPUs (weak scaling: every rank renders its own batch; the forward path has no collective).
+
+One "step" = one `Generator.forward` (pose/latent sampling -> rays -> hierarchical sampling ->
+FiLM-SIREN MLP with analytic normals + albedo -> compositing + Phong maps) over `--batch` images
+per GPU with inputs generated on the device, followed by one ADA-discriminator forward
+(`ADADiscriminatorView`, 64^2) on the rendered images.  Timing: W warm-up steps, then exactly K
+steps bracketed by barrier + torch.cuda.synchronize(), max over ranks; rank 0 prints ONE JSON line.
+
+Extra objects in that line:
+  roofline      dominant kernel (sdf_mlp_kernel, full variant): algorithmic FLOPs / launch divided by
+                its mean duration measured with HIP events on the launch stream inside the timed region
+  cpu_baseline  the oracle (CPU restatement, oracle/oi_oracle.py) timed on the host cores on the same
+                workload (N=1, rank 0 only) -- a reported baseline, not the target
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "object-intrinsics_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic FLOPs per point (GEMM MACs x 2 only), SURVEY.md 8(d) / BASELINE.md 4
+F_SDF, F_GRAD, F_COL = 230400, 230400, 34304
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}  # MI355X_MICROARCH.md (dense)
+NET_KW = dict(D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64)
+SDF_NPZ = os.path.join(ROOT, "tests", "golden", "weights_sdf.npz")
+
+
+def example_cfg(R):
+    """data/example/cfg.yaml + scripts/train.py:25-47, 88-115."""
+    fov, img, img_scene = 10.0, 256, 1588
+    cam_dist = float(1 / np.tan(0.5 * fov * np.pi / 180))
+    scene_fov = float(2 * np.arctan(img_scene / img * np.tan(0.5 * fov * np.pi / 180)) * 180 / np.pi)
+    return cam_dist, scene_fov, int(R * img_scene / img)
+
+
+def build_models(R, S, I, K, precision, device):
+    from oi_amd.config import build_from_config
+    cam_dist, scene_fov, scene_res = example_cfg(R)
+    net = lambda t, **kw: {"__target__": t, "kwargs": kw}
+    gen = build_from_config(net(
+        "src.models.generator.Generator",
+        color_network=net("src.models.fields.ColorNetwork", **NET_KW),
+        sdf_network=net("src.models.fields.ShapeNetwork", checkpoint_path=SDF_NPZ, **NET_KW),
+        deviation_network=net("src.third_party.neus.models.fields.SingleVarianceNetwork", init_val=0.3),
+        light_network=net("src.utils.prior.build_directional_light_optimizable", cam_loc=None, light_loc=None,
+                          ambient_color=0.33, diffuse_color=0.66, specular_color=0, shininess=10),
+        camera=net("src.models.camera_network.Camera", cam_dist=cam_dist, resolution=scene_res, fov=scene_fov),
+        z_dim=64, resolution=R, scene_resolution=scene_res,
+        renderer=net("src.third_party.neus.models.renderer.NeuSRenderer", n_importance=I, n_outside=0, n_samples=S,
+                     perturb=1, up_sample_steps=K),
+        anneal_end=50000,
+        pose_prior=net("src.utils.pose_sampler.Plane", cam_loc=[0, -1, 0], rot_degree_range_scale=360,
+                       rot_roll_degree_range_scale=20, xy_range_scale=[6, 3.5])))
+    gen.renderer.pack.set_precision(precision)
+    disc = build_from_config(net(
+        "src.models.discriminator.ADADiscriminatorView",
+        aug=net("src.third_party.ada.augment.AugmentPipe", scale=1, xint=1), aug_p=1, img_size=R, in_dim=3,
+        last_bias=False, n_feat=512, out_dim=7, out_dim_latent=0, out_dim_position=6))
+    return gen.to(device), disc.to(device)
+
+
+class KernelTimer:
+    """HIP events around selected launches on the current stream (where oi_amd launches)."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def wrap(self, fn):
+        def inner(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.pairs.append((e0, e1))
+            return out
+        return inner
+
+    def mean_ms(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else None
+
+
+def cpu_baseline(R, S, I, K, B):
+    """The oracle on the host cores: same workload (one B x R x R image, S+I samples/ray), forward."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oi_oracle as O
+    torch.manual_seed(0)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(SDF_NPZ).items()}
+    csd = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(ROOT, "tests", "golden", "weights_color.npz")).items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    N = B * R * R
+    g = torch.Generator().manual_seed(0)
+    ro = torch.tensor([0.0, 0.0, -3.0]).expand(N, 3) + 0.05 * torch.randn(N, 3, generator=g)
+    rd = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + 0.1 * torch.randn(N, 3, generator=g), dim=-1)
+    near, far = O.near_far_from_sphere(ro, rd)
+    w = O.style_mlp(sd, torch.randn(B, 64, generator=g))
+    lsd = {"param_direction": torch.tensor([0.0, 0.0, -1.0]), "param_ambient": torch.tensor(-0.7),
+           "param_specular": torch.tensor(0.0), "param_shininess": torch.tensor(10.0)}
+    w2b = torch.eye(4).repeat(B, 1, 1)
+    t0 = time.time()
+    with torch.no_grad():
+        out = O.render(sd, csd, torch.tensor(0.3), ro, rd, near, far, w, S, I, K, 0.0)
+        O.render_maps(out, ro, lsd, w2b, torch.rand(B, 3), B, R, R)
+    dt = time.time() - t0
+    return {"value": N / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"one full {B}x{R}x{R} image, {S}+{I} samples/ray, forward render + maps, 1 run "
+                      f"({dt:.1f} s, torch CPU fp32, {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "bf16"])
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (training.batch_size: 1)")
+    ap.add_argument("--res", type=int, default=64)
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--importance", type=int, default=64)
+    ap.add_argument("--up-steps", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-disc", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", init_method="env://")
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
+
+    torch.manual_seed(1234 + rank)
+    np.random.seed(1234 + rank)  # scripts/train.py:136: seed + rank
+    R, S, I, K, B = args.res, args.samples, args.importance, args.up_steps, args.batch
+    gen, disc = build_models(R, S, I, K, args.precision, device)
+    gen.train()   # perturb on: per-ray jitter drawn on the device, random poses / latents / bg per step
+    disc.eval()
+
+    import oi_amd.autograd as A
+    timer = KernelTimer()
+    orig = A.sdf_mlp
+
+    def sdf_mlp_timed(pack, pts, gamma, beta, B_, want_grad, want_rgb, want_feat, scratch=None):
+        fn = timer.wrap(orig) if (want_grad and timer_on[0]) else orig
+        return fn(pack, pts, gamma, beta, B_, want_grad, want_rgb, want_feat, scratch)
+
+    timer_on = [False]
+    A.sdf_mlp = sdf_mlp_timed
+    import oi_amd.renderer as RR
+    RR.sdf_mlp = sdf_mlp_timed
+
+    def step(it):
+        with torch.no_grad():
+            out = gen(bs=B, it=it, data={})["box"]["render_out"]
+            d = None if args.no_disc else disc(out["image"].contiguous(), it=it)
+        return out, d
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    # discriminator-only timing (images/s), untimed with respect to the main region
+    d_img_s = None
+    if not args.no_disc:
+        x = torch.rand(B, 3, R, R, device=device)
+        barrier()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for _ in range(args.steps):
+                disc(x, it=0)
+        barrier()
+        d_img_s = B * args.steps / (time.perf_counter() - t0)
+
+    timer_on[0] = True
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    timer_on[0] = False
+
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    dd = torch.tensor([d_img_s or 0.0], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(dd, op=dist.ReduceOp.SUM)
+    dt = float(t)
+    rays_per_step = world * B * R * R
+    value = rays_per_step * args.steps / dt
+
+    if rank == 0:
+        n_pts = B * R * R * (S + I)
+        kern_ms = timer.mean_ms()
+        flops = n_pts * (F_SDF + F_GRAD + F_COL)
+        achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms else None
+        peak = PEAK_TFLOPS[args.precision]
+        line = {
+            "metric": "rendered rays/sec (64x64 img, 128 samples/ray) + D-images/sec",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 split into 2 bf16 MFMA operands, fp32 accumulate)",
+                      "bf16": "bf16"}[args.precision],
+            "data": "synthetic (random poses/latents/backgrounds from the data/example prior; sphere-initialised SDF "
+                    "weights, seeded default-init colour/discriminator weights)",
+            "config": {"workload": f"C2: {B}x{R}x{R} crop per GPU, {S}+{I} samples/ray, {K} up-sampling step(s), "
+                                   f"Generator.forward (render + Phong maps) + ADADiscriminatorView forward",
+                       "rays_per_step_per_gpu": B * R * R, "points_per_step_per_gpu": n_pts,
+                       "parallelism": f"dp{world} (independent renders, no data-path collective)"},
+            "d_images_per_s": float(dd) if d_img_s else None,
+            "roofline": {"bound": "mfma", "kernel": "sdf_mlp_kernel<full> (sdf + d sdf/dx + albedo at the fine samples)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": (achieved / peak) if achieved else None, "traffic": None,
+                         "algorithmic_flops_per_launch": flops, "kernel_ms": kern_ms,
+                         "note": "algorithmic = GEMM MACs x2 of sdf fwd + analytic gradient sweep + colour head per "
+                                 "point; bf16x3 executes 3 MFMAs per algorithmic MAC"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(R, S, I, K, B)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,64 @@
+"""DC discriminators -- drop-ins for src.models.discriminator.DCDiscriminator / ADADiscriminator /
+ADADiscriminatorView (discriminator.py:49-108): same constructor kwargs, `forward(x, **kwargs)`,
+`get_resolution()`, `.aug`, and state_dict keys `blocks.{i}.weight`, `conv_out.weight[/bias]`,
+`aug.p`, `aug.Hz_geom`, `aug.Hz_fbank`.  Convolutions are the implicit-GEMM MFMA kernels of
+csrc/disc.hip with the LeakyReLU fused."""
+from math import log2
+
+import torch
+import torch.nn as nn
+
+from .autograd_disc import conv4x4_lrelu
+from .config import build_from_config
+
+
+class _ConvParam(nn.Module):
+    """Holds `weight` (and optional `bias`) under the same names as nn.Conv2d(…, 4, s, p)."""
+
+    def __init__(self, cin, cout, bias=False):
+        super().__init__()
+        conv = nn.Conv2d(cin, cout, 4, bias=bias)  # identical default initialisation to the reference's layers
+        self.weight = nn.Parameter(conv.weight.detach().clone())
+        if bias:
+            self.bias = nn.Parameter(conv.bias.detach().clone())
+        else:
+            self.register_parameter("bias", None)
+
+
+class DCDiscriminator(nn.Module):
+    def __init__(self, in_dim=3, out_dim=1, n_feat=512, img_size=64, last_bias=False):
+        super().__init__()
+        self.in_dim, self.out_dim = in_dim, out_dim
+        n_layers = int(log2(img_size) - 2)
+        chans = [in_dim] + [int(n_feat / (2 ** (n_layers - 1 - i))) for i in range(n_layers)]
+        self.blocks = nn.ModuleList([_ConvParam(chans[i], chans[i + 1]) for i in range(n_layers)])
+        self.conv_out = _ConvParam(n_feat, out_dim, bias=last_bias)
+
+    def forward(self, x, **kwargs):
+        batch_size = x.shape[0]
+        assert x.shape[1] == self.in_dim, x.shape
+        for layer in self.blocks:
+            x = conv4x4_lrelu(x, layer.weight, None, stride=2, pad=1, slope=0.2)
+        out = conv4x4_lrelu(x, self.conv_out.weight, self.conv_out.bias, stride=1, pad=0, slope=1.0)
+        return out.reshape(batch_size, self.out_dim)
+
+
+class ADADiscriminator(DCDiscriminator):
+    def __init__(self, aug, aug_p, **kwargs):
+        super().__init__(**kwargs)
+        self.aug = build_from_config(aug)
+        self.aug.p.copy_(torch.tensor(aug_p, dtype=torch.float32))
+        self.resolution = kwargs["img_size"]
+
+    def get_resolution(self):
+        return self.resolution
+
+    def forward(self, x, **kwargs):
+        return super().forward(self.aug(x), **kwargs)
+
+
+class ADADiscriminatorView(ADADiscriminator):
+    def __init__(self, out_dim_position, out_dim_latent, **kwargs):
+        self.out_dim_position = out_dim_position
+        self.out_dim_latent = out_dim_latent
+        super().__init__(**kwargs)

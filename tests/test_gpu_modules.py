@@ -174,3 +174,45 @@ def test_generator_multi_chunk_matches_single(monkeypatch):
         b = gen(bs=2, it=0, data=dict(data))["box"]["render_out"]
     for k in a:
         assert maxdiff(a[k], b[k]) < 1e-6, k
+
+
+@pytest.mark.parametrize("pct", [0.1, 0.5, 0.9])
+def test_augment_pipe_golden_f8(pct):
+    """AugmentPipe(xint=1, scale=1) with the reference's deterministic debug_percentile hook."""
+    from oi_amd.augment import AugmentPipe
+    g = load_golden("f8_augment")
+    aug = AugmentPipe(xint=1, scale=1).cuda()
+    assert maxdiff(aug.Hz_geom.cpu(), g["Hz_geom"]) < 1e-7
+    tag = str(pct).replace(".", "p")
+    with torch.no_grad():
+        for key in ("32", "64"):
+            y = aug(g["x" + key].cuda(), debug_percentile=pct)
+            ref = g[f"y{key}_{tag}"]
+            assert tuple(y.shape) == tuple(ref.shape)
+            assert maxdiff(y.cpu(), ref) < 2e-5, (key, maxdiff(y.cpu(), ref))
+
+
+@pytest.mark.parametrize("tag,res,nf,cin,cout", [("r16c3_", 16, 32, 3, 7), ("r64c3_", 64, 64, 3, 7), ("r64c1_", 64, 32, 1, 1)])
+def test_dc_discriminator_module_golden_f7(tag, res, nf, cin, cout):
+    from oi_amd.discriminator import DCDiscriminator
+    g = load_golden("f7_discriminator")
+    D = DCDiscriminator(in_dim=cin, out_dim=cout, n_feat=nf, img_size=res)
+    D.load_state_dict(sub_sd(g, tag + "w."))
+    D = D.cuda()
+    with torch.no_grad():
+        d = D(g[tag + "x"].cuda(), it=3)
+    assert maxdiff(d.cpu(), g[tag + "d"]) < 2e-5
+
+
+def test_ada_discriminator_view_shapes():
+    from oi_amd.config import build_from_config
+    cfg = {"__target__": "src.models.discriminator.ADADiscriminatorView",
+           "kwargs": dict(aug={"__target__": "src.third_party.ada.augment.AugmentPipe", "kwargs": {"scale": 1, "xint": 1}},
+                          aug_p=1, img_size=64, in_dim=3, last_bias=False, n_feat=512, out_dim=7, out_dim_latent=0,
+                          out_dim_position=6)}
+    D = build_from_config(cfg).cuda()
+    assert sum(p.numel() for p in D.parameters()) == 2812928
+    with torch.no_grad():
+        out = D(torch.rand(3, 3, 64, 64, device="cuda"), it=0)
+    assert out.shape == (3, 7) and torch.isfinite(out).all()
+    assert D.get_resolution() == 64
