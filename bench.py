@@ -100,7 +100,9 @@ def cpu_baseline(R, S, I, K, B):
     torch.manual_seed(0)
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(SDF_NPZ).items()}
     csd = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(ROOT, "tests", "golden", "weights_color.npz")).items()}
-    cores = os.cpu_count() or 1
+    # torch-CPU elementwise/GEMM ops of this size stop scaling (and collapse from oversubscription) beyond
+    # ~32 threads: measured on the 256-core GPU-box host, 16/32/64/256 threads -> 564/576/401/26 rays/s
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     N = B * R * R
     g = torch.Generator().manual_seed(0)

@@ -17,9 +17,11 @@ SYM6 = [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.04
 
 
 def _mat(rows, ref):
-    """3x3 matrices from python scalars / (B,) tensors, batched over ref's batch."""
+    """3x3 matrices from python scalars / (B,) tensors, batched over ref's batch.  Host tensors: the
+    augmentation parameters are O(B) scalars, so they are sampled and composed on the CPU (no launches,
+    and the data-dependent padding margins need no device->host read, unlike augment.py:283)."""
     B = ref.shape[0]
-    out = torch.zeros(B, 3, 3, device=ref.device, dtype=torch.float32)
+    out = torch.zeros(B, 3, 3, dtype=torch.float32)
     for i, row in enumerate(rows):
         for j, v in enumerate(row):
             out[:, i, j] = v
@@ -62,12 +64,20 @@ class AugmentPipe(torch.nn.Module):
             self.Hz_fbank = torch.zeros_like(state_dict[k])
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
+    def _p_host(self):
+        """`p` is a buffer the trainer sets once at construction (discriminator.py:91); mirror it on the host."""
+        key = (self.p.data_ptr(), self.p._version)
+        if getattr(self, "_p_cache", (None, None))[0] != key:
+            self._p_cache = (key, float(self.p))
+        return self._p_cache[1]
+
     def sample_G_inv(self, images, debug_percentile=None):
         """augment.py:191-268 for the geometric branches.  Returns (B,3,3) or None (identity)."""
         B, _, H, W = images.shape
-        dev = images.device
+        dev = torch.device("cpu")
         ref = images
-        pct = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32, device=dev)
+        p_host = float(self._p_host()) if not isinstance(self.p, float) else self.p
+        pct = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32)
         G = None
 
         def mul(G, M):
@@ -77,29 +87,29 @@ class AugmentPipe(torch.nn.Module):
         randn = lambda *s: torch.randn(list(s), device=dev)
         if self.xflip > 0:
             i = torch.floor(rand(B) * 2)
-            i = torch.where(rand(B) < self.xflip * self.p, i, torch.zeros_like(i))
+            i = torch.where(rand(B) < self.xflip * p_host, i, torch.zeros_like(i))
             if pct is not None:
                 i = torch.full_like(i, torch.floor(pct * 2))
             G = mul(G, scale2d(1 / (1 - 2 * i), 1, ref))
         if self.rotate90 > 0:
             i = torch.floor(rand(B) * 4)
-            i = torch.where(rand(B) < self.rotate90 * self.p, i, torch.zeros_like(i))
+            i = torch.where(rand(B) < self.rotate90 * p_host, i, torch.zeros_like(i))
             if pct is not None:
                 i = torch.full_like(i, torch.floor(pct * 4))
             G = mul(G, rotate2d(np.pi / 2 * i, ref))
         if self.xint > 0:
             t = (rand(B, 2) * 2 - 1) * self.xint_max
-            t = torch.where(rand(B, 1) < self.xint * self.p, t, torch.zeros_like(t))
+            t = torch.where(rand(B, 1) < self.xint * p_host, t, torch.zeros_like(t))
             if pct is not None:
                 t = torch.full_like(t, (pct * 2 - 1) * self.xint_max)
             G = mul(G, translate2d(-torch.round(t[:, 0] * W), -torch.round(t[:, 1] * H), ref))
         if self.scale > 0:
             s = torch.exp2(randn(B) * self.scale_std)
-            s = torch.where(rand(B) < self.scale * self.p, s, torch.ones_like(s))
+            s = torch.where(rand(B) < self.scale * p_host, s, torch.ones_like(s))
             if pct is not None:
                 s = torch.full_like(s, torch.exp2(torch.erfinv(pct * 2 - 1) * self.scale_std))
             G = mul(G, scale2d(1 / s, 1 / s, ref))
-        p_rot = 1 - torch.sqrt((1 - self.rotate * self.p).clamp(0, 1))
+        p_rot = 1 - torch.sqrt(torch.tensor(1 - self.rotate * p_host).clamp(0, 1))
         if self.rotate > 0:
             th = (rand(B) * 2 - 1) * np.pi * self.rotate_max
             th = torch.where(rand(B) < p_rot, th, torch.zeros_like(th))
@@ -108,7 +118,7 @@ class AugmentPipe(torch.nn.Module):
             G = mul(G, rotate2d(th, ref))
         if self.aniso > 0:
             s = torch.exp2(randn(B) * self.aniso_std)
-            s = torch.where(rand(B) < self.aniso * self.p, s, torch.ones_like(s))
+            s = torch.where(rand(B) < self.aniso * p_host, s, torch.ones_like(s))
             if pct is not None:
                 s = torch.full_like(s, torch.exp2(torch.erfinv(pct * 2 - 1) * self.aniso_std))
             G = mul(G, scale2d(1 / s, s, ref))
@@ -120,7 +130,7 @@ class AugmentPipe(torch.nn.Module):
             G = mul(G, rotate2d(th, ref))
         if self.xfrac > 0:
             t = randn(B, 2) * self.xfrac_std
-            t = torch.where(rand(B, 1) < self.xfrac * self.p, t, torch.zeros_like(t))
+            t = torch.where(rand(B, 1) < self.xfrac * p_host, t, torch.zeros_like(t))
             if pct is not None:
                 t = torch.full_like(t, torch.erfinv(pct * 2 - 1) * self.xfrac_std)
             G = mul(G, translate2d(-t[:, 0] * W, -t[:, 1] * H, ref))
@@ -132,18 +142,16 @@ class AugmentPipe(torch.nn.Module):
         G_inv = self.sample_G_inv(images, debug_percentile)
         if G_inv is None:
             return images
-        dev = images.device
         ref = images
-        # padding margins (augment.py:272-283).  Data dependent output shape -> one D2H read, as in
-        # the reference (`.to(int32)` unpacked to python ints).
+        # padding margins (augment.py:272-283), computed on the host copy of G_inv
         cx, cy = (W - 1) / 2, (H - 1) / 2
-        cp = torch.tensor([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]], device=dev)
+        cp = torch.tensor([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]])
         cp = G_inv @ cp.t()
         Hz_pad = self.Hz_geom.shape[0] // 4
         m = cp[:, :2, :].permute(1, 0, 2).flatten(1)
         m = torch.cat([-m, m]).max(dim=1).values
-        m = m + torch.tensor([Hz_pad * 2 - cx, Hz_pad * 2 - cy] * 2, device=dev)
-        m = m.max(torch.zeros(4, device=dev)).min(torch.tensor([W - 1, H - 1] * 2, dtype=torch.float32, device=dev))
+        m = m + torch.tensor([Hz_pad * 2 - cx, Hz_pad * 2 - cy] * 2)
+        m = m.max(torch.zeros(4)).min(torch.tensor([W - 1, H - 1] * 2, dtype=torch.float32))
         mx0, my0, mx1, my1 = (int(v) for v in m.ceil().to(torch.int32).tolist())
 
         x = reflect_pad(images, mx0, mx1, my0, my1)
@@ -153,6 +161,7 @@ class AugmentPipe(torch.nn.Module):
         G_inv = translate2d(-0.5, -0.5, ref) @ G_inv @ translate2d(0.5, 0.5, ref)
         Ho, Wo = (H + Hz_pad * 2) * 2, (W + Hz_pad * 2) * 2
         G_inv = scale2d(2 / x.shape[3], 2 / x.shape[2], ref) @ G_inv @ scale2d(Wo / 2, Ho / 2, ref)
-        x = affine_grid_sample(x, G_inv[:, :2, :].contiguous(), Ho, Wo)
+        theta = G_inv[:, :2, :].contiguous().to(images.device, non_blocking=True)
+        x = affine_grid_sample(x, theta, Ho, Wo)
         # downsample2d(padding=-2*Hz_pad, flip_filter=True): pad = -6 + (12-2+1)//2 = -1, -6 + 5 = -1
         return upfirdn2d_separable(x, self.Hz_geom, down=2, pad=(-1, -1, -1, -1), flip=True, gain=1.0)
