@@ -90,6 +90,23 @@ int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, con
                    float* sdf, float* grad, float* rgb, float* feat, void* scratch,
                    int B, long long n_per_elem, int prec, int fast_trig, oi_stream_t stream);
 
+/* Backward of oi_sdf_mlp_fwd w.r.t. every parameter and the FiLM vectors -- including the second-order
+ * terms that arise because d sdf/dx is a forward output (the reference: autograd with create_graph=True
+ * through fields.py:104-122, backward at gan_pose_trainer.py:141).  Upstream gradients g_sdf [B*n],
+ * g_grad [B*n][3], g_rgb [B*n][3] may be NULL.  grad_fwd / rgb_fwd are the forward outputs (needed when
+ * g_rgb != NULL).  Results are ACCUMULATED (atomics) into caller-zeroed buffers:
+ *   d_small  oi_mlp_bwd_small_floats() floats: dW0 [128][3] | db [9][128] (b0..b7, bv) | dwsig [128] | dbsig [1]+3 |
+ *            dWv[:,128:131] [128][3] | dWrgb [3][128] | dbrgb [3]+1
+ *   d_wmat   [8][128][128]: dW_1..dW_7, dWv[:, :128]
+ *   d_gamma, d_beta [B][9][128]
+ * scratch: oi_mlp_bwd_scratch_bytes(B, n) bytes. */
+size_t oi_mlp_bwd_scratch_bytes(int B, long long n_per_elem);
+int oi_mlp_bwd_small_floats(void);
+int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, const float* beta,
+                   const float* grad_fwd, const float* rgb_fwd, const float* g_sdf, const float* g_grad,
+                   const float* g_rgb, float* d_small, float* d_wmat, float* d_gamma, float* d_beta,
+                   void* scratch, int B, long long n_per_elem, int prec, int fast_trig, oi_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a13 + a14: crop rays.  Replaces Generator.gen_rays_at + build_rays + near_far_from_sphere
  * (src/models/generator.py:255-279, 317-333, 336-342).
@@ -181,6 +198,35 @@ typedef struct oi_composite_params {
 
 int oi_composite_fwd(const oi_composite_params* p, oi_stream_t stream);
 
+/* Backward of oi_composite_fwd (what autograd derives for renderer.py:266-311 + generator.py:107-172 in the
+ * reference).  `fwd` repeats the forward inputs (outputs ignored).  Upstream gradients (any may be NULL):
+ * per-ray [N] / [N][3] for the maps, g_weights [N][T], g_reduce4 [4] (device; grads of the three global sums).
+ * Results: d_sdf [N][T], d_grad [N][T][3], d_rgb [N][T][3] (written), and accumulated with atomics into
+ * caller-zeroed d_variance [1], d_light [3] (param_ambient, param_specular, param_shininess),
+ * d_light_dir [B][3] (w.r.t. the normalised direction). */
+typedef struct oi_composite_grads {
+  const float* g_weights;
+  const float* g_weight_sum;
+  const float* g_color_fine;
+  const float* g_image_no_bg;
+  const float* g_image;
+  const float* g_shading;
+  const float* g_normal;
+  const float* g_mask;
+  const float* g_z_map;
+  const float* g_specular_map;
+  const float* g_diffuse_map;
+  const float* g_reduce4;
+  float* d_sdf;
+  float* d_grad;
+  float* d_rgb;
+  float* d_variance;
+  float* d_light;
+  float* d_light_dir;
+} oi_composite_grads;
+
+int oi_composite_bwd(const oi_composite_params* fwd, const oi_composite_grads* grads, oi_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a16: DC discriminator convolutions.  Replaces nn.Conv2d(4,2,1,bias=False)+LeakyReLU(0.2) blocks
  * and the 4x4 valid head of DCDiscriminator.forward (src/models/discriminator.py:63-85) (cuDNN in the
@@ -189,6 +235,20 @@ int oi_composite_fwd(const oi_composite_params* p, oi_stream_t stream);
  */
 int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin,
                    int H, int W, int Cout, int stride, int pad, float slope, oi_stream_t stream);
+
+/* Backward of the convolution (cuDNN bwd-data / bwd-filter in the reference, issued by autograd for
+ * discriminator.py:80-83).  g = dL/d(conv output, pre-activation) [B][Cout][Ho][Wo].
+ *   dgrad: gx [B][Cin][H][W] = conv_transpose(g, w);  wgrad: gw [Cout][Cin][4][4] = correlate(x, g).
+ * {fwd, dgrad, wgrad} is closed under differentiation, which is how the R1 double-backward
+ * (src/loss/gan.py:5-14) is served.  oi_lrelu_mask_mul: out = ref > 0 ? v : slope*v (LeakyReLU and
+ * its gradient through the saved output); oi_channel_sum: bias gradient. */
+int oi_conv4x4_dgrad(const float* g, const float* w, float* gx, int B, int Cin, int H, int W, int Cout,
+                     int stride, int pad, oi_stream_t stream);
+int oi_conv4x4_wgrad(const float* g, const float* x, float* gw, int B, int Cin, int H, int W, int Cout,
+                     int stride, int pad, oi_stream_t stream);
+int oi_lrelu_mask_mul(const float* v, const float* ref, float* out, long long n, float slope,
+                      oi_stream_t stream);
+int oi_channel_sum(const float* g, float* gb, int B, int C, int HW, oi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a18: upfirdn2d.  Same contract as the reference plugin entry

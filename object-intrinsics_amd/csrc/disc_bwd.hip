@@ -1,0 +1,228 @@
+// Backward kernels of the DC discriminator convolutions for gfx950.
+//
+// Replaces the cuDNN bwd-data / bwd-filter calls autograd issues for DCDiscriminator
+// (reference src/models/discriminator.py:63-85) and, re-composed by oi_amd/autograd_conv.py, the
+// double-backward the R1 penalty needs (src/loss/gan.py:5-14): the set {fwd, dgrad, wgrad} is closed
+// under differentiation.
+//
+// Both are implicit GEMMs on v_mfma_f32_32x32x2_f32 in the same "pixel on the MFMA column" form as
+// the forward kernel (csrc/disc.hip):
+//   dgrad  D[c][m]      = sum_{n,tap} W[n][c][tap] * G[n][pix(m,tap)]      m = input pixel of ONE parity class
+//   wgrad  D[n][(c,tap)] = sum_{pix}   G[n][pix]    * X[c][in(pix,tap)]
+// K is split across wavefronts when the tile count is small; partial tiles are combined with fp32
+// atomics into a zeroed output.
+#include "oi_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------
+// dgrad.  For stride S the taps that reach input row iy are ky = (iy + pad) % S + S*j; the input
+// pixels are processed per parity class (a, b) = ((iy+pad)%S, (ix+pad)%S) so that a tile of 32 pixels
+// shares its tap set: 4/S x 4/S taps per output channel.
+// ------------------------------------------------------------------------------------------
+template <int S>
+__global__ void __launch_bounds__(256)
+conv4x4_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ gx, int B, int Cin,
+                     int H, int W, int Cout, int Ho, int Wo, int pad, int m_tiles, int n_tiles, int k_splits,
+                     int couts_per_split, int Hc, int Wc) {
+  constexpr int TJ = 4 / S;      // taps per axis
+  const int lane = threadIdx.x & 63;
+  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long n_items = (long long)S * S * m_tiles * n_tiles * k_splits;
+  if (item >= n_items) return;
+  const int ks = item % k_splits;
+  const int nt = (item / k_splits) % n_tiles;
+  const int mt = (item / ((long long)k_splits * n_tiles)) % m_tiles;
+  const int cls = item / ((long long)k_splits * n_tiles * m_tiles);
+  const int ca = cls / S, cb = cls % S;  // parity of (iy + pad), (ix + pad)
+
+  const int h = lane >> 5, j = lane & 31;
+  // pixels of this class: iy = S*yy + ((ca - pad) mod S), yy in [0, Hc)
+  const int y_first = ((ca - pad) % S + S) % S, x_first = ((cb - pad) % S + S) % S;
+  const int Mc = B * Hc * Wc;
+  const int m = mt * 32 + j;
+  const bool m_ok = m < Mc;
+  const int mm = m_ok ? m : 0;
+  const int xx = mm % Wc, yy = (mm / Wc) % Hc, b = mm / (Wc * Hc);
+  const int iy = S * yy + y_first, ix = S * xx + x_first;
+  const bool pix_ok = m_ok && iy < H && ix < W;
+  // output pixel reached through tap (ky, kx): oy = (iy + pad - ky) / S
+  const int oy_base = (iy + pad - ca) / S, ox_base = (ix + pad - cb) / S;  // for ky = ca, kx = cb; ky = ca + S*jy -> oy_base - jy
+
+  const int c = nt * 32 + j;  // A side: input channel of this lane
+  const bool c_ok = c < Cin;
+
+  f32x16 acc = {0};
+  const int n_begin = ks * couts_per_split, n_end = min(Cout, n_begin + couts_per_split);
+  for (int n0 = n_begin; n0 < n_end; n0 += 2) {
+    const int n = n0 + h;
+    const bool n_ok = n < n_end;
+    const float* wn = w + ((size_t)(n_ok ? n : 0) * Cin + (c_ok ? c : 0)) * 16;
+    const float* gn = g + ((size_t)b * Cout + (n_ok ? n : 0)) * Ho * Wo;
+#pragma unroll
+    for (int jy = 0; jy < TJ; ++jy) {
+      const int ky = ca + S * jy, oy = oy_base - jy;
+      float a[TJ], bv[TJ];
+#pragma unroll
+      for (int jx = 0; jx < TJ; ++jx) {
+        const int kx = cb + S * jx, ox = ox_base - jx;
+        a[jx] = (n_ok && c_ok) ? wn[ky * 4 + kx] : 0.f;
+        bv[jx] = (n_ok && pix_ok && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) ? gn[oy * Wo + ox] : 0.f;
+      }
+#pragma unroll
+      for (int jx = 0; jx < TJ; ++jx) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jx], bv[jx], acc, 0, 0, 0);
+    }
+  }
+  if (!pix_ok) return;
+#pragma unroll
+  for (int rg = 0; rg < 16; ++rg) {
+    const int cc = nt * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * h;
+    if (cc >= Cin) continue;
+    float* dst = gx + (((size_t)b * Cin + cc) * H + iy) * W + ix;
+    if (k_splits == 1) *dst = acc[rg]; else atomicAdd(dst, acc[rg]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad.  A = G[n][pix] (rows = output channel), B = X gathered for ONE (c, ky) kernel row and the 4 kx
+// taps spread over ... columns j = (c_local * 16 + ky*4 + kx): 32 columns = 2 input channels x 16 taps.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+conv4x4_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ gw, int B, int Cin,
+                     int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int m_tiles, int n_tiles,
+                     int k_splits, int pix_per_split) {
+  const int lane = threadIdx.x & 63;
+  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long n_items = (long long)m_tiles * n_tiles * k_splits;
+  if (item >= n_items) return;
+  const int ks = item % k_splits;
+  const int nt = (item / k_splits) % n_tiles;   // tile over (c, tap) columns: 2 channels per tile
+  const int mt = item / ((long long)k_splits * n_tiles);  // tile over output channels
+  const int h = lane >> 5, j = lane & 31;
+
+  const int n = mt * 32 + j;  // A side: output channel
+  const bool n_ok = n < Cout;
+  const int c = nt * 2 + (j >> 4), tap = j & 15, ky = tap >> 2, kx = tap & 3;  // B side: (channel, tap)
+  const bool c_ok = c < Cin;
+  const int HW = Ho * Wo, P = B * HW;
+
+  f32x16 acc = {0};
+  const int p_begin = ks * pix_per_split, p_end = min(P, p_begin + pix_per_split);
+  for (int p0 = p_begin; p0 < p_end; p0 += 8) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + 4 * h + u;  // (half, u) -> k: both operands use the same map
+      const bool p_ok = p < p_end;
+      const int pp = p_ok ? p : 0;
+      const int b = pp / HW, pl = pp % HW, oy = pl / Wo, ox = pl % Wo;
+      const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+      const float a = (p_ok && n_ok) ? g[((size_t)b * Cout + n) * HW + pl] : 0.f;
+      const float bv = (p_ok && c_ok && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                           ? x[(((size_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    }
+  }
+  if (!c_ok) return;
+  // D: column = lane & 31 = (c, tap), row = channel n
+#pragma unroll
+  for (int rg = 0; rg < 16; ++rg) {
+    const int nn = mt * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * h;
+    if (nn >= Cout) continue;
+    float* dst = gw + ((size_t)nn * Cin + c) * 16 + tap;
+    if (k_splits == 1) *dst = acc[rg]; else atomicAdd(dst, acc[rg]);
+  }
+}
+
+// out = ref > 0 ? v : slope * v     (LeakyReLU forward with ref = v, and its gradient with ref = output)
+__global__ void lrelu_mask_mul_kernel(const float* __restrict__ v, const float* __restrict__ ref,
+                                      float* __restrict__ out, long long n, float slope) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = v[i];
+  out[i] = ref[i] > 0.f ? x : x * slope;
+}
+
+// bias gradient: gb[n] = sum_{b, pix} g[b][n][pix]
+__global__ void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ gb, int B, int C, int HW) {
+  const int n = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B * HW; i += blockDim.x) s += g[((size_t)(i / HW) * C + n) * HW + i % HW];
+  s = oi::wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) gb[n] = red[0] + red[1] + red[2] + red[3];
+}
+
+}  // namespace
+
+extern "C" {
+
+int oi_conv4x4_dgrad(const float* g, const float* w, float* gx, int B, int Cin, int H, int W, int Cout, int stride,
+                     int pad, oi_stream_t stream) {
+  OI_REQUIRE(g && w && gx, "oi_conv4x4_dgrad: null pointer");
+  OI_REQUIRE(stride == 1 || stride == 2, "oi_conv4x4_dgrad: stride %d (1 or 2 supported)", stride);
+  const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
+  OI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "oi_conv4x4_dgrad: bad shape");
+  const int Hc = oi::cdiv(H, stride), Wc = oi::cdiv(W, stride);
+  const int m_tiles = oi::cdiv((long long)B * Hc * Wc, 32), n_tiles = oi::cdiv(Cin, 32);
+  int k_splits = 1;
+  const long long tiles = (long long)stride * stride * m_tiles * n_tiles;
+  while (tiles * k_splits < 2048 && Cout / (k_splits * 2) >= 16) k_splits *= 2;
+  int cps = oi::cdiv(Cout, k_splits);
+  cps += cps & 1;
+  k_splits = oi::cdiv(Cout, cps);
+  hipStream_t st = oi::as_stream(stream);
+  // rows/cols no tap reaches (e.g. the last row when (H + 2 pad - 4) % stride != 0) keep the zero fill
+  hipError_t e = hipMemsetAsync(gx, 0, (size_t)B * Cin * H * W * sizeof(float), st);
+  if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_dgrad: memset: %s", hipGetErrorString(e));
+  const long long items = tiles * k_splits;
+  if (stride == 2)
+    hipLaunchKernelGGL(conv4x4_dgrad_kernel<2>, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, g, w, gx, B, Cin, H, W,
+                       Cout, Ho, Wo, pad, m_tiles, n_tiles, k_splits, cps, Hc, Wc);
+  else
+    hipLaunchKernelGGL(conv4x4_dgrad_kernel<1>, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, g, w, gx, B, Cin, H, W,
+                       Cout, Ho, Wo, pad, m_tiles, n_tiles, k_splits, cps, Hc, Wc);
+  return oi::check_launch("oi_conv4x4_dgrad");
+}
+
+int oi_conv4x4_wgrad(const float* g, const float* x, float* gw, int B, int Cin, int H, int W, int Cout, int stride,
+                     int pad, oi_stream_t stream) {
+  OI_REQUIRE(g && x && gw, "oi_conv4x4_wgrad: null pointer");
+  const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
+  OI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0 && stride > 0, "oi_conv4x4_wgrad: bad shape");
+  const int m_tiles = oi::cdiv(Cout, 32), n_tiles = oi::cdiv(Cin, 2);
+  const int P = B * Ho * Wo;
+  int k_splits = 1;
+  const long long tiles = (long long)m_tiles * n_tiles;
+  while (tiles * k_splits < 2048 && P / (k_splits * 2) >= 64) k_splits *= 2;
+  int pps = oi::cdiv(P, k_splits);
+  pps = (pps + 7) & ~7;
+  k_splits = oi::cdiv(P, pps);
+  hipStream_t st = oi::as_stream(stream);
+  if (k_splits > 1) {
+    hipError_t e = hipMemsetAsync(gw, 0, (size_t)Cout * Cin * 16 * sizeof(float), st);
+    if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_wgrad: memset: %s", hipGetErrorString(e));
+  }
+  const long long items = tiles * k_splits;
+  hipLaunchKernelGGL(conv4x4_wgrad_kernel, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, g, x, gw, B, Cin, H, W, Cout, Ho,
+                     Wo, stride, pad, m_tiles, n_tiles, k_splits, pps);
+  return oi::check_launch("oi_conv4x4_wgrad");
+}
+
+int oi_lrelu_mask_mul(const float* v, const float* ref, float* out, long long n, float slope, oi_stream_t stream) {
+  OI_REQUIRE(v && ref && out && n > 0, "oi_lrelu_mask_mul: bad argument");
+  hipLaunchKernelGGL(lrelu_mask_mul_kernel, dim3(oi::cdiv(n, 256)), dim3(256), 0, oi::as_stream(stream), v, ref, out,
+                     n, slope);
+  return oi::check_launch("oi_lrelu_mask_mul");
+}
+
+int oi_channel_sum(const float* g, float* gb, int B, int C, int HW, oi_stream_t stream) {
+  OI_REQUIRE(g && gb && B > 0 && C > 0 && HW > 0, "oi_channel_sum: bad argument");
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, oi::as_stream(stream), g, gb, B, C, HW);
+  return oi::check_launch("oi_channel_sum");
+}
+
+}  // extern "C"

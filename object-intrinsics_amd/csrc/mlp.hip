@@ -20,43 +20,11 @@
 //    the write and the read by the same wave) instead of re-running the network as autograd does.
 //  * MFMA operand precision is a template mode (oi_precision); accumulation, the FiLM phase and
 //    sin/cos are always fp32.
-#include "oi_common.h"
+#include "mlp_common.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int C = 128;           // hidden width (W in the reference config)
-constexpr int NL_SDF = 8;        // FiLM layers of the SDF net
-constexpr int NMAT = 15;         // 7 forward + 7 transposed + colour head
-constexpr int TILE_PTS = 128;    // points per workgroup
-constexpr int WAVE_PTS = 32;     // points per wavefront
-constexpr int NSLOT = 9;         // scratch slots per wave tile: c_0..c_7, feat
-
-// packed header (floats)
-constexpr int H_TAB0 = 0;        // [128][4]  (w0x, w0y, w0z, 0)
-constexpr int H_SIG = 512;       // [128] wsig, [128] = bsig
-constexpr int H_TABV = 656;      // [128][4]  (wv[:,128], wv[:,129], wv[:,130], 0)
-constexpr int H_RGB = 1168;      // [3][128] wrgb, then brgb[3]
-constexpr int H_TABS_END = 1568; // tab0..rgb are copied to LDS as one block
-constexpr int H_BIAS = 1568;     // [9][128]  b0, b1..b7, bv
-constexpr int H_FLOATS = 2816;
-constexpr size_t H_BYTES = H_FLOATS * 4;
-
-__host__ __device__ constexpr int layer_bytes(int prec) { return prec == OI_PREC_BF16 ? 32768 : 65536; }
-
-// LDS carve (bytes)
-// (small tables first so that every table access is <lane-constant VGPR> + 16-bit immediate)
-constexpr int L_FILM = 0;                 // gamma[128], beta[128], bias[128]
-constexpr int L_TABS = L_FILM + 1536;     // H_TABS_END floats
-constexpr int L_WBUF = L_TABS + H_TABS_END * 4;  // 7808, one layer image
-constexpr int L_TOTAL = L_WBUF + 65536;
-
-__host__ __device__ __forceinline__ int feat_of(int q, int h) {
-  return 32 * (q >> 4) + 8 * ((q >> 2) & 3) + 4 * h + (q & 3);
-}
+using namespace oimlp;
 
 // ------------------------------------------------------------------------------------------
 // a1 + a2: style MLP + FiLM parameters.  One block of 128 threads per batch element.
@@ -111,10 +79,12 @@ __global__ void film_params_kernel(const float* __restrict__ style_w, const floa
 // weight pre-pack
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float mat_elem(const float* wh, const float* wv, int m, int row, int k) {
-  // m: 0..6 forward layer 1..7 -> W[row][k]; 7..13 transposed layer 1..7 -> W[k][row]; 14 colour -> Wv[row][k]
+  // m: 0..6 forward layer 1..7 -> W[row][k]; 7..13 transposed layer 1..7 -> W[k][row]; 14 colour -> Wv[row][k];
+  // 15 colour transposed -> Wv[k][row] (first 128 input columns)
   if (m < 7) return wh[((size_t)m * C + row) * C + k];
   if (m < 14) return wh[((size_t)(m - 7) * C + k) * C + row];
-  return wv[(size_t)row * (C + 3) + k];
+  if (m == 14) return wv[(size_t)row * (C + 3) + k];
+  return wv[(size_t)k * (C + 3) + row];
 }
 
 template <int PREC>
@@ -164,207 +134,6 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
     const __bf16 hi = (__bf16)v;
     reinterpret_cast<__bf16*>(base)[idx] = hi;
     if (PREC == OI_PREC_BF16X3) reinterpret_cast<__bf16*>(base + 32768)[idx] = (__bf16)(v - (float)hi);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// the MLP kernel
-// ------------------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// All LDS accesses are "<laundered per-lane VGPR> + compile-time immediate" so that hipcc emits
-// ds_read_b128 v, vbase offset:imm and cannot hoist 60+ loop-invariant address registers out of the
-// layer loop (that, not the data, is what overflowed the 256-VGPR budget in the first version).
-struct LaneOff {
-  int h16;    // 16 * (lane >> 5)        : selects the lane-half's 4 features inside a group of 8
-  int h64;    // 64 * (lane >> 5)        : same for [128][4] tables
-  int l16;    // 16 * lane               : lane-linear weight image, first 32 KiB
-  int l16hi;  // 16 * lane + 32768       : second 32 KiB of the image
-};
-
-__device__ __forceinline__ f32x4 lds_f4(const char* lds, int imm, int var) {
-  return *reinterpret_cast<const f32x4*>(lds + imm + var);
-}
-// 16 bytes of the staged layer image at byte offset `imm` (compile-time) for this lane
-__device__ __forceinline__ f32x4 wimg_f4(const char* lds, const LaneOff& o, int imm) {
-  return imm < 32768 ? lds_f4(lds, L_WBUF + imm, o.l16) : lds_f4(lds, L_WBUF + imm - 32768, o.l16hi);
-}
-// group g (0..15) of 4 consecutive features of this lane: first feature = 32*(g>>2) + 8*(g&3) + 4h
-__device__ __forceinline__ constexpr int grp_f0(int g) { return 32 * (g >> 2) + 8 * (g & 3); }
-
-template <int PREC>
-__device__ __forceinline__ void stage_layer(char* lds, const char* __restrict__ src, int tid) {
-  constexpr int N16 = layer_bytes(PREC) / 16;
-  const f32x4* s = reinterpret_cast<const f32x4*>(src);
-  f32x4* d = reinterpret_cast<f32x4*>(lds + L_WBUF);
-#pragma unroll
-  for (int i = 0; i < N16 / 256; ++i) d[i * 256 + tid] = s[i * 256 + tid];
-}
-
-__device__ __forceinline__ void stage_film(char* lds, const float* __restrict__ gamma,
-                                           const float* __restrict__ beta, const float* __restrict__ hdr,
-                                           int e, int l, int tid) {
-  float* film = reinterpret_cast<float*>(lds + L_FILM);
-  if (tid < C) {
-    film[tid] = gamma[((size_t)e * 9 + l) * C + tid];
-    film[C + tid] = beta[((size_t)e * 9 + l) * C + tid];
-    film[2 * C + tid] = hdr[H_BIAS + l * C + tid];
-  }
-}
-
-// acc[t][r] (+)= sum_k A[32t + row][k] * act[k]   with the packed A image in LDS.
-// The A fragments are prefetched exactly one k-group ahead; sched_barrier pins that window.
-template <int PREC>
-__device__ __forceinline__ void gemm_layer(const char* lds, const LaneOff& o, const float (&act)[64],
-                                           f32x16 (&acc)[4]) {
-  if constexpr (PREC == OI_PREC_F32) {
-    f32x4 a[4], an[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a[t] = wimg_f4(lds, o, (t * 16 + 0) * 1024);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      if (g < 15) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) an[t] = wimg_f4(lds, o, (t * 16 + g + 1) * 1024);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][k], act[4 * g + k], acc[t], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) a[t] = an[t];
-    }
-  } else {
-    f32x4 ah[4], ahn[4], al[4], aln[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      ah[t] = lds_f4(lds, L_WBUF + (t * 8 + 0) * 1024, o.l16);
-      if constexpr (PREC == OI_PREC_BF16X3) al[t] = lds_f4(lds, L_WBUF + (t * 8 + 0) * 1024, o.l16hi);
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      if (s < 7) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          ahn[t] = lds_f4(lds, L_WBUF + (t * 8 + s + 1) * 1024, o.l16);
-          if constexpr (PREC == OI_PREC_BF16X3) aln[t] = lds_f4(lds, L_WBUF + (t * 8 + s + 1) * 1024, o.l16hi);
-        }
-      }
-      bf16x8 bh, bl;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float v = act[8 * s + i];
-        bh[i] = (__bf16)v;
-        if constexpr (PREC == OI_PREC_BF16X3) bl[i] = (__bf16)(v - (float)bh[i]);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, ah[t]);
-        if constexpr (PREC == OI_PREC_BF16X3) {
-          const bf16x8 wl = __builtin_bit_cast(bf16x8, al[t]);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc[t], 0, 0, 0);
-        }
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc[t], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        ah[t] = ahn[t];
-        if constexpr (PREC == OI_PREC_BF16X3) al[t] = aln[t];
-      }
-    }
-  }
-}
-
-// sin and cos of one fp32 phase.  Accurate form: 2-constant Cody-Waite reduction by pi/2 with FMA
-// (|phi| stays below a few hundred radians: gamma ~ 30 +- 15, |u| of order one) followed by the
-// classic minimax kernels on [-pi/4, pi/4]; <1e-7 abs error, no stack, ~22 VALU ops for the pair.
-// Fast form: v_sin_f32 / v_cos_f32 on phi/(2 pi) (used by the bf16 throughput mode).
-template <bool FAST>
-__device__ __forceinline__ void sincos_(float x, float& s, float& c) {
-  if constexpr (FAST) {
-    s = __sinf(x);
-    c = __cosf(x);
-  } else {
-    const float n = rintf(x * 0.63661977236758134308f);
-    float r = fmaf(n, -1.57079637050628662109375f, x);
-    r = fmaf(n, 4.37113882867379e-08f, r);
-    const float r2 = r * r;
-    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = fmaf(r2, ps, -1.6666654611e-1f);
-    ps = fmaf(r2 * r, ps, r);
-    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = fmaf(r2, pc, 4.166664568298827e-2f);
-    pc = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
-    const int q = (int)n;
-    const float sa = (q & 1) ? pc : ps;
-    const float ca = (q & 1) ? ps : pc;
-    s = (q & 2) ? -sa : sa;
-    c = ((q + 1) & 2) ? -ca : ca;
-  }
-}
-
-// scratch of one wave tile, addressed through a buffer descriptor: voffset = 16*lane (VGPR),
-// soffset = slot*16 KiB + g*1 KiB (SGPR / immediate) -> no per-access address VGPRs.
-struct WaveScratch {
-  __amdgpu_buffer_rsrc_t rs;
-  __device__ __forceinline__ void store(int slot, int g, int l16, f32x4 v) const {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024, 0);
-  }
-  __device__ __forceinline__ f32x4 load(int slot, int g, int l16) const {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, l16, slot * 16384 + g * 1024, 0));
-  }
-};
-
-// FiLM + sin; act <- sin(phi); optionally parks gamma*cos(phi) in scratch slot `slot`.
-// SRC selects where the pre-activation u comes from, computed right where it is consumed so that no
-// table value outlives its group of four features:
-//   0: u = acc (MFMA layers, bias already in the accumulator)
-//   1: u = tab[f].xyz . v + bias[f]         (layer 0: v = the point;  F.linear, volume_renderer.py:52)
-//   2: u = acc + tab[f].xyz . v             (colour head: v = d sdf/dx, the 3 extra input columns)
-template <bool FAST, bool FULL, int SRC>
-__device__ __forceinline__ void film_sin(const char* lds, const LaneOff& o, const f32x16 (&acc)[4],
-                                         float (&act)[64], const WaveScratch& ws, int slot, int tab_imm,
-                                         float vx, float vy, float vz) {
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int t = g >> 2, rr = g & 3;
-    const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
-    const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
-    f32x4 bs;
-    if constexpr (SRC == 1) bs = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
-    f32x4 cv;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float u;
-      if constexpr (SRC == 0) {
-        u = acc[t][4 * rr + k];
-      } else {
-        const f32x4 w = lds_f4(lds, L_TABS + tab_imm * 4 + (grp_f0(g) + k) * 16, o.h64);
-        const float d = fmaf(vz, w[2], fmaf(vy, w[1], vx * w[0]));
-        u = SRC == 1 ? d + bs[k] : acc[t][4 * rr + k] + d;
-      }
-      const float phi = fmaf(gm[k], u, bt[k]);
-      float s, c;
-      sincos_<FAST>(phi, s, c);
-      act[4 * g + k] = s;
-      cv[k] = gm[k] * c;
-    }
-    if constexpr (FULL) ws.store(slot, g, o.l16, cv);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-__device__ __forceinline__ void init_bias(const char* lds, const LaneOff& o, f32x16 (&acc)[4]) {
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const f32x4 b = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[g >> 2][4 * (g & 3) + k] = b[k];
   }
 }
 

@@ -1,0 +1,128 @@
+"""Autograd of the 4x4 convolutions: three Functions (forward conv, data gradient, weight gradient)
+whose backward passes are expressed with each other, so derivatives of any order run on the HIP
+implicit-GEMM kernels (csrc/disc.hip, csrc/disc_bwd.hip).  The fused LeakyReLU is differentiated
+through the saved *output* (sign(y) == sign(pre-activation))."""
+import torch
+
+from . import ops
+
+
+class _Conv(torch.autograd.Function):
+    """y = conv(x, w) (linear, no bias)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad)
+        return ops.conv4x4_fwd(x, w, None, stride, pad, 1.0)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        gx = _Dgrad.apply(gy, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
+        gw = _Wgrad.apply(gy, x, stride, pad) if ctx.needs_input_grad[1] else None
+        return gx, gw, None, None
+
+
+class _Dgrad(torch.autograd.Function):
+    """gx = conv_transpose(g, w): bilinear in (g, w)."""
+
+    @staticmethod
+    def forward(ctx, g, w, H, W, stride, pad):
+        ctx.save_for_backward(g, w)
+        ctx.cfg = (stride, pad)
+        return ops.conv4x4_dgrad(g, w, H, W, stride, pad)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        g, w = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        d_g = _Conv.apply(ggx, w, stride, pad) if ctx.needs_input_grad[0] else None
+        d_w = _Wgrad.apply(g, ggx, stride, pad) if ctx.needs_input_grad[1] else None
+        return d_g, d_w, None, None, None, None
+
+
+class _Wgrad(torch.autograd.Function):
+    """gw = correlate(x, g): bilinear in (g, x)."""
+
+    @staticmethod
+    def forward(ctx, g, x, stride, pad):
+        ctx.save_for_backward(g, x)
+        ctx.cfg = (stride, pad)
+        return ops.conv4x4_wgrad(g, x, stride, pad)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        g, x = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        d_g = _Conv.apply(x, ggw, stride, pad) if ctx.needs_input_grad[0] else None
+        d_x = _Dgrad.apply(g, ggw, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[1] else None
+        return d_g, d_x, None, None
+
+
+class _MaskMul(torch.autograd.Function):
+    """out = ref > 0 ? v : slope * v; linear in v, piecewise constant in ref."""
+
+    @staticmethod
+    def forward(ctx, v, ref, slope):
+        ctx.save_for_backward(ref)
+        ctx.slope = slope
+        return ops.lrelu_mask_mul(v, ref, slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ref,) = ctx.saved_tensors
+        return _MaskMul.apply(g, ref, ctx.slope), None, None
+
+
+class _ConvLrelu(torch.autograd.Function):
+    """Fused forward (one kernel); backward re-expressed with the differentiable pieces above."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad, slope):
+        y = ops.conv4x4_fwd(x, w, None, stride, pad, slope)
+        ctx.save_for_backward(x, w, y)
+        ctx.cfg = (stride, pad, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, slope = ctx.cfg
+        g_pre = _MaskMul.apply(gy, y, slope)
+        gx = _Dgrad.apply(g_pre, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
+        gw = _Wgrad.apply(g_pre, x, stride, pad) if ctx.needs_input_grad[1] else None
+        return gx, gw, None, None, None
+
+
+class _ChannelSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g):
+        ctx.shape = g.shape
+        return ops.channel_sum(g)
+
+    @staticmethod
+    def backward(ctx, gg):
+        return gg.view(1, -1, 1, 1).expand(ctx.shape)
+
+
+class _AddBias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, b):
+        return y + b.view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, _ChannelSum.apply(g)
+
+
+def conv4x4_lrelu_autograd(x, w, bias, stride, pad, slope):
+    if bias is None and slope != 1.0:
+        return _ConvLrelu.apply(x, w, stride, pad, float(slope))
+    y = _Conv.apply(x, w, stride, pad)
+    if bias is not None:
+        y = _AddBias.apply(y, bias)
+    if slope != 1.0:
+        y = _MaskMul.apply(y, y.detach(), float(slope))
+    return y

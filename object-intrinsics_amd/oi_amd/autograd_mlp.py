@@ -1,0 +1,50 @@
+"""autograd.Function of the FiLM-SIREN MLP (forward csrc/mlp.hip, backward csrc/mlp_bwd.hip).
+
+The Function takes the *stacked* parameter views (oi_amd.params.stack_field_params) as explicit
+inputs, so the gradients the HIP backward produces flow on through torch.stack to the
+reference-named nn.Parameters.  The backward already contains the second-order terms of the
+forward's d sdf/dx output, so the Function itself is once-differentiable."""
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import ops
+
+_PKEYS = ("w0", "b0", "wh", "bh", "wsig", "bsig", "wv", "bv", "wrgb", "brgb")
+
+
+class SdfMlpFunction(torch.autograd.Function):
+    @staticmethod
+    def run(pack, pts, gamma, beta, B, want_grad, want_rgb, want_feat):
+        P = pack.stacked()
+        out = SdfMlpFunction.apply(pack, pts, gamma, beta, B, want_grad, want_rgb, want_feat, *[P[k] for k in _PKEYS])
+        return out
+
+    @staticmethod
+    def forward(ctx, pack, pts, gamma, beta, B, want_grad, want_rgb, want_feat, *params):
+        packed = pack.packed()
+        sdf, grad, rgb, feat, _ = ops.sdf_mlp_fwd(pts, packed, gamma, beta, B, pack.prec, pack.fast_trig, want_grad,
+                                                  want_rgb, want_feat)
+        ctx.pack, ctx.B = pack, B
+        ctx.packed = packed  # the image the forward used (parameters may be stepped before backward is called)
+        ctx.save_for_backward(pts, gamma, beta, grad, rgb)
+        if feat is not None:
+            ctx.mark_non_differentiable(feat)
+        return sdf, grad, rgb, feat
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_sdf, g_grad, g_rgb, _g_feat):
+        pts, gamma, beta, grad, rgb = ctx.saved_tensors
+        pack = ctx.pack
+        d_small, d_wmat, d_gamma, d_beta = ops.sdf_mlp_bwd(pts, ctx.packed, gamma, beta, grad, rgb, g_sdf, g_grad,
+                                                           g_rgb if rgb is not None else None, ctx.B, pack.prec,
+                                                           pack.fast_trig)
+        s = d_small
+        d_w0 = s[0:384].view(128, 3)
+        d_b = s[384:1536].view(9, 128)
+        d_wsig, d_bsig = s[1536:1664], s[1664:1665]
+        d_wvx = s[1668:2052].view(128, 3)
+        d_wrgb, d_brgb = s[2052:2436].view(3, 128), s[2436:2439]
+        d_wv = torch.cat([d_wmat[7], d_wvx], dim=1)
+        grads = (d_w0, d_b[0], d_wmat[:7], d_b[1:8], d_wsig, d_bsig, d_wv, d_b[8], d_wrgb, d_brgb)
+        return (None, None, d_gamma, d_beta, None, None, None, None) + grads

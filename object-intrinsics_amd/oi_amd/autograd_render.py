@@ -1,0 +1,40 @@
+"""autograd.Function of the fused compositing + Phong maps kernel (csrc/render.hip / render_bwd.hip)."""
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import ops
+
+OUT_KEYS = ops.PER_SAMPLE_OUT + tuple(ops.PER_RAY_OUT) + ("reduce4",)
+NON_DIFF = ("cdf", "alpha", "inside_sphere", "pts_norm", "weight_max")
+
+
+class CompositeFunction(torch.autograd.Function):
+    @staticmethod
+    def run(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light, cos_anneal_ratio, B,
+            outputs=None):
+        # the kernel normalises the light direction; doing it here too (idempotent) lets autograd own the
+        # Jacobian of the normalisation, the kernel returns d/d(unit vector)
+        ldir_n = torch.nn.functional.normalize(light_dir, dim=-1, eps=1e-6)
+        outs = CompositeFunction.apply(sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg,
+                                       float(cos_anneal_ratio), B)
+        res = dict(zip(OUT_KEYS, outs))
+        if outputs is not None:
+            res = {k: v for k, v in res.items() if k in outputs}
+        return res
+
+    @staticmethod
+    def forward(ctx, sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg, car, B):
+        out = ops.composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, ldir_n, bg, variance, light, car, B)
+        ctx.save_for_backward(sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg)
+        ctx.car, ctx.B = car, B
+        ctx.mark_non_differentiable(*[out[k] for k in NON_DIFF])
+        return tuple(out[k] for k in OUT_KEYS)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gouts):
+        sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg = ctx.saved_tensors
+        g = {k: v for k, v in zip(OUT_KEYS, gouts) if k in ops.GRAD_IN and v is not None}
+        d_sdf, d_grad, d_rgb, d_var, d_light, d_ldir = ops.composite_bwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d,
+                                                                         ldir_n, bg, variance, light, ctx.car, ctx.B, g)
+        return (d_sdf, d_grad, d_rgb, d_var.reshape(variance.shape), d_light, d_ldir) + (None,) * 7

@@ -28,6 +28,13 @@ class CompositeParams(ctypes.Structure):
                                     "specular_map", "diffuse_map", "reduce4")])
 
 
+class CompositeGrads(ctypes.Structure):
+    """Mirror of `oi_composite_grads` (include/oi_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("g_weights", "g_weight_sum", "g_color_fine", "g_image_no_bg", "g_image", "g_shading",
+                                   "g_normal", "g_mask", "g_z_map", "g_specular_map", "g_diffuse_map", "g_reduce4",
+                                   "d_sdf", "d_grad", "d_rgb", "d_variance", "d_light", "d_light_dir")]
+
+
 _SIGS = {
     "oi_version": (_i, []),
     "oi_arch": (ctypes.c_char_p, []),
@@ -37,6 +44,10 @@ _SIGS = {
     "oi_mlp_pack_weights": (_i, [_vp] * 11 + [_i, _vp]),
     "oi_mlp_scratch_bytes": (_sz, [_i, _ll]),
     "oi_sdf_mlp_fwd": (_i, [_vp] * 9 + [_i, _ll, _i, _i, _vp]),
+    "oi_mlp_bwd_scratch_bytes": (_sz, [_i, _ll]),
+    "oi_mlp_bwd_small_floats": (_i, []),
+    "oi_sdf_mlp_bwd": (_i, [_vp] * 14 + [_i, _ll, _i, _i, _vp]),
+    "oi_composite_bwd": (_i, [ctypes.POINTER(CompositeParams), ctypes.POINTER(CompositeGrads), _vp]),
     "oi_gen_rays": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "oi_coarse_samples": (_i, [_vp] * 5 + [_ll, _i, _vp, _vp, _vp]),
     "oi_upsample": (_i, [_vp] * 4 + [_ll, _i, _i, _f, _vp, _vp, _vp, _vp]),
@@ -44,6 +55,10 @@ _SIGS = {
     "oi_midpoints": (_i, [_vp] * 3 + [_ll, _i, _f, _vp, _vp, _vp, _vp]),
     "oi_composite_fwd": (_i, [ctypes.POINTER(CompositeParams), _vp]),
     "oi_conv4x4_fwd": (_i, [_vp] * 4 + [_i] * 7 + [_f, _vp]),
+    "oi_conv4x4_dgrad": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
+    "oi_conv4x4_wgrad": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
+    "oi_lrelu_mask_mul": (_i, [_vp] * 3 + [_ll, _f, _vp]),
+    "oi_channel_sum": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "oi_upfirdn2d": (_i, [_vp] * 3 + [_i] * 14 + [_f, _vp]),
     "oi_affine_grid_sample_fwd": (_i, [_vp] * 3 + [_i] * 6 + [_vp]),
     "oi_affine_grid_sample_bwd": (_i, [_vp] * 3 + [_i] * 6 + [_vp]),
@@ -52,7 +67,14 @@ _SIGS = {
 }
 
 # entry points added by later source files (backward kernels); bound when present in the .so
-_OPTIONAL_SIGS = {}
+_OPTIONALclass CompositeGrads(ctypes.Structure):
+    """Mirror of `oi_composite_grads` (include/oi_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("g_weights", "g_weight_sum", "g_color_fine", "g_image_no_bg", "g_image", "g_shading",
+                                   "g_normal", "g_mask", "g_z_map", "g_specular_map", "g_diffuse_map", "g_reduce4",
+                                   "d_sdf", "d_grad", "d_rgb", "d_variance", "d_light", "d_light_dir")]
+
+
+_SIGS = {}
 
 
 class OiHipError(RuntimeError):

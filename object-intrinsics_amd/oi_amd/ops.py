@@ -88,6 +88,24 @@ def sdf_mlp_fwd(pts, packed, gamma, beta, B, prec, fast_trig=False, want_grad=Fa
     return sdf, grad, rgb, feat, scratch
 
 
+def sdf_mlp_bwd(pts, packed, gamma, beta, grad_fwd, rgb_fwd, g_sdf, g_grad, g_rgb, B, prec, fast_trig=False):
+    """-> d_small (flat), d_wmat (8,128,128), d_gamma (B,9,128), d_beta (B,9,128)."""
+    L = _l.load()
+    pts = _c(pts)
+    n = pts.shape[0] // B
+    dev = pts.device
+    d_small = torch.zeros(L.oi_mlp_bwd_small_floats(), dtype=torch.float32, device=dev)
+    d_wmat = torch.zeros(8, 128, 128, dtype=torch.float32, device=dev)
+    d_gamma = torch.zeros(B, 9, 128, dtype=torch.float32, device=dev)
+    d_beta = torch.zeros(B, 9, 128, dtype=torch.float32, device=dev)
+    scratch = torch.empty(L.oi_mlp_bwd_scratch_bytes(B, n), dtype=torch.uint8, device=dev)
+    args = [_c(t) for t in (grad_fwd, rgb_fwd, g_sdf, g_grad, g_rgb)]
+    _l.check(L.oi_sdf_mlp_bwd(_p(pts), _p(packed), _p(_c(gamma)), _p(_c(beta)), *[_p(a) for a in args], _p(d_small),
+                              _p(d_wmat), _p(d_gamma), _p(d_beta), _p(scratch), B, n, prec, int(bool(fast_trig)),
+                              _stream()), "oi_sdf_mlp_bwd")
+    return d_small, d_wmat, d_gamma, d_beta
+
+
 # ------------------------------------------------------------------------------------------
 # rays / sampling / compositing
 # ------------------------------------------------------------------------------------------
@@ -177,6 +195,42 @@ def composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, v
     return out
 
 
+GRAD_IN = ("weights", "weight_sum", "color_fine", "image_no_bg", "image", "shading", "normal", "mask", "z_map",
+           "specular_map", "diffuse_map", "reduce4")
+
+
+def composite_bwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light, cos_anneal_ratio, B,
+                  gouts):
+    """gouts: dict name -> upstream gradient (missing / None = zero).  -> d_sdf, d_grad, d_rgb, d_variance (1,),
+    d_light (3,), d_light_dir (B,3)."""
+    L = _l.load()
+    N, T = dists.shape
+    P = _l.CompositeParams()
+    keep = []
+    for name, t in (("sdf", sdf), ("grad", grad), ("rgb", rgb), ("dists", dists), ("mid_z", mid_z), ("rays_o", rays_o),
+                    ("rays_d", rays_d), ("light_dir", light_dir), ("bg", bg), ("variance", variance.reshape(1)),
+                    ("light", light)):
+        t = _c(t)
+        keep.append(t)
+        setattr(P, name, _p(t))
+    P.cos_anneal_ratio = float(cos_anneal_ratio)
+    P.N, P.T, P.B = N, T, B
+    G = _l.CompositeGrads()
+    for name in GRAD_IN:
+        t = _c(gouts.get(name))
+        keep.append(t)
+        setattr(G, "g_" + name, _p(t))
+    dev = dists.device
+    d_sdf, d_grad, d_rgb = _new(dists, N, T), _new(dists, N, T, 3), _new(dists, N, T, 3)
+    d_var = torch.zeros(1, dtype=torch.float32, device=dev)
+    d_light = torch.zeros(3, dtype=torch.float32, device=dev)
+    d_ldir = torch.zeros(B, 3, dtype=torch.float32, device=dev)
+    G.d_sdf, G.d_grad, G.d_rgb = _p(d_sdf), _p(d_grad), _p(d_rgb)
+    G.d_variance, G.d_light, G.d_light_dir = _p(d_var), _p(d_light), _p(d_ldir)
+    _l.check(L.oi_composite_bwd(ctypes.byref(P), ctypes.byref(G), _stream()), "oi_composite_bwd")
+    return d_sdf, d_grad, d_rgb, d_var, d_light, d_ldir
+
+
 # ------------------------------------------------------------------------------------------
 # discriminator side
 # ------------------------------------------------------------------------------------------
@@ -192,6 +246,43 @@ def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2):
     _l.check(L.oi_conv4x4_fwd(_p(x), _p(w), _p(_c(bias)), _p(y), B, Cin, H, W, Cout, stride, pad, float(slope),
                               _stream()), "oi_conv4x4_fwd")
     return y
+
+
+def conv4x4_dgrad(g, w, H, W, stride=2, pad=1):
+    L = _l.load()
+    g, w = _c(g), _c(w)
+    B, Cout = g.shape[:2]
+    Cin = w.shape[1]
+    gx = _new(g, B, Cin, H, W)
+    _l.check(L.oi_conv4x4_dgrad(_p(g), _p(w), _p(gx), B, Cin, H, W, Cout, stride, pad, _stream()), "oi_conv4x4_dgrad")
+    return gx
+
+
+def conv4x4_wgrad(g, x, stride=2, pad=1):
+    L = _l.load()
+    g, x = _c(g), _c(x)
+    B, Cin, H, W = x.shape
+    Cout = g.shape[1]
+    gw = _new(g, Cout, Cin, 4, 4)
+    _l.check(L.oi_conv4x4_wgrad(_p(g), _p(x), _p(gw), B, Cin, H, W, Cout, stride, pad, _stream()), "oi_conv4x4_wgrad")
+    return gw
+
+
+def lrelu_mask_mul(v, ref, slope):
+    L = _l.load()
+    v, ref = _c(v), _c(ref)
+    out = torch.empty_like(v)
+    _l.check(L.oi_lrelu_mask_mul(_p(v), _p(ref), _p(out), v.numel(), float(slope), _stream()), "oi_lrelu_mask_mul")
+    return out
+
+
+def channel_sum(g):
+    L = _l.load()
+    g = _c(g)
+    B, C = g.shape[:2]
+    gb = _new(g, C)
+    _l.check(L.oi_channel_sum(_p(g), _p(gb), B, C, g[0, 0].numel(), _stream()), "oi_channel_sum")
+    return gb
 
 
 def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, pady1=0, flip=False, gain=1.0):

@@ -1,0 +1,275 @@
+"""GPU parity of the backward HIP kernels against autograd through the oracle (CPU) and against the
+reference's own gradients (golden fixtures F6, F7): first-order parameter gradients of losses that
+contain second-order terms (normals / eikonal in the generator, R1 in the discriminators)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oi_oracle as O
+from conftest import GOLDEN, load_golden, maxdiff, sub_sd
+
+pytestmark = pytest.mark.gpu
+NET_KW = dict(D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64)
+SDF_NPZ = os.path.join(GOLDEN, "weights_sdf.npz")
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(1e-12, float(b.abs().max())))
+
+
+# ---------------------------------------------------------------------------------------------
+# discriminator
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Cin,H,Cout,stride,pad", [(2, 3, 16, 8, 2, 1), (1, 64, 16, 128, 2, 1), (3, 32, 4, 7, 1, 0),
+                                                      (2, 5, 9, 6, 2, 1), (1, 256, 8, 512, 2, 1)])
+def test_conv_dgrad_wgrad_vs_torch(B, Cin, H, Cout, stride, pad):
+    from oi_amd import ops
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(B, Cin, H, H, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 4, 4, generator=g, dtype=torch.float64) / math.sqrt(Cin * 16)).requires_grad_(True)
+    y = torch.nn.functional.conv2d(x, w, stride=stride, padding=pad)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    gx, gw = torch.autograd.grad(y, (x, w), gy)
+    dx = ops.conv4x4_dgrad(gy.float().cuda(), w.detach().float().cuda(), H, H, stride, pad)
+    dw = ops.conv4x4_wgrad(gy.float().cuda(), x.detach().float().cuda(), stride, pad)
+    assert rel_err(dx, gx) < 2e-5 and rel_err(dw, gw) < 2e-5
+
+
+@pytest.mark.parametrize("tag,res,nf,cin,cout", [("r16c3_", 16, 32, 3, 7), ("r64c3_", 64, 64, 3, 7), ("r64c1_", 64, 32, 1, 1)])
+def test_discriminator_r1_grads_golden_f7(tag, res, nf, cin, cout):
+    """loss = BCE(D(x)[:, :1], 1) + 10 * R1: weight gradients need the conv double-backward."""
+    from oi_amd.discriminator import DCDiscriminator
+    from oi_amd.losses import GANLoss, compute_grad2
+    g = load_golden("f7_discriminator")
+    D = DCDiscriminator(in_dim=cin, out_dim=cout, n_feat=nf, img_size=res)
+    D.load_state_dict(sub_sd(g, tag + "w."))
+    D = D.cuda()
+    x = g[tag + "x"].cuda().requires_grad_(True)
+    d = D(x)
+    assert maxdiff(d.cpu(), g[tag + "d"]) < 2e-5
+    d1 = d[:, :1]
+    reg = compute_grad2(d1, x)
+    assert abs(float(reg) - float(g[tag + "reg"])) < 1e-4 * max(1.0, float(g[tag + "reg"]))
+    loss = GANLoss("bce")(d1, 1) + 10.0 * reg
+    (gx,) = torch.autograd.grad(d1.sum(), x, retain_graph=True)
+    assert maxdiff(gx.cpu(), g[tag + "gx"]) < 1e-5
+    gw = torch.autograd.grad(loss, list(D.parameters()))
+    for (k, _), gr in zip(D.named_parameters(), gw):
+        ref = g[tag + "g." + k]
+        assert rel_err(gr, ref) < 2e-4, (k, rel_err(gr, ref))
+
+
+def test_ada_discriminator_backward_vs_oracle():
+    """Full ADA pipeline (pad, upfirdn2d x4, grid sample, convs) input-gradient and R1 vs the oracle."""
+    from oi_amd.discriminator import ADADiscriminator
+    from oi_amd.losses import compute_grad2
+    torch.manual_seed(0)
+    D = ADADiscriminator(aug={"__target__": "src.third_party.ada.augment.AugmentPipe", "kwargs": {"xint": 1, "scale": 1}},
+                         aug_p=1, in_dim=3, out_dim=1, n_feat=32, img_size=32, last_bias=False)
+    dsd = {k: v.detach().clone().requires_grad_(True) for k, v in D.state_dict().items() if "aug." not in k}
+    x0 = torch.rand(2, 3, 32, 32)
+    pct = 0.7
+    p = torch.tensor(pct)
+    G = O.ada_G_inv(2, 32, 32, ((p * 2 - 1) * 0.125).expand(2, 2), torch.exp2(torch.erfinv(p * 2 - 1) * 0.2).expand(2))
+    xo = x0.clone().requires_grad_(True)
+    do = O.dc_discriminator(dsd, O.ada_geometric(xo, G)[0])
+    rego = O.r1_penalty(do, xo)
+    lo = O.bce_logits_const(do, 1) + 10.0 * rego
+    gwo = torch.autograd.grad(lo, list(dsd.values()))
+
+    D = D.cuda()
+    orig = D.aug.forward
+    D.aug.forward = lambda im: orig(im, debug_percentile=pct)
+    x = x0.cuda().requires_grad_(True)
+    d = D(x)
+    assert maxdiff(d.cpu(), do) < 2e-5
+    reg = compute_grad2(d, x)
+    assert abs(float(reg) - float(rego)) < 1e-4 * max(1.0, float(rego))
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(d, torch.ones_like(d)) + 10.0 * reg
+    names = [k for k in dsd]
+    gw = torch.autograd.grad(loss, [dict(D.named_parameters())[k] for k in names])
+    for k, a, b in zip(names, gw, gwo):
+        assert rel_err(a, b) < 3e-4, (k, rel_err(a, b))
+
+
+# ---------------------------------------------------------------------------------------------
+# compositing
+# ---------------------------------------------------------------------------------------------
+def test_composite_backward_vs_oracle(sdf_sd, col_sd):
+    from oi_amd import ops
+    from oi_amd.autograd_render import CompositeFunction
+    g = torch.Generator().manual_seed(5)
+    B, H, W, T = 2, 3, 4, 70
+    N = B * H * W
+    ro = torch.tensor([0.0, 0.0, -3.0]).expand(N, 3) + 0.05 * torch.randn(N, 3, generator=g)
+    rd = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + 0.2 * torch.randn(N, 3, generator=g), dim=-1)
+    near, far = O.near_far_from_sphere(ro, rd)
+    z = torch.sort(near + (far - near) * torch.rand(N, T, generator=g), -1).values
+    w = O.style_mlp(sdf_sd, torch.randn(B, 64, generator=g))
+    S = 35
+    dists = torch.cat([z[:, 1:] - z[:, :-1], torch.full((N, 1), 2.0 / S)], -1)
+    mid = z + dists * 0.5
+    pts = ro[:, None] + rd[:, None] * mid[..., None]
+    with torch.no_grad():
+        sdf0, feat0, grad0 = O.sdf_forward(sdf_sd, pts.reshape(-1, 3), w, want_grad=True)
+        rgb0 = O.color_head(col_sd, feat0, grad0, w)
+    lsd = {"param_direction": torch.tensor([0.3, -0.5, -0.8]), "param_ambient": torch.tensor(-0.4),
+           "param_specular": torch.tensor(0.35), "param_shininess": torch.tensor(6.0)}
+    w2b = torch.eye(4).repeat(B, 1, 1)
+    w2b[:, :3, :3] = torch.linalg.qr(torch.randn(B, 3, 3, generator=g)).Q
+    bg = torch.rand(B, 3, generator=g)
+    car = 0.37
+    cot = {k: torch.randn(s, generator=g) for k, s in
+           (("image", (B, 3, H, W)), ("mask", (B, 1, H, W)), ("shading_map", (B, 3, H, W)), ("normal_map", (B, 3, H, W)),
+            ("z_map", (B, 1, H, W)), ("color_map", (B, 3, H, W)), ("weights", (N, T)), ("specular_map", (B, 3, H, W)),
+            ("diff_shading_map", (B, 3, H, W)))}
+
+    # ---- oracle (fp64 autograd on CPU)
+    dd = lambda t: t.double().clone().requires_grad_(True)
+    sdf_o, grad_o, rgb_o, var_o = dd(sdf0.reshape(N, T)), dd(grad0.reshape(N, T, 3)), dd(rgb0.reshape(N, T, 3)), dd(torch.tensor(0.3))
+    lsd_o = {k: dd(v) for k, v in lsd.items()}
+    inv_s = O.inv_s_from_variance(var_o)
+    true_cos = (rd.double()[:, None, :] * grad_o).sum(-1)
+    ic = -(torch.relu(-true_cos * 0.5 + 0.5) * (1 - car) + torch.relu(-true_cos) * car)
+    dO = dists.double()
+    pc = torch.sigmoid((sdf_o - ic * dO * 0.5) * inv_s)
+    nc = torch.sigmoid((sdf_o + ic * dO * 0.5) * inv_s)
+    alpha = ((pc - nc + 1e-5) / (pc + 1e-5)).clamp(0, 1)
+    wts = O.transmittance_weights(alpha)
+    pn = torch.linalg.norm(pts.double(), dim=-1)
+    relax = (pn < 1.2).double()
+    eik = (relax * (torch.linalg.norm(grad_o, dim=-1) - 1) ** 2).sum() / (relax.sum() + 1e-5)
+    ro_dict = {"pts": pts.double(), "weights": wts, "weight_sum": wts.sum(-1, keepdim=True), "gradients": grad_o,
+               "raw_color": rgb_o, "color_fine": (rgb_o * wts[..., None]).sum(1), "mid_z_vals": mid.double()}
+    maps = O.render_maps(ro_dict, ro.double(), lsd_o, w2b.double(), bg.double(), B, H, W, return_raw=True)
+    loss_o = sum((maps[k] * cot[k].double()).sum() for k in cot if k != "weights") + (wts * cot["weights"].double()).sum() + 7.0 * eik
+    leaves = [sdf_o, grad_o, rgb_o, var_o, lsd_o["param_ambient"], lsd_o["param_specular"], lsd_o["param_shininess"],
+              lsd_o["param_direction"]]
+    g_o = torch.autograd.grad(loss_o, leaves)
+
+    # ---- HIP
+    c = lambda t: t.float().cuda().requires_grad_(True)
+    sdf_h, grad_h, rgb_h, var_h = c(sdf0.reshape(N, T)), c(grad0.reshape(N, T, 3)), c(rgb0.reshape(N, T, 3)), c(torch.tensor(0.3))
+    lp = {k: c(v) for k, v in lsd.items()}
+    light = torch.stack([lp["param_ambient"], lp["param_specular"], lp["param_shininess"]])
+    dirn = lp["param_direction"] / torch.linalg.norm(lp["param_direction"])
+    ldir = torch.einsum("bij,j->bi", w2b.cuda()[:, :3, :3], dirn)
+    out = CompositeFunction.run(sdf_h, grad_h, rgb_h, dists.cuda(), mid.cuda(), ro.cuda(), rd.cuda(), ldir, bg.cuda(),
+                                var_h, light, car, B)
+    to_map = lambda x: x.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+    m = {"image": to_map(out["image"]), "mask": to_map(out["mask"]), "shading_map": to_map(out["shading"]).expand(B, 3, H, W),
+         "normal_map": to_map(out["normal"]), "z_map": to_map(out["z_map"]), "color_map": to_map(out["color_fine"]),
+         "specular_map": to_map(out["specular_map"]).expand(B, 3, H, W),
+         "diff_shading_map": to_map(out["diffuse_map"]).expand(B, 3, H, W)}
+    eik_h = out["reduce4"][0] / (out["reduce4"][1] + 1e-5)
+    loss_h = sum((m[k] * cot[k].cuda()).sum() for k in m) + (out["weights"] * cot["weights"].cuda()).sum() + 7.0 * eik_h
+    assert abs(float(loss_h) - float(loss_o)) < 1e-3 * max(1.0, abs(float(loss_o)))
+    g_h = torch.autograd.grad(loss_h, [sdf_h, grad_h, rgb_h, var_h, lp["param_ambient"], lp["param_specular"],
+                                       lp["param_shininess"], lp["param_direction"]])
+    for name, a, b in zip(("sdf", "grad", "rgb", "variance", "ambient", "specular", "shininess", "direction"), g_h, g_o):
+        assert rel_err(a, b) < 2e-3, (name, rel_err(a, b), a.flatten()[:4], b.flatten()[:4])
+
+
+# ---------------------------------------------------------------------------------------------
+# MLP
+# ---------------------------------------------------------------------------------------------
+def _oracle_mlp_grads(sdf_sd, col_sd, pts, w, cs, cg, cr):
+    sd = {k: v.double().clone().requires_grad_(True) for k, v in sdf_sd.items()}
+    csd = {k: v.double().clone().requires_grad_(True) for k, v in col_sd.items()}
+    wd = w.double().clone().requires_grad_(True)
+    sdf, feat, grad = O.sdf_forward(sd, pts.double(), wd, want_grad=True)
+    rgb = O.color_head(csd, feat, grad, wd)
+    loss = (sdf.squeeze(-1) * cs.double()).sum() + (grad * cg.double()).sum() + (rgb * cr.double()).sum()
+    names = [("sdf." + k, v) for k, v in sd.items() if not k.startswith("style.")] + [("col." + k, v) for k, v in csd.items()] + [("w", wd)]
+    gr = torch.autograd.grad(loss, [v for _, v in names])
+    return float(loss), {n: g_ for (n, _), g_ in zip(names, gr)}
+
+
+@pytest.mark.parametrize("n,B,precision,tol", [(96, 2, "f32", 2e-3), (300, 1, "f32", 2e-3), (64, 2, "bf16x3", 1e-2)])
+def test_mlp_backward_vs_oracle(sdf_sd, col_sd, n, B, precision, tol):
+    """dL/d(every parameter, w) for L = <cs, sdf> + <cg, d sdf/dx> + <cr, rgb> (random cotangents)."""
+    from oi_amd.fields import ShapeNetwork, ColorNetwork, FieldPack
+    from oi_amd.autograd import sdf_mlp
+    g = torch.Generator().manual_seed(n)
+    pts = torch.rand(B * n, 3, generator=g) * 2.0 - 1.0
+    w = O.style_mlp(sdf_sd, torch.randn(B, 64, generator=g))
+    cs, cg, cr = torch.randn(B * n, generator=g), 0.1 * torch.randn(B * n, 3, generator=g), torch.randn(B * n, 3, generator=g)
+    loss_o, g_o = _oracle_mlp_grads(sdf_sd, col_sd, pts, w, cs, cg, cr)
+
+    sdf_net = ShapeNetwork(SDF_NPZ, **NET_KW).cuda()
+    col_net = ColorNetwork(**NET_KW)
+    col_net.load_state_dict(col_sd)
+    col_net = col_net.cuda()
+    pack = FieldPack(sdf_net, col_net, precision)
+    wh = w.cuda().requires_grad_(True)
+    _, gamma, beta = pack.film(w=wh)
+    sdf, grad, rgb, _ = sdf_mlp(pack, pts.cuda(), gamma, beta, B, True, True, False)
+    loss = (sdf * cs.cuda()).sum() + (grad * cg.cuda()).sum() + (rgb * cr.cuda()).sum()
+    assert abs(float(loss) - loss_o) < 1e-3 * max(1.0, abs(loss_o))
+    named = [("sdf." + k, v) for k, v in sdf_net.named_parameters() if not k.startswith("style.")] + \
+            [("col." + k, v) for k, v in col_net.named_parameters()] + [("w", wh)]
+    gr = torch.autograd.grad(loss, [v for _, v in named])
+    worst = {}
+    for (name, _), a in zip(named, gr):
+        worst[name] = rel_err(a, g_o[name])
+    bad = {k: v for k, v in worst.items() if v > tol}
+    assert not bad, bad
+
+
+def test_generator_grads_golden_f6():
+    """The reference's own parameter gradients for loss = sum(image) + 10*eikonal + sum(shading) + 0.5*sum(mask)
+    (training mode: jitter on, cos_anneal 0.4) -- exercises MLP double-backward + compositing backward + light."""
+    from oi_amd.fields import ShapeNetwork, ColorNetwork, SingleVarianceNetwork
+    from oi_amd.renderer import NeuSRenderer
+    from oi_amd.lighting import DirectionalLightWithSpecularFixInit
+    g = load_golden("f6_grads")
+    p = sub_sd(g, "p.")
+    sdf = ShapeNetwork(None, **NET_KW)
+    sdf.load_state_dict(sub_sd(p, "sdf_network."))
+    col = ColorNetwork(**NET_KW)
+    col.load_state_dict(sub_sd(p, "color_network."))
+    dev = SingleVarianceNetwork(0.3)
+    dev.load_state_dict(sub_sd(p, "deviation_network."))
+    light = DirectionalLightWithSpecularFixInit(direction=[0, 0, -1.0])
+    light.load_state_dict(sub_sd(p, "light."))
+    sdf, col, dev, light = sdf.cuda(), col.cuda(), dev.cuda(), light.cuda()
+    r = NeuSRenderer(None, sdf, dev, col, n_samples=8, n_importance=8, n_outside=0, up_sample_steps=1, perturb=1)
+    ro, rd = g["rays_o"].cuda(), g["rays_d"].cuda()
+    near, far = O.near_far_from_sphere(g["rays_o"], g["rays_d"])
+    # inject the reference's jitter draw (first RNG call of render, renderer.py:372)
+    import oi_amd.renderer as RR
+    real_rand = torch.rand
+    try:
+        torch.rand = lambda *a, **k: g["jitter"].cuda()
+        w = sdf.style(g["z"].cuda())
+        w2b = O.invert_rot_t(g["b2w"]).cuda()
+        s, c = r.render_full(ro, rd, near.cuda(), far.cuda(), perturb_overwrite=1, cos_anneal_ratio=float(g["cos_anneal_ratio"]),
+                             z=g["z"].cuda(), w=w, light=light.packed(), light_dir=light.batch_direction(w2b), bg=g["bg"].cuda())
+    finally:
+        torch.rand = real_rand
+    to_map = lambda x: x.reshape(1, 8, 8, -1).permute(0, 3, 1, 2)
+    image, shading, mask = to_map(c["image"]), to_map(c["shading"]).expand(1, 3, 8, 8), to_map(c["mask"])
+    eik = c["reduce4"][0] / (c["reduce4"][1] + 1e-5)
+    assert maxdiff(image.cpu(), g["image"]) < 1e-4 and maxdiff(mask.cpu(), g["mask"]) < 1e-4
+    assert abs(float(eik) - float(g["eikonal"])) < 1e-4
+    loss = image.sum() + 10.0 * eik + shading.sum() + 0.5 * mask.sum()
+    assert abs(float(loss) - float(g["loss"])) < 1e-3
+    named = [("sdf_network." + k, v) for k, v in sdf.named_parameters()] + [("color_network." + k, v) for k, v in col.named_parameters()] + \
+            [("deviation_network." + k, v) for k, v in dev.named_parameters()] + [("light." + k, v) for k, v in light.named_parameters()]
+    grads = torch.autograd.grad(loss, [v for _, v in named], allow_unused=True)
+    checked, bad = 0, {}
+    for (name, _), gr in zip(named, grads):
+        key = "g." + name
+        if key not in g:
+            assert gr is None or float(gr.abs().max()) == 0.0, name
+            continue
+        ref = g[key]
+        err = maxdiff(gr.cpu(), ref) / max(1.0, float(ref.abs().max()))
+        if err > 3e-3:
+            bad[name] = err
+        checked += 1
+    assert checked > 60 and not bad, bad
