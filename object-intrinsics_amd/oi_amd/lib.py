@@ -35,6 +35,13 @@ class CompositeGrads(ctypes.Structure):
                                    "d_sdf", "d_grad", "d_rgb", "d_variance", "d_light", "d_light_dir")]
 
 
+class CompositeGrads(ctypes.Structure):
+    """Mirror of `oi_composite_grads` (include/oi_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("g_weights", "g_weight_sum", "g_color_fine", "g_image_no_bg", "g_image", "g_shading",
+                                   "g_normal", "g_mask", "g_z_map", "g_specular_map", "g_diffuse_map", "g_reduce4",
+                                   "d_sdf", "d_grad", "d_rgb", "d_variance", "d_light", "d_light_dir")]
+
+
 _SIGS = {
     "oi_version": (_i, []),
     "oi_arch": (ctypes.c_char_p, []),
@@ -67,14 +74,7 @@ _SIGS = {
 }
 
 # entry points added by later source files (backward kernels); bound when present in the .so
-_OPTIONALclass CompositeGrads(ctypes.Structure):
-    """Mirror of `oi_composite_grads` (include/oi_hip.h)."""
-    _fields_ = [(n, _vp) for n in ("g_weights", "g_weight_sum", "g_color_fine", "g_image_no_bg", "g_image", "g_shading",
-                                   "g_normal", "g_mask", "g_z_map", "g_specular_map", "g_diffuse_map", "g_reduce4",
-                                   "d_sdf", "d_grad", "d_rgb", "d_variance", "d_light", "d_light_dir")]
-
-
-_SIGS = {}
+_OPTIONAL_SIGS = {}
 
 
 class OiHipError(RuntimeError):
