@@ -1,0 +1,95 @@
+"""One GAN training iteration over the oi_amd modules, with the call pattern, loss composition and
+weights of the reference trainer (src/trainers/gan_pose_trainer.py:77-202; configs/train.yaml:120-147):
+
+    G step:   render (grad) -> D(image)[:, :1], maskD(mask) -> BCE(.,1) + 0.1*BCE(.,1) + 10*eikonal -> backward, Adam
+    D step:   render (no grad) -> BCE(D(real),1) + BCE(D(fake)[:, :1],0) + 10*R1(real) + w(it)*MSE(D(fake)[:,1:7], pose)
+    maskD:    render (no grad) -> same without the pose term
+i.e. 3 renders, 3+3 discriminator forwards, 3 backward passes (each followed by the flat-gradient
+all-reduce when wrapped in oi_amd.ddp.FlatGradDDP) per iteration.  The reference's own Trainer class
+also runs unmodified on these modules (they keep its interfaces); this compact restatement exists so
+that bench.py / tests can drive a full iteration without the reference's logging/visualisation stack
+(tu.*, tensorboard, torchvision: absent from this image)."""
+import torch
+
+from .losses import GANLoss, PositionLoss, compute_grad2, linear_increase
+
+MODULE_KEYS = ("generator", "discriminator", "mask_discriminator")
+DATA_KEYS = {"generator": ["image"], "discriminator": ["image"], "mask_discriminator": ["mask"]}
+
+
+def toggle_grad(model, requires_grad):
+    for p in model.parameters():
+        p.requires_grad_(requires_grad)
+
+
+def _unwrap(m):
+    return m.module if hasattr(m, "module") and isinstance(m.module, torch.nn.Module) else m
+
+
+class Trainer:
+    def __init__(self, modules, loss_weight=None, it=-1):
+        self.modules = modules
+        for k in MODULE_KEYS:
+            setattr(self, k, modules[k])
+            setattr(self, f"opt_{k}", modules[f"opt_{k}"])
+        lw = dict(disc_in_gen=1.0, mask_disc_in_gen=0.1, eikonal=10.0, reg=10.0, aux_pose=linear_increase(1000, 1))
+        lw.update(loss_weight or {})
+        self.loss_weight = lw
+        self.gan, self.aux_pose = GANLoss("bce"), PositionLoss("mse")
+        self.it = it
+
+    def train_step(self, data):
+        self.it += 1
+        for k in MODULE_KEYS:
+            self.modules[k].train()
+        bs = data["image"].shape[0]
+        out = {}
+        out.update(self.train_step_generator(bs))
+        with torch.no_grad():
+            blob = self.generator(bs=bs, it=self.it, data={}, return_raw=False)["box"]
+        out.update(self.train_step_discriminator("discriminator", data, {**blob["render_out"], "c2b": blob["prior_info"]["c2b"]}))
+        with torch.no_grad():
+            blob = self.generator(bs=bs, it=self.it, data={}, return_raw=False)["box"]
+        out.update(self.train_step_discriminator("mask_discriminator", data, blob["render_out"]))
+        return out
+
+    def train_step_generator(self, bs):
+        for k in MODULE_KEYS:
+            toggle_grad(self.modules[k], k == "generator")
+        self.opt_generator.zero_grad(set_to_none=False)
+        blob = self.generator(bs=bs, it=self.it, data={}, return_raw=False)["box"]
+        x_fake = torch.cat([blob["render_out"][k] for k in DATA_KEYS["discriminator"]], dim=-3)
+        loss_disc = self.gan(self.discriminator(x_fake, it=self.it)[:, :1], 1)
+        m_fake = torch.cat([blob["render_out"][k] for k in DATA_KEYS["mask_discriminator"]], dim=-3)
+        loss_mask = self.gan(self.mask_discriminator(m_fake, it=self.it), 1)
+        loss = loss_disc * self.loss_weight["disc_in_gen"] + loss_mask * self.loss_weight["mask_disc_in_gen"]
+        ret = {"generator/loss": loss_disc, "generator/loss_mask": loss_mask}
+        for k, v in blob["loss"].items():
+            loss = loss + self.loss_weight[k] * v
+            ret[f"generator/{k}"] = v
+        loss.backward()
+        self.opt_generator.step()
+        return ret
+
+    def train_step_discriminator(self, key, real, fake):
+        for k in MODULE_KEYS:
+            toggle_grad(self.modules[k], k == key)
+        disc, opt = self.modules[key], self.modules[f"opt_{key}"]
+        opt.zero_grad(set_to_none=False)
+        x_real = torch.cat([real[k] for k in DATA_KEYS[key]], dim=-3).detach().clone().requires_grad_()
+        d_real = disc(x_real, it=self.it)[:, :1]
+        loss_real = self.gan(d_real, 1)
+        loss_reg = compute_grad2(d_real, x_real)
+        x_fake = torch.cat([fake[k] for k in DATA_KEYS[key]], dim=-3).detach().clone().requires_grad_()
+        d_fake = disc(x_fake, it=self.it)
+        loss_aux = 0
+        if d_fake.size(1) > 1:
+            prior = _unwrap(self.generator).pose_prior
+            d_fake, d_aux = torch.split(d_fake, (1, prior.repr_dim), dim=1)
+            loss_aux = self.aux_pose(d_aux, prior.pose_to_vec_repr(fake["c2b"]))
+        loss_fake = self.gan(d_fake, 0)
+        loss = loss_real + loss_fake + loss_reg * self.loss_weight["reg"] + loss_aux * self.loss_weight["aux_pose"](self.it)
+        loss.backward()
+        opt.step()
+        return {f"{key}/loss": loss_fake + loss_real, f"{key}/reg": loss_reg, f"{key}/fake": loss_fake,
+                f"{key}/real": loss_real, f"{key}/aux_pose": loss_aux}

@@ -481,6 +481,33 @@ def ada_margins(G_inv, width, height, hz_pad=3):
     return [int(v) for v in m.ceil().to(torch.int32)]
 
 
+def affine_bilinear_sample(x, theta, Ho, Wo):
+    """F.affine_grid + F.grid_sample(bilinear, zeros, align_corners=False) restated with gathers so that
+    it is differentiable to any order (ATen's grid_sampler backward has no derivative formula, which
+    is why the reference carries grid_sample_gradfix.py:69-97)."""
+    B, C, Hi, Wi = x.shape
+    dt = x.dtype
+    xs = (2.0 * torch.arange(Wo, dtype=dt) + 1.0) / Wo - 1.0
+    ys = (2.0 * torch.arange(Ho, dtype=dt) + 1.0) / Ho - 1.0
+    gx = theta[:, 0, 0, None, None] * xs[None, None, :] + theta[:, 0, 1, None, None] * ys[None, :, None] + theta[:, 0, 2, None, None]
+    gy = theta[:, 1, 0, None, None] * xs[None, None, :] + theta[:, 1, 1, None, None] * ys[None, :, None] + theta[:, 1, 2, None, None]
+    ix = ((gx + 1.0) * Wi - 1.0) * 0.5
+    iy = ((gy + 1.0) * Hi - 1.0) * 0.5
+    x0, y0 = torch.floor(ix), torch.floor(iy)
+    tx, ty = ix - x0, iy - y0
+    x0, y0 = x0.long(), y0.long()
+    out = 0
+    flat = x.reshape(B, C, Hi * Wi)
+    for dy, wy in ((0, 1 - ty), (1, ty)):
+        for dx, wx in ((0, 1 - tx), (1, tx)):
+            xi, yi = x0 + dx, y0 + dy
+            ok = ((xi >= 0) & (xi < Wi) & (yi >= 0) & (yi < Hi)).to(dt)
+            idx = (yi.clamp(0, Hi - 1) * Wi + xi.clamp(0, Wi - 1)).reshape(B, 1, Ho * Wo).expand(B, C, Ho * Wo)
+            v = torch.gather(flat, 2, idx).reshape(B, C, Ho, Wo)
+            out = out + v * (wx * wy * ok)[:, None]
+    return out
+
+
 def ada_geometric(images, G_inv):
     """Execute the geometric part of AugmentPipe for a given per-sample G_inv (B,3,3):
     reflect pad -> x2 sym6 upsample -> affine bilinear resample -> /2 sym6 downsample.
@@ -498,8 +525,7 @@ def ada_geometric(images, G_inv):
     shape = [B, C, (H + hz_pad * 2) * 2, (W_ + hz_pad * 2) * 2]
     G = _s2d(2 / up.shape[3], 2 / up.shape[2], dt) @ G @ _s2d(shape[3] / 2, shape[2] / 2, dt)
     theta = G[:, :2, :]
-    grid = F.affine_grid(theta, shape, align_corners=False)
-    smp = F.grid_sample(up, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    smp = affine_bilinear_sample(up, theta, shape[2], shape[3])
     out = downsample2d(smp, f1, down=2, padding=-hz_pad * 2, flip=True)
     return out, {"padded": x, "up": up, "theta": theta, "sampled": smp,
                  "margins": (mx0, my0, mx1, my1)}
