@@ -123,6 +123,45 @@ def cpu_baseline(R, S, I, K, B):
                       f"({dt:.1f} s, torch CPU fp32, {cores} threads)"}
 
 
+def bench_training(args, gen, disc, device, world, barrier):
+    from oi_amd.config import build_from_config
+    from oi_amd.ddp import FlatGradDDP
+    from oi_amd.trainer import Trainer
+    R, B = args.res, args.batch
+    net = lambda t, **kw: {"__target__": t, "kwargs": kw}
+    mdisc = build_from_config(net("src.models.discriminator.ADADiscriminator",
+                                  aug=net("src.third_party.ada.augment.AugmentPipe", scale=1, xint=1), aug_p=1,
+                                  img_size=R, in_dim=1, last_bias=False, n_feat=512, out_dim=1)).to(device)
+    nets = {"generator": gen, "discriminator": disc, "mask_discriminator": mdisc}
+    if world > 1:
+        nets = {k: FlatGradDDP(v) for k, v in nets.items()}
+    mods = dict(nets)
+    mods["opt_generator"] = torch.optim.Adam(nets["generator"].parameters(), lr=2e-5, betas=(0.0, 0.9))
+    mods["opt_discriminator"] = torch.optim.RMSprop(nets["discriminator"].parameters(), lr=1e-4)
+    mods["opt_mask_discriminator"] = torch.optim.RMSprop(nets["mask_discriminator"].parameters(), lr=1e-4)
+    tr = Trainer(mods)
+    data = {"image": torch.rand(B, 3, R, R, device=device), "mask": torch.rand(B, 1, R, R, device=device)}
+    for _ in range(2):
+        tr.train_step(data)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        out = tr.train_step(data)
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt)
+    it_s = args.train_steps / dt
+    return {"it_per_s": it_s, "ms_per_it": 1e3 / it_s, "steps": args.train_steps,
+            "rays_per_s": 3 * world * B * R * R * it_s, "d_train_images_per_s": 4 * world * B * it_s,
+            "what": "Trainer.train_step: G step (render fwd+bwd incl. double-backward, 2 D fwd+bwd-to-input) + D step "
+                    "+ mask-D step (each: real fwd + R1 double-backward + fake fwd + bwd), Adam/RMSprop steps"
+                    + (", flat-gradient RCCL all-reduce x3" if world > 1 else ""),
+            "finite": bool(all(torch.isfinite(torch.as_tensor(v)).all() for v in out.values()))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,6 +173,7 @@ def main():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--importance", type=int, default=64)
     ap.add_argument("--up-steps", type=int, default=1)
+    ap.add_argument("--train-steps", type=int, default=8, help="full GAN training iterations timed after the main region (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-disc", action="store_true")
     args = ap.parse_args()
@@ -202,6 +242,15 @@ def main():
     dt = time.perf_counter() - t0
     timer_on[0] = False
 
+    # ---- full training iteration (3 renders, 6 D forwards, 3 backward + optimiser steps, flat-gradient
+    #      all-reduce per network when N > 1); reported next to the headline, not part of `value`
+    train = None
+    if args.train_steps > 0 and not args.no_disc:
+        try:
+            train = bench_training(args, gen, disc, device, world, barrier)
+        except Exception as ex:  # never lose the headline line because of the secondary measurement
+            train = {"error": f"{type(ex).__name__}: {ex}"}
+
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     dd = torch.tensor([d_img_s or 0.0], device=device, dtype=torch.float64)
     if world > 1:
@@ -230,6 +279,7 @@ def main():
                        "rays_per_step_per_gpu": B * R * R, "points_per_step_per_gpu": n_pts,
                        "parallelism": f"dp{world} (independent renders, no data-path collective)"},
             "d_images_per_s": float(dd) if d_img_s else None,
+            "training": train,
             "roofline": {"bound": "mfma", "kernel": "sdf_mlp_kernel<full> (sdf + d sdf/dx + albedo at the fine samples)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": None,

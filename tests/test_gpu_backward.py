@@ -293,7 +293,7 @@ def test_full_training_iteration_runs_and_learns():
     disc = mk(3, 7, "ADADiscriminatorView", dict(out_dim_latent=0, out_dim_position=6))
     mdisc = mk(1, 1, "ADADiscriminator", {})
     modules = {"generator": gen, "discriminator": disc, "mask_discriminator": mdisc,
-               "opt_generator": torch.optim.Adam(gen.parameters(), lr=2e-5, betas=(0, 0.9)),
+               "opt_generator": torch.optim.Adam(gen.parameters(), lr=2e-5, betas=(0.0, 0.9)),
                "opt_discriminator": torch.optim.RMSprop(disc.parameters(), lr=1e-4),
                "opt_mask_discriminator": torch.optim.RMSprop(mdisc.parameters(), lr=1e-4)}
     tr = Trainer(modules)
