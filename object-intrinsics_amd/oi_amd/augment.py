@@ -16,28 +16,31 @@ SYM6 = [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.04
         -0.021060292512300564, 0.04472490177066578, 0.0017677118642428036, -0.007800708325034148]
 
 
-def _mat(rows, ref):
-    """3x3 matrices from python scalars / (B,) tensors, batched over ref's batch.  Host tensors: the
-    augmentation parameters are O(B) scalars, so they are sampled and composed on the CPU (no launches,
-    and the data-dependent padding margins need no device->host read, unlike augment.py:283)."""
-    B = ref.shape[0]
-    out = torch.zeros(B, 3, 3, dtype=torch.float32)
+def _mat(rows, B):
+    """(B,3,3) float32 matrices from python scalars / (B,) arrays.  numpy on the host: the augmentation
+    parameters are O(B) scalars, so they are sampled and composed on the CPU (no kernel launches, and the
+    data-dependent padding margins need no device->host read, unlike augment.py:283)."""
+    out = np.zeros((B, 3, 3), dtype=np.float32)
     for i, row in enumerate(rows):
         for j, v in enumerate(row):
             out[:, i, j] = v
     return out
 
 
-def translate2d(tx, ty, ref):
-    return _mat([[1, 0, tx], [0, 1, ty], [0, 0, 1]], ref)
+def translate2d(tx, ty, B):
+    return _mat([[1, 0, tx], [0, 1, ty], [0, 0, 1]], B)
 
 
-def scale2d(sx, sy, ref):
-    return _mat([[sx, 0, 0], [0, sy, 0], [0, 0, 1]], ref)
+def scale2d(sx, sy, B):
+    return _mat([[sx, 0, 0], [0, sy, 0], [0, 0, 1]], B)
 
 
-def rotate2d(theta, ref):
-    return _mat([[torch.cos(theta), torch.sin(-theta), 0], [torch.sin(theta), torch.cos(theta), 0], [0, 0, 1]], ref)
+def rotate2d(theta, B):
+    return _mat([[np.cos(theta), np.sin(-theta), 0], [np.sin(theta), np.cos(theta), 0], [0, 0, 1]], B)
+
+
+def _erfinv(x):
+    return float(torch.erfinv(torch.tensor(float(x), dtype=torch.float32)))
 
 
 class AugmentPipe(torch.nn.Module):
@@ -72,68 +75,67 @@ class AugmentPipe(torch.nn.Module):
         return self._p_cache[1]
 
     def sample_G_inv(self, images, debug_percentile=None):
-        """augment.py:191-268 for the geometric branches.  Returns (B,3,3) or None (identity)."""
+        """augment.py:191-268 for the geometric branches.  Returns a (B,3,3) float32 numpy array or None."""
         B, _, H, W = images.shape
-        dev = torch.device("cpu")
-        ref = images
-        p_host = float(self._p_host()) if not isinstance(self.p, float) else self.p
-        pct = None if debug_percentile is None else torch.as_tensor(debug_percentile, dtype=torch.float32)
+        p = self._p_host()
+        pct = None if debug_percentile is None else float(debug_percentile)
+        f32 = np.float32
         G = None
 
         def mul(G, M):
-            return M if G is None else G @ M
+            return M if G is None else (G @ M).astype(f32)
 
-        rand = lambda *s: torch.rand(list(s), device=dev)
-        randn = lambda *s: torch.randn(list(s), device=dev)
+        rand = lambda *s: np.random.rand(*s).astype(f32)
+        randn = lambda *s: np.random.randn(*s).astype(f32)
         if self.xflip > 0:
-            i = torch.floor(rand(B) * 2)
-            i = torch.where(rand(B) < self.xflip * p_host, i, torch.zeros_like(i))
+            i = np.floor(rand(B) * 2)
+            i = np.where(rand(B) < self.xflip * p, i, 0).astype(f32)
             if pct is not None:
-                i = torch.full_like(i, torch.floor(pct * 2))
-            G = mul(G, scale2d(1 / (1 - 2 * i), 1, ref))
+                i = np.full(B, np.floor(f32(pct) * 2), f32)
+            G = mul(G, scale2d(1 / (1 - 2 * i), 1, B))
         if self.rotate90 > 0:
-            i = torch.floor(rand(B) * 4)
-            i = torch.where(rand(B) < self.rotate90 * p_host, i, torch.zeros_like(i))
+            i = np.floor(rand(B) * 4)
+            i = np.where(rand(B) < self.rotate90 * p, i, 0).astype(f32)
             if pct is not None:
-                i = torch.full_like(i, torch.floor(pct * 4))
-            G = mul(G, rotate2d(np.pi / 2 * i, ref))
+                i = np.full(B, np.floor(f32(pct) * 4), f32)
+            G = mul(G, rotate2d((np.pi / 2 * i).astype(f32), B))
         if self.xint > 0:
-            t = (rand(B, 2) * 2 - 1) * self.xint_max
-            t = torch.where(rand(B, 1) < self.xint * p_host, t, torch.zeros_like(t))
+            t = (rand(B, 2) * 2 - 1) * f32(self.xint_max)
+            t = np.where(rand(B, 1) < self.xint * p, t, 0).astype(f32)
             if pct is not None:
-                t = torch.full_like(t, (pct * 2 - 1) * self.xint_max)
-            G = mul(G, translate2d(-torch.round(t[:, 0] * W), -torch.round(t[:, 1] * H), ref))
+                t = np.full((B, 2), (f32(pct) * 2 - 1) * f32(self.xint_max), f32)
+            G = mul(G, translate2d(-np.round(t[:, 0] * f32(W)), -np.round(t[:, 1] * f32(H)), B))
         if self.scale > 0:
-            s = torch.exp2(randn(B) * self.scale_std)
-            s = torch.where(rand(B) < self.scale * p_host, s, torch.ones_like(s))
+            s = np.exp2(randn(B) * f32(self.scale_std))
+            s = np.where(rand(B) < self.scale * p, s, 1).astype(f32)
             if pct is not None:
-                s = torch.full_like(s, torch.exp2(torch.erfinv(pct * 2 - 1) * self.scale_std))
-            G = mul(G, scale2d(1 / s, 1 / s, ref))
-        p_rot = 1 - torch.sqrt(torch.tensor(1 - self.rotate * p_host).clamp(0, 1))
+                s = np.full(B, np.exp2(f32(_erfinv(pct * 2 - 1)) * f32(self.scale_std)), f32)
+            G = mul(G, scale2d(1 / s, 1 / s, B))
+        p_rot = 1 - np.sqrt(np.clip(1 - self.rotate * p, 0, 1))
         if self.rotate > 0:
-            th = (rand(B) * 2 - 1) * np.pi * self.rotate_max
-            th = torch.where(rand(B) < p_rot, th, torch.zeros_like(th))
+            th = (rand(B) * 2 - 1) * f32(np.pi * self.rotate_max)
+            th = np.where(rand(B) < p_rot, th, 0).astype(f32)
             if pct is not None:
-                th = torch.full_like(th, (pct * 2 - 1) * np.pi * self.rotate_max)
-            G = mul(G, rotate2d(th, ref))
+                th = np.full(B, (f32(pct) * 2 - 1) * f32(np.pi * self.rotate_max), f32)
+            G = mul(G, rotate2d(th, B))
         if self.aniso > 0:
-            s = torch.exp2(randn(B) * self.aniso_std)
-            s = torch.where(rand(B) < self.aniso * p_host, s, torch.ones_like(s))
+            s = np.exp2(randn(B) * f32(self.aniso_std))
+            s = np.where(rand(B) < self.aniso * p, s, 1).astype(f32)
             if pct is not None:
-                s = torch.full_like(s, torch.exp2(torch.erfinv(pct * 2 - 1) * self.aniso_std))
-            G = mul(G, scale2d(1 / s, s, ref))
+                s = np.full(B, np.exp2(f32(_erfinv(pct * 2 - 1)) * f32(self.aniso_std)), f32)
+            G = mul(G, scale2d(1 / s, s, B))
         if self.rotate > 0:
-            th = (rand(B) * 2 - 1) * np.pi * self.rotate_max
-            th = torch.where(rand(B) < p_rot, th, torch.zeros_like(th))
+            th = (rand(B) * 2 - 1) * f32(np.pi * self.rotate_max)
+            th = np.where(rand(B) < p_rot, th, 0).astype(f32)
             if pct is not None:
-                th = torch.zeros_like(th)
-            G = mul(G, rotate2d(th, ref))
+                th = np.zeros(B, f32)
+            G = mul(G, rotate2d(th, B))
         if self.xfrac > 0:
-            t = randn(B, 2) * self.xfrac_std
-            t = torch.where(rand(B, 1) < self.xfrac * p_host, t, torch.zeros_like(t))
+            t = randn(B, 2) * f32(self.xfrac_std)
+            t = np.where(rand(B, 1) < self.xfrac * p, t, 0).astype(f32)
             if pct is not None:
-                t = torch.full_like(t, torch.erfinv(pct * 2 - 1) * self.xfrac_std)
-            G = mul(G, translate2d(-t[:, 0] * W, -t[:, 1] * H, ref))
+                t = np.full((B, 2), f32(_erfinv(pct * 2 - 1)) * f32(self.xfrac_std), f32)
+            G = mul(G, translate2d(-t[:, 0] * f32(W), -t[:, 1] * f32(H), B))
         return G
 
     def forward(self, images, debug_percentile=None):
@@ -142,26 +144,27 @@ class AugmentPipe(torch.nn.Module):
         G_inv = self.sample_G_inv(images, debug_percentile)
         if G_inv is None:
             return images
-        ref = images
-        # padding margins (augment.py:272-283), computed on the host copy of G_inv
+        f32 = np.float32
+        # padding margins (augment.py:272-283), on the host copy of G_inv
         cx, cy = (W - 1) / 2, (H - 1) / 2
-        cp = torch.tensor([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]])
-        cp = G_inv @ cp.t()
+        cp = np.array([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]], f32)
+        cp = G_inv @ cp.T                                     # (B, 3, 4)
         Hz_pad = self.Hz_geom.shape[0] // 4
-        m = cp[:, :2, :].permute(1, 0, 2).flatten(1)
-        m = torch.cat([-m, m]).max(dim=1).values
-        m = m + torch.tensor([Hz_pad * 2 - cx, Hz_pad * 2 - cy] * 2)
-        m = m.max(torch.zeros(4)).min(torch.tensor([W - 1, H - 1] * 2, dtype=torch.float32))
-        mx0, my0, mx1, my1 = (int(v) for v in m.ceil().to(torch.int32).tolist())
+        m = cp[:, :2, :].transpose(1, 0, 2).reshape(2, -1)    # [xy, batch * idx]
+        m = np.concatenate([-m, m]).max(axis=1)               # [x0, y0, x1, y1]
+        m = m + np.array([Hz_pad * 2 - cx, Hz_pad * 2 - cy] * 2, f32)
+        m = np.minimum(np.maximum(m, 0), np.array([W - 1, H - 1] * 2, f32))
+        mx0, my0, mx1, my1 = (int(v) for v in np.ceil(m))
 
         x = reflect_pad(images, mx0, mx1, my0, my1)
-        G_inv = translate2d((mx0 - mx1) / 2, (my0 - my1) / 2, ref) @ G_inv
+        mm = lambda a, b: (a @ b).astype(f32)
+        G_inv = mm(translate2d((mx0 - mx1) / 2, (my0 - my1) / 2, B), G_inv)
         x = upfirdn2d_separable(x, self.Hz_geom, up=2, pad=(6, 5, 6, 5), flip=False, gain=4.0)  # upsample2d
-        G_inv = scale2d(2, 2, ref) @ G_inv @ scale2d(0.5, 0.5, ref)
-        G_inv = translate2d(-0.5, -0.5, ref) @ G_inv @ translate2d(0.5, 0.5, ref)
+        G_inv = mm(mm(scale2d(2, 2, B), G_inv), scale2d(0.5, 0.5, B))
+        G_inv = mm(mm(translate2d(-0.5, -0.5, B), G_inv), translate2d(0.5, 0.5, B))
         Ho, Wo = (H + Hz_pad * 2) * 2, (W + Hz_pad * 2) * 2
-        G_inv = scale2d(2 / x.shape[3], 2 / x.shape[2], ref) @ G_inv @ scale2d(Wo / 2, Ho / 2, ref)
-        theta = G_inv[:, :2, :].contiguous().to(images.device, non_blocking=True)
+        G_inv = mm(mm(scale2d(2 / x.shape[3], 2 / x.shape[2], B), G_inv), scale2d(Wo / 2, Ho / 2, B))
+        theta = torch.from_numpy(np.ascontiguousarray(G_inv[:, :2, :])).to(images.device, non_blocking=True)
         x = affine_grid_sample(x, theta, Ho, Wo)
         # downsample2d(padding=-2*Hz_pad, flip_filter=True): pad = -6 + (12-2+1)//2 = -1, -6 + 5 = -1
         return upfirdn2d_separable(x, self.Hz_geom, down=2, pad=(-1, -1, -1, -1), flip=True, gain=1.0)
