@@ -137,8 +137,162 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Forward kernel, v2: 8 wavefronts (256 points) per workgroup, the 15 layer images stream through a
+// DOUBLE-BUFFERED LDS ring filled by global_load_lds (LDS-DMA, no VGPR round trip): the image of layer
+// i+1 is in flight while layer i's MFMAs run, and there is ONE barrier per layer.  FiLM vectors of all
+// 9 layers are staged once.  (v1 staged synchronously with two barriers per layer: 56 % of the fp32
+// MFMA peak, matrix pipe 64 % busy -- profiles/r1_*.)
+// ------------------------------------------------------------------------------------------
+constexpr int V2_WAVES = 8;
+constexpr int V2_TILE = V2_WAVES * WAVE_PTS;  // 256 points
+constexpr int V2_FILM = 0;                    // [9][gamma 128 | beta 128 | bias 128]
+constexpr int V2_TABS = 9 * 1536;             // 13824
+constexpr int V2_WBUF = V2_TABS + H_TABS_END * 4;  // 20096
+__host__ __device__ constexpr int v2_lds_total(int prec) { return V2_WBUF + 2 * layer_bytes(prec); }
+
+struct LayOff {  // per-layer runtime VGPR bases (everything else is an immediate)
+  int wl;   // 16*lane + ring slot base
+  int wh;   // wl + 32768
+  int f16;  // 16*h + 1536*layer  (FiLM rows of this layer)
+};
+
+template <int PREC>
+__device__ __forceinline__ void prefetch_image(char* lds, const char* __restrict__ src, int slot, int wave, int lane) {
+  constexpr int NCHUNK = layer_bytes(PREC) / 1024;
+#pragma unroll
+  for (int c0 = 0; c0 < NCHUNK / V2_WAVES; ++c0) {
+    const int c = c0 * V2_WAVES + wave;
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(src + c * 1024 + lane * 16),
+        (__attribute__((address_space(3))) void*)(lds + V2_WBUF + slot * layer_bytes(PREC) + c * 1024), 16, 0, 0);
+  }
+}
+
+template <int PREC>
+__device__ __forceinline__ LayOff lay_off(const LaneOff& o, int slot, int layer) {
+  LayOff r;
+  r.wl = o.l16 + V2_WBUF + slot * layer_bytes(PREC);
+  r.wh = r.wl + 32768;
+  r.f16 = o.h16 + V2_FILM + layer * 1536;
+  return r;
+}
+
+template <int PREC>
+__device__ __forceinline__ void gemm_layer2(const char* lds, const LayOff& y, const float (&act)[64], f32x16 (&acc)[4]) {
+  if constexpr (PREC == OI_PREC_F32) {
+    f32x4 a[4], an[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = lds_f4(lds, ((t * 16 + 0) * 1024) & 32767, t < 2 ? y.wl : y.wh);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      if (g < 15) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) an[t] = lds_f4(lds, ((t * 16 + g + 1) * 1024) & 32767, t < 2 ? y.wl : y.wh);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][k], act[4 * g + k], acc[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = an[t];
+    }
+  } else {
+    f32x4 ah[4], ahn[4], al[4], aln[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ah[t] = lds_f4(lds, (t * 8 + 0) * 1024, y.wl);
+      if constexpr (PREC == OI_PREC_BF16X3) al[t] = lds_f4(lds, (t * 8 + 0) * 1024, y.wh);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < 7) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          ahn[t] = lds_f4(lds, (t * 8 + s + 1) * 1024, y.wl);
+          if constexpr (PREC == OI_PREC_BF16X3) aln[t] = lds_f4(lds, (t * 8 + s + 1) * 1024, y.wh);
+        }
+      }
+      bf16x8 bh, bl;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = act[8 * s + i];
+        bh[i] = (__bf16)v;
+        if constexpr (PREC == OI_PREC_BF16X3) bl[i] = (__bf16)(v - (float)bh[i]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, ah[t]);
+        if constexpr (PREC == OI_PREC_BF16X3) {
+          const bf16x8 wl = __builtin_bit_cast(bf16x8, al[t]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc[t], 0, 0, 0);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        ah[t] = ahn[t];
+        if constexpr (PREC == OI_PREC_BF16X3) al[t] = aln[t];
+      }
+    }
+  }
+}
+
+template <bool FAST, bool FULL, int SRC>
+__device__ __forceinline__ void film_sin2(const char* lds, const LaneOff& o, const LayOff& y, const f32x16 (&acc)[4],
+                                          float (&act)[64], const WaveScratch& ws, int slot, int tab_imm, float vx,
+                                          float vy, float vz) {
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int t = g >> 2, rr = g & 3;
+    const f32x4 gm = lds_f4(lds, grp_f0(g) * 4, y.f16);
+    const f32x4 bt = lds_f4(lds, (C + grp_f0(g)) * 4, y.f16);
+    f32x4 bs;
+    if constexpr (SRC == 1) bs = lds_f4(lds, (2 * C + grp_f0(g)) * 4, y.f16);
+    f32x4 cv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float u;
+      if constexpr (SRC == 0) {
+        u = acc[t][4 * rr + k];
+      } else {
+        const f32x4 w = lds_f4(lds, V2_TABS + tab_imm * 4 + (grp_f0(g) + k) * 16, o.h64);
+        const float d = fmaf(vz, w[2], fmaf(vy, w[1], vx * w[0]));
+        u = SRC == 1 ? d + bs[k] : acc[t][4 * rr + k] + d;
+      }
+      const float phi = fmaf(gm[k], u, bt[k]);
+      float s, c;
+      sincos_<FAST>(phi, s, c);
+      act[4 * g + k] = s;
+      cv[k] = gm[k] * c;
+    }
+    if constexpr (FULL) ws.store(slot, g, o.l16, cv);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ void init_bias2(const char* lds, const LayOff& y, f32x16 (&acc)[4]) {
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const f32x4 b = lds_f4(lds, (2 * C + grp_f0(g)) * 4, y.f16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[g >> 2][4 * (g & 3) + k] = b[k];
+  }
+}
+
+// wait for this wave's LDS-DMA, then rendezvous: next image resident, previous ring slot free
+__device__ __forceinline__ void ring_sync() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 template <int PREC, bool FAST, bool FULL>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(512, 2)
 sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, const float* __restrict__ gamma,
                const float* __restrict__ beta, float* __restrict__ sdf_out, float* __restrict__ grad_out,
                float* __restrict__ rgb_out, float* __restrict__ feat_out, char* __restrict__ scratch,
@@ -150,6 +304,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   const int e = blockIdx.y;
   const float* hdr = reinterpret_cast<const float*>(packed);
   const char* mats = packed + H_BYTES;
+  constexpr int LB = layer_bytes(PREC);
 
   LaneOff o;
   o.h16 = 16 * h;
@@ -158,42 +313,55 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   o.l16hi = 16 * lane + 32768;
   asm volatile("" : "+v"(o.h16), "+v"(o.h64), "+v"(o.l16), "+v"(o.l16hi));
 
-  const long long local = (long long)blockIdx.x * TILE_PTS + wave * WAVE_PTS + j;
+  const long long local = (long long)blockIdx.x * V2_TILE + wave * WAVE_PTS + j;
   const bool valid = local < n_per_elem;
   const long long pt = (long long)e * n_per_elem + (valid ? local : n_per_elem - 1);
 
-  // scratch of this wave tile: [slot(9)][g(16)][lane(64)] x float4
   WaveScratch ws;
   {
-    const long long wt = ((long long)e * gridDim.x + blockIdx.x) * 4 + wave;
+    const long long wt = ((long long)e * gridDim.x + blockIdx.x) * V2_WAVES + wave;
     char* wbase = FULL ? scratch + wt * (long long)(NSLOT * 16384) : nullptr;
     ws.rs = __builtin_amdgcn_make_buffer_rsrc(wbase, 0, FULL ? NSLOT * 16384 : 0, 0x00020000);
   }
 
-  // stage the small tables + layer-0 FiLM
-  {
-    float* tabs = reinterpret_cast<float*>(lds + L_TABS);
-    for (int i = tid; i < H_TABS_END; i += 256) tabs[i] = hdr[i];
-    stage_film(lds, gamma, beta, hdr, e, 0, tid);
+  // image sequence: i = 0..6 forward layers 1..7 (mats 0..6), i = 7..13 transposed layers 7..1 (mats 13..7),
+  // i = 14 colour head (mat 14); image i lives in ring slot i & 1.
+  prefetch_image<PREC>(lds, mats + 0 * (size_t)LB, 0, wave, lane);
+  {  // small tables + FiLM rows of all 9 layers (gamma | beta | bias), once
+    float* tabs = reinterpret_cast<float*>(lds + V2_TABS);
+    for (int i = tid; i < H_TABS_END; i += 512) tabs[i] = hdr[i];
+    float* film = reinterpret_cast<float*>(lds + V2_FILM);
+    for (int i = tid; i < 9 * C; i += 512) {
+      const int l = i / C, f = i % C;
+      film[l * 384 + f] = gamma[((size_t)e * 9 + l) * C + f];
+      film[l * 384 + C + f] = beta[((size_t)e * 9 + l) * C + f];
+      film[l * 384 + 2 * C + f] = hdr[H_BIAS + l * C + f];
+    }
   }
   const float px = pts[pt * 3 + 0], py = pts[pt * 3 + 1], pz = pts[pt * 3 + 2];
-  __syncthreads();
+  __syncthreads();  // tables visible (image 0 still in flight)
 
   float act[64];
   f32x16 acc[4];
 
-  // ---- layer 0 (K = 3) on the VALU
-  film_sin<FAST, FULL, 1>(lds, o, acc, act, ws, 0, H_TAB0, px, py, pz);
+  // ---- layer 0 (K = 3) on the VALU, overlapping the first image's DMA
+  {
+    const LayOff y = lay_off<PREC>(o, 0, 0);
+    film_sin2<FAST, FULL, 1>(lds, o, y, acc, act, ws, 0, H_TAB0, px, py, pz);
+  }
+  ring_sync();
 
   // ---- layers 1..7 on MFMA
   for (int l = 1; l < NL_SDF; ++l) {
-    __syncthreads();
-    stage_layer<PREC>(lds, mats + (size_t)(l - 1) * layer_bytes(PREC), tid);
-    stage_film(lds, gamma, beta, hdr, e, l, tid);
-    __syncthreads();
-    init_bias(lds, o, acc);
-    gemm_layer<PREC>(lds, o, act, acc);
-    film_sin<FAST, FULL, 0>(lds, o, acc, act, ws, l, 0, 0.f, 0.f, 0.f);
+    const int i = l - 1;
+    // next image: forward layer l+1, or the first transposed image (layer 7) / nothing for the sdf-only variant
+    if (l < NL_SDF - 1) prefetch_image<PREC>(lds, mats + (size_t)l * LB, (i + 1) & 1, wave, lane);
+    else if (FULL) prefetch_image<PREC>(lds, mats + (size_t)13 * LB, (i + 1) & 1, wave, lane);
+    const LayOff y = lay_off<PREC>(o, i & 1, l);
+    init_bias2(lds, y, acc);
+    gemm_layer2<PREC>(lds, y, act, acc);
+    film_sin2<FAST, FULL, 0>(lds, o, y, acc, act, ws, l, 0, 0.f, 0.f, 0.f);
+    ring_sync();
   }
 
   // ---- sdf = a8 . wsig + bsig   (fields.py:68; LinearLayer std_init=1, bias_init=0)
@@ -202,12 +370,12 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
     float part = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const f32x4 w = lds_f4(lds, L_TABS + (H_SIG + grp_f0(g)) * 4, o.h16);
+      const f32x4 w = lds_f4(lds, V2_TABS + (H_SIG + grp_f0(g)) * 4, o.h16);
 #pragma unroll
       for (int k = 0; k < 4; ++k) part = fmaf(act[4 * g + k], w[k], part);
     }
     part += __shfl_xor(part, 32, 64);
-    sdf_v = part + *reinterpret_cast<const float*>(lds + L_TABS + (H_SIG + C) * 4);
+    sdf_v = part + *reinterpret_cast<const float*>(lds + V2_TABS + (H_SIG + C) * 4);
   }
   if (valid && h == 0) sdf_out[pt] = sdf_v;
 
@@ -232,14 +400,12 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
     }
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const f32x4 w = lds_f4(lds, L_TABS + (H_SIG + grp_f0(g)) * 4, o.h16);
+      const f32x4 w = lds_f4(lds, V2_TABS + (H_SIG + grp_f0(g)) * 4, o.h16);
 #pragma unroll
       for (int k = 0; k < 4; ++k) act[4 * g + k] = w[k];
     }
     for (int l = NL_SDF - 1; l >= 1; --l) {
-      __syncthreads();
-      stage_layer<PREC>(lds, mats + (size_t)(7 + l - 1) * layer_bytes(PREC), tid);
-      __syncthreads();
+      const int i = 14 - l;  // image index of transposed layer l
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const f32x4 c = ws.load(l, g, o.l16);
@@ -247,15 +413,21 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
         for (int k = 0; k < 4; ++k) act[4 * g + k] *= c[k];
         if ((g & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
+      // next image after the scratch loads have been consumed (an in-flight LDS-DMA would otherwise be
+      // drained by the vmcnt wait hipcc places in front of the first use of an ordinary load)
+      if (l > 1) prefetch_image<PREC>(lds, mats + (size_t)(7 + l - 2) * LB, (i + 1) & 1, wave, lane);
+      else if (rgb_out != nullptr) prefetch_image<PREC>(lds, mats + (size_t)14 * LB, (i + 1) & 1, wave, lane);
+      const LayOff y = lay_off<PREC>(o, i & 1, l);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-      gemm_layer<PREC>(lds, o, act, acc);
+      gemm_layer2<PREC>(lds, y, act, acc);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) act[16 * t + r] = acc[t][r];
+      ring_sync();
     }
     // layer 0: grad = W0^T (g1 * c0)
     float gx = 0.f, gy = 0.f, gz = 0.f;
@@ -265,7 +437,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float v = act[4 * g + k] * c[k];
-        const f32x4 w = lds_f4(lds, L_TABS + H_TAB0 * 4 + (grp_f0(g) + k) * 16, o.h64);
+        const f32x4 w = lds_f4(lds, V2_TABS + H_TAB0 * 4 + (grp_f0(g) + k) * 16, o.h64);
         gx = fmaf(v, w[0], gx);
         gy = fmaf(v, w[1], gy);
         gz = fmaf(v, w[2], gz);
@@ -283,10 +455,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
 
     if (rgb_out != nullptr) {
       // ---- colour head: sigmoid(Wrgb sin(gv * (Wv [feat, grad] + bv) + bv') + brgb)   (fields.py:89-101)
-      __syncthreads();
-      stage_layer<PREC>(lds, mats + (size_t)14 * layer_bytes(PREC), tid);
-      stage_film(lds, gamma, beta, hdr, e, 8, tid);
-      __syncthreads();
+      // image 14 (ring slot 0) was prefetched during transposed layer 1 and is resident after its ring_sync
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const f32x4 v = ws.load(8, g, o.l16);
@@ -294,15 +463,16 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
         for (int k = 0; k < 4; ++k) act[4 * g + k] = v[k];
         if ((g & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
-      init_bias(lds, o, acc);
-      gemm_layer<PREC>(lds, o, act, acc);
-      film_sin<FAST, false, 2>(lds, o, acc, act, ws, 0, H_TABV, gx, gy, gz);
+      const LayOff y = lay_off<PREC>(o, 0, 8);
+      init_bias2(lds, y, acc);
+      gemm_layer2<PREC>(lds, y, act, acc);
+      film_sin2<FAST, false, 2>(lds, o, y, acc, act, ws, 0, H_TABV, gx, gy, gz);
       float r0 = 0.f, r1 = 0.f, r2 = 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        const f32x4 w0 = lds_f4(lds, L_TABS + (H_RGB + 0 * C + grp_f0(g)) * 4, o.h16);
-        const f32x4 w1 = lds_f4(lds, L_TABS + (H_RGB + 1 * C + grp_f0(g)) * 4, o.h16);
-        const f32x4 w2 = lds_f4(lds, L_TABS + (H_RGB + 2 * C + grp_f0(g)) * 4, o.h16);
+        const f32x4 w0 = lds_f4(lds, V2_TABS + (H_RGB + 0 * C + grp_f0(g)) * 4, o.h16);
+        const f32x4 w1 = lds_f4(lds, V2_TABS + (H_RGB + 1 * C + grp_f0(g)) * 4, o.h16);
+        const f32x4 w2 = lds_f4(lds, V2_TABS + (H_RGB + 2 * C + grp_f0(g)) * 4, o.h16);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           r0 = fmaf(act[4 * g + k], w0[k], r0);
@@ -315,7 +485,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       r1 += __shfl_xor(r1, 32, 64);
       r2 += __shfl_xor(r2, 32, 64);
       if (valid && h == 0) {
-        const float* brgb = reinterpret_cast<const float*>(lds + L_TABS + (H_RGB + 3 * C) * 4);
+        const float* brgb = reinterpret_cast<const float*>(lds + V2_TABS + (H_RGB + 3 * C) * 4);
         rgb_out[pt * 3 + 0] = oi::sigmoidf_(r0 + brgb[0]);
         rgb_out[pt * 3 + 1] = oi::sigmoidf_(r1 + brgb[1]);
         rgb_out[pt * 3 + 2] = oi::sigmoidf_(r2 + brgb[2]);
@@ -327,25 +497,26 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
 template <int PREC, bool FAST>
 int launch_mlp(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf,
                float* grad, float* rgb, float* feat, void* scratch, int B, long long n, hipStream_t st) {
-  dim3 grid(oi::cdiv(n, TILE_PTS), B), block(256);
+  dim3 grid(oi::cdiv(n, V2_TILE), B), block(512);
   const char* pk = reinterpret_cast<const char*>(packed);
+  constexpr int LDS_BYTES = v2_lds_total(PREC);
   if (grad != nullptr) {
     auto k = sdf_mlp_kernel<PREC, FAST, true>;
     static thread_local bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       attr = true;
     }
-    hipLaunchKernelGGL(k, grid, block, L_TOTAL, st, pts, pk, gamma, beta, sdf, grad, rgb, feat,
+    hipLaunchKernelGGL(k, grid, block, LDS_BYTES, st, pts, pk, gamma, beta, sdf, grad, rgb, feat,
                        reinterpret_cast<char*>(scratch), n);
   } else {
     auto k = sdf_mlp_kernel<PREC, FAST, false>;
     static thread_local bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       attr = true;
     }
-    hipLaunchKernelGGL(k, grid, block, L_TOTAL, st, pts, pk, gamma, beta, sdf, (float*)nullptr, (float*)nullptr,
+    hipLaunchKernelGGL(k, grid, block, LDS_BYTES, st, pts, pk, gamma, beta, sdf, (float*)nullptr, (float*)nullptr,
                        feat, (char*)nullptr, n);
   }
   return oi::check_launch("oi_sdf_mlp_fwd");
@@ -396,8 +567,8 @@ int oi_mlp_pack_weights(const float* w0, const float* b0, const float* wh, const
 }
 
 size_t oi_mlp_scratch_bytes(int B, long long n_per_elem) {
-  const long long tiles = (n_per_elem + TILE_PTS - 1) / TILE_PTS;
-  return (size_t)B * tiles * 4 * NSLOT * 16 * 64 * 16;
+  const long long tiles = (n_per_elem + V2_TILE - 1) / V2_TILE;
+  return (size_t)B * tiles * V2_WAVES * NSLOT * 16 * 64 * 16;
 }
 
 int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf,
