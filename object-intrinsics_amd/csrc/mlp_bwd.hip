@@ -62,6 +62,10 @@ struct WaveScratchB {
 
 // sum of v over the 32 points (lanes of one half) -> LDS accumulator row `row` at this lane's feature
 __device__ __forceinline__ void reduce_group(char* lds, int row, int g, int h, int j, f32x4 v) {
+  // NOTE: a DPP formulation of this reduction (oi::half_sum32) produced deterministic wrong sums for a few
+  // (group, k) slots of this kernel on gfx950 / ROCm 7.2 although the same sequence is exact in isolation
+  // (tools/dbg/d.hip) and in the compositing kernels; until that is root-caused the reduction stays on
+  // ds_bpermute shuffles here (5 LDS-crossbar round trips per value).
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float x = v[k];
@@ -467,7 +471,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         float s, c;
         sincos_<FAST>(ph[k], s, c);
         const float phb = act[4 * g + k] * c - cb[k] * gm[k] * s;   // phibar_l
-        const float u = (ph[k] - bt[k]) / gm[k];                    // u_l
+        const float u = (ph[k] - bt[k]) * __builtin_amdgcn_rcpf(gm[k]);  // u_l
         r_g[k] = fmaf(phb, u, cb[k] * c);                           // d gamma_l
         r_b[k] = phb;                                               // d beta_l
         ub[k] = phb * gm[k];                                        // ubar_l

@@ -37,16 +37,44 @@ inline hipStream_t as_stream(oi_stream_t s) { return reinterpret_cast<hipStream_
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// 64-lane butterfly sum / max; every lane ends with the result.
+// DPP data movement (one VALU instruction, fused into the consuming op by hipcc); __shfl_xor would lower to
+// ds_bpermute_b32 + s_waitcnt (an LDS round trip per step).
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ float dpp_mov(float x, float old = 0.f) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x),
+                                                                CTRL, ROWMASK, 0xf, false));
+}
+// sum over each 32-lane half of the wavefront; the result is valid in lanes 16..31 of each half
+__device__ __forceinline__ float half_sum32(float x) {
+  // HAZARD (observed on gfx950 / ROCm 7.2): a DPP instruction issued within 5 wait states of an SALU
+  // write to EXEC (the s_or_b64 exec that closes a preceding divergent `if`, e.g. the one-lane atomic
+  // after the previous reduction) still sees the OLD exec mask: disabled source lanes read as 0 and the
+  // sum comes out wrong for whichever values the scheduler placed there.  hipcc pads only VALU writes of
+  // EXEC (v_cmpx), so the operand is passed through an explicit s_nop 4.
+  asm volatile("s_nop 4" : "+v"(x));
+  x += dpp_mov<0xB1>(x);        // quad_perm [1,0,3,2]
+  x += dpp_mov<0x4E>(x);        // quad_perm [2,3,0,1]
+  x += dpp_mov<0x141>(x);       // row_half_mirror
+  x += dpp_mov<0x140>(x);       // row_mirror
+  x += dpp_mov<0x142, 0xa>(x);  // row_bcast15 -> rows 1, 3
+  return x;
+}
+// 64-lane sum / max; every lane ends with the result (broadcast through an SGPR).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = half_sum32(v);
+  v += dpp_mov<0x143, 0xc>(v);  // row_bcast31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  const float ninf = -3.0e38f;
+  asm volatile("s_nop 4" : "+v"(v));
+  v = fmaxf(v, dpp_mov<0xB1>(v, ninf));
+  v = fmaxf(v, dpp_mov<0x4E>(v, ninf));
+  v = fmaxf(v, dpp_mov<0x141>(v, ninf));
+  v = fmaxf(v, dpp_mov<0x140>(v, ninf));
+  v = fmaxf(v, dpp_mov<0x142, 0xa>(v, ninf));
+  v = fmaxf(v, dpp_mov<0x143, 0xc>(v, ninf));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll

@@ -17,7 +17,10 @@ from . import ops
 from .config import build_from_config
 from .renderer import assemble_render_dict
 
+import weakref
+
 MAX_RAY_BATCH_SIZE = 128 * 128 * 1
+_STAGE_RINGS = weakref.WeakKeyDictionary()
 
 
 def invert_rot_t(pose):
@@ -51,8 +54,32 @@ class Generator(nn.Module):
                                           deviation_network=self.deviation_network, color_network=self.color_network)
 
     # -- host-side sampling (generator.py:65-78, 176-184; prior.py:11-29) -------------------------
+    def _h2d(self, arr):
+        """numpy -> device through a small ring of pinned staging buffers with a non-blocking copy.
+        `torch.tensor(x, device='cuda')` (what the reference does, generator.py:71,161) is a pageable copy:
+        it serialises the host behind everything already queued on the stream, once per render."""
+        dev = self.it.device
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        if dev.type != "cuda":
+            return torch.from_numpy(arr).to(dev)
+        ring = _STAGE_RINGS.setdefault(self, {"bufs": [], "events": [], "i": 0})  # not in __dict__: deepcopy (EMA)
+        n = arr.size
+        if not ring["bufs"] or ring["bufs"][0].numel() < n:
+            ring["bufs"] = [torch.empty(max(n, 256), dtype=torch.float32, pin_memory=True) for _ in range(8)]
+            ring["events"] = [None] * 8
+        i = ring["i"] = (ring["i"] + 1) % 8
+        if ring["events"][i] is not None:
+            ring["events"][i].synchronize()  # the copy that last used this buffer has executed
+        buf = ring["bufs"][i][:n]
+        buf.numpy()[:] = arr.reshape(-1)
+        out = buf.to(dev, non_blocking=True).view(arr.shape)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring["events"][i] = ev
+        return out
+
     def bg_color(self, bs):
-        return torch.tensor(np.random.uniform(low=0, high=1, size=(bs, 3)), dtype=torch.float32)
+        return np.random.uniform(low=0, high=1, size=(bs, 3))
 
     def sample_prior(self, bs, data):
         dev = self.it.device
@@ -60,7 +87,7 @@ class Generator(nn.Module):
             assert not self.training
             b2w = data["b2w"].to(dev)
         else:
-            b2w = torch.tensor(self.pose_prior(bs), dtype=torch.float32, device=dev)
+            b2w = self._h2d(self.pose_prior(bs))
         w2b = invert_rot_t(b2w)
         c2b = torch.einsum("bij,jk->bik", w2b, self.camera.c2w)
         return {"c2b": c2b, "b2w": b2w, "w2b": w2b, "light": self.light.batch_transform(w2b=w2b)}
@@ -97,7 +124,7 @@ class Generator(nn.Module):
         h = w = self.resolution
         n_rays = bs * h * w
         cos_anneal_ratio = min(1.0, self._it_host / self.anneal_end)
-        bg = self.bg_color(bs).to(self.it.device)
+        bg = self._h2d(self.bg_color(bs))
         ldir = prior["light"].direction()
         lpk = self.light.packed()
 
