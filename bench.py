@@ -282,7 +282,12 @@ def main():
             "training": train,
             "roofline": {"bound": "mfma", "kernel": "sdf_mlp_kernel<full> (sdf + d sdf/dx + albedo at the fine samples)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": (achieved / peak) if achieved else None, "traffic": None,
+                         "frac": (achieved / peak) if achieved else None,
+                         # HBM bytes/launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
+                         # WRITE_SIZE, KiB -> bytes), measured on this workload in f32 mode and committed under profiles/;
+                         # it cannot be collected from inside the timed process.
+                         "traffic": 4.92e9 if (args.precision == "f32" and (B, R, S, I) == (1, 64, 64, 64)) else None,
+                         "traffic_source": "profiles/r1_pmc_fetch.txt + profiles/r1_pmc_write.txt",
                          "algorithmic_flops_per_launch": flops, "kernel_ms": kern_ms,
                          "note": "algorithmic = GEMM MACs x2 of sdf fwd + analytic gradient sweep + colour head per "
                                  "point; bf16x3 executes 3 MFMAs per algorithmic MAC"},
