@@ -144,6 +144,37 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
 // 9 layers are staged once.  (v1 staged synchronously with two barriers per layer: 56 % of the fp32
 // MFMA peak, matrix pipe 64 % busy -- profiles/r1_*.)
 // ------------------------------------------------------------------------------------------
+// Scratch accessor of the forward kernel.  In the bf16 throughput mode the parked gamma*cos(phi) / feature
+// fragments are stored as fp16 (|c| < 64, 2^-11 relative: far below the bf16 operand rounding), halving the
+// one HBM stream that bounds that mode (profiles/r1_*: 4.9 GB per launch in fp32).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <bool HALF>
+struct FwdScratch {
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ void store(int slot, int g, const LaneOff& o, f32x4 v) const {
+    if constexpr (HALF) {
+      f16x4 hv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rs, o.l16 >> 1, slot * 8192 + g * 512, 0);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, o.l16, slot * 16384 + g * 1024, 0);
+    }
+  }
+  __device__ __forceinline__ f32x4 load(int slot, int g, const LaneOff& o) const {
+    if constexpr (HALF) {
+      const f16x4 hv = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, o.l16 >> 1, slot * 8192 + g * 512, 0));
+      f32x4 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (float)hv[k];
+      return v;
+    } else {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o.l16, slot * 16384 + g * 1024, 0));
+    }
+  }
+};
+
 constexpr int V2_WAVES = 8;
 constexpr int V2_TILE = V2_WAVES * WAVE_PTS;  // 256 points
 constexpr int V2_FILM = 0;                    // [9][gamma 128 | beta 128 | bias 128]
@@ -243,9 +274,9 @@ __device__ __forceinline__ void gemm_layer2(const char* lds, const LayOff& y, co
   }
 }
 
-template <bool FAST, bool FULL, int SRC>
+template <bool FAST, bool FULL, int SRC, class SCR>
 __device__ __forceinline__ void film_sin2(const char* lds, const LaneOff& o, const LayOff& y, const f32x16 (&acc)[4],
-                                          float (&act)[64], const WaveScratch& ws, int slot, int tab_imm, float vx,
+                                          float (&act)[64], const SCR& ws, int slot, int tab_imm, float vx,
                                           float vy, float vz) {
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
@@ -271,7 +302,7 @@ __device__ __forceinline__ void film_sin2(const char* lds, const LaneOff& o, con
       act[4 * g + k] = s;
       cv[k] = gm[k] * c;
     }
-    if constexpr (FULL) ws.store(slot, g, o.l16, cv);
+    if constexpr (FULL) ws.store(slot, g, o, cv);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -317,11 +348,13 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   const bool valid = local < n_per_elem;
   const long long pt = (long long)e * n_per_elem + (valid ? local : n_per_elem - 1);
 
-  WaveScratch ws;
+  constexpr bool HALF_SCR = PREC == OI_PREC_BF16;
+  constexpr int SLOT_B = HALF_SCR ? 8192 : 16384;
+  FwdScratch<HALF_SCR> ws;
   {
     const long long wt = ((long long)e * gridDim.x + blockIdx.x) * V2_WAVES + wave;
-    char* wbase = FULL ? scratch + wt * (long long)(NSLOT * 16384) : nullptr;
-    ws.rs = __builtin_amdgcn_make_buffer_rsrc(wbase, 0, FULL ? NSLOT * 16384 : 0, 0x00020000);
+    char* wbase = FULL ? scratch + wt * (long long)(NSLOT * SLOT_B) : nullptr;
+    ws.rs = __builtin_amdgcn_make_buffer_rsrc(wbase, 0, FULL ? NSLOT * SLOT_B : 0, 0x00020000);
   }
 
   // image sequence: i = 0..6 forward layers 1..7 (mats 0..6), i = 7..13 transposed layers 7..1 (mats 13..7),
@@ -396,7 +429,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       f32x4 v;
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = act[4 * g + k];
-      ws.store(8, g, o.l16, v);
+      ws.store(8, g, o, v);
     }
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -408,7 +441,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       const int i = 14 - l;  // image index of transposed layer l
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        const f32x4 c = ws.load(l, g, o.l16);
+        const f32x4 c = ws.load(l, g, o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) act[4 * g + k] *= c[k];
         if ((g & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -433,7 +466,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
     float gx = 0.f, gy = 0.f, gz = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const f32x4 c = ws.load(0, g, o.l16);
+      const f32x4 c = ws.load(0, g, o);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float v = act[4 * g + k] * c[k];
@@ -458,7 +491,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       // image 14 (ring slot 0) was prefetched during transposed layer 1 and is resident after its ring_sync
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        const f32x4 v = ws.load(8, g, o.l16);
+        const f32x4 v = ws.load(8, g, o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) act[4 * g + k] = v[k];
         if ((g & 3) == 3) __builtin_amdgcn_sched_barrier(0);

@@ -216,3 +216,25 @@ def test_ada_discriminator_view_shapes():
         out = D(torch.rand(3, 3, 64, 64, device="cuda"), it=0)
     assert out.shape == (3, 7) and torch.isfinite(out).all()
     assert D.get_resolution() == 64
+
+
+def test_inference_walks_and_depth_multiplier():
+    """Inference driver: camera / latent walk frames at 2x resolution and 2x depth, multi-chunk."""
+    from oi_amd import inference
+    g = load_golden("f5_generator")
+    gen = build_generator(32, 16, 16, 1).eval()   # "test_resolution 32, depth x2" of a 16^2 / 8+8 training config
+    z0, z1 = g["z"][0], g["z"][1]
+    np.random.seed(0)
+    fr = inference.camera_walk(gen, z0, g["b2w"][0], n_frames=3, max_ray_batch=300)
+    assert fr["image"].shape == (3, 3, 32, 32) and torch.isfinite(fr["image"]).all()
+    assert float((fr["image"][0] - fr["image"][1]).abs().max()) > 1e-3        # the view changes
+    np.random.seed(0)
+    one = inference.camera_walk(gen, z0, g["b2w"][0], n_frames=1)
+    assert maxdiff(one["mask"][0], fr["mask"][0]) < 1e-6                        # chunking does not change a frame
+    lw = inference.latent_walk(gen, z0, z1, g["b2w"][0], n_frames=3)
+    assert float((lw["normal_map"][0] - lw["normal_map"][2]).abs().max()) > 1e-3
+    kw = {"renderer": {"kwargs": {"n_importance": 4, "n_samples": 16}}, "resolution": 128, "scene_resolution": 794,
+          "camera": {"kwargs": {"resolution": 794}}}
+    kw2 = inference.scale_config(kw, 128, test_resolution=256, depth_multiplier=16)
+    assert kw2["renderer"]["kwargs"] == {"n_importance": 64, "n_samples": 256} and kw2["resolution"] == 256
+    assert kw2["scene_resolution"] == 1588 and kw["resolution"] == 128
