@@ -41,8 +41,11 @@ enum oi_status {
 /* MFMA operand precision of the MLP contractions (accumulation is always fp32, FiLM phase and
  * sin/cos always fp32).  F32 = v_mfma_f32_32x32x2_f32 (exact fp32, the 1e-4 parity path);
  * BF16X3 = three bf16 MFMAs on hi/lo splits of both operands (fp32-class accuracy at 3/16 of the
- * fp32 matrix cost); BF16 = one bf16 MFMA (throughput path, tolerance stated in DESIGN.md). */
-enum oi_precision { OI_PREC_F32 = 0, OI_PREC_BF16X3 = 1, OI_PREC_BF16 = 2 };
+ * fp32 matrix cost); BF16 = one bf16 MFMA (throughput path, tolerance stated in DESIGN.md);
+ * BF16X6 = fp32 operands split THREE ways (hi/mid/lo bf16 = the full 24-bit mantissa) and the six products
+ * whose weight is >= 2^-24 accumulated in fp32: fp32-exact contractions on the bf16 matrix cores at 6/16 of the
+ * fp32 MFMA cost (forward kernel only; the backward kernels take the F32 image). */
+enum oi_precision { OI_PREC_F32 = 0, OI_PREC_BF16X3 = 1, OI_PREC_BF16 = 2, OI_PREC_BF16X6 = 3 };
 
 int oi_version(void);
 const char* oi_arch(void);       /* "gfx950" */

@@ -134,6 +134,12 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
     const __bf16 hi = (__bf16)v;
     reinterpret_cast<__bf16*>(base)[idx] = hi;
     if (PREC == OI_PREC_BF16X3) reinterpret_cast<__bf16*>(base + 32768)[idx] = (__bf16)(v - (float)hi);
+    if (PREC == OI_PREC_BF16X6) {  // exact 3-way split: hi + mid + lo == v (24-bit mantissa)
+      const float r1 = v - (float)hi;
+      const __bf16 mid = (__bf16)r1;
+      reinterpret_cast<__bf16*>(base + 32768)[idx] = mid;
+      reinterpret_cast<__bf16*>(base + 65536)[idx] = (__bf16)(r1 - (float)mid);
+    }
   }
 }
 
@@ -180,11 +186,14 @@ constexpr int V2_TILE = V2_WAVES * WAVE_PTS;  // 256 points
 constexpr int V2_FILM = 0;                    // [9][gamma 128 | beta 128 | bias 128]
 constexpr int V2_TABS = 9 * 1536;             // 13824
 constexpr int V2_WBUF = V2_TABS + H_TABS_END * 4;  // 20096
-__host__ __device__ constexpr int v2_lds_total(int prec) { return V2_WBUF + 2 * layer_bytes(prec); }
+// BF16X6 images are 96 KiB: a single ring slot, refilled behind a barrier while the VALU phase runs
+__host__ __device__ constexpr bool v2_two_slots(int prec) { return prec != OI_PREC_BF16X6; }
+__host__ __device__ constexpr int v2_lds_total(int prec) { return V2_WBUF + (v2_two_slots(prec) ? 2 : 1) * layer_bytes(prec); }
 
 struct LayOff {  // per-layer runtime VGPR bases (everything else is an immediate)
   int wl;   // 16*lane + ring slot base
   int wh;   // wl + 32768
+  int wq;   // wl + 65536
   int f16;  // 16*h + 1536*layer  (FiLM rows of this layer)
 };
 
@@ -205,6 +214,7 @@ __device__ __forceinline__ LayOff lay_off(const LaneOff& o, int slot, int layer)
   LayOff r;
   r.wl = o.l16 + V2_WBUF + slot * layer_bytes(PREC);
   r.wh = r.wl + 32768;
+  r.wq = r.wl + 65536;
   r.f16 = o.h16 + V2_FILM + layer * 1536;
   return r;
 }
@@ -230,6 +240,33 @@ __device__ __forceinline__ void gemm_layer2(const char* lds, const LayOff& y, co
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 4; ++t) a[t] = an[t];
+    }
+  } else if constexpr (PREC == OI_PREC_BF16X6) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      bf16x8 bh, bm, bl;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = act[8 * s + i];
+        bh[i] = (__bf16)v;
+        const float r1 = v - (float)bh[i];
+        bm[i] = (__bf16)r1;
+        bl[i] = (__bf16)(r1 - (float)bm[i]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, lds_f4(lds, (t * 8 + s) * 1024, y.wl));
+        const bf16x8 wm = __builtin_bit_cast(bf16x8, lds_f4(lds, (t * 8 + s) * 1024, y.wh));
+        const bf16x8 wl = __builtin_bit_cast(bf16x8, lds_f4(lds, (t * 8 + s) * 1024, y.wq));
+        // the six products of weight >= 2^-24, smallest first
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else {
     f32x4 ah[4], ahn[4], al[4], aln[4];
@@ -336,6 +373,19 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   const float* hdr = reinterpret_cast<const float*>(packed);
   const char* mats = packed + H_BYTES;
   constexpr int LB = layer_bytes(PREC);
+  constexpr bool RING2 = v2_two_slots(PREC);
+  // double-buffered ring: the next image is requested at the START of a layer into the other slot.
+  // single slot (BF16X6): it is requested right AFTER the layer's MFMAs, behind a barrier, and lands while the
+  // FiLM/sin VALU phase runs.
+  auto stage_early = [&](const char* src, int slot) {
+    if constexpr (RING2) prefetch_image<PREC>(lds, src, slot, wave, lane);
+  };
+  auto stage_late = [&](const char* src) {
+    if constexpr (!RING2) {
+      __syncthreads();
+      prefetch_image<PREC>(lds, src, 0, wave, lane);
+    }
+  };
 
   LaneOff o;
   o.h16 = 16 * h;
@@ -388,11 +438,12 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   for (int l = 1; l < NL_SDF; ++l) {
     const int i = l - 1;
     // next image: forward layer l+1, or the first transposed image (layer 7) / nothing for the sdf-only variant
-    if (l < NL_SDF - 1) prefetch_image<PREC>(lds, mats + (size_t)l * LB, (i + 1) & 1, wave, lane);
-    else if (FULL) prefetch_image<PREC>(lds, mats + (size_t)13 * LB, (i + 1) & 1, wave, lane);
-    const LayOff y = lay_off<PREC>(o, i & 1, l);
+    const char* next = (l < NL_SDF - 1) ? mats + (size_t)l * LB : (FULL ? mats + (size_t)13 * LB : nullptr);
+    if (next) stage_early(next, (i + 1) & 1);
+    const LayOff y = lay_off<PREC>(o, RING2 ? (i & 1) : 0, l);
     init_bias2(lds, y, acc);
     gemm_layer2<PREC>(lds, y, act, acc);
+    if (next) stage_late(next);
     film_sin2<FAST, FULL, 0>(lds, o, y, acc, act, ws, l, 0, 0.f, 0.f, 0.f);
     ring_sync();
   }
@@ -448,14 +499,15 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       }
       // next image after the scratch loads have been consumed (an in-flight LDS-DMA would otherwise be
       // drained by the vmcnt wait hipcc places in front of the first use of an ordinary load)
-      if (l > 1) prefetch_image<PREC>(lds, mats + (size_t)(7 + l - 2) * LB, (i + 1) & 1, wave, lane);
-      else if (rgb_out != nullptr) prefetch_image<PREC>(lds, mats + (size_t)14 * LB, (i + 1) & 1, wave, lane);
-      const LayOff y = lay_off<PREC>(o, i & 1, l);
+      const char* next = (l > 1) ? mats + (size_t)(7 + l - 2) * LB : (rgb_out != nullptr ? mats + (size_t)14 * LB : nullptr);
+      if (next) stage_early(next, (i + 1) & 1);
+      const LayOff y = lay_off<PREC>(o, RING2 ? (i & 1) : 0, l);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
       gemm_layer2<PREC>(lds, y, act, acc);
+      if (next) stage_late(next);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -593,6 +645,10 @@ int oi_mlp_pack_weights(const float* w0, const float* b0, const float* wh, const
       hipLaunchKernelGGL(pack_weights_kernel<OI_PREC_BF16>, grid, block, 0, st, w0, b0, wh, bh, wsig, bsig, wv, bv,
                          wrgb, brgb, p);
       break;
+    case OI_PREC_BF16X6:
+      hipLaunchKernelGGL(pack_weights_kernel<OI_PREC_BF16X6>, grid, block, 0, st, w0, b0, wh, bh, wsig, bsig, wv, bv,
+                         wrgb, brgb, p);
+      break;
     default:
       return oi::fail(OI_ERR_INVALID_ARG, "oi_mlp_pack_weights: bad precision %d", prec);
   }
@@ -620,6 +676,7 @@ int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, con
     OI_MLP_CASE(OI_PREC_F32)
     OI_MLP_CASE(OI_PREC_BF16X3)
     OI_MLP_CASE(OI_PREC_BF16)
+    OI_MLP_CASE(OI_PREC_BF16X6)
     default:
       return oi::fail(OI_ERR_INVALID_ARG, "oi_sdf_mlp_fwd: bad precision %d", prec);
   }

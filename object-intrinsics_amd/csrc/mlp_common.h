@@ -25,7 +25,9 @@ constexpr int H_BIAS = 1568;     // [9][128]  b0, b1..b7, bv
 constexpr int H_FLOATS = 2816;
 constexpr size_t H_BYTES = H_FLOATS * 4;
 
-__host__ __device__ constexpr int layer_bytes(int prec) { return prec == OI_PREC_BF16 ? 32768 : 65536; }
+__host__ __device__ constexpr int layer_bytes(int prec) {
+  return prec == OI_PREC_BF16 ? 32768 : (prec == OI_PREC_BF16X6 ? 98304 : 65536);
+}
 
 // LDS carve (bytes)
 // (small tables first so that every table access is <lane-constant VGPR> + 16-bit immediate)

@@ -25,7 +25,8 @@ class SdfMlpFunction(torch.autograd.Function):
         sdf, grad, rgb, feat, _ = ops.sdf_mlp_fwd(pts, packed, gamma, beta, B, pack.prec, pack.fast_trig, want_grad,
                                                   want_rgb, want_feat)
         ctx.pack, ctx.B = pack, B
-        ctx.packed = packed  # the image the forward used (parameters may be stepped before backward is called)
+        # the image of the weights the forward used (parameters may be stepped before backward is called)
+        ctx.packed = packed if pack.prec_bwd == pack.prec else pack.packed(for_backward=True)
         ctx.save_for_backward(pts, gamma, beta, grad, rgb)
         if feat is not None:
             ctx.mark_non_differentiable(feat)
@@ -37,7 +38,7 @@ class SdfMlpFunction(torch.autograd.Function):
         pts, gamma, beta, grad, rgb = ctx.saved_tensors
         pack = ctx.pack
         d_small, d_wmat, d_gamma, d_beta = ops.sdf_mlp_bwd(pts, ctx.packed, gamma, beta, grad, rgb, g_sdf, g_grad,
-                                                           g_rgb if rgb is not None else None, ctx.B, pack.prec,
+                                                           g_rgb if rgb is not None else None, ctx.B, pack.prec_bwd,
                                                            pack.fast_trig)
         s = d_small
         d_w0 = s[0:384].view(128, 3)

@@ -156,11 +156,11 @@ class FieldPack:
     """Per (sdf_network, color_network) cache of what the kernels consume: stacked parameter views
     (differentiable torch.stack) and the packed MFMA weight image, keyed by parameter versions."""
 
-    def __init__(self, sdf_network, color_network, precision="f32", fast_trig=None):
+    def __init__(self, sdf_network, color_network, precision="bf16x6", fast_trig=None):
         self.sdf_network, self.color_network = sdf_network, color_network
         self.set_precision(precision, fast_trig)
         self._key = None
-        self._packed = None
+        self._packs = {}
 
     def set_precision(self, precision, fast_trig=None):
         self.prec = _l.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
@@ -182,16 +182,24 @@ class FieldPack:
     def stacked(self):
         return stack_field_params(*self._sds())
 
-    def packed(self):
+    @property
+    def prec_bwd(self):
+        """The backward kernels have no BF16X6 variant: that mode differentiates through the exact-fp32 image."""
+        return _l.OI_PREC_F32 if self.prec == _l.OI_PREC_BF16X6 else self.prec
+
+    def packed(self, for_backward=False):
         sd, csd = self._sds()
-        key = (self.prec,) + tuple((p.data_ptr(), p._version) for p in list(sd.values()) + list(csd.values()))
+        prec = self.prec_bwd if for_backward else self.prec
+        key = tuple((p.data_ptr(), p._version) for p in list(sd.values()) + list(csd.values()))
         if key != self._key:
+            self._packs = {}
+            self._key = key
+        if prec not in self._packs:
             with torch.no_grad():
                 P = stack_field_params(sd, csd)
-                self._packed = ops.mlp_pack_weights(P["w0"], P["b0"], P["wh"], P["bh"], P["wsig"], P["bsig"], P["wv"],
-                                                    P["bv"], P["wrgb"], P["brgb"], self.prec)
-            self._key = key
-        return self._packed
+                self._packs[prec] = ops.mlp_pack_weights(P["w0"], P["b0"], P["wh"], P["bh"], P["wsig"], P["bsig"],
+                                                         P["wv"], P["bv"], P["wrgb"], P["brgb"], prec)
+        return self._packs[prec]
 
     def film(self, z=None, w=None):
         from .autograd import film_params

@@ -28,6 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert L.oi_arch() == b"gfx950"
     assert L.oi_mlp_packed_bytes(0) == 2816 * 4 + 16 * 65536
     assert L.oi_mlp_packed_bytes(2) == 2816 * 4 + 16 * 32768
+    assert L.oi_mlp_packed_bytes(3) == 2816 * 4 + 16 * 98304
 
 
 def test_ops_fail_loudly_without_gpu_tensors():

@@ -33,12 +33,13 @@ def _rays(N, seed):
     return ro, rd, near, far
 
 
-@pytest.mark.parametrize("name,B,R,S,I,K", [("C2", 1, 64, 64, 64, 1), ("C4", 1, 128, 128, 128, 4)])
-def test_full_size_render_properties(sdf_sd, col_sd, name, B, R, S, I, K):
+@pytest.mark.parametrize("name,B,R,S,I,K,precision", [("C2", 1, 64, 64, 64, 1, "bf16x6"), ("C2", 1, 64, 64, 64, 1, "f32"),
+                                                      ("C4", 1, 128, 128, 128, 4, "bf16x6")])
+def test_full_size_render_properties(sdf_sd, col_sd, name, B, R, S, I, K, precision):
     N = B * R * R
     ro, rd, near, far = _rays(N, 11)
     w = O.style_mlp(sdf_sd, torch.randn(B, 64, generator=torch.Generator().manual_seed(5)))
-    r = _renderer(col_sd, S, I, K)
+    r = _renderer(col_sd, S, I, K, precision)
     with torch.no_grad():
         out = r.render(ro.cuda(), rd.cuda(), near.cuda(), far.cuda(), perturb_overwrite=0, cos_anneal_ratio=0.5, w=w.cuda())
         T = S + I
