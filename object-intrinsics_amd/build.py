@@ -16,7 +16,8 @@ OUT_DIR = os.path.join(HERE, "oi_amd")
 LIB = os.path.join(OUT_DIR, "liboi_hip.so")
 STAMP = os.path.join(OUT_DIR, ".liboi_hip.stamp")
 SOURCES = ["mlp.hip", "render.hip", "disc.hip", "mlp_bwd.hip", "render_bwd.hip", "disc_bwd.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + os.environ.get("OI_FLAGS", "").split()
+EXTRA = {}  # per-file extra flags
 
 
 def _hipcc():
@@ -39,6 +40,7 @@ def _digest():
             h.update(f.encode())
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(EXTRA).encode())
     return h.hexdigest()
 
 
@@ -52,7 +54,7 @@ def build(force=False, verbose=True):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for s in _sources():
         o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc, *FLAGS, *EXTRA.get(s, []), "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

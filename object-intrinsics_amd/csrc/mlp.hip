@@ -165,7 +165,7 @@ struct FwdScratch {
       for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rs, o.l16 >> 1, slot * 8192 + g * 512, 0);
     } else {
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, o.l16, slot * 16384 + g * 1024, 0);
+      oi::buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, o.l16, slot * 16384 + g * 1024);
     }
   }
   __device__ __forceinline__ f32x4 load(int slot, int g, const LaneOff& o) const {

@@ -53,7 +53,7 @@ constexpr int L_TOTAL_BWD = L_RACC + 8 * C * 4;
 struct WaveScratchB {
   __amdgpu_buffer_rsrc_t rs;
   __device__ __forceinline__ void store(int slot, int g, int l16, f32x4 v) const {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024, 0);
+    oi::buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024);
   }
   __device__ __forceinline__ f32x4 load(int slot, int g, int l16) const {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, l16, slot * 16384 + g * 1024, 0));
@@ -62,18 +62,9 @@ struct WaveScratchB {
 
 // sum of v over the 32 points (lanes of one half) -> LDS accumulator row `row` at this lane's feature
 __device__ __forceinline__ void reduce_group(char* lds, int row, int g, int h, int j, f32x4 v) {
-  // NOTE: a DPP formulation of this reduction (oi::half_sum32) produced deterministic wrong sums for a few
-  // (group, k) slots of this kernel on gfx950 / ROCm 7.2 although the same sequence is exact in isolation
-  // (tools/dbg/d.hip) and in the compositing kernels; until that is root-caused the reduction stays on
-  // ds_bpermute shuffles here (5 LDS-crossbar round trips per value).
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float x = v[k];
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    v[k] = x;
-  }
-  if (j == 0) {
+  for (int k = 0; k < 4; ++k) v[k] = oi::half_sum32(v[k]);  // 5 DPP adds; valid in lanes 16..31 of each half
+  if (j == 16) {
     float* racc = reinterpret_cast<float*>(lds + L_RACC) + row * C + grp_f0(g) + 4 * h;
 #pragma unroll
     for (int k = 0; k < 4; ++k) atomicAdd(racc + k, v[k]);
