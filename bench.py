@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the object-intrinsics hot path on MI355X (contract: see the task statement).
 
-    python bench.py --gpus N --steps K --warmup W [--precision f32|bf16x3|bf16] [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--precision f16x3|bf16x6|f32|bf16x3|bf16] [--batch B]
 
 Metric (BASELINE.json): rendered rays/sec at a 64x64 crop with 128 samples/ray (64 coarse + 64
 importance, 1 up-sampling step = BASELINE config C2), plus discriminator images/sec, whole job
@@ -34,8 +34,8 @@ import torch.distributed as dist  # noqa: E402
 
 # algorithmic FLOPs per point (GEMM MACs x 2 only), SURVEY.md 8(d) / BASELINE.md 4
 F_SDF, F_GRAD, F_COL = 230400, 230400, 34304
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "bf16x6": 2500.0}  # MI355X_MICROARCH.md (dense)
-MFMA_PER_MAC = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6}
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0, "bf16x6": 2500.0, "f16x3": 2500.0}  # MI355X_MICROARCH.md (dense)
+MFMA_PER_MAC = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3}
 NET_KW = dict(D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64)
 SDF_NPZ = os.path.join(ROOT, "tests", "golden", "weights_sdf.npz")
 
@@ -168,7 +168,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16x6", choices=["f32", "bf16x6", "bf16x3", "bf16"],
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "bf16x6", "f16x3", "bf16x3", "bf16"],
                     help="MFMA operand mode of the MLP contractions. bf16x6 (default) and f32 are the fp32-exact 1e-4 "
                          "parity paths (same tolerances in tests/); bf16x3 ~2e-4; bf16 ~1e-2")
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (training.batch_size: 1)")
@@ -276,6 +276,8 @@ def main():
             "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 split into 2 bf16 MFMA operands, fp32 accumulate)",
                       "bf16x6": "f32 via bf16x6 (fp32 operands split 3-way, 6 bf16 MFMAs per product, fp32 accumulate: "
                                 "fp32-exact contractions, 1e-4 parity path)",
+                      "f16x3": "f32 via f16x3 (fp32 operands split into 2 fp16 limbs = 22 mantissa bits, 3 fp16 MFMAs "
+                               "per product, fp32 accumulate: 2^-22 relative per product, 1e-4 parity path)",
                       "bf16": "bf16"}[args.precision],
             "data": "synthetic (random poses/latents/backgrounds from the data/example prior; sphere-initialised SDF "
                     "weights, seeded default-init colour/discriminator weights)",
@@ -291,7 +293,7 @@ def main():
                          # HBM bytes/launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
                          # WRITE_SIZE, KiB -> bytes), measured on this workload in f32 mode and committed under profiles/;
                          # it cannot be collected from inside the timed process.
-                         "traffic": 4.95e9 if (args.precision in ("f32", "bf16x6", "bf16x3") and (B, R, S, I) == (1, 64, 64, 64)) else None,
+                         "traffic": 4.95e9 if (args.precision in ("f32", "bf16x6", "f16x3", "bf16x3") and (B, R, S, I) == (1, 64, 64, 64)) else None,
                          "traffic_source": "profiles/r1_pmc_fetch*.txt + profiles/r1_pmc_write*.txt (the fp32 gamma*cos(phi) "
                                            "scratch: 2.43 GB written + 2.5 GB read per launch in the f32/bf16x6/bf16x3 modes)",
                          "algorithmic_flops_per_launch": flops, "kernel_ms": kern_ms,

@@ -44,8 +44,14 @@ enum oi_status {
  * fp32 matrix cost); BF16 = one bf16 MFMA (throughput path, tolerance stated in DESIGN.md);
  * BF16X6 = fp32 operands split THREE ways (hi/mid/lo bf16 = the full 24-bit mantissa) and the six products
  * whose weight is >= 2^-24 accumulated in fp32: fp32-exact contractions on the bf16 matrix cores at 6/16 of the
- * fp32 MFMA cost (forward kernel only; the backward kernels take the F32 image). */
-enum oi_precision { OI_PREC_F32 = 0, OI_PREC_BF16X3 = 1, OI_PREC_BF16 = 2, OI_PREC_BF16X6 = 3 };
+ * fp32 MFMA cost (forward kernel only; the backward kernels take the F32 image);
+ * F16X3 = fp32 operands split TWO ways into fp16 limbs (hi + lo = 22 mantissa bits; fp16 subnormals are kept by
+ * v_cvt and by the MFMA on gfx950) and the three products hi*hi, hi*lo, lo*hi accumulated in fp32: 2^-22 relative
+ * per product (fp32-class, inside the 1e-4 parity bar) at HALF the MFMA work and 2/3 of the LDS image of BF16X6.
+ * Activations are sin() outputs in [-1,1]; the adjoint vectors of the analytic-gradient sweep are normalised per
+ * point by a power of two before the split, so the fp16 range is never exceeded; weights must satisfy |w| < 65504
+ * (forward kernel only). */
+enum oi_precision { OI_PREC_F32 = 0, OI_PREC_BF16X3 = 1, OI_PREC_BF16 = 2, OI_PREC_BF16X6 = 3, OI_PREC_F16X3 = 4 };
 
 int oi_version(void);
 const char* oi_arch(void);       /* "gfx950" */

@@ -87,6 +87,33 @@ __device__ __forceinline__ float mat_elem(const float* wh, const float* wv, int 
   return wv[(size_t)k * (C + 3) + row];
 }
 
+// F16X3: SIREN weights are O(1e-2), so the lo limb of an unscaled fp16 split would be subnormal (absolute step
+// 2^-24, i.e. only ~2^-17 relative -- no better than a bf16 split).  Every image is therefore scaled by the power
+// of two that puts max |W_m| in [2^13, 2^14); the forward kernel folds 2^-k_m into the FiLM gamma it stages (and
+// thereby into the parked gamma*cos(phi)), which cancels against the scaled transposed image in the reverse sweep:
+// exact, and free.  Returns the scale; *inv gets 2^-k_m.  Must be called by all 256 threads of the block.
+template <int PREC>
+__device__ float image_scale(const float* wh, const float* wv, int m, float* red, float* inv) {
+  if (PREC != OI_PREC_F16X3) {
+    *inv = 1.f;
+    return 1.f;
+  }
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < C * C; i += 256) mx = fmaxf(mx, fabsf(mat_elem(wh, wv, m, i >> 7, i & 127)));
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  mx = red[0];
+  __syncthreads();
+  int eb = (__builtin_bit_cast(int, mx) >> 23) & 0xff;
+  eb = eb < 14 ? 14 : (eb > 254 ? 254 : eb);
+  *inv = __builtin_bit_cast(float, (eb - 13) << 23);
+  return __builtin_bit_cast(float, (267 - eb) << 23);
+}
+
 template <int PREC>
 __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* __restrict__ b0,
                                     const float* __restrict__ wh, const float* __restrict__ bh,
@@ -96,7 +123,16 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
                                     char* __restrict__ packed) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   float* hdr = reinterpret_cast<float*>(packed);
+  __shared__ float red[256];
   if (blockIdx.y == NMAT) {  // header
+    if (blockIdx.x == H_WSCALE / 256) {  // the block that owns the image scales (block-uniform branch)
+      for (int m = 0; m < NMAT; ++m) {
+        float inv;
+        image_scale<PREC>(wh, wv, m, red, &inv);
+        if (idx == H_WSCALE + m) hdr[idx] = inv;
+      }
+      if (idx >= H_WSCALE && idx < H_WSCALE + NMAT) return;
+    }
     if (idx >= H_FLOATS) return;
     float v = 0.f;
     if (idx < H_SIG) {
@@ -119,6 +155,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
     return;
   }
   const int m = blockIdx.y;
+  float inv_unused;
+  const float wscale = image_scale<PREC>(wh, wv, m, red, &inv_unused);
   if (idx >= C * C) return;
   char* base = packed + H_BYTES + (size_t)m * layer_bytes(PREC);
   if (PREC == OI_PREC_F32) {
@@ -130,7 +168,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
     // image [t(4)][s(8)][lane(64)][i'(8)] bf16 (hi; lo image 32 KiB later), q = 8s + i'
     const int ip = idx & 7, lane = (idx >> 3) & 63, s = (idx >> 9) & 7, t = idx >> 12;
     const int q = 8 * s + ip, h = lane >> 5, i = lane & 31;
-    const float v = mat_elem(wh, wv, m, 32 * t + i, feat_of(q, h));
+    const float v = mat_elem(wh, wv, m, 32 * t + i, feat_of(q, h)) * wscale;
+    if (PREC == OI_PREC_F16X3) {  // fp16 hi + lo limbs (22 mantissa bits), same image geometry as BF16X3
+      const _Float16 fh = (_Float16)v;
+      reinterpret_cast<_Float16*>(base)[idx] = fh;
+      reinterpret_cast<_Float16*>(base + 32768)[idx] = (_Float16)(v - (float)fh);
+      return;
+    }
     const __bf16 hi = (__bf16)v;
     reinterpret_cast<__bf16*>(base)[idx] = hi;
     if (PREC == OI_PREC_BF16X3) reinterpret_cast<__bf16*>(base + 32768)[idx] = (__bf16)(v - (float)hi);
@@ -181,28 +225,32 @@ struct FwdScratch {
   }
 };
 
-constexpr int V2_WAVES = 8;
+constexpr int V2_WAVES = 8;                   // scratch is sized for 8-wave tiles (an upper bound for 4-wave tiles)
 constexpr int V2_TILE = V2_WAVES * WAVE_PTS;  // 256 points
-constexpr int V2_FILM = 0;                    // [9][gamma 128 | beta 128 | bias 128]
-constexpr int V2_TABS = 9 * 1536;             // 13824
-constexpr int V2_WBUF = V2_TABS + H_TABS_END * 4;  // 20096
+constexpr int V2_FILM = 0;                    // [9][gamma 128 | beta' 128],  beta' = gamma * bias + beta
+constexpr int V2_TABS = 9 * 1024;             // 9216
+constexpr int V2_WBUF = V2_TABS + H_TABS_END * 4;  // 15488
+// Workgroup shape per mode.  F16X3: 4 wavefronts (128 points) and ONE 64 KiB image slot = 79 KiB of LDS, so TWO
+// independent workgroups share a CU (one wave per SIMD each) and run out of phase: one's MFMA phase overlaps the
+// other's FiLM/sin VALU phase, scratch traffic and image refill.  Other modes: 8 wavefronts, one workgroup per CU.
+__host__ __device__ constexpr int v2_waves(int prec) { return prec == OI_PREC_F16X3 ? 4 : 8; }
 // BF16X6 images are 96 KiB: a single ring slot, refilled behind a barrier while the VALU phase runs
-__host__ __device__ constexpr bool v2_two_slots(int prec) { return prec != OI_PREC_BF16X6; }
+__host__ __device__ constexpr bool v2_two_slots(int prec) { return prec != OI_PREC_BF16X6 && prec != OI_PREC_F16X3; }
 __host__ __device__ constexpr int v2_lds_total(int prec) { return V2_WBUF + (v2_two_slots(prec) ? 2 : 1) * layer_bytes(prec); }
 
 struct LayOff {  // per-layer runtime VGPR bases (everything else is an immediate)
   int wl;   // 16*lane + ring slot base
   int wh;   // wl + 32768
   int wq;   // wl + 65536
-  int f16;  // 16*h + 1536*layer  (FiLM rows of this layer)
+  int f16;  // 16*h + 1024*layer  (FiLM rows of this layer)
 };
 
 template <int PREC>
 __device__ __forceinline__ void prefetch_image(char* lds, const char* __restrict__ src, int slot, int wave, int lane) {
   constexpr int NCHUNK = layer_bytes(PREC) / 1024;
 #pragma unroll
-  for (int c0 = 0; c0 < NCHUNK / V2_WAVES; ++c0) {
-    const int c = c0 * V2_WAVES + wave;
+  for (int c0 = 0; c0 < NCHUNK / v2_waves(PREC); ++c0) {
+    const int c = c0 * v2_waves(PREC) + wave;
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)(src + c * 1024 + lane * 16),
         (__attribute__((address_space(3))) void*)(lds + V2_WBUF + slot * layer_bytes(PREC) + c * 1024), 16, 0, 0);
@@ -215,7 +263,7 @@ __device__ __forceinline__ LayOff lay_off(const LaneOff& o, int slot, int layer)
   r.wl = o.l16 + V2_WBUF + slot * layer_bytes(PREC);
   r.wh = r.wl + 32768;
   r.wq = r.wl + 65536;
-  r.f16 = o.h16 + V2_FILM + layer * 1536;
+  r.f16 = o.h16 + V2_FILM + layer * 1024;
   return r;
 }
 
@@ -267,6 +315,44 @@ __device__ __forceinline__ void gemm_layer2(const char* lds, const LayOff& y, co
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc[t], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (PREC == OI_PREC_F16X3) {
+    f32x4 ah[4], ahn[4], al[4], aln[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ah[t] = lds_f4(lds, (t * 8 + 0) * 1024, y.wl);
+      al[t] = lds_f4(lds, (t * 8 + 0) * 1024, y.wh);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < 7) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          ahn[t] = lds_f4(lds, (t * 8 + s + 1) * 1024, y.wl);
+          aln[t] = lds_f4(lds, (t * 8 + s + 1) * 1024, y.wh);
+        }
+      }
+      f16x8 bh, bl;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = act[8 * s + i];
+        bh[i] = (_Float16)v;
+        bl[i] = (_Float16)(v - (float)bh[i]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f16x8 wh = __builtin_bit_cast(f16x8, ah[t]);
+        const f16x8 wl = __builtin_bit_cast(f16x8, al[t]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, acc[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        ah[t] = ahn[t];
+        al[t] = aln[t];
+      }
     }
   } else {
     f32x4 ah[4], ahn[4], al[4], aln[4];
@@ -320,8 +406,6 @@ __device__ __forceinline__ void film_sin2(const char* lds, const LaneOff& o, con
     const int t = g >> 2, rr = g & 3;
     const f32x4 gm = lds_f4(lds, grp_f0(g) * 4, y.f16);
     const f32x4 bt = lds_f4(lds, (C + grp_f0(g)) * 4, y.f16);
-    f32x4 bs;
-    if constexpr (SRC == 1) bs = lds_f4(lds, (2 * C + grp_f0(g)) * 4, y.f16);
     f32x4 cv;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -331,7 +415,7 @@ __device__ __forceinline__ void film_sin2(const char* lds, const LaneOff& o, con
       } else {
         const f32x4 w = lds_f4(lds, V2_TABS + tab_imm * 4 + (grp_f0(g) + k) * 16, o.h64);
         const float d = fmaf(vz, w[2], fmaf(vy, w[1], vx * w[0]));
-        u = SRC == 1 ? d + bs[k] : acc[t][4 * rr + k] + d;
+        u = SRC == 1 ? d : acc[t][4 * rr + k] + d;
       }
       const float phi = fmaf(gm[k], u, bt[k]);
       float s, c;
@@ -344,13 +428,12 @@ __device__ __forceinline__ void film_sin2(const char* lds, const LaneOff& o, con
   }
 }
 
-__device__ __forceinline__ void init_bias2(const char* lds, const LayOff& y, f32x16 (&acc)[4]) {
+// the layer bias lives in beta' (phi = gamma * (W a + b) + beta = gamma * (W a) + beta'), accumulators start at 0
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const f32x4 b = lds_f4(lds, (2 * C + grp_f0(g)) * 4, y.f16);
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[g >> 2][4 * (g & 3) + k] = b[k];
-  }
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 }
 
 // wait for this wave's LDS-DMA, then rendezvous: next image resident, previous ring slot free
@@ -360,7 +443,7 @@ __device__ __forceinline__ void ring_sync() {
 }
 
 template <int PREC, bool FAST, bool FULL>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(64 * v2_waves(PREC), 2)
 sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, const float* __restrict__ gamma,
                const float* __restrict__ beta, float* __restrict__ sdf_out, float* __restrict__ grad_out,
                float* __restrict__ rgb_out, float* __restrict__ feat_out, char* __restrict__ scratch,
@@ -394,7 +477,8 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   o.l16hi = 16 * lane + 32768;
   asm volatile("" : "+v"(o.h16), "+v"(o.h64), "+v"(o.l16), "+v"(o.l16hi));
 
-  const long long local = (long long)blockIdx.x * V2_TILE + wave * WAVE_PTS + j;
+  constexpr int NW = v2_waves(PREC), NT = 64 * NW;
+  const long long local = (long long)blockIdx.x * (NW * WAVE_PTS) + wave * WAVE_PTS + j;
   const bool valid = local < n_per_elem;
   const long long pt = (long long)e * n_per_elem + (valid ? local : n_per_elem - 1);
 
@@ -402,7 +486,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   constexpr int SLOT_B = HALF_SCR ? 8192 : 16384;
   FwdScratch<HALF_SCR> ws;
   {
-    const long long wt = ((long long)e * gridDim.x + blockIdx.x) * V2_WAVES + wave;
+    const long long wt = ((long long)e * gridDim.x + blockIdx.x) * NW + wave;
     char* wbase = FULL ? scratch + wt * (long long)(NSLOT * SLOT_B) : nullptr;
     ws.rs = __builtin_amdgcn_make_buffer_rsrc(wbase, 0, FULL ? NSLOT * SLOT_B : 0, 0x00020000);
   }
@@ -412,13 +496,15 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   prefetch_image<PREC>(lds, mats + 0 * (size_t)LB, 0, wave, lane);
   {  // small tables + FiLM rows of all 9 layers (gamma | beta | bias), once
     float* tabs = reinterpret_cast<float*>(lds + V2_TABS);
-    for (int i = tid; i < H_TABS_END; i += 512) tabs[i] = hdr[i];
+    for (int i = tid; i < H_TABS_END; i += NT) tabs[i] = hdr[i];
     float* film = reinterpret_cast<float*>(lds + V2_FILM);
-    for (int i = tid; i < 9 * C; i += 512) {
+    for (int i = tid; i < 9 * C; i += NT) {
       const int l = i / C, f = i % C;
-      film[l * 384 + f] = gamma[((size_t)e * 9 + l) * C + f];
-      film[l * 384 + C + f] = beta[((size_t)e * 9 + l) * C + f];
-      film[l * 384 + 2 * C + f] = hdr[H_BIAS + l * C + f];
+      const float gm = gamma[((size_t)e * 9 + l) * C + f];
+      // image scale of the layer's MFMA operand folded into the multiplier of u (layer 0 runs on the VALU)
+      const float ws = l == 0 ? 1.f : hdr[H_WSCALE + (l < NL_SDF ? l - 1 : 14)];
+      film[l * 256 + f] = gm * ws;
+      film[l * 256 + C + f] = fmaf(gm, hdr[H_BIAS + l * C + f], beta[((size_t)e * 9 + l) * C + f]);
     }
   }
   const float px = pts[pt * 3 + 0], py = pts[pt * 3 + 1], pz = pts[pt * 3 + 2];
@@ -441,7 +527,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
     const char* next = (l < NL_SDF - 1) ? mats + (size_t)l * LB : (FULL ? mats + (size_t)13 * LB : nullptr);
     if (next) stage_early(next, (i + 1) & 1);
     const LayOff y = lay_off<PREC>(o, RING2 ? (i & 1) : 0, l);
-    init_bias2(lds, y, acc);
+    zero_acc(acc);
     gemm_layer2<PREC>(lds, y, act, acc);
     if (next) stage_late(next);
     film_sin2<FAST, FULL, 0>(lds, o, y, acc, act, ws, l, 0, 0.f, 0.f, 0.f);
@@ -497,21 +583,36 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
         for (int k = 0; k < 4; ++k) act[4 * g + k] *= c[k];
         if ((g & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
+      float unscale = 1.f;
+      if constexpr (PREC == OI_PREC_F16X3) {
+        // adjoints have no a-priori range: bring this point's vector (its 128 entries live in lanes j and j+32)
+        // to max |.| in [2^13, 2^14) with an exact power-of-two scale, undone on the accumulators below
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 64; k += 2) m = fmaxf(m, fmaxf(fabsf(act[k]), fabsf(act[k + 1])));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        int eb = (__builtin_bit_cast(int, m) >> 23) & 0xff;
+        eb = eb < 14 ? 14 : (eb > 254 ? 254 : eb);
+        float sc = __builtin_bit_cast(float, (267 - eb) << 23);  // 2^(13 - (eb - 127))
+        // fence tied to sc (= to every c * g product): keeps the GEMM's A-fragment ds_reads from being scheduled
+        // into the scratch-load phase while the 64 c registers are still live (140 spilled VGPRs otherwise)
+        asm volatile("" : "+v"(sc) : : "memory");
+        unscale = __builtin_bit_cast(float, (eb - 13) << 23);          // 1 / sc
+#pragma unroll
+        for (int k = 0; k < 64; ++k) act[k] *= sc;
+      }
       // next image after the scratch loads have been consumed (an in-flight LDS-DMA would otherwise be
       // drained by the vmcnt wait hipcc places in front of the first use of an ordinary load)
       const char* next = (l > 1) ? mats + (size_t)(7 + l - 2) * LB : (rgb_out != nullptr ? mats + (size_t)14 * LB : nullptr);
       if (next) stage_early(next, (i + 1) & 1);
       const LayOff y = lay_off<PREC>(o, RING2 ? (i & 1) : 0, l);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      zero_acc(acc);
       gemm_layer2<PREC>(lds, y, act, acc);
       if (next) stage_late(next);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) act[16 * t + r] = acc[t][r];
+        for (int r = 0; r < 16; ++r) act[16 * t + r] = PREC == OI_PREC_F16X3 ? acc[t][r] * unscale : acc[t][r];
       ring_sync();
     }
     // layer 0: grad = W0^T (g1 * c0)
@@ -549,9 +650,11 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
         if ((g & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       const LayOff y = lay_off<PREC>(o, 0, 8);
-      init_bias2(lds, y, acc);
+      zero_acc(acc);
       gemm_layer2<PREC>(lds, y, act, acc);
-      film_sin2<FAST, false, 2>(lds, o, y, acc, act, ws, 0, H_TABV, gx, gy, gz);
+      // the accumulators carry the image scale 2^k (1 unless F16X3): bring the rank-3 gradient term to the same scale
+      const float cs = 1.0f / hdr[H_WSCALE + 14];
+      film_sin2<FAST, false, 2>(lds, o, y, acc, act, ws, 0, H_TABV, gx * cs, gy * cs, gz * cs);
       float r0 = 0.f, r1 = 0.f, r2 = 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
@@ -582,7 +685,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
 template <int PREC, bool FAST>
 int launch_mlp(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf,
                float* grad, float* rgb, float* feat, void* scratch, int B, long long n, hipStream_t st) {
-  dim3 grid(oi::cdiv(n, V2_TILE), B), block(512);
+  dim3 grid(oi::cdiv(n, v2_waves(PREC) * WAVE_PTS), B), block(64 * v2_waves(PREC));
   const char* pk = reinterpret_cast<const char*>(packed);
   constexpr int LDS_BYTES = v2_lds_total(PREC);
   if (grad != nullptr) {
@@ -649,6 +752,10 @@ int oi_mlp_pack_weights(const float* w0, const float* b0, const float* wh, const
       hipLaunchKernelGGL(pack_weights_kernel<OI_PREC_BF16X6>, grid, block, 0, st, w0, b0, wh, bh, wsig, bsig, wv, bv,
                          wrgb, brgb, p);
       break;
+    case OI_PREC_F16X3:
+      hipLaunchKernelGGL(pack_weights_kernel<OI_PREC_F16X3>, grid, block, 0, st, w0, b0, wh, bh, wsig, bsig, wv, bv,
+                         wrgb, brgb, p);
+      break;
     default:
       return oi::fail(OI_ERR_INVALID_ARG, "oi_mlp_pack_weights: bad precision %d", prec);
   }
@@ -677,6 +784,7 @@ int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, con
     OI_MLP_CASE(OI_PREC_BF16X3)
     OI_MLP_CASE(OI_PREC_BF16)
     OI_MLP_CASE(OI_PREC_BF16X6)
+    OI_MLP_CASE(OI_PREC_F16X3)
     default:
       return oi::fail(OI_ERR_INVALID_ARG, "oi_sdf_mlp_fwd: bad precision %d", prec);
   }

@@ -626,7 +626,8 @@ int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, con
   OI_REQUIRE(B > 0 && n_per_elem > 0, "oi_sdf_mlp_bwd: B=%d n=%lld", B, n_per_elem);
   OI_REQUIRE((rgb_fwd == nullptr) == (g_rgb == nullptr) || g_rgb == nullptr, "oi_sdf_mlp_bwd: g_rgb needs rgb_fwd");
   OI_REQUIRE(g_rgb == nullptr || grad_fwd != nullptr, "oi_sdf_mlp_bwd: colour backward needs the forward gradient");
-  OI_REQUIRE(prec != OI_PREC_BF16X6, "oi_sdf_mlp_bwd: pass the OI_PREC_F32 image for the backward of the BF16X6 mode");
+  OI_REQUIRE(prec != OI_PREC_BF16X6 && prec != OI_PREC_F16X3,
+             "oi_sdf_mlp_bwd: pass the OI_PREC_F32 image for the backward of the BF16X6 / F16X3 modes");
   hipStream_t st = oi::as_stream(stream);
 #define OI_BWD_CASE(P)                                                                                              \
   case P:                                                                                                           \

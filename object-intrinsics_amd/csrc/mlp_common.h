@@ -7,6 +7,7 @@ namespace oimlp {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int C = 128;           // hidden width (W in the reference config)
 constexpr int NL_SDF = 8;        // FiLM layers of the SDF net
@@ -22,6 +23,7 @@ constexpr int H_TABV = 656;      // [128][4]  (wv[:,128], wv[:,129], wv[:,130], 
 constexpr int H_RGB = 1168;      // [3][128] wrgb, then brgb[3]
 constexpr int H_TABS_END = 1568; // tab0..rgb are copied to LDS as one block
 constexpr int H_BIAS = 1568;     // [9][128]  b0, b1..b7, bv
+constexpr int H_WSCALE = 2720;   // [16] 2^-k_m: inverse of the power-of-two scale baked into image m (1 unless F16X3)
 constexpr int H_FLOATS = 2816;
 constexpr size_t H_BYTES = H_FLOATS * 4;
 
@@ -153,9 +155,11 @@ __device__ __forceinline__ void gemm_layer(const char* lds, const LaneOff& o, co
   }
 }
 
-// sin and cos of one fp32 phase.  Accurate form: 2-constant Cody-Waite reduction by pi/2 with FMA
-// (|phi| stays below a few hundred radians: gamma ~ 30 +- 15, |u| of order one) followed by the
-// classic minimax kernels on [-pi/4, pi/4]; <1e-7 abs error, no stack, ~22 VALU ops for the pair.
+// sin and cos of one fp32 phase.  Accurate form: phi = n*pi + r with n = round(phi/pi) taken from the low mantissa
+// bit of a magic-number FMA (no cvt / rint), 2-constant Cody-Waite reduction with FMA (|phi| stays below a few
+// hundred radians: gamma ~ 30 +- 15, |u| of order one), then sin r and cos r from weighted-minimax polynomials on
+// [-pi/2, pi/2] (1.4e-8 / 7e-9 approximation error with the fp32 coefficients) and ONE shared sign (-1)^n applied
+// by xor -- no quadrant swap, no selects: 19 VALU ops for the pair, all but 3 of them packable (v_pk_fma_f32).
 // Fast form: v_sin_f32 / v_cos_f32 on phi/(2 pi) (used by the bf16 throughput mode).
 template <bool FAST>
 __device__ __forceinline__ void sincos_(float x, float& s, float& c) {
@@ -163,21 +167,23 @@ __device__ __forceinline__ void sincos_(float x, float& s, float& c) {
     s = __sinf(x);
     c = __cosf(x);
   } else {
-    const float n = rintf(x * 0.63661977236758134308f);
-    float r = fmaf(n, -1.57079637050628662109375f, x);
-    r = fmaf(n, 4.37113882867379e-08f, r);
-    const float r2 = r * r;
-    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = fmaf(r2, ps, -1.6666654611e-1f);
-    ps = fmaf(r2 * r, ps, r);
-    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = fmaf(r2, pc, 4.166664568298827e-2f);
-    pc = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
-    const int q = (int)n;
-    const float sa = (q & 1) ? pc : ps;
-    const float ca = (q & 1) ? ps : pc;
-    s = (q & 2) ? -sa : sa;
-    c = ((q + 1) & 2) ? -ca : ca;
+    constexpr float MAGIC = 12582912.f;  // 1.5 * 2^23: nf = MAGIC + round(x / pi), parity of n in mantissa bit 0
+    const float nf = fmaf(x, 0.318309886183790671538f, MAGIC);
+    const float n = nf - MAGIC;
+    float r = fmaf(n, -3.1415927410125732f, x);
+    r = fmaf(n, 8.742278000372485e-08f, r);  // float(pi) - pi
+    const float t = r * r;
+    float ps = fmaf(t, 2.5999420359e-06f, -1.9806565251e-04f);
+    ps = fmaf(t, ps, 8.3330161870e-03f);
+    ps = fmaf(t, ps, -1.6666656733e-01f);
+    ps = fmaf(t * r, ps, r);
+    float pc = fmaf(t, -2.6192776659e-07f, 2.4769255106e-05f);
+    pc = fmaf(t, pc, -1.3888567919e-03f);
+    pc = fmaf(t, pc, 4.1666656733e-02f);
+    pc = fmaf(t * t, pc, fmaf(t, -0.5f, 1.0f));
+    const unsigned sign = __builtin_bit_cast(unsigned, nf) << 31;
+    s = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, ps) ^ sign);
+    c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, pc) ^ sign);
   }
 }
 

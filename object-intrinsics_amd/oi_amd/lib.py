@@ -12,9 +12,9 @@ LIB_PATH = os.path.join(_HERE, "liboi_hip.so")
 _lock = threading.Lock()
 _lib = None
 
-OI_PREC_F32, OI_PREC_BF16X3, OI_PREC_BF16, OI_PREC_BF16X6 = 0, 1, 2, 3
+OI_PREC_F32, OI_PREC_BF16X3, OI_PREC_BF16, OI_PREC_BF16X6, OI_PREC_F16X3 = 0, 1, 2, 3, 4
 PRECISIONS = {"f32": OI_PREC_F32, "fp32": OI_PREC_F32, "bf16x3": OI_PREC_BF16X3, "bf16": OI_PREC_BF16,
-              "bf16x6": OI_PREC_BF16X6}
+              "bf16x6": OI_PREC_BF16X6, "f16x3": OI_PREC_F16X3}
 
 _vp, _i, _ll, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t
 

@@ -18,7 +18,7 @@ from .fields import FieldPack
 
 class NeuSRenderer:
     def __init__(self, nerf, sdf_network, deviation_network, color_network, n_samples, n_importance, n_outside,
-                 up_sample_steps, perturb, precision="bf16x6", fast_trig=None):
+                 up_sample_steps, perturb, precision="f16x3", fast_trig=None):
         if n_outside != 0:
             raise NotImplementedError("n_outside > 0 (NeRF++ background) is dead on the path (train.yaml:73)")
         self.nerf = nerf

@@ -190,7 +190,7 @@ def _oracle_mlp_grads(sdf_sd, col_sd, pts, w, cs, cg, cr):
 
 
 @pytest.mark.parametrize("n,B,precision,tol", [(96, 2, "f32", 2e-3), (300, 1, "f32", 2e-3), (64, 2, "bf16x3", 1e-2),
-                                               (160, 1, "bf16x6", 2e-3)])
+                                               (160, 1, "bf16x6", 2e-3), (160, 1, "f16x3", 2e-3)])
 def test_mlp_backward_vs_oracle(sdf_sd, col_sd, n, B, precision, tol):
     """dL/d(every parameter, w) for L = <cs, sdf> + <cg, d sdf/dx> + <cr, rgb> (random cotangents)."""
     from oi_amd.fields import ShapeNetwork, ColorNetwork, FieldPack

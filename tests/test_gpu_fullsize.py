@@ -33,8 +33,8 @@ def _rays(N, seed):
     return ro, rd, near, far
 
 
-@pytest.mark.parametrize("name,B,R,S,I,K,precision", [("C2", 1, 64, 64, 64, 1, "bf16x6"), ("C2", 1, 64, 64, 64, 1, "f32"),
-                                                      ("C4", 1, 128, 128, 128, 4, "bf16x6")])
+@pytest.mark.parametrize("name,B,R,S,I,K,precision", [("C2", 1, 64, 64, 64, 1, "f16x3"), ("C2", 1, 64, 64, 64, 1, "bf16x6"), ("C2", 1, 64, 64, 64, 1, "f32"),
+                                                      ("C4", 1, 128, 128, 128, 4, "f16x3")])
 def test_full_size_render_properties(sdf_sd, col_sd, name, B, R, S, I, K, precision):
     N = B * R * R
     ro, rd, near, far = _rays(N, 11)

@@ -29,7 +29,7 @@ def packed_all(ops, sdf_sd, col_sd):
     from oi_amd.params import stack_field_params
     P = stack_field_params(dev(sdf_sd), dev(col_sd))
     packs = {}
-    for name, prec in (("f32", 0), ("bf16x3", 1), ("bf16", 2), ("bf16x6", 3)):
+    for name, prec in (("f32", 0), ("bf16x3", 1), ("bf16", 2), ("bf16x6", 3), ("f16x3", 4)):
         packs[name] = ops.mlp_pack_weights(P["w0"], P["b0"], P["wh"], P["bh"], P["wsig"], P["bsig"], P["wv"], P["bv"],
                                            P["wrgb"], P["brgb"], prec)
     return P, packs
@@ -55,13 +55,13 @@ def test_film_params(ops, packed_all, sdf_sd, col_sd):
     assert maxdiff(gamma2, gamma) < 1e-4
 
 
-@pytest.mark.parametrize("mode,tol_sdf,tol_grad,tol_rgb", [("f32", 2e-5, 1e-4, 2e-5), ("bf16x6", 2e-5, 1e-4, 2e-5),
+@pytest.mark.parametrize("mode,tol_sdf,tol_grad,tol_rgb", [("f32", 2e-5, 1e-4, 2e-5), ("bf16x6", 2e-5, 1e-4, 2e-5), ("f16x3", 2e-5, 1e-4, 2e-5),
                                                            ("bf16x3", 5e-5, 2e-4, 5e-5), ("bf16", 3e-2, 1.5e-1, 3e-2)])
 def test_sdf_mlp_golden(ops, packed_all, col_sd, mode, tol_sdf, tol_grad, tol_rgb):
     """F1/F2: sdf, features, analytic gradient and colour head vs the reference's own outputs."""
     P, packs = packed_all
     g1, g2 = load_golden("f1_film_siren"), load_golden("f2_color")
-    prec = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16x6": 3}[mode]
+    prec = {"f32": 0, "bf16x3": 1, "bf16": 2, "bf16x6": 3, "f16x3": 4}[mode]
     w, gamma, beta = ops.film_params(P["style_w"], P["style_b"], P["gw"], P["gb"], P["bw"], P["bb"], w=g1["w"].cuda())
     sdf, grad, rgb, feat, _ = ops.sdf_mlp_fwd(g1["pts"].cuda(), packs[mode], gamma, beta, 2, prec,
                                               fast_trig=(mode == "bf16"), want_grad=True, want_rgb=True, want_feat=True)
@@ -72,7 +72,8 @@ def test_sdf_mlp_golden(ops, packed_all, col_sd, mode, tol_sdf, tol_grad, tol_rg
     print(f"[{mode}] sdf {e_sdf:.2e} feat {e_feat:.2e} grad(rel {gscale:.1f}) {e_grad:.2e} rgb {e_rgb:.2e}")
     assert e_sdf < tol_sdf and e_grad < tol_grad and e_rgb < tol_rgb
     # intermediate 128-d features (not a renderer output): bf16x3 drops the lo*lo product terms
-    assert e_feat < {"f32": 1e-4, "bf16x6": 1e-4, "bf16x3": 3e-4, "bf16": 1e-1}[mode]
+    # (2^-16 relative per product, amplified by the gamma ~ 30 FiLM phases over 8 layers)
+    assert e_feat < {"f32": 1e-4, "bf16x6": 1e-4, "f16x3": 1e-4, "bf16x3": 3e-4, "bf16": 1e-1}[mode]
     # sdf-only variant agrees with the full variant
     sdf2, _, _, _, _ = ops.sdf_mlp_fwd(g1["pts"].cuda(), packs[mode], gamma, beta, 2, prec, fast_trig=(mode == "bf16"))
     assert maxdiff(sdf2, sdf) < 1e-6

@@ -56,8 +56,9 @@ KEYS = ("s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights",
 # f32 = the 1e-4 parity path of the north star.  bf16x3 (hi/lo split operands on the bf16 matrix cores) carries
 # ~2^-16 relative error per product; amplified by the gamma~30 FiLM phases it reaches 3e-4 (relative) on
 # d sdf/dx and stays within 2e-4 on every other renderer output -- stated here and in DESIGN.md.
-# bf16x6 (3-way split, the 6 products of weight >= 2^-24): fp32-exact contractions -> the same 1e-4 bar as f32.
-@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("bf16x6", 1e-4), ("bf16x3", 2e-4)])
+# bf16x6 (3-way bf16 split, the 6 products of weight >= 2^-24) and f16x3 (2-way fp16 split of power-of-two scaled
+# operands, 3 products, 2^-22 per product): fp32-class contractions -> the same 1e-4 bar as f32.
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("bf16x6", 1e-4), ("f16x3", 1e-4), ("bf16x3", 2e-4)])
 @pytest.mark.parametrize("tag,car", [("c0p0", 0.0), ("c0p5", 0.5), ("c1p0", 1.0)])
 def test_render_golden_f4(col_sd, tag, car, precision, tol):
     """NeuSRenderer.render on identical rays / weights: every key of the returned dict within 1e-4."""
@@ -98,8 +99,12 @@ def test_render_vs_oracle_hierarchical(sdf_sd, col_sd, K, I):
     dz = (out["mid_z_vals"].cpu() - ref["mid_z_vals"]).abs().max(-1).values
     ok = dz < 1e-4
     assert ok.float().mean() >= 0.97, float(ok.float().mean())
+    # alpha = f(sdf * inv_s) with inv_s doubling per up-sampling step (64 * 2^(K-1) in the last one): an fp32-level
+    # sdf difference of ~2e-6 between two correct MLP evaluations moves a weight by ~ inv_s * 2e-6 * 0.25, i.e.
+    # ~6e-5 at K <= 2 and ~2.6e-4 at K = 4 -- the bound scales with K accordingly.
+    tol = 2e-4 if K <= 2 else 4e-4
     for k in ("weights", "color_fine", "weight_sum", "sdf", "raw_color"):
-        assert maxdiff(out[k].cpu()[ok], ref[k][ok]) < 2e-4, (k, maxdiff(out[k].cpu()[ok], ref[k][ok]))
+        assert maxdiff(out[k].cpu()[ok], ref[k][ok]) < tol, (k, maxdiff(out[k].cpu()[ok], ref[k][ok]))
     assert abs(float(out["color_fine"].cpu().mean()) - float(ref["color_fine"].mean())) < 1e-4
 
 
@@ -134,7 +139,7 @@ def build_generator(R, S, I, K, precision="f32"):
     return gen.cuda()
 
 
-@pytest.mark.parametrize("precision", ["bf16x6", "f32"])
+@pytest.mark.parametrize("precision", ["f16x3", "bf16x6", "f32"])
 def test_generator_golden_f5(precision):
     """Full Generator.forward(return_raw=True) vs the reference's own output (rays, maps, stats)."""
     g = load_golden("f5_generator")
