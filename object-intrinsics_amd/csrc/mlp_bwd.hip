@@ -131,6 +131,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   float act[64];
   f32x16 acc[4];
   const float* film = reinterpret_cast<const float*>(lds + L_FILM);
+  // F16X3: the images carry a power-of-two scale 2^k_m (header H_WSCALE holds 2^-k_m); every GEMM returns the factor
+  // its accumulators still need (gemm_scaled), adjoint vectors are normalised per point before the fp16 split.
+  constexpr bool SC = PREC == OI_PREC_F16X3;
 
   // ================= phase A: recompute phi_l (ascending) =================
 #pragma unroll
@@ -156,16 +159,19 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     stage_layer<PREC>(lds, mats + (size_t)(l - 1) * layer_bytes(PREC), tid);
     stage_film(lds, gamma, beta, hdr, e, l, tid);
     __syncthreads();
-    init_bias(lds, o, acc);
-    gemm_layer<PREC>(lds, o, act, acc);
+    if constexpr (SC) acc_zero(acc); else init_bias(lds, o, acc);
+    const float fA = gemm_scaled<PREC, false>(lds, o, act, acc, SC ? hdr[H_WSCALE + l - 1] : 1.f);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
       const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
+      f32x4 bs;
+      if constexpr (SC) bs = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
       f32x4 ph;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        ph[k] = fmaf(gm[k], acc[g >> 2][4 * (g & 3) + k], bt[k]);
+        const float u = SC ? fmaf(acc[g >> 2][4 * (g & 3) + k], fA, bs[k]) : acc[g >> 2][4 * (g & 3) + k];
+        ph[k] = fmaf(gm[k], u, bt[k]);
         float s, c;
         sincos_<FAST>(ph[k], s, c);
         act[4 * g + k] = s;
@@ -189,8 +195,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       const float rv = rgb_fwd[pt * 3 + k];
       rho[k] = g_rgb[pt * 3 + k] * rv * (1.0f - rv) * vmask;  // through the sigmoid
     }
-    init_bias(lds, o, acc);
-    gemm_layer<PREC>(lds, o, act, acc);
+    if constexpr (SC) acc_zero(acc); else init_bias(lds, o, acc);
+    const float fV = gemm_scaled<PREC, false>(lds, o, act, acc, SC ? hdr[H_WSCALE + 14] : 1.f);
     // uv -> phiv -> hv; then uvbar.  Reductions: rows 0 gamma_v, 1 beta_v, 2 bv, 3..5 Wrgb, (6,7 free)
     float dGx = 0.f, dGy = 0.f, dGz = 0.f;
 #pragma unroll
@@ -200,11 +206,13 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       const f32x4 w0 = lds_f4(lds, L_TABS + (H_RGB + 0 * C + grp_f0(g)) * 4, o.h16);
       const f32x4 w1 = lds_f4(lds, L_TABS + (H_RGB + 1 * C + grp_f0(g)) * 4, o.h16);
       const f32x4 w2 = lds_f4(lds, L_TABS + (H_RGB + 2 * C + grp_f0(g)) * 4, o.h16);
-      f32x4 uvb, r_g, r_b, r0, r1, r2;
+      f32x4 uvb, r_g, r_b, r0, r1, r2, bsv;
+      if constexpr (SC) bsv = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const f32x4 wx = lds_f4(lds, L_TABS + H_TABV * 4 + (grp_f0(g) + k) * 16, o.h64);
-        const float uv = acc[g >> 2][4 * (g & 3) + k] + fmaf(fz, wx[2], fmaf(fy, wx[1], fx * wx[0]));
+        const float ua = SC ? fmaf(acc[g >> 2][4 * (g & 3) + k], fV, bsv[k]) : acc[g >> 2][4 * (g & 3) + k];
+        const float uv = ua + fmaf(fz, wx[2], fmaf(fy, wx[1], fx * wx[0]));
         const float phiv = fmaf(gm[k], uv, bt[k]);
         float hv, cv;
         sincos_<FAST>(phiv, hv, cv);
@@ -274,16 +282,13 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       for (int k = 0; k < 4; ++k) uvb[k] = act[4 * g + k];
       reduce_group(lds, 0, g, h, j, uvb * fz);
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    gemm_layer<PREC>(lds, o, act, acc);
+    acc_zero(acc);
+    const float fT = gemm_scaled<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + 15] : 1.f);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       f32x4 v;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = acc[g >> 2][4 * (g & 3) + k];
+      for (int k = 0; k < 4; ++k) v[k] = SC ? acc[g >> 2][4 * (g & 3) + k] * fT : acc[g >> 2][4 * (g & 3) + k];
       ws.store(S_AC, g, o.l16, v);
     }
     __syncthreads();
@@ -321,15 +326,12 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       ws.store(S_V + l - 1, g, o.l16, vv);
       __builtin_amdgcn_sched_barrier(0);
     }
+    acc_zero(acc);
+    const float fB = gemm_scaled<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + 7 + l - 1] : 1.f);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    gemm_layer<PREC>(lds, o, act, acc);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) act[16 * t + r] = acc[t][r];
+      for (int r = 0; r < 16; ++r) act[16 * t + r] = SC ? acc[t][r] * fB : acc[t][r];
   }
 #pragma unroll
   for (int g = 0; g < 16; ++g) {  // g_1
@@ -384,11 +386,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       for (int k = 0; k < 4; ++k) v[k] = act[4 * g + k];
       ws.store(S_GB + l - 1, g, o.l16, v);
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    gemm_layer<PREC>(lds, o, act, acc);  // vbar_l = W_l gbar_l
+    acc_zero(acc);
+    const float fC = gemm_scaled<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + l - 1] : 1.f);  // vbar_l = W_l gbar_l
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const f32x4 ph = ws.load(S_PHI + l, g, o.l16);
@@ -401,7 +400,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       for (int k = 0; k < 4; ++k) {
         float s, c;
         sincos_<FAST>(ph[k], s, c);
-        const float vb = acc[g >> 2][4 * (g & 3) + k];
+        const float vb = SC ? acc[g >> 2][4 * (g & 3) + k] * fC : acc[g >> 2][4 * (g & 3) + k];
         act[4 * g + k] = vb * gm[k] * c;  // gbar_{l+1}
         cb[k] = vb * gn[k];               // cbar_l
       }
@@ -481,15 +480,12 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       __builtin_amdgcn_sched_barrier(0);
     }
     if (l >= 1) {
+      acc_zero(acc);
+      const float fD = gemm_scaled<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + 7 + l - 1] : 1.f);  // abar_l = W_l^T ubar_l
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-      gemm_layer<PREC>(lds, o, act, acc);  // abar_l = W_l^T ubar_l
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) act[16 * t + r] = acc[t][r];
+        for (int r = 0; r < 16; ++r) act[16 * t + r] = SC ? acc[t][r] * fD : acc[t][r];
     }
     __syncthreads();
     racc_flush_row(lds, 0, d_gamma + ((size_t)e * 9 + l) * C, 1, tid);
@@ -626,8 +622,7 @@ int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, con
   OI_REQUIRE(B > 0 && n_per_elem > 0, "oi_sdf_mlp_bwd: B=%d n=%lld", B, n_per_elem);
   OI_REQUIRE((rgb_fwd == nullptr) == (g_rgb == nullptr) || g_rgb == nullptr, "oi_sdf_mlp_bwd: g_rgb needs rgb_fwd");
   OI_REQUIRE(g_rgb == nullptr || grad_fwd != nullptr, "oi_sdf_mlp_bwd: colour backward needs the forward gradient");
-  OI_REQUIRE(prec != OI_PREC_BF16X6 && prec != OI_PREC_F16X3,
-             "oi_sdf_mlp_bwd: pass the OI_PREC_F32 image for the backward of the BF16X6 / F16X3 modes");
+  OI_REQUIRE(prec != OI_PREC_BF16X6, "oi_sdf_mlp_bwd: pass the OI_PREC_F32 image for the backward of the BF16X6 mode");
   hipStream_t st = oi::as_stream(stream);
 #define OI_BWD_CASE(P)                                                                                              \
   case P:                                                                                                           \
@@ -639,6 +634,7 @@ int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, con
     OI_BWD_CASE(OI_PREC_F32)
     OI_BWD_CASE(OI_PREC_BF16X3)
     OI_BWD_CASE(OI_PREC_BF16)
+    OI_BWD_CASE(OI_PREC_F16X3)
     default:
       return oi::fail(OI_ERR_INVALID_ARG, "oi_sdf_mlp_bwd: bad precision %d", prec);
   }

@@ -112,6 +112,44 @@ __device__ __forceinline__ void gemm_layer(const char* lds, const LaneOff& o, co
 #pragma unroll
       for (int t = 0; t < 4; ++t) a[t] = an[t];
     }
+  } else if constexpr (PREC == OI_PREC_F16X3) {
+    f32x4 ah[4], ahn[4], al[4], aln[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ah[t] = lds_f4(lds, L_WBUF + (t * 8 + 0) * 1024, o.l16);
+      al[t] = lds_f4(lds, L_WBUF + (t * 8 + 0) * 1024, o.l16hi);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < 7) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          ahn[t] = lds_f4(lds, L_WBUF + (t * 8 + s + 1) * 1024, o.l16);
+          aln[t] = lds_f4(lds, L_WBUF + (t * 8 + s + 1) * 1024, o.l16hi);
+        }
+      }
+      f16x8 bh, bl;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = act[8 * s + i];
+        bh[i] = (_Float16)v;
+        bl[i] = (_Float16)(v - (float)bh[i]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f16x8 wh = __builtin_bit_cast(f16x8, ah[t]);
+        const f16x8 wl = __builtin_bit_cast(f16x8, al[t]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, acc[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        ah[t] = ahn[t];
+        al[t] = aln[t];
+      }
+    }
   } else {
     f32x4 ah[4], ahn[4], al[4], aln[4];
 #pragma unroll
@@ -236,6 +274,45 @@ __device__ __forceinline__ void film_sin(const char* lds, const LaneOff& o, cons
     if constexpr (FULL) ws.store(slot, g, o.l16, cv);
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// Power-of-two normalisation of one point's 128-vector (64 entries in this lane, 64 in lane ^ 32) to max |.| in
+// [2^13, 2^14): the fp16 split of the F16X3 mode then never leaves the normal range of its hi limb and keeps 22
+// mantissa bits.  Scales `act` in place and returns 1/scale (exact).
+__device__ __forceinline__ float pow2_normalise(float (&act)[64]) {
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < 64; k += 2) m = fmaxf(m, fmaxf(fabsf(act[k]), fabsf(act[k + 1])));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  int eb = (__builtin_bit_cast(int, m) >> 23) & 0xff;
+  eb = eb < 14 ? 14 : (eb > 254 ? 254 : eb);
+  float sc = __builtin_bit_cast(float, (267 - eb) << 23);  // 2^(13 - (eb - 127))
+  asm volatile("" : "+v"(sc) : : "memory");                // keeps the GEMM's ds_reads behind the producers of act
+#pragma unroll
+  for (int k = 0; k < 64; ++k) act[k] *= sc;
+  return __builtin_bit_cast(float, (eb - 13) << 23);
+}
+
+// GEMM of the backward kernels: acc = W_img * act (accumulators must come in zeroed).  Returns the factor the
+// accumulators still have to be multiplied by: 1 for the unscaled images, 2^-k_m (x 1/normalisation) for F16X3.
+// NORM = false for inputs known to lie in [-1, 1] (sin activations).
+template <int PREC, bool NORM>
+__device__ __forceinline__ float gemm_scaled(const char* lds, const LaneOff& o, float (&act)[64], f32x16 (&acc)[4],
+                                             float inv_img) {
+  float f = 1.f;
+  if constexpr (PREC == OI_PREC_F16X3) {
+    f = inv_img;
+    if constexpr (NORM) f *= pow2_normalise(act);
+  }
+  gemm_layer<PREC>(lds, o, act, acc);
+  return f;
+}
+
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[4]) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 }
 
 __device__ __forceinline__ void init_bias(const char* lds, const LaneOff& o, f32x16 (&acc)[4]) {

@@ -184,8 +184,8 @@ class FieldPack:
 
     @property
     def prec_bwd(self):
-        """The backward kernels have no BF16X6 / F16X3 variant: those modes differentiate through the exact-fp32 image."""
-        return _l.OI_PREC_F32 if self.prec in (_l.OI_PREC_BF16X6, _l.OI_PREC_F16X3) else self.prec
+        """The backward kernels have no BF16X6 variant: that mode differentiates through the exact-fp32 image."""
+        return _l.OI_PREC_F32 if self.prec == _l.OI_PREC_BF16X6 else self.prec
 
     def packed(self, for_backward=False):
         sd, csd = self._sds()

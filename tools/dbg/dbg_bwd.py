@@ -16,7 +16,7 @@ w = O.style_mlp(sdf_sd, torch.randn(B, 64, generator=g))
 cs, cg, cr = torch.randn(B * n, generator=g), 0.1 * torch.randn(B * n, 3, generator=g), torch.randn(B * n, 3, generator=g)
 loss_o, g_o = _oracle_mlp_grads(sdf_sd, col_sd, pts, w, cs, cg, cr)
 sdf_net = ShapeNetwork(SDF_NPZ, **NET_KW).cuda(); col_net = ColorNetwork(**NET_KW); col_net.load_state_dict(col_sd); col_net = col_net.cuda()
-pack = FieldPack(sdf_net, col_net, "f32")
+pack = FieldPack(sdf_net, col_net, sys.argv[1] if len(sys.argv) > 1 else "f32")
 wh = w.cuda().requires_grad_(True)
 _, gamma, beta = pack.film(w=wh)
 gamma.retain_grad(); beta.retain_grad()
