@@ -124,7 +124,7 @@ def cpu_baseline(R, S, I, K, B):
                       f"({dt:.1f} s, torch CPU fp32, {cores} threads)"}
 
 
-def bench_training(args, gen, disc, device, world, barrier):
+def bench_training(args, gen, disc, device, world, barrier, distributed):
     from oi_amd.config import build_from_config
     from oi_amd.ddp import FlatGradDDP
     from oi_amd.trainer import Trainer
@@ -134,7 +134,7 @@ def bench_training(args, gen, disc, device, world, barrier):
                                   aug=net("src.third_party.ada.augment.AugmentPipe", scale=1, xint=1), aug_p=1,
                                   img_size=R, in_dim=1, last_bias=False, n_feat=512, out_dim=1)).to(device)
     nets = {"generator": gen, "discriminator": disc, "mask_discriminator": mdisc}
-    if world > 1:
+    if distributed:
         nets = {k: FlatGradDDP(v) for k, v in nets.items()}
     mods = dict(nets)
     mods["opt_generator"] = torch.optim.Adam(nets["generator"].parameters(), lr=2e-5, betas=(0.0, 0.9))
@@ -151,7 +151,7 @@ def bench_training(args, gen, disc, device, world, barrier):
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
+    if distributed:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt)
     it_s = args.train_steps / dt
@@ -159,7 +159,7 @@ def bench_training(args, gen, disc, device, world, barrier):
             "rays_per_s": 3 * world * B * R * R * it_s, "d_train_images_per_s": 4 * world * B * it_s,
             "what": "Trainer.train_step: G step (render fwd+bwd incl. double-backward, 2 D fwd+bwd-to-input) + D step "
                     "+ mask-D step (each: real fwd + R1 double-backward + fake fwd + bwd), Adam/RMSprop steps"
-                    + (", flat-gradient RCCL all-reduce x3" if world > 1 else ""),
+                    + (", flat-gradient RCCL all-reduce x3" if distributed else ""),
             "finite": bool(all(torch.isfinite(torch.as_tensor(v)).all() for v in out.values()))}
 
 
@@ -186,9 +186,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # OI_BENCH_FORCE_DIST=1 runs the RCCL code paths (process group, barrier, max/sum reductions, FlatGradDDP
+    # all-reduce) with a single rank: a smoke test of the N > 1 path on a 1-GPU box.
+    distributed = world > 1 or os.environ.get("OI_BENCH_FORCE_DIST") == "1"
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", init_method="env://")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", init_method="env://", device_id=device)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
 
     torch.manual_seed(1234 + rank)
@@ -218,8 +224,8 @@ def main():
         return out, d
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        if distributed:
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -250,13 +256,13 @@ def main():
     train = None
     if args.train_steps > 0 and not args.no_disc:
         try:
-            train = bench_training(args, gen, disc, device, world, barrier)
+            train = bench_training(args, gen, disc, device, world, barrier, distributed)
         except Exception as ex:  # never lose the headline line because of the secondary measurement
             train = {"error": f"{type(ex).__name__}: {ex}"}
 
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     dd = torch.tensor([d_img_s or 0.0], device=device, dtype=torch.float64)
-    if world > 1:
+    if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(dd, op=dist.ReduceOp.SUM)
     dt = float(t)
@@ -300,16 +306,22 @@ def main():
                          "executed_mfma_frac_of_peak": (achieved * MFMA_PER_MAC[args.precision] / peak) if achieved else None,
                          "vs_native_fp32_mfma_peak": (achieved / 157.3) if achieved else None,
                          "note": "algorithmic = GEMM MACs x2 of sdf fwd + analytic gradient sweep + colour head per "
-                                 "point. peak = dense MFMA peak of the unit the mode runs on (fp32 MFMA 157.3, bf16 MFMA 2500 "
-                                 "TFLOP/s); bf16x3 / bf16x6 execute 3 / 6 bf16 MFMAs per algorithmic MAC "
-                                 "(executed_mfma_frac_of_peak), so their frac is bounded by 1/3 / 1/6; "
+                                 "point. peak = dense MFMA peak of the unit the mode runs on (fp32 MFMA 157.3, fp16 / bf16 MFMA "
+                                 "2500 TFLOP/s); f16x3 / bf16x3 / bf16x6 execute 3 / 3 / 6 16-bit MFMAs per algorithmic MAC "
+                                 "(executed_mfma_frac_of_peak), so their frac is bounded by 1/3 / 1/3 / 1/6; "
                                  "vs_native_fp32_mfma_peak compares the fp32-exact result rate with the native fp32 roofline"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(R, S, I, K, B)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which is
+        # block-buffered on a pipe and would otherwise surface after it at exit
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
