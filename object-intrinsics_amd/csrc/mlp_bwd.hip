@@ -507,16 +507,20 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 // Operands are read from the sweep kernel's scratch slots (C-fragment order) and transposed via LDS.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int slot_index(int f, int p) {
-  // float index inside a 16 KiB slot of element (feature f, point p of the wave tile)
+  // float index of element (feature f, point p of the wave tile) in the LDS copy of a 16 KiB slot.  The copy is
+  // skewed by 8 floats per 32-point block (t, rr, hh): the 32 features a wave reads for one point then fall into 32
+  // distinct banks (unskewed, bank = 4p + k for every (rr, hh): an 8-way conflict).
   const int t = f >> 5, rr = (f >> 3) & 3, hh = (f >> 2) & 1, k = f & 3;
-  return ((4 * t + rr) * 64 + hh * 32 + p) * 4 + k;
+  const int blk = (4 * t + rr) * 2 + hh;
+  return (blk * 32 + p) * 4 + k + 8 * blk;
 }
+constexpr int WG_SLOT_FLOATS = 4096 + 8 * 32;
 
 template <bool FAST>
 __global__ void __launch_bounds__(256)
 mlp_wgrad_kernel(const char* __restrict__ scratch, float* __restrict__ d_wmat, long long n_wave_tiles,
                  int tiles_per_chunk, int has_col) {
-  __shared__ __attribute__((aligned(16))) float sx[4096], sy[4096];
+  __shared__ __attribute__((aligned(16))) float sx[WG_SLOT_FLOATS], sy[WG_SLOT_FLOATS];
   const int m = blockIdx.y;
   if (m == 7 && !has_col) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -542,8 +546,11 @@ mlp_wgrad_kernel(const char* __restrict__ scratch, float* __restrict__ d_wmat, l
       const f32x4* gy4 = reinterpret_cast<const f32x4*>(base + (size_t)syi * 16384);
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        reinterpret_cast<f32x4*>(sx)[it * 256 + tid] = gx4[it * 256 + tid];
-        f32x4 y = gy4[it * 256 + tid];
+        // f32x4 number q = it*256 + tid of the slot: 32-point block q >> 5 = ((4t + rr) * 2 + hh)
+        const int q = it * 256 + tid;
+        const int dq = q + 2 * (q >> 5);  // + 8 floats per 32-point block
+        reinterpret_cast<f32x4*>(sx)[dq] = gx4[q];
+        f32x4 y = gy4[q];
         if (y_is_phi) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -552,7 +559,7 @@ mlp_wgrad_kernel(const char* __restrict__ scratch, float* __restrict__ d_wmat, l
             y[k] = s;
           }
         }
-        reinterpret_cast<f32x4*>(sy)[it * 256 + tid] = y;
+        reinterpret_cast<f32x4*>(sy)[dq] = y;
       }
       __syncthreads();
       const int fo = 32 * wave + i;
