@@ -137,9 +137,10 @@ def bench_training(args, gen, disc, device, world, barrier, distributed):
     if distributed:
         nets = {k: FlatGradDDP(v) for k, v in nets.items()}
     mods = dict(nets)
-    mods["opt_generator"] = torch.optim.Adam(nets["generator"].parameters(), lr=2e-5, betas=(0.0, 0.9))
-    mods["opt_discriminator"] = torch.optim.RMSprop(nets["discriminator"].parameters(), lr=1e-4)
-    mods["opt_mask_discriminator"] = torch.optim.RMSprop(nets["mask_discriminator"].parameters(), lr=1e-4)
+    from oi_amd.optim import FusedAdam, FusedRMSprop  # configs/train.yaml:133-147, one launch per step each
+    mods["opt_generator"] = FusedAdam(nets["generator"].parameters(), lr=2e-5, betas=(0.0, 0.9))
+    mods["opt_discriminator"] = FusedRMSprop(nets["discriminator"].parameters(), lr=1e-4)
+    mods["opt_mask_discriminator"] = FusedRMSprop(nets["mask_discriminator"].parameters(), lr=1e-4)
     tr = Trainer(mods)
     data = {"image": torch.rand(B, 3, R, R, device=device), "mask": torch.rand(B, 1, R, R, device=device)}
     for _ in range(2):
@@ -158,7 +159,7 @@ def bench_training(args, gen, disc, device, world, barrier, distributed):
     return {"it_per_s": it_s, "ms_per_it": 1e3 / it_s, "steps": args.train_steps,
             "rays_per_s": 3 * world * B * R * R * it_s, "d_train_images_per_s": 4 * world * B * it_s,
             "what": "Trainer.train_step: G step (render fwd+bwd incl. double-backward, 2 D fwd+bwd-to-input) + D step "
-                    "+ mask-D step (each: real fwd + R1 double-backward + fake fwd + bwd), Adam/RMSprop steps"
+                    "+ mask-D step (each: real fwd + R1 double-backward + fake fwd + bwd), fused Adam/RMSprop steps"
                     + (", flat-gradient RCCL all-reduce x3" if distributed else ""),
             "finite": bool(all(torch.isfinite(torch.as_tensor(v)).all() for v in out.values()))}
 

@@ -288,6 +288,33 @@ int oi_reflect_pad_fwd(const float* x, float* y, int BC, int H, int W, int px0, 
 int oi_reflect_pad_bwd(const float* gy, float* gx, int BC, int H, int W, int px0, int px1, int py0,
                        int py1, oi_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * multi-tensor optimiser / EMA steps -- one launch per network per step.
+ * Replaces the torch.optim.Adam / torch.optim.RMSprop steps of the reference's training loop
+ * (configs/train.yaml:133-147; src/trainers/gan_pose_trainer.py:142,191) and the EMA lerp
+ * `p_ema.copy_(p.lerp(p_ema, beta))` (src/utils/ema.py:26-32).
+ * `table` is a DEVICE array of n_chunks descriptors; each covers at most oi_mt_chunk_elems() contiguous fp32
+ * elements of one parameter: p = parameter (EMA: the averaged copy), g = gradient (EMA: the live parameter),
+ * s0/s1 = optimiser state (Adam: exp_avg / exp_avg_sq; RMSprop: square_avg / unused; EMA: unused).
+ * Formulas (fp32, as torch's single-tensor path, no weight decay / amsgrad / momentum / centering):
+ *   Adam:    m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2; p -= lr/bc1 * m / (sqrt(v)/bc2_sqrt + eps)
+ *   RMSprop: s = alpha s + (1-alpha) g^2; p -= lr * g / (sqrt(s) + eps)
+ *   EMA:     p = lerp(g, p, beta)
+ * bias_correction1 = 1 - b1^step, bias_correction2_sqrt = sqrt(1 - b2^step) are computed by the caller. */
+typedef struct oi_mt_chunk {
+  float* p;
+  const float* g;
+  float* s0;
+  float* s1;
+  int n;
+  int reserved;
+} oi_mt_chunk;
+int oi_mt_chunk_elems(void);
+int oi_multi_adam(const oi_mt_chunk* table, int n_chunks, float lr, float beta1, float beta2, float eps,
+                  float bias_correction1, float bias_correction2_sqrt, oi_stream_t stream);
+int oi_multi_rmsprop(const oi_mt_chunk* table, int n_chunks, float lr, float alpha, float eps, oi_stream_t stream);
+int oi_multi_lerp(const oi_mt_chunk* table, int n_chunks, float beta, oi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

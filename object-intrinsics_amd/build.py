@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "oi_amd")
 LIB = os.path.join(OUT_DIR, "liboi_hip.so")
 STAMP = os.path.join(OUT_DIR, ".liboi_hip.stamp")
-SOURCES = ["mlp.hip", "render.hip", "disc.hip", "mlp_bwd.hip", "render_bwd.hip", "disc_bwd.hip"]
+SOURCES = ["mlp.hip", "render.hip", "disc.hip", "mlp_bwd.hip", "render_bwd.hip", "disc_bwd.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + os.environ.get("OI_FLAGS", "").split()
 EXTRA = {}  # per-file extra flags
 

@@ -20,6 +20,8 @@ TARGET_MAP = {
     "src.loss.gan.compute_grad2": "oi_amd.losses.compute_grad2",
     "src.loss.position.PositionLoss": "oi_amd.losses.PositionLoss",
     "src.loss.position.linear_increase": "oi_amd.losses.linear_increase",
+    "src.datasets.eval_dataset.Dataset": "oi_amd.dataset.Dataset",
+    "src.utils.ema.EMA": "oi_amd.ema.EMA",
 }
 
 

@@ -1,5 +1,6 @@
 """Parameter EMA of the generator (src/utils/ema.py:7-41): p_ema <- lerp(p, p_ema, beta), buffers copied.
-One multi-tensor launch per update (torch._foreach_lerp_) instead of one lerp + copy per parameter."""
+On the GPU the parameter loop is ONE launch of `oi_multi_lerp` (oi_amd.optim.ema_update, csrc/optim.hip) instead of
+one lerp + copy per parameter; host-resident modules (unit tests of the host logic) take torch._foreach_lerp_."""
 import copy
 
 import torch
@@ -24,8 +25,12 @@ class EMA:
     @torch.no_grad()
     def update(self, it=None):
         pe, p = list(self.m_ema.parameters()), [q.detach() for q in self.m.parameters()]
-        # p.lerp(p_ema, beta) = p + beta (p_ema - p)  ==  p_ema.lerp_(p, 1 - beta)
-        torch._foreach_lerp_(pe, p, 1.0 - self.beta)
+        if pe and all(q.is_cuda for q in pe):
+            from .optim import ema_update
+            ema_update(pe, p, self.beta)
+        else:
+            # p.lerp(p_ema, beta) = p + beta (p_ema - p)  ==  p_ema.lerp_(p, 1 - beta)
+            torch._foreach_lerp_(pe, p, 1.0 - self.beta)
         for b_ema, b in zip(self.m_ema.buffers(), self.m.buffers()):
             b_ema.copy_(b)
 

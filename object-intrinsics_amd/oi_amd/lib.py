@@ -72,6 +72,10 @@ _SIGS = {
     "oi_affine_grid_sample_bwd": (_i, [_vp] * 3 + [_i] * 6 + [_vp]),
     "oi_reflect_pad_fwd": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
     "oi_reflect_pad_bwd": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
+    "oi_mt_chunk_elems": (_i, []),
+    "oi_multi_adam": (_i, [_vp, _i, _f, _f, _f, _f, _f, _f, _vp]),
+    "oi_multi_rmsprop": (_i, [_vp, _i, _f, _f, _f, _vp]),
+    "oi_multi_lerp": (_i, [_vp, _i, _f, _vp]),
 }
 
 # entry points added by later source files (backward kernels); bound when present in the .so

@@ -1,0 +1,144 @@
+"""Fused optimiser steps and EMA update: one HIP launch per network per step.
+
+`FusedAdam` / `FusedRMSprop` are drop-ins for the `torch.optim.Adam` / `torch.optim.RMSprop` instances the reference
+builds from configs/train.yaml:133-147 (same constructor keywords, same `state_dict()` layout -- `step`,
+`exp_avg`, `exp_avg_sq` / `square_avg` per parameter -- so optimiser checkpoints interchange), restricted to the
+options that configuration uses (no weight decay, amsgrad, momentum, centering, maximize).  `ema_update` is the
+parameter loop of `EMA.update` (src/utils/ema.py:26-32).  The kernels are `oi_multi_adam`, `oi_multi_rmsprop`,
+`oi_multi_lerp` (csrc/optim.hip); there is no PyTorch fallback.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import lib as _l
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _ChunkTable:
+    """Device array of `oi_mt_chunk` descriptors, rebuilt only when a pointer changes."""
+
+    def __init__(self):
+        self.key, self.table, self.n = None, None, 0
+
+    def get(self, quads):
+        """quads: list of (p, g, s0, s1) tensors (s0 / s1 may be None)."""
+        key = tuple((p.data_ptr(), g.data_ptr(), 0 if a is None else a.data_ptr(), 0 if b is None else b.data_ptr(),
+                     p.numel()) for p, g, a, b in quads)
+        if key != self.key:
+            chunk = _l.load().oi_mt_chunk_elems()
+            rows = []
+            for pp, gp, ap, bp, n in key:
+                for off in range(0, n, chunk):
+                    m = min(chunk, n - off)
+                    rows.append((pp + 4 * off, gp + 4 * off, ap + 4 * off if ap else 0, bp + 4 * off if bp else 0, m))
+            arr = np.array(rows, dtype=np.int64).reshape(-1, 5)  # 4 pointers + (n | reserved << 32): 40-byte structs
+            dev = quads[0][0].device if quads else torch.device("cuda")
+            self.table = torch.from_numpy(arr).to(dev) if len(rows) else None
+            self.key, self.n = key, len(rows)
+        return self.table, self.n
+
+
+def _check(p):
+    if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+        raise ValueError("fused optimisers need contiguous fp32 CUDA parameters")
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError("FusedAdam: weight_decay / amsgrad are not used by configs/train.yaml")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
+        self._tables = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _l.load()
+        for gi, group in enumerate(self.param_groups):
+            by_step = {}  # parameters that skipped steps (grad None) carry their own bias correction: one launch each
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _check(p)
+                if p.grad.is_sparse:
+                    raise RuntimeError("FusedAdam does not support sparse gradients")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                by_step.setdefault(int(st["step"]), []).append(
+                    (p, p.grad if p.grad.is_contiguous() else p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"]))
+            b1, b2 = group["betas"]
+            for k, (step, quads) in enumerate(sorted(by_step.items())):
+                table, n = self._tables.setdefault((gi, k), _ChunkTable()).get(quads)
+                rc = L.oi_multi_adam(table.data_ptr(), n, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                     1.0 - b1 ** step, math.sqrt(1.0 - b2 ** step), _stream())
+                if rc:
+                    raise _l.OiHipError(L.oi_last_error().decode())
+        return loss
+
+
+class FusedRMSprop(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0, momentum=0, centered=False):
+        if weight_decay != 0 or momentum != 0 or centered:
+            raise NotImplementedError("FusedRMSprop: weight_decay / momentum / centered are not used by configs/train.yaml")
+        super().__init__(params, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=0, momentum=0, centered=False))
+        self._tables = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _l.load()
+        for gi, group in enumerate(self.param_groups):
+            quads = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _check(p)
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                quads.append((p, p.grad.contiguous() if not p.grad.is_contiguous() else p.grad, st["square_avg"], None))
+            if not quads:
+                continue
+            table, n = self._tables.setdefault(gi, _ChunkTable()).get(quads)
+            rc = L.oi_multi_rmsprop(table.data_ptr(), n, float(group["lr"]), float(group["alpha"]), float(group["eps"]),
+                                    _stream())
+            if rc:
+                raise _l.OiHipError(L.oi_last_error().decode())
+        return loss
+
+
+_EMA_TABLES = {}
+
+
+@torch.no_grad()
+def ema_update(ema_params, params, beta):
+    """p_ema <- p.lerp(p_ema, beta) for every parameter pair, one launch (ema.py:26-30)."""
+    pairs = [(pe, p, None, None) for pe, p in zip(ema_params, params)]
+    if not pairs:
+        return
+    for pe, p, _, _ in pairs:
+        _check(pe)
+        _check(p)
+    key = id(pairs[0][0])
+    table, n = _EMA_TABLES.setdefault(key, _ChunkTable()).get(pairs)
+    L = _l.load()
+    rc = L.oi_multi_lerp(table.data_ptr(), n, float(beta), _stream())
+    if rc:
+        raise _l.OiHipError(L.oi_last_error().decode())

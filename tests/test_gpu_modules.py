@@ -245,3 +245,56 @@ def test_inference_walks_and_depth_multiplier():
     kw2 = inference.scale_config(kw, 128, test_resolution=256, depth_multiplier=16)
     assert kw2["renderer"]["kwargs"] == {"n_importance": 64, "n_samples": 256} and kw2["resolution"] == 256
     assert kw2["scene_resolution"] == 1588 and kw["resolution"] == 128
+
+
+# ---------------------------------------------------------------- fused optimiser / EMA steps
+def _param_set(seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(128, 3), (128,), (7, 128, 128), (512, 256, 4, 4), (1,), (5000,)]
+    return [torch.randn(s, generator=g).cuda().requires_grad_() for s in shapes]
+
+
+@pytest.mark.parametrize("kind", ["adam", "rmsprop"])
+def test_fused_optimizer_matches_torch(kind):
+    """Five steps of the configs/train.yaml optimisers: FusedAdam(lr 2e-5, betas (0, 0.9)) / FusedRMSprop(lr 1e-4)
+    vs torch.optim on identical gradients; state_dict layouts interchange."""
+    from oi_amd.optim import FusedAdam, FusedRMSprop
+    pa, pb = _param_set(0), _param_set(0)
+    if kind == "adam":
+        oa, ob = FusedAdam(pa, lr=2e-5, betas=(0.0, 0.9)), torch.optim.Adam(pb, lr=2e-5, betas=(0.0, 0.9))
+    else:
+        oa, ob = FusedRMSprop(pa, lr=1e-4), torch.optim.RMSprop(pb, lr=1e-4)
+    g = torch.Generator().manual_seed(1)
+    for it in range(5):
+        for x, y in zip(pa, pb):
+            gr = torch.randn(x.shape, generator=g).cuda() * (10.0 ** (it - 2))
+            x.grad, y.grad = gr.clone(), gr.clone()
+        if it == 2:
+            pa[4].grad = pb[4].grad = None  # a parameter without gradient is skipped
+        oa.step()
+        ob.step()
+    for x, y in zip(pa, pb):
+        assert maxdiff(x, y) <= 2e-7 * max(1.0, float(y.abs().max())), (x.shape, maxdiff(x, y))
+    sa, sb = oa.state_dict(), ob.state_dict()
+    for k in sb["state"]:
+        assert set(sa["state"][k]) == set(sb["state"][k])
+        for name, v in sb["state"][k].items():
+            assert maxdiff(sa["state"][k][name].float().cpu(), v.float().cpu()) <= 1e-6 * max(1.0, float(v.abs().max())), name
+    # a torch optimiser checkpoint loads into the fused one (and keeps stepping)
+    oa.load_state_dict(sb)
+    oa.step()
+
+
+def test_fused_ema_matches_reference_formula():
+    from oi_amd.ema import EMA
+    net = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Linear(53, 5000)).cuda()
+    ema = EMA(net, 0.999)
+    ref = [p.detach().clone() for p in net.parameters()]
+    for it in range(3):
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(torch.randn_like(p))
+        ema.update(it)
+        ref = [p.detach().lerp(r, 0.999) for p, r in zip(net.parameters(), ref)]  # ema.py:29
+    for a, b in zip(ema.module.parameters(), ref):
+        assert maxdiff(a, b) <= 1e-6

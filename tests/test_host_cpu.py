@@ -2,6 +2,8 @@
 EMA update rule, pose prior / augmentation parameter distributions."""
 import os
 
+import pytest
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -62,3 +64,62 @@ def test_augment_parameter_distribution():
     assert abs(np.log2(s).std() - 0.2) < 0.02 and np.allclose(G[:, 0, 0], G[:, 1, 1])  # isotropic scale, std 0.2 in log2
     t = -G[:, 0, 2]  # G = T(-t) S(1/s): the translation column is the integer pixel shift
     assert np.abs(t).max() <= 1.0 + 1e-5 and np.allclose(t, np.round(t), atol=1e-4)  # round(U(-.125,.125)*8) in {-1,0,1}
+
+
+# ---------------------------------------------------------------- dataset loader (no cv2)
+def _write_rgba(path, arr):
+    from PIL import Image
+    Image.fromarray(arr, "RGBA").save(path)
+
+
+def test_dataset_loader_matches_reference_semantics(tmp_path):
+    """eval_dataset.py:13-52 / preprocess.py:5-20: sorted *.png, uint8 bilinear resize, mask = alpha >= 128,
+    item = rgb * mask + random bg * (1 - mask) with one np.random.uniform(size=(1,3)) draw per item."""
+    from oi_amd.dataset import Dataset, read_rgba, resize_linear_u8
+    rng = np.random.default_rng(0)
+    imgs = [rng.integers(0, 256, size=(48, 40, 4), dtype=np.uint8) for _ in range(3)]
+    for i, a in enumerate(imgs):
+        _write_rgba(str(tmp_path / f"{2 - i:02d}.png"), a)   # written out of order: the loader sorts by name
+    (tmp_path / "ignored.jpg").write_bytes(b"x")
+    ds = Dataset(16, str(tmp_path))
+    assert len(ds) == 3 and [os.path.basename(p) for p in ds.data["path"]] == ["00.png", "01.png", "02.png"]
+    assert ds.data["rgb"].shape == (3, 3, 16, 16) and ds.data["alpha"].shape == (3, 1, 16, 16)
+    assert ds.data["rgb"].dtype == torch.float32 and set(ds.data["alpha"].unique().tolist()) <= {0.0, 1.0}
+    # resize: within half a grey level of float64 bilinear at cv2's half-pixel-centre sample positions
+    src = imgs[2].astype(np.float64)   # file 00.png
+    ys = np.clip((np.arange(16) + 0.5) * 48 / 16 - 0.5, 0, 47); xs = np.clip((np.arange(16) + 0.5) * 40 / 16 - 0.5, 0, 39)
+    y0 = np.floor(ys).astype(int); x0 = np.floor(xs).astype(int)
+    y1 = np.minimum(y0 + 1, 47); x1 = np.minimum(x0 + 1, 39)
+    fy = (ys - y0)[:, None, None]; fx = (xs - x0)[None, :, None]
+    ref = (src[y0][:, x0] * (1 - fx) + src[y0][:, x1] * fx) * (1 - fy) + (src[y1][:, x0] * (1 - fx) + src[y1][:, x1] * fx) * fy
+    got = resize_linear_u8(imgs[2], (16, 16)).astype(np.float64)
+    assert np.abs(got - ref).max() <= 0.5 + 1e-3
+    assert np.array_equal(ds.data["rgb"][0].permute(1, 2, 0).numpy() * 255.0, got[:, :, :3].astype(np.float32))
+    assert np.array_equal(ds.data["alpha"][0, 0].numpy() > 0.5, got[:, :, 3] >= 128)
+    # identity size returns the pixels untouched; non-RGBA input is rejected like the reference's assert
+    assert np.array_equal(resize_linear_u8(imgs[0], (40, 48)), imgs[0])
+    from PIL import Image
+    Image.fromarray(imgs[0][:, :, :3], "RGB").save(str(tmp_path / "rgb_only.png"))
+    with pytest.raises(AssertionError):
+        read_rgba(str(tmp_path / "rgb_only.png"))
+    with pytest.raises(ValueError):
+        read_rgba(str(tmp_path / "missing.png"))
+    # item: composite over the random background drawn from numpy's global stream
+    np.random.seed(7)
+    item = ds[1]
+    np.random.seed(7)
+    bg = torch.tensor(np.random.uniform(low=0, high=1, size=(1, 3)), dtype=torch.float32)[0, :, None, None]
+    exp = ds.data["rgb"][1] * ds.data["alpha"][1] + bg * (1 - ds.data["alpha"][1])
+    assert torch.equal(item["image"], exp) and torch.equal(item["mask"], ds.data["alpha"][1])
+    assert item["pose_indices"] == 1 and item["image_path"].endswith("01.png")
+    # empty folder: a valid zero-length dataset
+    os.makedirs(tmp_path / "empty")
+    assert len(Dataset(16, str(tmp_path / "empty"))) == 0
+
+
+def test_config_seam_redirects_dataset_and_ema():
+    from oi_amd.config import get_obj_from_str
+    from oi_amd.dataset import Dataset
+    from oi_amd.ema import EMA
+    assert get_obj_from_str("src.datasets.eval_dataset.Dataset") is Dataset
+    assert get_obj_from_str("src.utils.ema.EMA") is EMA
