@@ -98,6 +98,11 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
+        # PyTorch bundles its own libamdhip64.so.7; liboi_hip.so needs the same SONAME.  Importing torch FIRST makes the
+        # dynamic loader resolve our dependency to the runtime torch already mapped -- one HIP runtime per process.
+        # (Loaded the other way round, /opt/rocm's copy comes in through our RUNPATH, torch then maps its own by
+        # path, and launches on torch's streams fail with "no ROCm-capable device is detected".)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise OiHipError(
                 f"{LIB_PATH} not found: build it with `python object-intrinsics_amd/build.py` (hipcc, gfx950). "
