@@ -424,7 +424,9 @@ __device__ __forceinline__ void film_sin2(const char* lds, const LaneOff& o, con
       cv[k] = gm[k] * c;
     }
     if constexpr (FULL) ws.store(slot, g, o, cv);
-    __builtin_amdgcn_sched_barrier(0);
+    // two groups (8 values = 4 packed sin/cos chains) per scheduling window: one group alone leaves the dependent
+    // v_pk_fma chains latency-bound
+    if ((g & 1) == 1) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -437,10 +439,27 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
 }
 
 // wait for this wave's LDS-DMA, then rendezvous: next image resident, previous ring slot free
+// TRAILING = number of this wave's VMEM operations issued AFTER its LDS-DMA loads that may stay in flight: the 16
+// scratch stores of the FiLM phase.  vmcnt retires in issue order on gfx9-class parts (hipcc relies on the same
+// property whenever it waits for a load with younger stores outstanding), so vmcnt(16) = "the image has landed"
+// without paying for the write acknowledgements of stores nobody in this workgroup reads before the next layer.
+template <int TRAILING = 0>
 __device__ __forceinline__ void ring_sync() {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TRAILING) : "memory");
   __syncthreads();
 }
+
+#ifdef OI_PROF
+__device__ unsigned long long oi_prof[16];
+#define PROF_T(i)                                                  \
+  do {                                                             \
+    const unsigned long long t_ = __builtin_readcyclecounter();    \
+    pacc[i] += t_ - tprev;                                         \
+    tprev = t_;                                                    \
+  } while (0)
+#else
+#define PROF_T(i)
+#endif
 
 template <int PREC, bool FAST, bool FULL>
 __global__ void __launch_bounds__(64 * v2_waves(PREC), 2)
@@ -512,13 +531,20 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
 
   float act[64];
   f32x16 acc[4];
+#ifdef OI_PROF
+  unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_readcyclecounter();
+  const unsigned long long tstart = tprev;
+#endif
 
   // ---- layer 0 (K = 3) on the VALU, overlapping the first image's DMA
   {
     const LayOff y = lay_off<PREC>(o, 0, 0);
     film_sin2<FAST, FULL, 1>(lds, o, y, acc, act, ws, 0, H_TAB0, px, py, pz);
   }
-  ring_sync();
+  PROF_T(0);
+  ring_sync<FULL ? 16 : 0>();
+  PROF_T(4);
 
   // ---- layers 1..7 on MFMA
   for (int l = 1; l < NL_SDF; ++l) {
@@ -529,9 +555,13 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
     const LayOff y = lay_off<PREC>(o, RING2 ? (i & 1) : 0, l);
     zero_acc(acc);
     gemm_layer2<PREC>(lds, y, act, acc);
+    PROF_T(1);
     if (next) stage_late(next);
+    PROF_T(2);
     film_sin2<FAST, FULL, 0>(lds, o, y, acc, act, ws, l, 0, 0.f, 0.f, 0.f);
-    ring_sync();
+    PROF_T(3);
+    ring_sync<FULL ? 16 : 0>();
+    PROF_T(4);
   }
 
   // ---- sdf = a8 . wsig + bsig   (fields.py:68; LinearLayer std_init=1, bias_init=0)
@@ -607,13 +637,17 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       if (next) stage_early(next, (i + 1) & 1);
       const LayOff y = lay_off<PREC>(o, RING2 ? (i & 1) : 0, l);
       zero_acc(acc);
+      PROF_T(5);
       gemm_layer2<PREC>(lds, y, act, acc);
+      PROF_T(6);
       if (next) stage_late(next);
+      PROF_T(7);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) act[16 * t + r] = PREC == OI_PREC_F16X3 ? acc[t][r] * unscale : acc[t][r];
       ring_sync();
+      PROF_T(8);
     }
     // layer 0: grad = W0^T (g1 * c0)
     float gx = 0.f, gy = 0.f, gz = 0.f;
@@ -680,6 +714,14 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       }
     }
   }
+#ifdef OI_PROF
+  PROF_T(9);
+  if (lane == 0 && FULL) {
+    for (int i = 0; i < 10; ++i) atomicAdd(&oi_prof[i], pacc[i]);
+    atomicAdd(&oi_prof[10], __builtin_readcyclecounter() - tstart);
+    atomicAdd(&oi_prof[11], 1ull);
+  }
+#endif
 }
 
 template <int PREC, bool FAST>
@@ -724,6 +766,18 @@ int oi_film_params(const float* style_w, const float* style_b, const float* z, f
                      gw, gb, bw, bb, gamma, beta, NL);
   return oi::check_launch("oi_film_params");
 }
+
+#ifdef OI_PROF
+int oi_prof_read(unsigned long long* out, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(oi_prof), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(oi_prof), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 size_t oi_mlp_packed_bytes(int prec) { return H_BYTES + (size_t)NMAT * layer_bytes(prec); }
 
