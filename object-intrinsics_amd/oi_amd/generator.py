@@ -87,10 +87,42 @@ class Generator(nn.Module):
             assert not self.training
             b2w = data["b2w"].to(dev)
         else:
-            b2w = self._h2d(self.pose_prior(bs))
+            # Poses come from the host RNG: do the 4x4 algebra that depends only on them (rigid inverse, camera-to-box,
+            # crop offsets; ~20 tiny device kernels in the reference) on the host in fp32 and ship ONE staged buffer.
+            b2w_h = np.ascontiguousarray(self.pose_prior(bs), dtype=np.float32)
+            cam = self._camera_host()
+            Rt = b2w_h[:, :3, :3].transpose(0, 2, 1)
+            w2b_h = np.zeros_like(b2w_h)
+            w2b_h[:, :3, :3] = Rt
+            w2b_h[:, :3, 3:4] = -(Rt @ b2w_h[:, :3, 3:4])
+            w2b_h[:, 3, 3] = 1.0
+            c2b_h = w2b_h @ cam["c2w"]
+            xy_h = self._crop_offsets_host(b2w_h, cam)
+            flat = self._h2d(np.concatenate([b2w_h.ravel(), w2b_h.ravel(), c2b_h.ravel(), xy_h.ravel()]))
+            n = bs * 16
+            b2w, w2b, c2b = flat[:n].view(bs, 4, 4), flat[n:2 * n].view(bs, 4, 4), flat[2 * n:3 * n].view(bs, 4, 4)
+            self._xy_off = flat[3 * n:].view(bs, 2)
+            return {"c2b": c2b, "b2w": b2w, "w2b": w2b, "light": self.light.batch_transform(w2b=w2b)}
+        self._xy_off = None
         w2b = invert_rot_t(b2w)
         c2b = torch.einsum("bij,jk->bik", w2b, self.camera.c2w)
         return {"c2b": c2b, "b2w": b2w, "w2b": w2b, "light": self.light.batch_transform(w2b=w2b)}
+
+    def _camera_host(self):
+        cam = getattr(self, "_cam_np", None)
+        if cam is None:
+            cam = self._cam_np = {"c2w": self.camera.c2w.detach().cpu().numpy().astype(np.float32),
+                                  "w2c": self.camera.w2c.detach().cpu().numpy().astype(np.float32)}
+        return cam
+
+    def _crop_offsets_host(self, b2w_h, cam):
+        """(x_offset, y_offset) of generator.py:262-268 in fp32 numpy, same operation order as the device path below."""
+        R = np.float32(self.resolution)
+        t = (cam["w2c"] @ b2w_h)[:, :3, 3]
+        cd, half = np.float32(self.camera.cam_dist), np.float32(0.5 * self.scene_resolution)
+        cx = cd / t[:, 2] * t[:, 0] * R / np.float32(2) + half
+        cy = cd / t[:, 2] * t[:, 1] * R / np.float32(2) + half
+        return np.stack([cx - R / np.float32(2), cy - R / np.float32(2)], -1).astype(np.float32)
 
     def sample_latent(self, bs, data):
         if "w" in data:
@@ -104,12 +136,17 @@ class Generator(nn.Module):
     def gen_rays_at(self, data, prior_info):
         """generator.py:255-279 + build_rays :317-333 + near_far_from_sphere :336-342 (one kernel)."""
         b2w, R = prior_info["b2w"], self.resolution
-        b2c_t = torch.einsum("ij,bjk->bik", self.camera.w2c, b2w)[..., :3, 3]
-        cx = self.camera.cam_dist / b2c_t[..., 2] * b2c_t[..., 0] * R / 2 + 0.5 * self.scene_resolution
-        cy = self.camera.cam_dist / b2c_t[..., 2] * b2c_t[..., 1] * R / 2 + 0.5 * self.scene_resolution
-        x_off, y_off = cx - R / 2, cy - R / 2
-        ro, rd, near, far = ops.gen_rays(prior_info["c2b"], self.camera.intrinsics_inv[:3, :3].contiguous(),
-                                         torch.stack([x_off, y_off], -1), R)
+        xy = getattr(self, "_xy_off", None)
+        if xy is None:  # poses given on the device (eval / inference): the reference's tensor arithmetic
+            b2c_t = torch.einsum("ij,bjk->bik", self.camera.w2c, b2w)[..., :3, 3]
+            cx = self.camera.cam_dist / b2c_t[..., 2] * b2c_t[..., 0] * R / 2 + 0.5 * self.scene_resolution
+            cy = self.camera.cam_dist / b2c_t[..., 2] * b2c_t[..., 1] * R / 2 + 0.5 * self.scene_resolution
+            xy = torch.stack([cx - R / 2, cy - R / 2], -1)
+        x_off, y_off = xy[:, 0], xy[:, 1]
+        kinv = getattr(self, "_kinv33", None)
+        if kinv is None or kinv.device != b2w.device:
+            kinv = self._kinv33 = self.camera.intrinsics_inv[:3, :3].contiguous()
+        ro, rd, near, far = ops.gen_rays(prior_info["c2b"], kinv, xy, R)
         return {"rays_o": ro, "rays_d": rd, "x_offset": x_off, "y_offset": y_off, "near": near, "far": far}
 
     # -- forward --------------------------------------------------------------------------------

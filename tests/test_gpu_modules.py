@@ -298,3 +298,23 @@ def test_fused_ema_matches_reference_formula():
         ref = [p.detach().lerp(r, 0.999) for p, r in zip(net.parameters(), ref)]  # ema.py:29
     for a, b in zip(ema.module.parameters(), ref):
         assert maxdiff(a, b) <= 1e-6
+
+
+def test_host_pose_algebra_matches_device_path():
+    """Training-mode forward computes w2b / c2b / crop offsets on the host (fp32 numpy) and ships one buffer; the
+    eval path (poses given on the device) runs the reference's tensor arithmetic: identical within fp32 round-off."""
+    gen = build_generator(16, 8, 8, 1)
+    gen.train()
+    np.random.seed(3)
+    prior_h = gen.sample_prior(3, {})
+    rays_h = gen.gen_rays_at({}, prior_h)
+    gen.eval()
+    prior_d = gen.sample_prior(3, {"b2w": prior_h["b2w"].clone()})
+    rays_d = gen.gen_rays_at({}, prior_d)
+    for k in ("b2w", "w2b", "c2b"):
+        assert maxdiff(prior_h[k], prior_d[k]) < 1e-5, k
+    for k in ("x_offset", "y_offset"):
+        assert maxdiff(rays_h[k], rays_d[k]) < 2e-4 * max(1.0, float(rays_d[k].abs().max())), k
+    for k in ("rays_o", "rays_d", "near", "far"):
+        assert maxdiff(rays_h[k], rays_d[k]) < 1e-5, k
+    assert maxdiff(prior_h["light"].direction(), prior_d["light"].direction()) < 1e-6
