@@ -27,7 +27,8 @@ namespace {
 using namespace oimlp;
 
 // ------------------------------------------------------------------------------------------
-// a1 + a2: style MLP + FiLM parameters.  One block of 128 threads per batch element.
+// a1 + a2: style MLP + FiLM parameters.  grid (B, max(NL, 1)): one block of 128 threads per (batch element, FiLM
+// layer); every block re-derives w from z itself (3 x 64 x 64 MACs) instead of waiting for another block.
 // ------------------------------------------------------------------------------------------
 __global__ void film_params_kernel(const float* __restrict__ style_w, const float* __restrict__ style_b,
                                    const float* __restrict__ z, float* __restrict__ w_out,
@@ -52,7 +53,7 @@ __global__ void film_params_kernel(const float* __restrict__ style_w, const floa
       __syncthreads();
       cur ^= 1;
     }
-    if (t < 64) w_out[e * 64 + t] = h[cur][t];
+    if (t < 64 && blockIdx.y == 0) w_out[e * 64 + t] = h[cur][t];
     if (cur != 0) {
       if (t < 64) h[0][t] = h[1][t];
     }
@@ -61,7 +62,8 @@ __global__ void film_params_kernel(const float* __restrict__ style_w, const floa
     if (t < 64) h[0][t] = w_out[e * 64 + t];
     __syncthreads();
   }
-  for (int l = 0; l < NL; ++l) {
+  const int l = blockIdx.y;
+  if (l < NL) {
     const float* g = gw + ((size_t)l * C + t) * 64;
     const float* b = bw + ((size_t)l * C + t) * 64;
     float ag = 0.f, ab = 0.f;
@@ -762,7 +764,7 @@ int oi_film_params(const float* style_w, const float* style_b, const float* z, f
   OI_REQUIRE(B > 0 && NL >= 0, "oi_film_params: B=%d NL=%d", B, NL);
   OI_REQUIRE(w_out && (NL == 0 || (gw && gb && bw && bb && gamma && beta)), "oi_film_params: null pointer");
   OI_REQUIRE(z == nullptr || (style_w && style_b), "oi_film_params: z given without style weights");
-  hipLaunchKernelGGL(film_params_kernel, dim3(B), dim3(C), 0, oi::as_stream(stream), style_w, style_b, z, w_out,
+  hipLaunchKernelGGL(film_params_kernel, dim3(B, NL > 0 ? NL : 1), dim3(C), 0, oi::as_stream(stream), style_w, style_b, z, w_out,
                      gw, gb, bw, bb, gamma, beta, NL);
   return oi::check_launch("oi_film_params");
 }

@@ -171,8 +171,9 @@ class Generator(nn.Module):
         n_chunks = math.ceil(h * w / chunk)
         if n_chunks > 1:
             assert not self.training, (n_rays, chunk)
-        if "w" not in latent:
-            latent["w"] = self.renderer.sdf_network.style(latent["z"])  # generator.py:235-238
+        # style MLP (generator.py:235-238) + FiLM parameters of all 9 layers: ONE launch, shared by every chunk
+        film = self.renderer.pack.film(z=None if "w" in latent else latent["z"], w=latent.get("w"))
+        latent["w"] = film[0]
         outs = []
         for ci in range(n_chunks):
             sl = slice(ci * chunk, (ci + 1) * chunk)
@@ -180,7 +181,7 @@ class Generator(nn.Module):
             s, c = self.renderer.render_full(flat(ro_all), flat(rd_all), flat(near_all), flat(far_all),
                                              perturb_overwrite=-1 if self.training else 0,
                                              cos_anneal_ratio=cos_anneal_ratio, z=latent["z"], w=latent["w"],
-                                             light=lpk, light_dir=ldir, bg=bg)
+                                             light=lpk, light_dir=ldir, bg=bg, film=film)
             outs.append((s, c))
         if n_chunks == 1:
             s, c = outs[0]

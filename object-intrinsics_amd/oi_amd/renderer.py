@@ -53,12 +53,13 @@ class NeuSRenderer:
         return z
 
     def render_full(self, rays_o, rays_d, near, far, perturb_overwrite=-1, cos_anneal_ratio=0.0, z=None, w=None,
-                    light=None, light_dir=None, bg=None, outputs=None):
+                    light=None, light_dir=None, bg=None, outputs=None, film=None):
         """Shared implementation: returns (per-sample/per-ray dict, composite dict)."""
         from .autograd import composite
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
         N = rays_o.shape[0]
-        w_, gamma, beta = self.pack.film(z=z if w is None else None, w=w)
+        # `film` = (w, gamma, beta) precomputed by the caller (one launch per forward instead of one per chunk + style)
+        w_, gamma, beta = film if film is not None else self.pack.film(z=z if w is None else None, w=w)
         B = w_.shape[0]
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
         zv = self.sample_z(rays_o, rays_d, near, far, gamma.detach(), beta.detach(), B, perturb)
