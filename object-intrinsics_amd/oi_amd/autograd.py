@@ -20,10 +20,13 @@ def film_params(pack, z=None, w=None):
     """-> (w, gamma[B,9,128], beta[B,9,128]).  Forward in one HIP launch.  These are O(B*128*64)
     flops; when parameter gradients are required the (tiny) graph is rebuilt with torch ops on the
     same device so that autograd reaches the reference-named parameters."""
-    P = pack.stacked()
     src = z if z is not None else w
-    if _needs_grad(src, P["style_w"], P["gw"], P["bw"]):
-        return _film_params_torch(P, z, w)
+    params = [p for n, p in pack.sdf_network.named_parameters() if n.startswith("style.") or ".gamma." in n or ".beta." in n]
+    if pack.color_network is not None:
+        params += [p for n, p in pack.color_network.named_parameters() if ".gamma." in n or ".beta." in n]
+    if _needs_grad(src, *params):
+        return _film_params_torch(pack.film_stacked(differentiable=True), z, w)
+    P = pack.film_stacked(differentiable=False)
     with torch.no_grad():
         return ops.film_params(P["style_w"], P["style_b"], P["gw"], P["gb"], P["bw"], P["bb"], z=z, w=w)
 

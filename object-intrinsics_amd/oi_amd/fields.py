@@ -182,18 +182,34 @@ class FieldPack:
     def stacked(self):
         return stack_field_params(*self._sds())
 
+    def _refresh_key(self):
+        sd, csd = self._sds()
+        key = tuple((p.data_ptr(), p._version) for p in list(sd.values()) + list(csd.values()))
+        if key != self._key:
+            self._packs = {}
+            self._key = key
+        return sd, csd
+
+    def film_stacked(self, differentiable):
+        """Stacked style / FiLM-head parameters for `oi_film_params`.  The non-differentiable copy is cached per
+        parameter version (six torch.stack launches per forward otherwise)."""
+        from .params import FILM_KEYS
+        sd, csd = self._refresh_key()
+        if differentiable:
+            return stack_field_params(sd, csd, keys=FILM_KEYS)
+        if "film" not in self._packs:
+            with torch.no_grad():
+                self._packs["film"] = stack_field_params(sd, csd, keys=FILM_KEYS)
+        return self._packs["film"]
+
     @property
     def prec_bwd(self):
         """The backward kernels have no BF16X6 variant: that mode differentiates through the exact-fp32 image."""
         return _l.OI_PREC_F32 if self.prec == _l.OI_PREC_BF16X6 else self.prec
 
     def packed(self, for_backward=False):
-        sd, csd = self._sds()
+        sd, csd = self._refresh_key()
         prec = self.prec_bwd if for_backward else self.prec
-        key = tuple((p.data_ptr(), p._version) for p in list(sd.values()) + list(csd.values()))
-        if key != self._key:
-            self._packs = {}
-            self._key = key
         if prec not in self._packs:
             with torch.no_grad():
                 P = stack_field_params(sd, csd)
