@@ -21,10 +21,7 @@ def film_params(pack, z=None, w=None):
     flops; when parameter gradients are required the (tiny) graph is rebuilt with torch ops on the
     same device so that autograd reaches the reference-named parameters."""
     src = z if z is not None else w
-    params = [p for n, p in pack.sdf_network.named_parameters() if n.startswith("style.") or ".gamma." in n or ".beta." in n]
-    if pack.color_network is not None:
-        params += [p for n, p in pack.color_network.named_parameters() if ".gamma." in n or ".beta." in n]
-    if _needs_grad(src, *params):
+    if _needs_grad(src, *pack.param_lists()[1]):
         return _film_params_torch(pack.film_stacked(differentiable=True), z, w)
     P = pack.film_stacked(differentiable=False)
     with torch.no_grad():
@@ -60,8 +57,7 @@ def style_mlp(style_module, z):
 
 def sdf_mlp(pack, pts, gamma, beta, B, want_grad, want_rgb, want_feat, scratch=None):
     """-> (sdf (n,), grad (n,3)|None, rgb (n,3)|None, feat (n,128)|None)."""
-    params = list(pack.sdf_network.parameters()) + (list(pack.color_network.parameters()) if pack.color_network else [])
-    if _needs_grad(pts, gamma, beta, *params):
+    if _needs_grad(pts, gamma, beta, *pack.param_lists()[0]):
         from .autograd_mlp import SdfMlpFunction
         return SdfMlpFunction.run(pack, pts, gamma, beta, B, want_grad, want_rgb, want_feat)
     with torch.no_grad():

@@ -168,6 +168,29 @@ class FieldPack:
         self._key = None
 
     def _sds(self):
+        # The module tree is static: walk it once (named_parameters() costs ~50 us per call, and this runs three times
+        # per render).  In-place updates, load_state_dict and .to() keep the Parameter objects, so the (data_ptr,
+        # _version) key below still sees every change; replacing a Parameter OBJECT needs `invalidate()`.
+        cached = getattr(self, "_sd_cache", None)
+        if cached is not None:
+            return cached
+        self._sd_cache = self._sds_walk()
+        return self._sd_cache
+
+    def invalidate(self):
+        self._sd_cache, self._key, self._packs, self._plists = None, None, {}, None
+
+    def param_lists(self):
+        """(all parameters, style + FiLM-head parameters): cached flat lists for the requires-grad checks."""
+        pl = getattr(self, "_plists", None)
+        if pl is None:
+            sd, csd = self._sds()
+            named = list(sd.items()) + (list(csd.items()) if self.color_network is not None else [])
+            film = [p for n, p in named if n.startswith("style.") or ".gamma." in n or ".beta." in n]
+            pl = self._plists = ([p for _, p in named], film)
+        return pl
+
+    def _sds_walk(self):
         sd = dict(self.sdf_network.named_parameters())
         if self.color_network is not None:
             csd = dict(self.color_network.named_parameters())

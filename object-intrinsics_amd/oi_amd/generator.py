@@ -68,8 +68,8 @@ class Generator(nn.Module):
             ring["bufs"] = [torch.empty(max(n, 256), dtype=torch.float32, pin_memory=True) for _ in range(8)]
             ring["events"] = [None] * 8
         i = ring["i"] = (ring["i"] + 1) % 8
-        if ring["events"][i] is not None:
-            ring["events"][i].synchronize()  # the copy that last used this buffer has executed
+        if ring["events"][i] is not None and not ring["events"][i].query():
+            ring["events"][i].synchronize()  # the copy that last used this buffer has not executed yet (rare)
         buf = ring["bufs"][i][:n]
         buf.numpy()[:] = arr.reshape(-1)
         out = buf.to(dev, non_blocking=True).view(arr.shape)

@@ -14,7 +14,9 @@ _vp = ctypes.c_void_p
 
 
 def _stream():
-    return _vp(torch.cuda.current_stream().cuda_stream)
+    """Raw hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() builds a Python
+    Stream object (~8 us); the two C accessors below cost ~0.3 us and this runs once per kernel launch."""
+    return _vp(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _p(t):

@@ -16,7 +16,7 @@ from . import lib as _l
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 class _ChunkTable:
