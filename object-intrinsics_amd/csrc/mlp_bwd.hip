@@ -586,6 +586,143 @@ mlp_wgrad_kernel(const char* __restrict__ scratch, float* __restrict__ d_wmat, l
     }
 }
 
+// ---- F16X3 variant of the weight-gradient GEMM (3 fp16 MFMAs per product instead of 8 fp32-MFMA k-steps per 16
+// points).  Both operands are data with no a-priori range, so every staged 32-point tile is normalised by the power
+// of two of its own max (block-wide), multiplied into a per-tile accumulator and merged into the running sum with the
+// exact inverse scale.  The fp32 slot copies sit in LDS with a 4-float skew per 32-point block: the 8 consecutive
+// points of one feature that a lane needs for its MFMA operand are then conflict-free dword reads.  The B fragments
+// (Y, all 128 columns) are the same for the four waves: each wave converts one column tile and shares it through LDS.
+__device__ __forceinline__ int slot_index4(int f, int p) {
+  const int t = f >> 5, rr = (f >> 3) & 3, hh = (f >> 2) & 1, k = f & 3;
+  const int blk = (4 * t + rr) * 2 + hh;
+  return (blk * 32 + p) * 4 + k + 4 * blk;
+}
+constexpr int WG16_SLOT_FLOATS = 4096 + 4 * 128;
+
+__device__ __forceinline__ void pow2_scale_of(float m, float& sc, float& inv) {
+  int eb = (__builtin_bit_cast(int, m) >> 23) & 0xff;
+  eb = eb < 14 ? 14 : (eb > 254 ? 254 : eb);
+  sc = __builtin_bit_cast(float, (267 - eb) << 23);
+  inv = __builtin_bit_cast(float, (eb - 13) << 23);
+}
+
+// 8 consecutive points of feature f (points p0 .. p0+7) from the skewed fp32 LDS copy -> scaled fp16 hi / lo limbs
+__device__ __forceinline__ void frag16(const float* sl, int f, int p0, float sc, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float v = sl[slot_index4(f, p0 + q)] * sc;
+    hi[q] = (_Float16)v;
+    lo[q] = (_Float16)(v - (float)hi[q]);
+  }
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(256)
+mlp_wgrad_f16_kernel(const char* __restrict__ scratch, float* __restrict__ d_wmat, long long n_wave_tiles,
+                     int tiles_per_chunk, int has_col) {
+  __shared__ __attribute__((aligned(16))) float sx[WG16_SLOT_FLOATS], sy[WG16_SLOT_FLOATS];
+  __shared__ __attribute__((aligned(16))) f16x8 sb[2][4][2][64];  // [hi|lo][column tile][k-step][lane]
+  __shared__ float smax[2][4];
+  const int m = blockIdx.y;
+  if (m == 7 && !has_col) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, i = lane & 31;
+  const long long t_begin = (long long)blockIdx.x * tiles_per_chunk;
+  const long long t_end = min(n_wave_tiles, t_begin + tiles_per_chunk);
+  f32x16 acc[4];
+  acc_zero(acc);
+  const int npair = (m == 7) ? 1 : 2;
+  const int fo = 32 * wave + i;
+  for (long long wt = t_begin; wt < t_end; ++wt) {
+    const char* base = scratch + wt * (long long)(NSLOT_BWD * 16384);
+    for (int pr = 0; pr < npair; ++pr) {
+      int sxi, syi;
+      bool y_is_phi;
+      if (m == 7) { sxi = S_UV; syi = S_PHI + 7; y_is_phi = true; }
+      else if (pr == 0) { sxi = S_V + m; syi = S_GB + m; y_is_phi = false; }
+      else { sxi = S_U + m; syi = S_PHI + m; y_is_phi = true; }
+      const f32x4* gx4 = reinterpret_cast<const f32x4*>(base + (size_t)sxi * 16384);
+      const f32x4* gy4 = reinterpret_cast<const f32x4*>(base + (size_t)syi * 16384);
+      f32x4 xv[4], yv[4];
+      float mx = 0.f, my = 0.f;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int q = it * 256 + tid;
+        xv[it] = gx4[q];
+        yv[it] = gy4[q];
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (y_is_phi) {
+            float sn, cs;
+            sincos_<FAST>(yv[it][k], sn, cs);
+            yv[it][k] = sn;
+          }
+          mx = fmaxf(mx, fabsf(xv[it][k]));
+          my = fmaxf(my, fabsf(yv[it][k]));
+        }
+      }
+      mx = oi::wave_max(mx);
+      my = oi::wave_max(my);
+      __syncthreads();  // previous tile's readers of sx / sy / sb are done
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int q = it * 256 + tid;
+        const int dq = q + (q >> 5);  // + 4 floats per 32-point block
+        reinterpret_cast<f32x4*>(sx)[dq] = xv[it];
+        reinterpret_cast<f32x4*>(sy)[dq] = yv[it];
+      }
+      if (lane == 0) {
+        smax[0][wave] = mx;
+        smax[1][wave] = my;
+      }
+      __syncthreads();
+      float scx, ivx, scy, ivy;
+      pow2_scale_of(fmaxf(fmaxf(smax[0][0], smax[0][1]), fmaxf(smax[0][2], smax[0][3])), scx, ivx);
+      pow2_scale_of(fmaxf(fmaxf(smax[1][0], smax[1][1]), fmaxf(smax[1][2], smax[1][3])), scy, ivy);
+      // this wave's column tile of Y -> shared fp16 fragments
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        f16x8 bh, bl;
+        frag16(sy, fo, 16 * ks + 8 * h, scy, bh, bl);
+        sb[0][wave][ks][lane] = bh;
+        sb[1][wave][ks][lane] = bl;
+      }
+      f16x8 ah[2], al[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) frag16(sx, fo, 16 * ks + 8 * h, scx, ah[ks], al[ks]);
+      __syncthreads();
+      f32x16 tacc[4];
+      acc_zero(tacc);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const f16x8 bh = sb[0][t][ks][lane], bl = sb[1][t][ks][lane];
+          tacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, tacc[t], 0, 0, 0);
+          tacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, tacc[t], 0, 0, 0);
+          tacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, tacc[t], 0, 0, 0);
+        }
+      }
+      const float inv = ivx * ivy;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(tacc[t][r], inv, acc[t][r]);
+    }
+  }
+  float* dst = d_wmat + (size_t)m * C * C;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int oo = 32 * wave + (rg & 3) + 8 * (rg >> 2) + 4 * h;
+      atomicAdd(dst + (size_t)oo * C + 32 * t + i, acc[t][rg]);
+    }
+}
+
 template <int PREC, bool FAST>
 int launch_bwd(const float* pts, const void* packed, const float* gamma, const float* beta, const float* grad_fwd,
                const float* rgb_fwd, const float* g_sdf, const float* g_grad, const float* g_rgb, float* d_small,
@@ -604,8 +741,13 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
   const long long n_wt = (long long)B * grid.x * 4;
   int chunk = (int)std::max<long long>(1, (n_wt * 8 + 2047) / 2048);  // ~2048 workgroups in total
   dim3 g2(oi::cdiv(n_wt, chunk), 8);
-  hipLaunchKernelGGL(mlp_wgrad_kernel<FAST>, g2, block, 0, st, reinterpret_cast<const char*>(scratch), d_wmat, n_wt,
-                     chunk, (rgb_fwd != nullptr && g_rgb != nullptr) ? 1 : 0);
+  if constexpr (PREC == OI_PREC_F16X3) {
+    hipLaunchKernelGGL(mlp_wgrad_f16_kernel<FAST>, g2, block, 0, st, reinterpret_cast<const char*>(scratch), d_wmat,
+                       n_wt, chunk, (rgb_fwd != nullptr && g_rgb != nullptr) ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL(mlp_wgrad_kernel<FAST>, g2, block, 0, st, reinterpret_cast<const char*>(scratch), d_wmat, n_wt,
+                       chunk, (rgb_fwd != nullptr && g_rgb != nullptr) ? 1 : 0);
+  }
   return oi::check_launch("oi_sdf_mlp_bwd(wgrad)");
 }
 
