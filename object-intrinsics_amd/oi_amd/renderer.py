@@ -58,9 +58,14 @@ class NeuSRenderer:
         from .autograd import composite
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
         N = rays_o.shape[0]
+        if N == 0:
+            raise ValueError("NeuSRenderer.render: empty ray batch (the reference reshapes rays to (B, N/B, 3), fields.py:55)")
         # `film` = (w, gamma, beta) precomputed by the caller (one launch per forward instead of one per chunk + style)
         w_, gamma, beta = film if film is not None else self.pack.film(z=z if w is None else None, w=w)
         B = w_.shape[0]
+        if N % B != 0:
+            raise ValueError(f"NeuSRenderer.render: {N} rays cannot be split over {B} latent codes (rows of one batch "
+                             "element are contiguous, fields.py:55)")
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
         zv = self.sample_z(rays_o, rays_d, near, far, gamma.detach(), beta.detach(), B, perturb)
         T = zv.shape[1]

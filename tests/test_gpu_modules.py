@@ -318,3 +318,30 @@ def test_host_pose_algebra_matches_device_path():
     for k in ("rays_o", "rays_d", "near", "far"):
         assert maxdiff(rays_h[k], rays_d[k]) < 1e-5, k
     assert maxdiff(prior_h["light"].direction(), prior_d["light"].direction()) < 1e-6
+
+
+@pytest.mark.parametrize("N", [1, 33])
+def test_render_ragged_ray_counts(sdf_sd, col_sd, N):
+    """Ray counts that fill neither a wavefront tile (32 points) nor a workgroup: tail lanes are masked, not dropped."""
+    g = torch.Generator().manual_seed(N)
+    ro = torch.tensor([0.0, 0.0, -3.0]).expand(N, 3) + 0.05 * torch.randn(N, 3, generator=g)
+    rd = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + 0.2 * torch.randn(N, 3, generator=g), dim=-1)
+    near, far = O.near_far_from_sphere(ro, rd)
+    w = O.style_mlp(sdf_sd, torch.randn(1, 64, generator=g))
+    ref = O.render(sdf_sd, col_sd, torch.tensor(0.3), ro, rd, near, far, w, 16, 16, 1, 0.5)
+    r = make_renderer(col_sd, 16, 16, 1, "f16x3")
+    with torch.no_grad():
+        out = r.render(ro.cuda(), rd.cuda(), near.cuda(), far.cuda(), perturb_overwrite=0, cos_anneal_ratio=0.5, w=w.cuda())
+    for k in ("weights", "color_fine", "weight_sum", "sdf", "mid_z_vals"):
+        assert tuple(out[k].shape) == tuple(ref[k].shape)
+        assert maxdiff(out[k].cpu(), ref[k]) < 1e-4, (k, maxdiff(out[k].cpu(), ref[k]))
+
+
+def test_render_rejects_empty_and_unsplittable_batches(col_sd):
+    r = make_renderer(col_sd, 16, 16, 1, "f16x3")
+    e = torch.zeros(0, 3).cuda()
+    with pytest.raises(ValueError):
+        r.render(e, e, torch.zeros(0, 1).cuda(), torch.zeros(0, 1).cuda(), perturb_overwrite=0, w=torch.zeros(1, 64).cuda())
+    x = torch.zeros(3, 3).cuda()
+    with pytest.raises(ValueError):
+        r.render(x, x, torch.zeros(3, 1).cuda(), torch.ones(3, 1).cuda(), perturb_overwrite=0, w=torch.zeros(2, 64).cuda())
