@@ -441,10 +441,9 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
 }
 
 // wait for this wave's LDS-DMA, then rendezvous: next image resident, previous ring slot free
-// TRAILING = number of this wave's VMEM operations issued AFTER its LDS-DMA loads that may stay in flight: the 16
-// scratch stores of the FiLM phase.  vmcnt retires in issue order on gfx9-class parts (hipcc relies on the same
-// property whenever it waits for a load with younger stores outstanding), so vmcnt(16) = "the image has landed"
-// without paying for the write acknowledgements of stores nobody in this workgroup reads before the next layer.
+// TRAILING > 0 would let that many younger VMEM operations (the FiLM phase's scratch stores) stay in flight; it relies
+// on in-order vmcnt retirement between LDS-DMA loads and stores and measured no gain (the wait is for the slowest
+// wave, not for write acknowledgements), so every call site waits for vmcnt(0).
 template <int TRAILING = 0>
 __device__ __forceinline__ void ring_sync() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TRAILING) : "memory");
@@ -545,7 +544,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
     film_sin2<FAST, FULL, 1>(lds, o, y, acc, act, ws, 0, H_TAB0, px, py, pz);
   }
   PROF_T(0);
-  ring_sync<FULL ? 16 : 0>();
+  ring_sync();
   PROF_T(4);
 
   // ---- layers 1..7 on MFMA
@@ -562,7 +561,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
     PROF_T(2);
     film_sin2<FAST, FULL, 0>(lds, o, y, acc, act, ws, l, 0, 0.f, 0.f, 0.f);
     PROF_T(3);
-    ring_sync<FULL ? 16 : 0>();
+    ring_sync();
     PROF_T(4);
   }
 
