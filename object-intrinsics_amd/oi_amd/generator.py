@@ -161,7 +161,9 @@ class Generator(nn.Module):
         h = w = self.resolution
         n_rays = bs * h * w
         cos_anneal_ratio = min(1.0, self._it_host / self.anneal_end)
-        bg = self._h2d(self.bg_color(bs))
+        # "bg_color": optional (bs, 3) device tensor -- an extension used by the HIP-graph wrapper (oi_amd.graphed), whose
+        # inputs must live at fixed device addresses; the reference always draws it from numpy (generator.py:161)
+        bg = data["bg_color"] if "bg_color" in data else self._h2d(self.bg_color(bs))
         ldir = prior["light"].direction()
         lpk = self.light.packed()
 

@@ -49,9 +49,26 @@ def rotation_walk(b2w0, n_frames, axis=(0.0, -1.0, 0.0)):
 
 
 @torch.no_grad()
-def render_frames(gen, zs, b2ws, keys=("image", "mask", "normal_map", "shading_map"), max_ray_batch=None):
-    """One frame per (z, b2w) pair, eval mode (perturb off, multi-chunk allowed: generator.py:286-305)."""
+def render_frames(gen, zs, b2ws, keys=("image", "mask", "normal_map", "shading_map"), max_ray_batch=None, graphed=False):
+    """One frame per (z, b2w) pair, eval mode (perturb off, multi-chunk allowed: generator.py:286-305).
+    graphed=True replays one captured hipGraph per frame (oi_amd.graphed.GraphedForward; background fixed to black)."""
     gen.eval()
+    if graphed:
+        from .graphed import GraphedForward
+        old = G.MAX_RAY_BATCH_SIZE
+        if max_ray_batch is not None:
+            G.MAX_RAY_BATCH_SIZE = max_ray_batch
+        try:
+            gf = GraphedForward(gen, bs=1, it=int(gen.it), return_raw=True, keys=keys).recapture()
+            dev = gen.it.device
+            frames = {k: [] for k in keys}
+            for z, b2w in zip(zs, b2ws):
+                out = gf(b2w[None].to(dev), z[None].to(dev))
+                for k in keys:
+                    frames[k].append(out[k][0].clone())
+            return {k: torch.stack(v) for k, v in frames.items()}
+        finally:
+            G.MAX_RAY_BATCH_SIZE = old
     old = G.MAX_RAY_BATCH_SIZE
     if max_ray_batch is not None:
         G.MAX_RAY_BATCH_SIZE = max_ray_batch

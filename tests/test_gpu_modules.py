@@ -240,6 +240,9 @@ def test_inference_walks_and_depth_multiplier():
     assert maxdiff(one["mask"][0], fr["mask"][0]) < 1e-6                        # chunking does not change a frame
     lw = inference.latent_walk(gen, z0, z1, g["b2w"][0], n_frames=3)
     assert float((lw["normal_map"][0] - lw["normal_map"][2]).abs().max()) > 1e-3
+    # hipGraph replay of the same walk (multi-chunk too): masks / normals do not depend on the random background
+    gw = inference.camera_walk(gen, z0, g["b2w"][0], n_frames=3, max_ray_batch=300, graphed=True)
+    assert torch.equal(gw["mask"], fr["mask"]) and torch.equal(gw["normal_map"], fr["normal_map"])
     kw = {"renderer": {"kwargs": {"n_importance": 4, "n_samples": 16}}, "resolution": 128, "scene_resolution": 794,
           "camera": {"kwargs": {"resolution": 794}}}
     kw2 = inference.scale_config(kw, 128, test_resolution=256, depth_multiplier=16)
@@ -345,3 +348,22 @@ def test_render_rejects_empty_and_unsplittable_batches(col_sd):
     x = torch.zeros(3, 3).cuda()
     with pytest.raises(ValueError):
         r.render(x, x, torch.zeros(3, 1).cuda(), torch.ones(3, 1).cuda(), perturb_overwrite=0, w=torch.zeros(2, 64).cuda())
+
+
+def test_graphed_forward_matches_eager():
+    """hipGraph replay of the eval forward == the eager forward, frame after frame with new poses / latents."""
+    from oi_amd.graphed import GraphedForward
+    gen = build_generator(16, 16, 16, 1, "f16x3")
+    gen.eval()
+    np.random.seed(5)
+    gf = GraphedForward(gen, bs=1, it=1000, return_raw=True).recapture()
+    g = torch.Generator().manual_seed(0)
+    for frame in range(3):
+        b2w = torch.tensor(np.asarray(gen.pose_prior(1), dtype=np.float32)).cuda()
+        z = torch.randn(1, 64, generator=g).cuda()
+        bg = torch.rand(1, 3, generator=g).cuda()
+        out = {k: v.clone() for k, v in gf(b2w, z, bg).items()}
+        with torch.no_grad():
+            ref = gen(bs=1, it=1000, data={"b2w": b2w, "z": z, "bg_color": bg}, return_raw=True)["box"]["render_out"]
+        for k in ("image", "mask", "normal_map", "shading_map", "z_map"):
+            assert torch.equal(out[k], ref[k]), (frame, k, maxdiff(out[k], ref[k]))
