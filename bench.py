@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--importance", type=int, default=64)
     ap.add_argument("--up-steps", type=int, default=1)
-    ap.add_argument("--train-steps", type=int, default=8, help="full GAN training iterations timed after the main region (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=20, help="full GAN training iterations timed after the main region (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-disc", action="store_true")
     args = ap.parse_args()

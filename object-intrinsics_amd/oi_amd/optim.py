@@ -20,10 +20,15 @@ def _stream():
 
 
 class _ChunkTable:
-    """Device array of `oi_mt_chunk` descriptors, rebuilt only when a pointer changes."""
+    """Device array of `oi_mt_chunk` descriptors, rebuilt only when a pointer changes (gradients dropped with
+    `zero_grad(set_to_none=True)` come back at new addresses).  Uploads go through a small ring of pinned buffers with
+    non-blocking copies: a pageable `.to(device)` would stall the host behind everything queued on the stream."""
+
+    RING = 4
 
     def __init__(self):
         self.key, self.table, self.n = None, None, 0
+        self._pinned, self._events, self._i = [], [], 0
 
     def get(self, quads):
         """quads: list of (p, g, s0, s1) tensors (s0 / s1 may be None)."""
@@ -37,8 +42,19 @@ class _ChunkTable:
                     m = min(chunk, n - off)
                     rows.append((pp + 4 * off, gp + 4 * off, ap + 4 * off if ap else 0, bp + 4 * off if bp else 0, m))
             arr = np.array(rows, dtype=np.int64).reshape(-1, 5)  # 4 pointers + (n | reserved << 32): 40-byte structs
-            dev = quads[0][0].device if quads else torch.device("cuda")
-            self.table = torch.from_numpy(arr).to(dev) if len(rows) else None
+            dev = quads[0][0].device
+            if self.table is None or self.table.shape[0] < len(rows):
+                self.table = torch.empty(max(len(rows), 1), 5, dtype=torch.int64, device=dev)
+                self._pinned = [torch.empty(max(len(rows), 1), 5, dtype=torch.int64, pin_memory=True) for _ in range(self.RING)]
+                self._events = [None] * self.RING
+            i = self._i = (self._i + 1) % self.RING
+            if self._events[i] is not None and not self._events[i].query():
+                self._events[i].synchronize()
+            self._pinned[i][:len(rows)].numpy()[:] = arr
+            self.table[:len(rows)].copy_(self._pinned[i][:len(rows)], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[i] = ev
             self.key, self.n = key, len(rows)
         return self.table, self.n
 

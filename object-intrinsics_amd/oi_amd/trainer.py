@@ -26,6 +26,16 @@ def _unwrap(m):
     return m.module if hasattr(m, "module") and isinstance(m.module, torch.nn.Module) else m
 
 
+def _zero_grad(net, opt):
+    """FlatGradDDP keeps every gradient as a view of one flat buffer: one fill.  Plain modules drop their gradients
+    (`set_to_none=True`, the reference's default `opt.zero_grad()`): no fill per parameter now, no `+=` per parameter in
+    the next backward (~250 launches per iteration for the three networks)."""
+    if hasattr(net, "flat_grad"):
+        net.zero_grad()
+    else:
+        opt.zero_grad(set_to_none=True)
+
+
 class Trainer:
     def __init__(self, modules, loss_weight=None, it=-1):
         self.modules = modules
@@ -56,7 +66,7 @@ class Trainer:
     def train_step_generator(self, bs):
         for k in MODULE_KEYS:
             toggle_grad(self.modules[k], k == "generator")
-        self.opt_generator.zero_grad(set_to_none=False)
+        _zero_grad(self.generator, self.opt_generator)
         blob = self.generator(bs=bs, it=self.it, data={}, return_raw=False)["box"]
         x_fake = torch.cat([blob["render_out"][k] for k in DATA_KEYS["discriminator"]], dim=-3)
         loss_disc = self.gan(self.discriminator(x_fake, it=self.it)[:, :1], 1)
@@ -75,7 +85,7 @@ class Trainer:
         for k in MODULE_KEYS:
             toggle_grad(self.modules[k], k == key)
         disc, opt = self.modules[key], self.modules[f"opt_{key}"]
-        opt.zero_grad(set_to_none=False)
+        _zero_grad(disc, opt)
         x_real = torch.cat([real[k] for k in DATA_KEYS[key]], dim=-3).detach().clone().requires_grad_()
         d_real = disc(x_real, it=self.it)[:, :1]
         loss_real = self.gan(d_real, 1)
