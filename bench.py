@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--up-steps", type=int, default=1)
     ap.add_argument("--train-steps", type=int, default=20, help="full GAN training iterations timed after the main region (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-timeout", type=int, default=300, help="watchdog (s) for the secondary training leg")
     ap.add_argument("--no-disc", action="store_true")
     args = ap.parse_args()
 
@@ -252,15 +253,7 @@ def main():
     dt = time.perf_counter() - t0
     timer_on[0] = False
 
-    # ---- full training iteration (3 renders, 6 D forwards, 3 backward + optimiser steps, flat-gradient
-    #      all-reduce per network when N > 1); reported next to the headline, not part of `value`
-    train = None
-    if args.train_steps > 0 and not args.no_disc:
-        try:
-            train = bench_training(args, gen, disc, device, world, barrier, distributed)
-        except Exception as ex:  # never lose the headline line because of the secondary measurement
-            train = {"error": f"{type(ex).__name__}: {ex}"}
-
+    # headline reductions first: nothing after this point can take the timed result away
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     dd = torch.tensor([d_img_s or 0.0], device=device, dtype=torch.float64)
     if distributed:
@@ -269,8 +262,53 @@ def main():
     dt = float(t)
     rays_per_step = world * B * R * R
     value = rays_per_step * args.steps / dt
+    line = None
+
+    # ---- full training iteration (3 renders, 6 D forwards, 3 backward + optimiser steps, flat-gradient
+    #      all-reduce per network when N > 1); reported next to the headline, not part of `value`.
+    #      A watchdog on every rank turns a stuck collective in this SECONDARY leg into "training: timed out"
+    #      instead of a hung job without a bench line.
+    train = None
+    if args.train_steps > 0 and not args.no_disc:
+        import threading
+
+        line_ref = []
+        if rank == 0:
+            line_ref.append(build_line(args, value, dt, world, timer, float(dd) if d_img_s else None, None, distributed))
+
+        def _watchdog():  # a thread, not SIGALRM: the main thread would be blocked inside a collective / synchronize
+            if rank == 0 and line_ref:
+                line_ref[0]["training"] = {"error": f"timed out after {args.train_timeout} s"}
+                print(json.dumps(line_ref[0]), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.train_timeout, _watchdog)
+        dog.daemon = True
+        dog.start()
+        try:
+            train = bench_training(args, gen, disc, device, world, barrier, distributed)
+        except Exception as ex:  # never lose the headline line because of the secondary measurement
+            train = {"error": f"{type(ex).__name__}: {ex}"}
+        dog.cancel()
 
     if rank == 0:
+        line = build_line(args, value, dt, world, timer, float(dd) if d_img_s else None, train, distributed)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.res, args.samples, args.importance, args.up_steps, args.batch)
+    if distributed:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which is
+        # block-buffered on a pipe and would otherwise surface after it at exit
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
+
+
+def build_line(args, value, dt, world, timer, d_img_s, train, distributed):
+    R, S, I, K, B = args.res, args.samples, args.importance, args.up_steps, args.batch
+    if True:
         n_pts = B * R * R * (S + I)
         kern_ms = timer.mean_ms()
         flops = n_pts * (F_SDF + F_GRAD + F_COL)
@@ -292,7 +330,7 @@ def main():
                                    f"Generator.forward (render + Phong maps) + ADADiscriminatorView forward",
                        "rays_per_step_per_gpu": B * R * R, "points_per_step_per_gpu": n_pts,
                        "parallelism": f"dp{world} (independent renders, no data-path collective)"},
-            "d_images_per_s": float(dd) if d_img_s else None,
+            "d_images_per_s": d_img_s,
             "training": train,
             "roofline": {"bound": "mfma", "kernel": "sdf_mlp_kernel<full> (sdf + d sdf/dx + albedo at the fine samples)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -312,17 +350,7 @@ def main():
                                  "(executed_mfma_frac_of_peak), so their frac is bounded by 1/3 / 1/3 / 1/6; "
                                  "vs_native_fp32_mfma_peak compares the fp32-exact result rate with the native fp32 roofline"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(R, S, I, K, B)
-    if distributed:
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
-    if rank == 0:
-        # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which is
-        # block-buffered on a pipe and would otherwise surface after it at exit
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        print(json.dumps(line), flush=True)
+    return line
 
 
 if __name__ == "__main__":
