@@ -232,13 +232,26 @@ constexpr int V2_TILE = V2_WAVES * WAVE_PTS;  // 256 points
 constexpr int V2_FILM = 0;                    // [9][gamma 128 | beta' 128],  beta' = gamma * bias + beta
 constexpr int V2_TABS = 9 * 1024;             // 9216
 constexpr int V2_WBUF = V2_TABS + H_TABS_END * 4;  // 15488
-// Workgroup shape per mode.  F16X3: 4 wavefronts (128 points) and ONE 64 KiB image slot = 79 KiB of LDS, so TWO
-// independent workgroups share a CU (one wave per SIMD each) and run out of phase: one's MFMA phase overlaps the
-// other's FiLM/sin VALU phase, scratch traffic and image refill.  Other modes: 8 wavefronts, one workgroup per CU.
-__host__ __device__ constexpr int v2_waves(int prec) { return prec == OI_PREC_F16X3 ? 4 : 8; }
+// Workgroup shape.  Every mode runs 8 wavefronts (256 points) per workgroup and CU with a double-buffered image
+// ring, except BF16X6 (96 KiB images: one slot).  F16X3 can alternatively be built with 4-wave workgroups and ONE
+// 64 KiB slot (79 KiB LDS, two independent workgroups per CU): measured 1.5 % slower (tools/bench_c5.py) -- on
+// gfx950 FP VALU and MFMA time of co-resident waves add up, so running the two workgroups out of phase buys nothing.
+#ifndef OI_F16X3_FULL_WAVES
+#define OI_F16X3_FULL_WAVES 8
+#endif
+#ifndef OI_F16X3_SDF_WAVES
+#define OI_F16X3_SDF_WAVES 8
+#endif
+__host__ __device__ constexpr int v2_waves(int prec, bool full) {
+  return prec == OI_PREC_F16X3 ? (full ? OI_F16X3_FULL_WAVES : OI_F16X3_SDF_WAVES) : 8;
+}
 // BF16X6 images are 96 KiB: a single ring slot, refilled behind a barrier while the VALU phase runs
-__host__ __device__ constexpr bool v2_two_slots(int prec) { return prec != OI_PREC_BF16X6 && prec != OI_PREC_F16X3; }
-__host__ __device__ constexpr int v2_lds_total(int prec) { return V2_WBUF + (v2_two_slots(prec) ? 2 : 1) * layer_bytes(prec); }
+__host__ __device__ constexpr bool v2_two_slots(int prec, bool full) {
+  return prec != OI_PREC_BF16X6 && !(prec == OI_PREC_F16X3 && v2_waves(prec, full) == 4);
+}
+__host__ __device__ constexpr int v2_lds_total(int prec, bool full) {
+  return V2_WBUF + (v2_two_slots(prec, full) ? 2 : 1) * layer_bytes(prec);
+}
 
 struct LayOff {  // per-layer runtime VGPR bases (everything else is an immediate)
   int wl;   // 16*lane + ring slot base
@@ -247,12 +260,12 @@ struct LayOff {  // per-layer runtime VGPR bases (everything else is an immediat
   int f16;  // 16*h + 1024*layer  (FiLM rows of this layer)
 };
 
-template <int PREC>
+template <int PREC, int NWAVES>
 __device__ __forceinline__ void prefetch_image(char* lds, const char* __restrict__ src, int slot, int wave, int lane) {
   constexpr int NCHUNK = layer_bytes(PREC) / 1024;
 #pragma unroll
-  for (int c0 = 0; c0 < NCHUNK / v2_waves(PREC); ++c0) {
-    const int c = c0 * v2_waves(PREC) + wave;
+  for (int c0 = 0; c0 < NCHUNK / NWAVES; ++c0) {
+    const int c = c0 * NWAVES + wave;
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)(src + c * 1024 + lane * 16),
         (__attribute__((address_space(3))) void*)(lds + V2_WBUF + slot * layer_bytes(PREC) + c * 1024), 16, 0, 0);
@@ -463,7 +476,7 @@ __device__ unsigned long long oi_prof[16];
 #endif
 
 template <int PREC, bool FAST, bool FULL>
-__global__ void __launch_bounds__(64 * v2_waves(PREC), 2)
+__global__ void __launch_bounds__(64 * v2_waves(PREC, FULL), 2)
 sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, const float* __restrict__ gamma,
                const float* __restrict__ beta, float* __restrict__ sdf_out, float* __restrict__ grad_out,
                float* __restrict__ rgb_out, float* __restrict__ feat_out, char* __restrict__ scratch,
@@ -476,17 +489,18 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   const float* hdr = reinterpret_cast<const float*>(packed);
   const char* mats = packed + H_BYTES;
   constexpr int LB = layer_bytes(PREC);
-  constexpr bool RING2 = v2_two_slots(PREC);
+  constexpr bool RING2 = v2_two_slots(PREC, FULL);
+  constexpr int NWV = v2_waves(PREC, FULL);
   // double-buffered ring: the next image is requested at the START of a layer into the other slot.
   // single slot (BF16X6): it is requested right AFTER the layer's MFMAs, behind a barrier, and lands while the
   // FiLM/sin VALU phase runs.
   auto stage_early = [&](const char* src, int slot) {
-    if constexpr (RING2) prefetch_image<PREC>(lds, src, slot, wave, lane);
+    if constexpr (RING2) prefetch_image<PREC, NWV>(lds, src, slot, wave, lane);
   };
   auto stage_late = [&](const char* src) {
     if constexpr (!RING2) {
       __syncthreads();
-      prefetch_image<PREC>(lds, src, 0, wave, lane);
+      prefetch_image<PREC, NWV>(lds, src, 0, wave, lane);
     }
   };
 
@@ -497,7 +511,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   o.l16hi = 16 * lane + 32768;
   asm volatile("" : "+v"(o.h16), "+v"(o.h64), "+v"(o.l16), "+v"(o.l16hi));
 
-  constexpr int NW = v2_waves(PREC), NT = 64 * NW;
+  constexpr int NW = NWV, NT = 64 * NW;
   const long long local = (long long)blockIdx.x * (NW * WAVE_PTS) + wave * WAVE_PTS + j;
   const bool valid = local < n_per_elem;
   const long long pt = (long long)e * n_per_elem + (valid ? local : n_per_elem - 1);
@@ -513,7 +527,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
 
   // image sequence: i = 0..6 forward layers 1..7 (mats 0..6), i = 7..13 transposed layers 7..1 (mats 13..7),
   // i = 14 colour head (mat 14); image i lives in ring slot i & 1.
-  prefetch_image<PREC>(lds, mats + 0 * (size_t)LB, 0, wave, lane);
+  prefetch_image<PREC, NWV>(lds, mats + 0 * (size_t)LB, 0, wave, lane);
   {  // small tables + FiLM rows of all 9 layers (gamma | beta | bias), once
     float* tabs = reinterpret_cast<float*>(lds + V2_TABS);
     for (int i = tid; i < H_TABS_END; i += NT) tabs[i] = hdr[i];
@@ -725,32 +739,30 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
 #endif
 }
 
+template <int PREC, bool FAST, bool FULL>
+int launch_mlp_variant(const float* pts, const char* pk, const float* gamma, const float* beta, float* sdf, float* grad,
+                       float* rgb, float* feat, char* scratch, int B, long long n, hipStream_t st) {
+  constexpr int NWV = v2_waves(PREC, FULL);
+  constexpr int LDS_BYTES = v2_lds_total(PREC, FULL);
+  dim3 grid(oi::cdiv(n, NWV * WAVE_PTS), B), block(64 * NWV);
+  auto k = sdf_mlp_kernel<PREC, FAST, FULL>;
+  static thread_local bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, grid, block, LDS_BYTES, st, pts, pk, gamma, beta, sdf, grad, rgb, feat, scratch, n);
+  return oi::check_launch("oi_sdf_mlp_fwd");
+}
+
 template <int PREC, bool FAST>
 int launch_mlp(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf,
                float* grad, float* rgb, float* feat, void* scratch, int B, long long n, hipStream_t st) {
-  dim3 grid(oi::cdiv(n, v2_waves(PREC) * WAVE_PTS), B), block(64 * v2_waves(PREC));
   const char* pk = reinterpret_cast<const char*>(packed);
-  constexpr int LDS_BYTES = v2_lds_total(PREC);
-  if (grad != nullptr) {
-    auto k = sdf_mlp_kernel<PREC, FAST, true>;
-    static thread_local bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      attr = true;
-    }
-    hipLaunchKernelGGL(k, grid, block, LDS_BYTES, st, pts, pk, gamma, beta, sdf, grad, rgb, feat,
-                       reinterpret_cast<char*>(scratch), n);
-  } else {
-    auto k = sdf_mlp_kernel<PREC, FAST, false>;
-    static thread_local bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      attr = true;
-    }
-    hipLaunchKernelGGL(k, grid, block, LDS_BYTES, st, pts, pk, gamma, beta, sdf, (float*)nullptr, (float*)nullptr,
-                       feat, (char*)nullptr, n);
-  }
-  return oi::check_launch("oi_sdf_mlp_fwd");
+  if (grad != nullptr)
+    return launch_mlp_variant<PREC, FAST, true>(pts, pk, gamma, beta, sdf, grad, rgb, feat,
+                                                reinterpret_cast<char*>(scratch), B, n, st);
+  return launch_mlp_variant<PREC, FAST, false>(pts, pk, gamma, beta, sdf, nullptr, nullptr, feat, nullptr, B, n, st);
 }
 
 }  // namespace
