@@ -313,3 +313,31 @@ def test_affine_grid_sample_and_pad(ops):
     torch.nn.functional.pad(xr2, list(p), mode="reflect").backward(gp)
     gxp = ops.reflect_pad_bwd(gp.cuda(), Hi, Wi, *p)
     assert maxdiff(gxp.cpu(), xr2.grad) < 1e-5
+
+
+@pytest.mark.parametrize("wscale,pscale,noise", [(1.0, 1.0, 0.0), (3.0, 1.0, 0.0), (1.0, 3.0, 0.0), (1.0, 1.0, 0.5)])
+def test_f16x3_tracks_native_fp32_off_distribution(ops, sdf_sd, col_sd, wscale, pscale, noise):
+    """The default operand mode (two scaled fp16 limbs, per-point normalised adjoints) against the native fp32 MFMA
+    path on inputs outside the golden vectors' range: 3x latents, points up to |x| = 3 (|d sdf/dx| ~ 35), weights
+    with 50 % multiplicative-scale noise.  No overflow, differences at fp32 round-off level."""
+    from oi_amd.params import stack_field_params
+    g = torch.Generator().manual_seed(7)
+    sd = {k: v.clone() for k, v in sdf_sd.items()}
+    if noise:
+        for k in sd:
+            if k.startswith("pts_linears") and k.endswith("weight") and ".gamma." not in k and ".beta." not in k:
+                sd[k] = sd[k] + noise * sd[k].abs().mean() * torch.randn(sd[k].shape, generator=g)
+    P = stack_field_params(dev(sd), dev(col_sd))
+    B, n = 2, 16384
+    pts = ((torch.rand(B * n, 3, generator=g) * 2 - 1) * pscale).cuda()
+    z = (torch.randn(B, 64, generator=g) * wscale).cuda()
+    _, gamma, beta = ops.film_params(P["style_w"], P["style_b"], P["gw"], P["gb"], P["bw"], P["bb"], z=z)
+    res = {}
+    for name, prec in (("f32", 0), ("f16x3", 4)):
+        pk = ops.mlp_pack_weights(P["w0"], P["b0"], P["wh"], P["bh"], P["wsig"], P["bsig"], P["wv"], P["bv"], P["wrgb"],
+                                  P["brgb"], prec)
+        res[name] = ops.sdf_mlp_fwd(pts, pk, gamma, beta, B, prec, want_grad=True, want_rgb=True)[:3]
+    a, b = res["f32"], res["f16x3"]
+    assert all(bool(torch.isfinite(t).all()) for t in b)
+    gs = max(1.0, float(a[1].abs().max()))
+    assert maxdiff(a[0], b[0]) < 2e-5 and maxdiff(a[1], b[1]) / gs < 2e-5 and maxdiff(a[2], b[2]) < 2e-5
