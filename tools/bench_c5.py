@@ -12,14 +12,16 @@ from oi_amd.fields import ShapeNetwork, ColorNetwork, FieldPack
 
 F_SDF, F_GRAD, F_COL = 230400, 230400, 34304
 ap = argparse.ArgumentParser()
-ap.add_argument("--points", type=int, default=1 << 21)
+ap.add_argument("--points", type=int, default=1 << 21, help="total points (BASELINE configs[4]: 2^20 rays x 512 = 2^29)")
+ap.add_argument("--chunk", type=int, default=1 << 24, help="points per launch (bounds the 4.6 KB/point scratch of the full pass)")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--modes", default="f16x3,bf16x6,f32,bf16x3,bf16")
 args = ap.parse_args()
 kw = dict(D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64)
 sdf = ShapeNetwork(os.path.join(ROOT, "tests", "golden", "weights_sdf.npz"), **kw).cuda()
 col = ColorNetwork(**kw); col.load_state_dict(load_golden("weights_color")); col = col.cuda()
-n = args.points
+n = min(args.points, args.chunk)
+launches = max(1, args.points // n)
 pts = (torch.rand(n, 3, device="cuda") * 2 - 1) * 0.9
 for mode in args.modes.split(","):
     pack = FieldPack(sdf, col, mode)
@@ -33,11 +35,12 @@ for mode in args.modes.split(","):
                 scratch = out[-1] if full else scratch
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(args.iters):
+            for _ in range(args.iters * launches):
                 ops.sdf_mlp_fwd(pts, pack.packed(), gamma, beta, 1, pack.prec, pack.fast_trig, full, full, False, scratch)
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.iters
-            fl = n * (F_SDF + (F_GRAD + F_COL if full else 0))
-            res["full" if full else "sdf_only"] = {"ms": round(ms, 4), "Mpoints_per_s": round(n / ms / 1e3, 1),
+            tot = n * launches
+            fl = tot * (F_SDF + (F_GRAD + F_COL if full else 0))
+            res["full" if full else "sdf_only"] = {"ms": round(ms, 4), "Mpoints_per_s": round(tot / ms / 1e3, 1),
                                                    "algorithmic_TFLOP_per_s": round(fl / ms / 1e9, 1)}
-    print(json.dumps({"mode": mode, "points": n, **res}))
+    print(json.dumps({"mode": mode, "points": n * launches, "points_per_launch": n, **res}))
