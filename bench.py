@@ -360,7 +360,7 @@ def build_line(args, value, dt, world, timer, d_img_s, train, distributed, bf16_
                       "bf16": "bf16"}[args.precision],
             "data": "synthetic (random poses/latents/backgrounds from the data/example prior; sphere-initialised SDF "
                     "weights, seeded default-init colour/discriminator weights)",
-            "config": {"workload": f"C2: {B}x{R}x{R} crop per GPU, {S}+{I} samples/ray, {K} up-sampling step(s), "
+            "config": {"workload": f"{ {(64, 64, 64, 1): 'C2', (128, 128, 128, 4): 'C4'}.get((R, S, I, K), 'custom') }: {B}x{R}x{R} crop per GPU, {S}+{I} samples/ray, {K} up-sampling step(s), "
                                    f"Generator.forward (render + Phong maps) + ADADiscriminatorView forward",
                        "rays_per_step_per_gpu": B * R * R, "points_per_step_per_gpu": n_pts,
                        "parallelism": f"dp{world} (independent renders, no data-path collective)"},
