@@ -69,6 +69,15 @@ const char* oi_last_error(void); /* thread local */
 int oi_film_params(const float* style_w, const float* style_b, const float* z, float* w_out,
                    const float* gw, const float* gb, const float* bw, const float* bb,
                    float* gamma, float* beta, int B, int NL, oi_stream_t stream);
+/* Backward of oi_film_params (what autograd derives for the three MappingLinear layers and the 2 x 9 FiLM heads,
+ * stylesdf/model.py:49-54, volume_renderer.py:27-30).  d_gamma, d_beta [B][NL][128] in; d_gw, d_bw [NL][128][64] and
+ * d_gb, d_bb [NL][128] are ASSIGNED; d_w [B][64] is ACCUMULATED (pass zeros, or the upstream gradient of w).
+ * With z != NULL the style MLP is back-propagated too: d_style_w [3][64][64] and d_style_b [3][64] are ACCUMULATED
+ * (zero them), d_z [B][64] (optional) is assigned. */
+int oi_film_params_bwd(const float* d_gamma, const float* d_beta, const float* w, const float* gw, const float* bw,
+                       float* d_gw, float* d_gb, float* d_bw, float* d_bb, float* d_w, const float* style_w,
+                       const float* style_b, const float* z, float* d_style_w, float* d_style_b, float* d_z, int B,
+                       int NL, oi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight pre-pack for the MFMA kernels (run when weights change; a few microseconds).

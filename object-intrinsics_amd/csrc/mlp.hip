@@ -77,6 +77,97 @@ __global__ void film_params_kernel(const float* __restrict__ style_w, const floa
   }
 }
 
+// a1 + a2 backward.  d_gamma / d_beta [B][NL][128] (from the MLP backward) ->
+//   d_gw[l][f][k] = 15 sum_b d_gamma[b][l][f] w[b][k],   d_gb[l][f] = 15 sum_b d_gamma[b][l][f]
+//   d_bw[l][f][k] = .25 sum_b d_beta[b][l][f] w[b][k],   d_bb[l][f] = .25 sum_b d_beta[b][l][f]
+//   d_w[b][k]    += sum_f 15 d_gamma[b][l][f] gw[l][f][k] + .25 d_beta[b][l][f] bw[l][f][k]     (atomics over l)
+// grid (NL), block 128 (thread = feature f).  All outputs are ASSIGNED except d_w (accumulated: caller zeroes it or
+// passes the upstream gradient of w).
+__global__ void film_heads_bwd_kernel(const float* __restrict__ d_gamma, const float* __restrict__ d_beta,
+                                      const float* __restrict__ w, const float* __restrict__ gw,
+                                      const float* __restrict__ bw, float* __restrict__ d_gw,
+                                      float* __restrict__ d_gb, float* __restrict__ d_bw, float* __restrict__ d_bb,
+                                      float* __restrict__ d_w, int B, int NL) {
+  __shared__ float ws[64];
+  __shared__ float red[2][64];
+  const int l = blockIdx.x, f = threadIdx.x;
+  float ag[64], ab[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) { ag[k] = 0.f; ab[k] = 0.f; }
+  float sg = 0.f, sb = 0.f;
+  const float* grow = gw + ((size_t)l * C + f) * 64;
+  const float* brow = bw + ((size_t)l * C + f) * 64;
+  for (int b = 0; b < B; ++b) {
+    __syncthreads();
+    if (f < 64) ws[f] = w[b * 64 + f];
+    __syncthreads();
+    const float dg = 15.0f * d_gamma[((size_t)b * NL + l) * C + f];
+    const float db = 0.25f * d_beta[((size_t)b * NL + l) * C + f];
+    sg += dg;
+    sb += db;
+    // d_w[b][k] += sum over this block's 128 features: two 64-lane waves, DPP sums, one atomic per (wave, k)
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+      ag[k] = fmaf(dg, ws[k], ag[k]);
+      ab[k] = fmaf(db, ws[k], ab[k]);
+      const float part = oi::wave_sum(fmaf(dg, grow[k], db * brow[k]));
+      if ((f & 63) == 0) red[f >> 6][k] = part;
+    }
+    __syncthreads();
+    if (f < 64) atomicAdd(d_w + b * 64 + f, red[0][f] + red[1][f]);
+  }
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    d_gw[((size_t)l * C + f) * 64 + k] = ag[k];
+    d_bw[((size_t)l * C + f) * 64 + k] = ab[k];
+  }
+  d_gb[l * C + f] = sg;
+  d_bb[l * C + f] = sb;
+}
+
+// Style MLP backward (3 x [64 -> 64, lrelu 0.2]): recompute the activations from z, back-propagate d_w.
+// grid (B), block 64; parameter gradients accumulate over the batch with atomics (caller zeroes them).
+__global__ void style_bwd_kernel(const float* __restrict__ style_w, const float* __restrict__ style_b,
+                                 const float* __restrict__ z, const float* __restrict__ d_w,
+                                 float* __restrict__ d_style_w, float* __restrict__ d_style_b,
+                                 float* __restrict__ d_z) {
+  __shared__ float h[4][64];
+  __shared__ float pre_pos[3][64];
+  __shared__ float dh[2][64];
+  const int e = blockIdx.x, t = threadIdx.x;
+  h[0][t] = z[e * 64 + t];
+  __syncthreads();
+  for (int l = 0; l < 3; ++l) {
+    const float* wr = style_w + (l * 64 + t) * 64;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) acc = fmaf(h[l][k], wr[k], acc);
+    acc += style_b[l * 64 + t];
+    pre_pos[l][t] = acc > 0.f ? 1.0f : 0.2f;
+    h[l + 1][t] = acc > 0.f ? acc : 0.2f * acc;
+    __syncthreads();
+  }
+  dh[0][t] = d_w[e * 64 + t];
+  __syncthreads();
+  int cur = 0;
+  for (int l = 2; l >= 0; --l) {
+    const float dp = dh[cur][t] * pre_pos[l][t];  // gradient at the pre-activation of unit t
+    atomicAdd(d_style_b + l * 64 + t, dp);
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) atomicAdd(d_style_w + (l * 64 + t) * 64 + k, dp * h[l][k]);
+    __syncthreads();
+    dh[cur][t] = dp;  // reuse as the dp vector
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll 8
+    for (int o = 0; o < 64; ++o) acc = fmaf(dh[cur][o], style_w[(l * 64 + o) * 64 + t], acc);
+    dh[cur ^ 1][t] = acc;
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (d_z != nullptr) d_z[e * 64 + t] = dh[cur][t];
+}
+
 // ------------------------------------------------------------------------------------------
 // weight pre-pack
 // ------------------------------------------------------------------------------------------
@@ -791,6 +882,23 @@ int oi_prof_read(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
+
+int oi_film_params_bwd(const float* d_gamma, const float* d_beta, const float* w, const float* gw, const float* bw,
+                       float* d_gw, float* d_gb, float* d_bw, float* d_bb, float* d_w, const float* style_w,
+                       const float* style_b, const float* z, float* d_style_w, float* d_style_b, float* d_z, int B,
+                       int NL, oi_stream_t stream) {
+  OI_REQUIRE(B > 0 && NL > 0, "oi_film_params_bwd: B=%d NL=%d", B, NL);
+  OI_REQUIRE(d_gamma && d_beta && w && gw && bw && d_gw && d_gb && d_bw && d_bb && d_w, "oi_film_params_bwd: null pointer");
+  OI_REQUIRE(z == nullptr || (style_w && style_b && d_style_w && d_style_b),
+             "oi_film_params_bwd: style backward needs style_w, style_b, d_style_w, d_style_b");
+  hipStream_t st = oi::as_stream(stream);
+  hipLaunchKernelGGL(film_heads_bwd_kernel, dim3(NL), dim3(C), 0, st, d_gamma, d_beta, w, gw, bw, d_gw, d_gb, d_bw, d_bb,
+                     d_w, B, NL);
+  int rc = oi::check_launch("oi_film_params_bwd(heads)");
+  if (rc != OI_OK || z == nullptr) return rc;
+  hipLaunchKernelGGL(style_bwd_kernel, dim3(B), dim3(64), 0, st, style_w, style_b, z, d_w, d_style_w, d_style_b, d_z);
+  return oi::check_launch("oi_film_params_bwd(style)");
+}
 
 size_t oi_mlp_packed_bytes(int prec) { return H_BYTES + (size_t)NMAT * layer_bytes(prec); }
 

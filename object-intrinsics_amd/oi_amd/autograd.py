@@ -22,10 +22,39 @@ def film_params(pack, z=None, w=None):
     same device so that autograd reaches the reference-named parameters."""
     src = z if z is not None else w
     if _needs_grad(src, *pack.param_lists()[1]):
-        return _film_params_torch(pack.film_stacked(differentiable=True), z, w)
+        P = pack.film_stacked(differentiable=True)
+        return FilmParamsFunction.apply(z, w, P["style_w"], P["style_b"], P["gw"], P["gb"], P["bw"], P["bb"])
     P = pack.film_stacked(differentiable=False)
     with torch.no_grad():
         return ops.film_params(P["style_w"], P["style_b"], P["gw"], P["gb"], P["bw"], P["bb"], z=z, w=w)
+
+
+class FilmParamsFunction(torch.autograd.Function):
+    """oi_film_params / oi_film_params_bwd.  First-order only (the FiLM heads are linear in their parameters and the
+    training losses never differentiate a gradient with respect to them a second time)."""
+
+    @staticmethod
+    def forward(ctx, z, w, style_w, style_b, gw, gb, bw, bb):
+        w_out, gamma, beta = ops.film_params(style_w, style_b, gw, gb, bw, bb, z=z, w=w)
+        ctx.save_for_backward(z, w_out, style_w, style_b, gw, bw)
+        ctx.from_z = z is not None
+        ctx.need_dz = bool(z is not None and z.requires_grad)
+        return w_out, gamma, beta
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_w_out, d_gamma, d_beta):
+        z, w_out, style_w, style_b, gw, bw = ctx.saved_tensors
+        if d_gamma is None:
+            d_gamma = torch.zeros(w_out.shape[0], gw.shape[0], 128, device=w_out.device)
+        if d_beta is None:
+            d_beta = torch.zeros_like(d_gamma)
+        r = ops.film_params_bwd(d_gamma, d_beta, w_out, gw, bw, style_w if ctx.from_z else None,
+                                style_b if ctx.from_z else None, z if ctx.from_z else None, d_w_in=d_w_out,
+                                want_dz=ctx.need_dz)
+        if ctx.from_z:
+            return r.get("d_z"), None, r["d_style_w"], r["d_style_b"], r["d_gw"], r["d_gb"], r["d_bw"], r["d_bb"]
+        return None, r["d_w"], None, None, r["d_gw"], r["d_gb"], r["d_bw"], r["d_bb"]
 
 
 def _film_params_torch(P, z, w):

@@ -48,6 +48,7 @@ _SIGS = {
     "oi_arch": (ctypes.c_char_p, []),
     "oi_last_error": (ctypes.c_char_p, []),
     "oi_film_params": (_i, [_vp] * 10 + [_i, _i, _vp]),
+    "oi_film_params_bwd": (_i, [_vp] * 16 + [_i, _i, _vp]),
     "oi_mlp_packed_bytes": (_sz, [_i]),
     "oi_mlp_pack_weights": (_i, [_vp] * 11 + [_i, _vp]),
     "oi_mlp_scratch_bytes": (_sz, [_i, _ll]),

@@ -57,6 +57,24 @@ def film_params(style_w, style_b, gw, gb, bw, bb, z=None, w=None):
     return w_out, gamma, beta
 
 
+def film_params_bwd(d_gamma, d_beta, w, gw, bw, style_w=None, style_b=None, z=None, d_w_in=None, want_dz=False):
+    """Backward of film_params -> dict(d_gw, d_gb, d_bw, d_bb, d_w [, d_style_w, d_style_b, d_z])."""
+    L = _l.load()
+    B, NL = d_gamma.shape[0], d_gamma.shape[1]
+    d_gamma, d_beta, w = _c(d_gamma), _c(d_beta), _c(w)
+    out = {"d_gw": torch.empty_like(gw), "d_gb": _new(w, NL, 128), "d_bw": torch.empty_like(bw), "d_bb": _new(w, NL, 128),
+           "d_w": torch.zeros_like(w) if d_w_in is None else d_w_in.contiguous().clone()}
+    if z is not None:
+        out["d_style_w"], out["d_style_b"] = torch.zeros_like(style_w), torch.zeros_like(style_b)
+        if want_dz:
+            out["d_z"] = torch.empty_like(z)
+    _l.check(L.oi_film_params_bwd(_p(d_gamma), _p(d_beta), _p(w), _p(_c(gw)), _p(_c(bw)), _p(out["d_gw"]), _p(out["d_gb"]),
+                                  _p(out["d_bw"]), _p(out["d_bb"]), _p(out["d_w"]), _p(_c(style_w)), _p(_c(style_b)),
+                                  _p(_c(z)), _p(out.get("d_style_w")), _p(out.get("d_style_b")), _p(out.get("d_z")), B, NL,
+                                  _stream()), "oi_film_params_bwd")
+    return out
+
+
 def mlp_pack_weights(w0, b0, wh, bh, wsig, bsig, wv, bv, wrgb, brgb, prec):
     L = _l.load()
     packed = torch.empty(L.oi_mlp_packed_bytes(prec), dtype=torch.uint8, device=w0.device)
