@@ -81,48 +81,62 @@ __global__ void film_params_kernel(const float* __restrict__ style_w, const floa
 //   d_gw[l][f][k] = 15 sum_b d_gamma[b][l][f] w[b][k],   d_gb[l][f] = 15 sum_b d_gamma[b][l][f]
 //   d_bw[l][f][k] = .25 sum_b d_beta[b][l][f] w[b][k],   d_bb[l][f] = .25 sum_b d_beta[b][l][f]
 //   d_w[b][k]    += sum_f 15 d_gamma[b][l][f] gw[l][f][k] + .25 d_beta[b][l][f] bw[l][f][k]     (atomics over l)
-// grid (NL), block 128 (thread = feature f).  All outputs are ASSIGNED except d_w (accumulated: caller zeroes it or
+// grid (NL), block 256.  The layer's two 128 x 64 head matrices are staged in LDS with coalesced loads; outer
+// products are written with coalesced stores; the d_w contraction runs over LDS columns (conflict-free) and is
+// reduced over four feature quarters.  All outputs are ASSIGNED except d_w (accumulated: the caller zeroes it or
 // passes the upstream gradient of w).
-__global__ void film_heads_bwd_kernel(const float* __restrict__ d_gamma, const float* __restrict__ d_beta,
-                                      const float* __restrict__ w, const float* __restrict__ gw,
-                                      const float* __restrict__ bw, float* __restrict__ d_gw,
-                                      float* __restrict__ d_gb, float* __restrict__ d_bw, float* __restrict__ d_bb,
-                                      float* __restrict__ d_w, int B, int NL) {
-  __shared__ float ws[64];
-  __shared__ float red[2][64];
-  const int l = blockIdx.x, f = threadIdx.x;
-  float ag[64], ab[64];
+__global__ void __launch_bounds__(256)
+film_heads_bwd_kernel(const float* __restrict__ d_gamma, const float* __restrict__ d_beta,
+                      const float* __restrict__ w, const float* __restrict__ gw, const float* __restrict__ bw,
+                      float* __restrict__ d_gw, float* __restrict__ d_gb, float* __restrict__ d_bw,
+                      float* __restrict__ d_bb, float* __restrict__ d_w, int B, int NL) {
+  __shared__ float sg[C * 64], sb[C * 64];      // gw[l], bw[l]: [f][k]
+  __shared__ float dg[C], db[C], ws[64];
+  __shared__ float part[4][64];
+  const int l = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < C * 64; i += 256) {
+    sg[i] = gw[(size_t)l * C * 64 + i];
+    sb[i] = bw[(size_t)l * C * 64 + i];
+  }
+  float ag[32], ab[32];                         // this thread's 32 outputs of each outer product: index i = tid + 256 j
 #pragma unroll
-  for (int k = 0; k < 64; ++k) { ag[k] = 0.f; ab[k] = 0.f; }
-  float sg = 0.f, sb = 0.f;
-  const float* grow = gw + ((size_t)l * C + f) * 64;
-  const float* brow = bw + ((size_t)l * C + f) * 64;
+  for (int j = 0; j < 32; ++j) { ag[j] = 0.f; ab[j] = 0.f; }
+  float sgb = 0.f, sbb = 0.f;
   for (int b = 0; b < B; ++b) {
     __syncthreads();
-    if (f < 64) ws[f] = w[b * 64 + f];
-    __syncthreads();
-    const float dg = 15.0f * d_gamma[((size_t)b * NL + l) * C + f];
-    const float db = 0.25f * d_beta[((size_t)b * NL + l) * C + f];
-    sg += dg;
-    sb += db;
-    // d_w[b][k] += sum over this block's 128 features: two 64-lane waves, DPP sums, one atomic per (wave, k)
-#pragma unroll
-    for (int k = 0; k < 64; ++k) {
-      ag[k] = fmaf(dg, ws[k], ag[k]);
-      ab[k] = fmaf(db, ws[k], ab[k]);
-      const float part = oi::wave_sum(fmaf(dg, grow[k], db * brow[k]));
-      if ((f & 63) == 0) red[f >> 6][k] = part;
+    if (tid < C) {
+      dg[tid] = 15.0f * d_gamma[((size_t)b * NL + l) * C + tid];
+      db[tid] = 0.25f * d_beta[((size_t)b * NL + l) * C + tid];
+    } else if (tid < C + 64) {
+      ws[tid - C] = w[b * 64 + tid - C];
     }
     __syncthreads();
-    if (f < 64) atomicAdd(d_w + b * 64 + f, red[0][f] + red[1][f]);
+    if (tid < C) { sgb += dg[tid]; sbb += db[tid]; }
+    const int k = tid & 63;                     // i = tid + 256 j  ->  f = (tid >> 6) + 4 j, k = tid & 63
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int f = (tid >> 6) + 4 * j;
+      ag[j] = fmaf(dg[f], ws[k], ag[j]);
+      ab[j] = fmaf(db[f], ws[k], ab[j]);
+    }
+    // d_w[b][k]: quarter q = tid >> 6 sums features 32 q .. 32 q + 31
+    float acc = 0.f;
+    const int q = tid >> 6;
+#pragma unroll 8
+    for (int f = 32 * q; f < 32 * q + 32; ++f) acc = fmaf(dg[f], sg[f * 64 + k], fmaf(db[f], sb[f * 64 + k], acc));
+    part[q][k] = acc;
+    __syncthreads();
+    if (tid < 64) atomicAdd(d_w + b * 64 + tid, part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
   }
 #pragma unroll
-  for (int k = 0; k < 64; ++k) {
-    d_gw[((size_t)l * C + f) * 64 + k] = ag[k];
-    d_bw[((size_t)l * C + f) * 64 + k] = ab[k];
+  for (int j = 0; j < 32; ++j) {
+    d_gw[(size_t)l * C * 64 + tid + 256 * j] = ag[j];
+    d_bw[(size_t)l * C * 64 + tid + 256 * j] = ab[j];
   }
-  d_gb[l * C + f] = sg;
-  d_bb[l * C + f] = sb;
+  if (tid < C) {
+    d_gb[l * C + tid] = sgb;
+    d_bb[l * C + tid] = sbb;
+  }
 }
 
 // Style MLP backward (3 x [64 -> 64, lrelu 0.2]): recompute the activations from z, back-propagate d_w.
@@ -892,7 +906,7 @@ int oi_film_params_bwd(const float* d_gamma, const float* d_beta, const float* w
   OI_REQUIRE(z == nullptr || (style_w && style_b && d_style_w && d_style_b),
              "oi_film_params_bwd: style backward needs style_w, style_b, d_style_w, d_style_b");
   hipStream_t st = oi::as_stream(stream);
-  hipLaunchKernelGGL(film_heads_bwd_kernel, dim3(NL), dim3(C), 0, st, d_gamma, d_beta, w, gw, bw, d_gw, d_gb, d_bw, d_bb,
+  hipLaunchKernelGGL(film_heads_bwd_kernel, dim3(NL), dim3(256), 0, st, d_gamma, d_beta, w, gw, bw, d_gw, d_gb, d_bw, d_bb,
                      d_w, B, NL);
   int rc = oi::check_launch("oi_film_params_bwd(heads)");
   if (rc != OI_OK || z == nullptr) return rc;
