@@ -327,7 +327,7 @@ struct FwdScratch {
       for (int k = 0; k < 4; ++k) v[k] = (float)hv[k];
       return v;
     } else {
-      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o.l16, slot * 16384 + g * 1024, 0));
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o.l16, slot * 16384 + g * 1024, OI_SCRATCH_NT));
     }
   }
 };

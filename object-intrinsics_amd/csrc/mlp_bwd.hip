@@ -56,7 +56,7 @@ struct WaveScratchB {
     oi::buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024);
   }
   __device__ __forceinline__ f32x4 load(int slot, int g, int l16) const {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, l16, slot * 16384 + g * 1024, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, l16, slot * 16384 + g * 1024, OI_SCRATCH_NT));
   }
 };
 

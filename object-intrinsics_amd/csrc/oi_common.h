@@ -99,9 +99,13 @@ __device__ __forceinline__ float wave_scan_add(float v, int lane) {
 // hazard only when the store's soffset is NOT a register (an SI-era exemption in the hazard recogniser that
 // does not hold on this part), so the uniform offset is folded into voffset (one v_add) and soffset stays 0;
 // the compiler then inserts the required s_nop itself.  Loads keep the SGPR soffset (no such hazard).
+// Cache policy of the scratch streams (buffer intrinsic aux operand, bit 1 = nt): every scratch slot is written once
+// and read once or twice much later, so it is marked non-temporal -- measured -1.5 % on the forward kernel, -2.8 % on a
+// training iteration (the 25 GB backward scratch no longer churns L2 / MALL).
+#define OI_SCRATCH_NT 2
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void buffer_store_b128(u32x4_t v, __amdgpu_buffer_rsrc_t rs, int voff, int uoff) {
-  __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + uoff, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + uoff, 0, OI_SCRATCH_NT);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
