@@ -724,6 +724,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
 #pragma unroll
       for (int k = 0; k < 4; ++k) act[4 * g + k] = w[k];
     }
+    float run = 1.f;
     for (int l = NL_SDF - 1; l >= 1; --l) {
       const int i = 14 - l;  // image index of transposed layer l
 #pragma unroll
@@ -733,10 +734,10 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
         for (int k = 0; k < 4; ++k) act[4 * g + k] *= c[k];
         if ((g & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
-      float unscale = 1.f;
       if constexpr (PREC == OI_PREC_F16X3) {
         // adjoints have no a-priori range: bring this point's vector (its 128 entries live in lanes j and j+32)
-        // to max |.| in [2^13, 2^14) with an exact power-of-two scale, undone on the accumulators below
+        // to max |.| in [2^13, 2^14) with an exact power-of-two scale.  The scale is NOT undone layer by layer: `run`
+        // carries the product of the inverse scales (true vector = act * run) and multiplies the final gradient once.
         float m = 0.f;
 #pragma unroll
         for (int k = 0; k < 64; k += 2) m = fmaxf(m, fmaxf(fabsf(act[k]), fabsf(act[k + 1])));
@@ -747,7 +748,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
         // fence tied to sc (= to every c * g product): keeps the GEMM's A-fragment ds_reads from being scheduled
         // into the scratch-load phase while the 64 c registers are still live (140 spilled VGPRs otherwise)
         asm volatile("" : "+v"(sc) : : "memory");
-        unscale = __builtin_bit_cast(float, (eb - 13) << 23);          // 1 / sc
+        run *= __builtin_bit_cast(float, (eb - 13) << 23);             // 1 / sc
 #pragma unroll
         for (int k = 0; k < 64; ++k) act[k] *= sc;
       }
@@ -765,7 +766,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) act[16 * t + r] = PREC == OI_PREC_F16X3 ? acc[t][r] * unscale : acc[t][r];
+        for (int r = 0; r < 16; ++r) act[16 * t + r] = acc[t][r];
       ring_sync();
       PROF_T(8);
     }
@@ -787,6 +788,9 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
     gx += __shfl_xor(gx, 32, 64);
     gy += __shfl_xor(gy, 32, 64);
     gz += __shfl_xor(gz, 32, 64);
+    gx *= run;  // identical in both lanes of a point (the max was taken over the pair)
+    gy *= run;
+    gz *= run;
     if (valid && h == 0) {
       grad_out[pt * 3 + 0] = gx;
       grad_out[pt * 3 + 1] = gy;
