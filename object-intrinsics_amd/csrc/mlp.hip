@@ -387,8 +387,15 @@ __device__ __forceinline__ LayOff lay_off(const LaneOff& o, int slot, int layer)
   return r;
 }
 
-template <int PREC>
-__device__ __forceinline__ void gemm_layer2(const char* lds, const LayOff& y, const float (&act)[64], f32x16 (&acc)[4]) {
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// HOOK(s), s = 0..7, runs after the MFMAs that consumed act[8s .. 8s+7]: the reverse sweep uses it to issue the NEXT
+// layer's scratch loads into registers that have just died, one full GEMM ahead of their use.
+template <int PREC, class HOOK = NoHook>
+__device__ __forceinline__ void gemm_layer2(const char* lds, const LayOff& y, const float (&act)[64], f32x16 (&acc)[4],
+                                            HOOK hook = HOOK()) {
   if constexpr (PREC == OI_PREC_F32) {
     f32x4 a[4], an[4];
 #pragma unroll
@@ -405,6 +412,7 @@ __device__ __forceinline__ void gemm_layer2(const char* lds, const LayOff& y, co
         for (int t = 0; t < 4; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][k], act[4 * g + k], acc[t], 0, 0, 0);
       }
+      if (g & 1) hook(g >> 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 4; ++t) a[t] = an[t];
@@ -434,6 +442,7 @@ __device__ __forceinline__ void gemm_layer2(const char* lds, const LayOff& y, co
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bm, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc[t], 0, 0, 0);
       }
+      hook(s);
       __builtin_amdgcn_sched_barrier(0);
     }
   } else if constexpr (PREC == OI_PREC_F16X3) {
@@ -467,6 +476,7 @@ __device__ __forceinline__ void gemm_layer2(const char* lds, const LayOff& y, co
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, acc[t], 0, 0, 0);
       }
+      hook(s);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -507,6 +517,7 @@ __device__ __forceinline__ void gemm_layer2(const char* lds, const LayOff& y, co
         }
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc[t], 0, 0, 0);
       }
+      hook(s);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -725,14 +736,18 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       for (int k = 0; k < 4; ++k) act[4 * g + k] = w[k];
     }
     float run = 1.f;
+    // gamma * cos(phi) of the layer about to be swept: requested ONE GEMM AHEAD (inside the previous layer's MFMA loop,
+    // into registers the consumed B operand has just freed) so that the HBM latency hides under the MFMAs instead of
+    // stalling the top of every layer
+    f32x4 cn[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) cn[g] = ws.load(NL_SDF - 1, g, o);
     for (int l = NL_SDF - 1; l >= 1; --l) {
       const int i = 14 - l;  // image index of transposed layer l
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        const f32x4 c = ws.load(l, g, o);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) act[4 * g + k] *= c[k];
-        if ((g & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < 4; ++k) act[4 * g + k] *= cn[g][k];
       }
       if constexpr (PREC == OI_PREC_F16X3) {
         // adjoints have no a-priori range: bring this point's vector (its 128 entries live in lanes j and j+32)
@@ -759,7 +774,10 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       const LayOff y = lay_off<PREC>(o, RING2 ? (i & 1) : 0, l);
       zero_acc(acc);
       PROF_T(5);
-      gemm_layer2<PREC>(lds, y, act, acc);
+      gemm_layer2<PREC>(lds, y, act, acc, [&](int s) {
+        cn[2 * s] = ws.load(l - 1, 2 * s, o);
+        cn[2 * s + 1] = ws.load(l - 1, 2 * s + 1, o);
+      });
       PROF_T(6);
       if (next) stage_late(next);
       PROF_T(7);
@@ -774,7 +792,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
     float gx = 0.f, gy = 0.f, gz = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const f32x4 c = ws.load(0, g, o);
+      const f32x4 c = cn[g];  // slot 0, requested during the last transposed GEMM
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float v = act[4 * g + k] * c[k];
