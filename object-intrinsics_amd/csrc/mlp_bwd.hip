@@ -81,6 +81,12 @@ __device__ __forceinline__ void racc_flush_row(char* lds, int row, float* dst, i
   if (tid < C) atomicAdd(dst + tid * stride, racc[tid]);
 }
 
+// this wave's LDS-DMA has landed (and so have its outstanding scratch loads), then rendezvous
+__device__ __forceinline__ void dma_sync() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 template <int PREC, bool FAST>
 __global__ void __launch_bounds__(256, 2)
 mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ packed, const float* __restrict__ gamma,
@@ -156,9 +162,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   }
   for (int l = 1; l < NL_SDF; ++l) {
     __syncthreads();
-    stage_layer<PREC>(lds, mats + (size_t)(l - 1) * layer_bytes(PREC), tid);
+    stage_layer_dma<PREC>(lds, mats + (size_t)(l - 1) * layer_bytes(PREC), wave, lane);
     stage_film(lds, gamma, beta, hdr, e, l, tid);
-    __syncthreads();
+    dma_sync();
     if constexpr (SC) acc_zero(acc); else init_bias(lds, o, acc);
     const float fA = gemm_scaled<PREC, false>(lds, o, act, acc, SC ? hdr[H_WSCALE + l - 1] : 1.f);
 #pragma unroll
@@ -185,9 +191,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   // ================= colour head backward =================
   if (has_col) {
     __syncthreads();
-    stage_layer<PREC>(lds, mats + (size_t)14 * layer_bytes(PREC), tid);
+    stage_layer_dma<PREC>(lds, mats + (size_t)14 * layer_bytes(PREC), wave, lane);
     stage_film(lds, gamma, beta, hdr, e, 8, tid);
-    __syncthreads();
+    dma_sync();
     const float fx = grad_fwd[pt * 3 + 0], fy = grad_fwd[pt * 3 + 1], fz = grad_fwd[pt * 3 + 2];
     float rho[3];
 #pragma unroll
@@ -273,8 +279,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     __syncthreads();
     racc_zero(lds, tid);
     // abar_8 from the colour head: Wv[:, :128]^T uvbar   (transposed colour image, matrix 15)
-    stage_layer<PREC>(lds, mats + (size_t)15 * layer_bytes(PREC), tid);
-    __syncthreads();
+    stage_layer_dma<PREC>(lds, mats + (size_t)15 * layer_bytes(PREC), wave, lane);
+    dma_sync();
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       f32x4 uvb;
@@ -305,13 +311,18 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     for (int k = 0; k < 4; ++k) act[4 * g + k] = w[k];
   }
   for (int l = NL_SDF - 1; l >= 1; --l) {
+    // the layer's phi fragments are requested before the image is staged: their HBM latency overlaps the staging and
+    // the two barriers instead of being paid once per group of four features (the sweep is latency-, not math-bound)
+    f32x4 phv[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) phv[g] = ws.load(S_PHI + l, g, o.l16);
     __syncthreads();
-    stage_layer<PREC>(lds, mats + (size_t)(7 + l - 1) * layer_bytes(PREC), tid);
+    stage_layer_dma<PREC>(lds, mats + (size_t)(7 + l - 1) * layer_bytes(PREC), wave, lane);
     stage_film(lds, gamma, beta, hdr, e, l, tid);
-    __syncthreads();
+    dma_sync();
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const f32x4 ph = ws.load(S_PHI + l, g, o.l16);
+      const f32x4 ph = phv[g];
       const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
       f32x4 gsv, vv;
 #pragma unroll
@@ -376,9 +387,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   for (int l = 1; l < NL_SDF; ++l) {
     __syncthreads();
     if (l == 1) racc_zero(lds, tid);
-    stage_layer<PREC>(lds, mats + (size_t)(l - 1) * layer_bytes(PREC), tid);
+    stage_layer_dma<PREC>(lds, mats + (size_t)(l - 1) * layer_bytes(PREC), wave, lane);
     stage_film(lds, gamma, beta, hdr, e, l, tid);
-    __syncthreads();
+    dma_sync();
 #pragma unroll
     for (int g = 0; g < 16; ++g) {  // park gbar_l for the weight-gradient GEMM
       f32x4 v;
@@ -388,12 +399,18 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     }
     acc_zero(acc);
     const float fC = gemm_scaled<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + l - 1] : 1.f);  // vbar_l = W_l gbar_l
+    f32x4 phc[16], gnc[16];
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const f32x4 ph = ws.load(S_PHI + l, g, o.l16);
+      phc[g] = ws.load(S_PHI + l, g, o.l16);
+      if (l < NL_SDF - 1) gnc[g] = ws.load(S_G + l, g, o.l16);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const f32x4 ph = phc[g];
       const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
       f32x4 gn;
-      if (l < NL_SDF - 1) gn = ws.load(S_G + l, g, o.l16);
+      if (l < NL_SDF - 1) gn = gnc[g];
       else gn = lds_f4(lds, L_TABS + (H_SIG + grp_f0(g)) * 4, o.h16);
       f32x4 cb;
 #pragma unroll
@@ -444,15 +461,21 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   __syncthreads();
   racc_flush_row(lds, 3, d_small + DS_WSIG, 1, tid);
   for (int l = NL_SDF - 1; l >= 0; --l) {
+    f32x4 phd[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) phd[g] = ws.load(S_PHI + l, g, o.l16);
     __syncthreads();
     racc_zero(lds, tid);
-    if (l >= 1) stage_layer<PREC>(lds, mats + (size_t)(7 + l - 1) * layer_bytes(PREC), tid);
+    if (l >= 1) stage_layer_dma<PREC>(lds, mats + (size_t)(7 + l - 1) * layer_bytes(PREC), wave, lane);
     stage_film(lds, gamma, beta, hdr, e, l, tid);
-    __syncthreads();
+    f32x4 cbv[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) cbv[g] = ws.load(S_CB + l, g, o.l16);
+    dma_sync();
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const f32x4 ph = ws.load(S_PHI + l, g, o.l16);
-      const f32x4 cb = ws.load(S_CB + l, g, o.l16);
+      const f32x4 ph = phd[g];
+      const f32x4 cb = cbv[g];
       const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
       const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
       f32x4 r_g, r_b, ub;

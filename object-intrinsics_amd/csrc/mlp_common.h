@@ -67,6 +67,19 @@ __device__ __forceinline__ f32x4 wimg_f4(const char* lds, const LaneOff& o, int 
 // group g (0..15) of 4 consecutive features of this lane: first feature = 32*(g>>2) + 8*(g&3) + 4h
 __device__ __forceinline__ constexpr int grp_f0(int g) { return 32 * (g >> 2) + 8 * (g & 3); }
 
+// Same copy through the LDS-DMA path (global_load_lds: 16 B per lane straight into LDS, no VGPR round trip, no
+// ds_write): 4 wavefronts x N/4 instructions of 1 KiB.  The caller waits for vmcnt(0) before its barrier.
+template <int PREC>
+__device__ __forceinline__ void stage_layer_dma(char* lds, const char* __restrict__ src, int wave, int lane) {
+  constexpr int NCHUNK = layer_bytes(PREC) / 1024;
+#pragma unroll
+  for (int c0 = 0; c0 < NCHUNK / 4; ++c0) {
+    const int c = c0 * 4 + wave;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c * 1024 + lane * 16),
+                                     (__attribute__((address_space(3))) void*)(lds + L_WBUF + c * 1024), 16, 0, 0);
+  }
+}
+
 template <int PREC>
 __device__ __forceinline__ void stage_layer(char* lds, const char* __restrict__ src, int tid) {
   constexpr int N16 = layer_bytes(PREC) / 16;
