@@ -212,7 +212,7 @@ def main():
         maps = gen.render_maps(bs=1, render_out=ro_, rays_info=rays, prior_info=prior, return_raw=False)
         loss = maps["image"].sum() + 10.0 * eik + maps["shading_map"].sum() + 0.5 * maps["mask"].sum()
         params = dict(gen.named_parameters())
-        grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+        grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True, retain_graph=True)  # F9 reuses the graph
         f6 = dict(b2w=b2w[:1], z=z6, bg=bg6, jitter=jit6, rays_o=ro6, rays_d=rd6, loss=loss, eikonal=eik,
                   image=maps["image"], shading_map=maps["shading_map"], mask=maps["mask"], cos_anneal_ratio=0.4)
         f6.update(sd_arrays("p.", gen))
@@ -220,6 +220,55 @@ def main():
             if gr is not None:
                 f6["g." + k] = gr
         save("f6_grads", **f6)
+
+        # ---------------- F9: one scripted training iteration assembled from the reference's pieces ----------------
+        # (the Trainer class itself cannot be imported here: torchvision / omegaconf / tensorboard are absent).  Same
+        # call pattern and loss composition as gan_pose_trainer.py:103-145 (G step) and :154-200 (D steps) with the
+        # weights of configs/train.yaml:120-129; inputs are the F6 ones, augmentation probability 0 (identity).
+        from src.models.discriminator import ADADiscriminatorView, ADADiscriminator
+        from src.loss.position import PositionLoss, linear_increase
+        torch.manual_seed(9)
+        aug_cfg = {"__target__": "src.third_party.ada.augment.AugmentPipe", "kwargs": {"scale": 1, "xint": 1}}
+        D9 = ADADiscriminatorView(out_dim_position=6, out_dim_latent=0, aug=aug_cfg, aug_p=0.0, in_dim=3, out_dim=7,
+                                  n_feat=32, img_size=8, last_bias=False)
+        M9 = ADADiscriminator(aug=aug_cfg, aug_p=0.0, in_dim=1, out_dim=1, n_feat=32, img_size=8, last_bias=False)
+        gan9, pos9 = GANLoss("bce"), PositionLoss("mse")
+        it9 = 500
+        # G step
+        ld = gan9(D9(maps["image"], it=it9)[:, :1], 1)
+        lm = gan9(M9(maps["mask"], it=it9), 1)
+        lg = ld * 1.0 + lm * 0.1 + 10.0 * eik
+        gg = torch.autograd.grad(lg, list(params.values()), allow_unused=True, retain_graph=True)
+        f9 = dict(it=it9, g_loss_disc=ld, g_loss_mask=lm, g_loss=lg)
+        for (k, _), gr in zip(params.items(), gg):
+            if gr is not None:
+                f9["gg." + k] = gr
+        # D step (real + R1 + fake + auxiliary pose regression) and mask-D step
+        x_real = torch.rand(1, 3, 8, 8)
+        m_real = (torch.rand(1, 1, 8, 8) > 0.5).float()
+        c2b9 = torch.einsum("bij,jk->bik", torch.linalg.inv(b2w[:1]), gen.camera.c2w)
+        f9.update(in_x_real=x_real, in_m_real=m_real, c2b=c2b9)
+        f9.update(image=maps["image"], mask=maps["mask"], eikonal=eik)
+        for tag, net, xr, xf, aux in (("d", D9, x_real, maps["image"], True), ("m", M9, m_real, maps["mask"], False)):
+            xr = xr.clone().requires_grad_()
+            d_real = net(xr, it=it9)[:, :1]
+            l_real = gan9(d_real, 1)
+            l_reg = compute_grad2(d_real, xr)
+            xf = xf.detach().clone().requires_grad_()
+            d_fake = net(xf, it=it9)
+            l_aux = torch.zeros(())
+            if aux:
+                d_fake, d_aux = torch.split(d_fake, (1, 6), dim=1)
+                l_aux = pos9(d_aux, c2b9[..., :2, :3].flatten(-2, -1))
+            l_fake = gan9(d_fake, 0)
+            loss9 = l_real + l_fake + l_reg * 10.0 + l_aux * linear_increase(1000, 1)(it9)
+            gw9 = torch.autograd.grad(loss9, list(net.parameters()))
+            f9.update({f"{tag}_real": l_real, f"{tag}_fake": l_fake, f"{tag}_reg": l_reg, f"{tag}_aux": l_aux,
+                       f"{tag}_loss": loss9})
+            f9.update(sd_arrays(f"{tag}_w.", net))
+            for (k, _), gr in zip(net.named_parameters(), gw9):
+                f9[f"{tag}_g." + k] = gr
+        save("f9_train_step", **f9)
 
         # ---------------- F7: DC discriminator fwd, input-grad, R1 weight grads ----------------
         f7 = {}

@@ -221,6 +221,100 @@ def test_mlp_backward_vs_oracle(sdf_sd, col_sd, n, B, precision, tol):
     assert not bad, bad
 
 
+def _f6_render():
+    """The F6 forward (reference weights, rays, latent, background, jitter draw) through the HIP path:
+    returns the golden dict, image / shading / mask maps, the eikonal term and the named generator parameters."""
+    from oi_amd.fields import ShapeNetwork, ColorNetwork, SingleVarianceNetwork
+    from oi_amd.renderer import NeuSRenderer
+    from oi_amd.lighting import DirectionalLightWithSpecularFixInit
+    g = load_golden("f6_grads")
+    p = sub_sd(g, "p.")
+    sdf = ShapeNetwork(None, **NET_KW)
+    sdf.load_state_dict(sub_sd(p, "sdf_network."))
+    col = ColorNetwork(**NET_KW)
+    col.load_state_dict(sub_sd(p, "color_network."))
+    dev = SingleVarianceNetwork(0.3)
+    dev.load_state_dict(sub_sd(p, "deviation_network."))
+    light = DirectionalLightWithSpecularFixInit(direction=[0, 0, -1.0])
+    light.load_state_dict(sub_sd(p, "light."))
+    sdf, col, dev, light = sdf.cuda(), col.cuda(), dev.cuda(), light.cuda()
+    r = NeuSRenderer(None, sdf, dev, col, n_samples=8, n_importance=8, n_outside=0, up_sample_steps=1, perturb=1)
+    ro, rd = g["rays_o"].cuda(), g["rays_d"].cuda()
+    near, far = O.near_far_from_sphere(g["rays_o"], g["rays_d"])
+    real_rand = torch.rand
+    try:
+        torch.rand = lambda *a, **k: g["jitter"].cuda()   # the reference's jitter draw (renderer.py:372)
+        w = sdf.style(g["z"].cuda())
+        w2b = O.invert_rot_t(g["b2w"]).cuda()
+        s, c = r.render_full(ro, rd, near.cuda(), far.cuda(), perturb_overwrite=1, cos_anneal_ratio=float(g["cos_anneal_ratio"]),
+                             z=g["z"].cuda(), w=w, light=light.packed(), light_dir=light.batch_direction(w2b), bg=g["bg"].cuda())
+    finally:
+        torch.rand = real_rand
+    to_map = lambda x: x.reshape(1, 8, 8, -1).permute(0, 3, 1, 2)
+    named = [("sdf_network." + k, v) for k, v in sdf.named_parameters()] + [("color_network." + k, v) for k, v in col.named_parameters()] + \
+            [("deviation_network." + k, v) for k, v in dev.named_parameters()] + [("light." + k, v) for k, v in light.named_parameters()]
+    return g, to_map(c["image"]), to_map(c["shading"]).expand(1, 3, 8, 8), to_map(c["mask"]), c["reduce4"][0] / (c["reduce4"][1] + 1e-5), named
+
+
+def test_scripted_train_step_golden_f9():
+    """F9: one training iteration assembled from the reference's own pieces (gan_pose_trainer.py:103-200 call pattern,
+    configs/train.yaml loss weights): G-step loss + generator gradients through both discriminators, D / mask-D step
+    losses (real, fake, R1, auxiliary pose regression) + their weight gradients."""
+    from oi_amd.config import build_from_config
+    from oi_amd.losses import GANLoss, PositionLoss, compute_grad2, linear_increase
+    g6, image, _, mask, eik, named = _f6_render()
+    g = load_golden("f9_train_step")
+    it = int(g["it"])
+    aug = {"__target__": "src.third_party.ada.augment.AugmentPipe", "kwargs": {"scale": 1, "xint": 1}}
+    D = build_from_config({"__target__": "src.models.discriminator.ADADiscriminatorView", "kwargs": dict(
+        out_dim_position=6, out_dim_latent=0, aug=aug, aug_p=0.0, in_dim=3, out_dim=7, n_feat=32, img_size=8, last_bias=False)})
+    M = build_from_config({"__target__": "src.models.discriminator.ADADiscriminator", "kwargs": dict(
+        aug=aug, aug_p=0.0, in_dim=1, out_dim=1, n_feat=32, img_size=8, last_bias=False)})
+    D.load_state_dict(sub_sd(g, "d_w."))
+    M.load_state_dict(sub_sd(g, "m_w."))
+    D, M = D.cuda(), M.cuda()
+    gan, pos = GANLoss("bce"), PositionLoss("mse")
+    # ---- G step
+    ld = gan(D(image, it=it)[:, :1], 1)
+    lm = gan(M(mask, it=it), 1)
+    lg = ld * 1.0 + lm * 0.1 + 10.0 * eik
+    for name, a, b in (("disc", ld, g["g_loss_disc"]), ("mask", lm, g["g_loss_mask"]), ("total", lg, g["g_loss"])):
+        assert abs(float(a) - float(b)) < 1e-4 * max(1.0, abs(float(b))), (name, float(a), float(b))
+    grads = torch.autograd.grad(lg, [v for _, v in named], allow_unused=True, retain_graph=True)
+    checked, bad = 0, {}
+    for (name, _), gr in zip(named, grads):
+        key = "gg." + name
+        if key not in g:
+            assert gr is None or float(gr.abs().max()) == 0.0, name
+            continue
+        err = maxdiff(gr.cpu(), g[key]) / max(1e-3, float(g[key].abs().max()))
+        if err > 3e-3:
+            bad[name] = err
+        checked += 1
+    assert checked > 60 and not bad, bad
+    # ---- D step and mask-D step
+    for tag, net, xr, xf, aux in (("d", D, g["in_x_real"], image, True), ("m", M, g["in_m_real"], mask, False)):
+        xr = xr.cuda().clone().requires_grad_()
+        d_real = net(xr, it=it)[:, :1]
+        l_real = gan(d_real, 1)
+        l_reg = compute_grad2(d_real, xr)
+        xf = xf.detach().clone().requires_grad_()
+        d_fake = net(xf, it=it)
+        l_aux = torch.zeros((), device="cuda")
+        if aux:
+            d_fake, d_aux = torch.split(d_fake, (1, 6), dim=1)
+            l_aux = pos(d_aux, g["c2b"].cuda()[..., :2, :3].flatten(-2, -1))
+        l_fake = gan(d_fake, 0)
+        loss = l_real + l_fake + l_reg * 10.0 + l_aux * linear_increase(1000, 1)(it)
+        for nm, a in (("real", l_real), ("fake", l_fake), ("reg", l_reg), ("aux", l_aux), ("loss", loss)):
+            b = float(g[f"{tag}_{nm}"])
+            assert abs(float(a) - b) < 2e-4 * max(1.0, abs(b)), (tag, nm, float(a), b)
+        gw = torch.autograd.grad(loss, list(net.parameters()))
+        for (k, _), gr in zip(net.named_parameters(), gw):
+            ref = g[f"{tag}_g." + k]
+            assert maxdiff(gr.cpu(), ref) < 2e-3 * max(1e-3, float(ref.abs().max())), (tag, k, maxdiff(gr.cpu(), ref), float(ref.abs().max()))
+
+
 def test_generator_grads_golden_f6():
     """The reference's own parameter gradients for loss = sum(image) + 10*eikonal + sum(shading) + 0.5*sum(mask)
     (training mode: jitter on, cos_anneal 0.4) -- exercises MLP double-backward + compositing backward + light."""

@@ -177,3 +177,37 @@ def test_f8_upfirdn2d():
     assert maxdiff(gx, g["ufd_gx"]) < 1e-4
     y = O.upfirdn2d(g["ufd_x"], g["ufd_f2d"], up=(2, 1), down=(1, 3), pad=(1, 2, 0, 3), flip=False, gain=1.7)
     assert maxdiff(y, g["ufd_general"]) < 1e-5
+
+
+def test_f9_scripted_train_step_discriminator_side():
+    """F9 (one training iteration assembled from the reference's pieces): the oracle's discriminator / loss
+    restatements reproduce the G-step adversarial terms and both D-step losses and weight gradients."""
+    g = load_golden("f9_train_step")
+    it = int(g["it"])
+    w_aux = min(it / 1000, 1) * 1          # linear_increase(1000, 1), configs/train.yaml:128
+    nets = {t: {k: v.clone().requires_grad_(True) for k, v in sub_sd(g, t + "_w.").items() if not k.startswith("aug.")}
+            for t in ("d", "m")}
+    # G step: BCE(D(image)[:, :1], 1) + 0.1 BCE(maskD(mask), 1) + 10 eikonal  (gan_pose_trainer.py:110-133)
+    ld = O.bce_logits_const(O.dc_discriminator(nets["d"], g["image"])[:, :1], 1)
+    lm = O.bce_logits_const(O.dc_discriminator(nets["m"], g["mask"]), 1)
+    assert abs(float(ld) - float(g["g_loss_disc"])) < 1e-5 and abs(float(lm) - float(g["g_loss_mask"])) < 1e-5
+    assert abs(float(ld + 0.1 * lm + 10.0 * g["eikonal"]) - float(g["g_loss"])) < 1e-5
+    # D steps  (gan_pose_trainer.py:154-200)
+    for tag, x_real, x_fake, aux in (("d", g["in_x_real"], g["image"], True), ("m", g["in_m_real"], g["mask"], False)):
+        sd = nets[tag]
+        xr = x_real.clone().requires_grad_(True)
+        d_real = O.dc_discriminator(sd, xr)[:, :1]
+        l_real, l_reg = O.bce_logits_const(d_real, 1), O.r1_penalty(d_real, xr)
+        d_fake = O.dc_discriminator(sd, x_fake.clone())
+        l_aux = torch.zeros(())
+        if aux:
+            d_fake, d_aux = d_fake[:, :1], d_fake[:, 1:7]
+            l_aux = torch.nn.functional.mse_loss(d_aux, O.pose_to_vec(g["c2b"]))
+        l_fake = O.bce_logits_const(d_fake, 0)
+        loss = l_real + l_fake + 10.0 * l_reg + w_aux * l_aux
+        for nm, a in (("real", l_real), ("fake", l_fake), ("reg", l_reg), ("aux", l_aux), ("loss", loss)):
+            assert abs(float(a) - float(g[f"{tag}_{nm}"])) < 1e-5 * max(1.0, abs(float(g[f"{tag}_{nm}"]))), (tag, nm)
+        gw = torch.autograd.grad(loss, list(sd.values()))
+        for (k, _), gr in zip(sd.items(), gw):
+            ref = g[f"{tag}_g." + k]
+            assert maxdiff(gr, ref) < 1e-4 * max(1e-3, float(ref.abs().max())), (tag, k)
