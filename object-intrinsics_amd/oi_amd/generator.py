@@ -219,18 +219,23 @@ class Generator(nn.Module):
                 "z_map": to_map(c["z_map"]),
                 "z_min": s["mid_z_vals"].min(-1).values.reshape(bs, -1).min(-1).values,
             })
+        # logging scalars (generator.py:208-223).  Four per-ray means in two launches instead of four; the light colours
+        # are `expand(3)` of one scalar in the reference, so their means are that scalar: three launches instead of
+        # nine.  All stay device tensors (the reference calls .item() on the light terms: four host syncs per forward).
+        ray_stats = torch.cat([render_out["s_val"], render_out["cdf_fine"][:, :1], render_out["weight_max"],
+                               render_out["weight_sum"]], 1).mean(0)
+        amb = torch.sigmoid(self.light.param_ambient.detach())
         blob = {
             "loss": {"eikonal": render_out["gradient_error"]},
             "stats": {
                 "surface": render_out["surface_loss"],
-                "s_val": render_out["s_val"].mean(),
-                "cdf": render_out["cdf_fine"][:, :1].mean(),
-                "weight_max": render_out["weight_max"].mean(),
-                "weight_sum": render_out["weight_sum"].mean(),
-                # device scalars (the reference calls .item() here: 4 host syncs per forward, generator.py:220-223)
-                "light/ambient": self.light.ambient_color.mean().detach(),
-                "light/diffuse": self.light.diffuse_color.mean().detach(),
-                "light/specular": self.light.specular_color.mean().detach(),
+                "s_val": ray_stats[0],
+                "cdf": ray_stats[1],
+                "weight_max": ray_stats[2],
+                "weight_sum": ray_stats[3],
+                "light/ambient": amb,
+                "light/diffuse": 1 - amb,
+                "light/specular": self.light.param_specular.detach().clamp(min=0),
                 "material/shininess": self.light.shininess.detach(),
             },
             "render_out": new,
