@@ -59,6 +59,13 @@ class _ChunkTable:
         return self.table, self.n
 
 
+def _written(tensors):
+    """The kernels write through raw pointers, which autograd's version counters do not see.  Everything keyed on
+    `Tensor._version` -- the packed MFMA weight images of `fields.FieldPack`, the cached light / variance scalars,
+    autograd's saved-tensor checks -- must observe the update, so count it the way an in-place torch op would."""
+    torch.autograd.graph.increment_version(tensors)
+
+
 def _check(p):
     if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
         raise ValueError("fused optimisers need contiguous fp32 CUDA parameters")
@@ -101,6 +108,7 @@ class FusedAdam(torch.optim.Optimizer):
                                      1.0 - b1 ** step, math.sqrt(1.0 - b2 ** step), _stream())
                 if rc:
                     raise _l.OiHipError(L.oi_last_error().decode())
+                _written([t for q in quads for t in (q[0], q[2], q[3])])
         return loss
 
 
@@ -137,6 +145,7 @@ class FusedRMSprop(torch.optim.Optimizer):
                                     _stream())
             if rc:
                 raise _l.OiHipError(L.oi_last_error().decode())
+            _written([t for q in quads for t in (q[0], q[2])])
         return loss
 
 
@@ -158,3 +167,4 @@ def ema_update(ema_params, params, beta):
     rc = L.oi_multi_lerp(table.data_ptr(), n, float(beta), _stream())
     if rc:
         raise _l.OiHipError(L.oi_last_error().decode())
+    _written([q[0] for q in pairs])

@@ -288,6 +288,44 @@ def test_fused_optimizer_matches_torch(kind):
     oa.step()
 
 
+def test_fused_step_invalidates_packed_weight_images():
+    """The fused optimiser / EMA kernels write parameters through raw pointers; the MFMA weight images
+    (fields.FieldPack) are cached on Tensor._version, so the writes must be counted like in-place torch ops --
+    otherwise every render after the first optimiser step would still use the initial weights."""
+    from oi_amd.ema import EMA
+    from oi_amd.optim import FusedAdam
+    gen = build_generator(8, 8, 8, 1, "f16x3").eval()
+    data = {"z": torch.randn(1, 64, device="cuda"), "b2w": torch.eye(4, device="cuda")[None],
+            "bg_color": torch.zeros(1, 3, device="cuda")}
+    render = lambda g: g(bs=1, it=0, data=dict(data))["box"]["render_out"]["image"].clone()
+    with torch.no_grad():
+        before = render(gen)
+    ema = EMA(gen, 0.5)
+    with torch.no_grad():
+        assert maxdiff(render(ema.module), before) == 0.0
+    params = list(gen.parameters())
+    v0 = [p._version for p in params]
+    opt = FusedAdam(params, lr=1e-2, betas=(0.0, 0.9))
+    g = torch.Generator().manual_seed(3)
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=g).cuda()
+    opt.step()
+    assert all(p._version > v for p, v in zip(params, v0))
+    with torch.no_grad():
+        cached = render(gen)                  # through the version-keyed cache
+        gen.renderer.pack.invalidate()
+        fresh = render(gen)                   # images rebuilt from scratch
+    assert maxdiff(cached, fresh) == 0.0
+    assert maxdiff(cached, before) > 1e-3     # lr 1e-2 sign steps move every weight: the image must change
+    ema.update(0)
+    with torch.no_grad():
+        e_cached = render(ema.module)
+        ema.module.renderer.pack.invalidate()
+        e_fresh = render(ema.module)
+    assert maxdiff(e_cached, e_fresh) == 0.0
+    assert maxdiff(e_cached, before) > 1e-4
+
+
 def test_fused_ema_matches_reference_formula():
     from oi_amd.ema import EMA
     net = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Linear(53, 5000)).cuda()
