@@ -134,6 +134,16 @@ int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, con
  */
 int oi_gen_rays(const float* c2b, const float* kinv, const float* offs, int B, int R,
                 float* rays_o, float* rays_d, float* near, float* far, oi_stream_t stream);
+/* The same launch also writing the light direction of every box frame,
+ *   light_dir[b] = w2b[b][:3,:3] (light_direction / |light_direction|)
+ * i.e. DirectionalLightWithSpecularFixInit.direction + BatchDirectionalLight...direction
+ * (src/models/lighting.py:62-64, 115-119): three tiny launches of the reference's tensor code folded into
+ * the ray kernel.  Forward-only (the host mirror keeps the tensor path when the direction needs a gradient).
+ *   w2b [B][4][4], light_direction [3] (the raw parameter), light_dir [B][3].
+ */
+int oi_gen_rays_light(const float* c2b, const float* kinv, const float* offs, int B, int R,
+                      float* rays_o, float* rays_d, float* near, float* far, const float* w2b,
+                      const float* light_direction, float* light_dir, oi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a8: coarse samples.  z[r][i] = near + (far-near) i/(S-1) (+ (jitter[r]-0.5)*2/S if jitter),

@@ -36,11 +36,22 @@ __device__ __forceinline__ float linspace_at(float start, float end, int n, int 
 // ------------------------------------------------------------------------------------------
 __global__ void gen_rays_kernel(const float* __restrict__ c2b, const float* __restrict__ kinv,
                                 const float* __restrict__ offs, int B, int R, float* __restrict__ rays_o,
-                                float* __restrict__ rays_d, float* __restrict__ near_, float* __restrict__ far_) {
+                                float* __restrict__ rays_d, float* __restrict__ near_, float* __restrict__ far_,
+                                const float* __restrict__ w2b, const float* __restrict__ light,
+                                float* __restrict__ light_dir) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long n = (long long)B * R * R;
   if (idx >= n) return;
   const int x = idx % R, y = (idx / R) % R, b = idx / ((long long)R * R);
+  if (light_dir != nullptr && x == 0 && y == 0) {
+    // light direction in this box frame: w2b[:3,:3] (d / |d|)   (lighting.py:62-64, 115-119)
+    const float l0 = light[0], l1 = light[1], l2 = light[2];
+    const float ln = sqrtf(l0 * l0 + l1 * l1 + l2 * l2);
+    const float* Wb = w2b + b * 16;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      light_dir[b * 3 + i] = Wb[i * 4 + 0] * (l0 / ln) + Wb[i * 4 + 1] * (l1 / ln) + Wb[i * 4 + 2] * (l2 / ln);
+  }
   // build_rays: pixels = linspace(0,1,R) * recp_size + offset   (generator.py:325-329)
   const float px = linspace_at(0.f, 1.f, R, x) * (float)R + offs[b * 2 + 0];
   const float py = linspace_at(0.f, 1.f, R, y) * (float)R + offs[b * 2 + 1];
@@ -430,8 +441,20 @@ int oi_gen_rays(const float* c2b, const float* kinv, const float* offs, int B, i
   OI_REQUIRE(B > 0 && R > 0, "oi_gen_rays: B=%d R=%d", B, R);
   const long long n = (long long)B * R * R;
   hipLaunchKernelGGL(gen_rays_kernel, dim3(oi::cdiv(n, 256)), dim3(256), 0, oi::as_stream(stream), c2b, kinv, offs, B,
-                     R, rays_o, rays_d, near_, far_);
+                     R, rays_o, rays_d, near_, far_, nullptr, nullptr, nullptr);
   return oi::check_launch("oi_gen_rays");
+}
+
+int oi_gen_rays_light(const float* c2b, const float* kinv, const float* offs, int B, int R, float* rays_o,
+                      float* rays_d, float* near_, float* far_, const float* w2b, const float* light_direction,
+                      float* light_dir, oi_stream_t stream) {
+  OI_REQUIRE(c2b && kinv && offs && rays_o && rays_d && near_ && far_ && w2b && light_direction && light_dir,
+             "oi_gen_rays_light: null pointer");
+  OI_REQUIRE(B > 0 && R > 0, "oi_gen_rays_light: B=%d R=%d", B, R);
+  const long long n = (long long)B * R * R;
+  hipLaunchKernelGGL(gen_rays_kernel, dim3(oi::cdiv(n, 256)), dim3(256), 0, oi::as_stream(stream), c2b, kinv, offs, B,
+                     R, rays_o, rays_d, near_, far_, w2b, light_direction, light_dir);
+  return oi::check_launch("oi_gen_rays_light");
 }
 
 int oi_coarse_samples(const float* rays_o, const float* rays_d, const float* near_, const float* far_,

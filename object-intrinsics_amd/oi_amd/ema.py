@@ -31,6 +31,8 @@ class EMA:
         else:
             # p.lerp(p_ema, beta) = p + beta (p_ema - p)  ==  p_ema.lerp_(p, 1 - beta)
             torch._foreach_lerp_(pe, p, 1.0 - self.beta)
+        if hasattr(self.m, "sync_it"):  # Generator keeps its iteration counter on the host between observations
+            self.m.sync_it()
         for b_ema, b in zip(self.m_ema.buffers(), self.m.buffers()):
             b_ema.copy_(b)
 

@@ -43,7 +43,11 @@ class Generator(nn.Module):
         self.z_dim = z_dim
         self.anneal_end = anneal_end
         self.register_buffer("it", torch.tensor(-1, dtype=torch.long))
-        self._it_host = -1
+        # The reference stores the iteration in the buffer on every forward (generator.py:187: one fill launch per
+        # render).  Here the host copy is authoritative and the buffer is written when somebody can observe it:
+        # state_dict() (checkpoints, EMA buffer copies go through `sync_it`).
+        self._it_host, self._it_dirty, self._it_buf, self._it_ver = -1, False, self.it, self.it._version
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.sync_it())
         self.camera = build_from_config(camera)
         self.light = build_from_config(light_network)
         self.pose_prior = build_from_config(pose_prior)
@@ -52,6 +56,28 @@ class Generator(nn.Module):
         self.deviation_network = build_from_config(deviation_network)
         self.renderer = build_from_config(renderer, nerf=None, sdf_network=self.sdf_network,
                                           deviation_network=self.deviation_network, color_network=self.color_network)
+
+    def _it_external_write(self):
+        buf = self.it
+        if buf is not self._it_buf:  # .to() / .cuda() re-created the buffer (and it may have been written since)
+            self._it_buf = buf
+            if not self._it_dirty:
+                return True
+            self._it_ver = buf._version  # a value pending on the host wins
+        return buf._version != self._it_ver
+
+    def sync_it(self):
+        """Write the host-side iteration counter into the `it` buffer (no-op when it is current)."""
+        if self._it_dirty and not self._it_external_write():
+            self.it.fill_(self._it_host)
+            self._it_dirty, self._it_ver = False, self.it._version
+
+    def iteration(self):
+        """The current iteration: the host copy, unless the buffer was written from outside since (load_state_dict,
+        EMA buffer copies, `gen.it.fill_`: all bump its version counter) -- then one D2H read."""
+        if self._it_external_write():
+            self._it_host, self._it_dirty, self._it_ver = int(self.it), False, self.it._version
+        return self._it_host
 
     # -- host-side sampling (generator.py:65-78, 176-184; prior.py:11-29) -------------------------
     def _h2d(self, arr):
@@ -133,8 +159,9 @@ class Generator(nn.Module):
             return {"z": data["z"]}
         return {"z": torch.randn(bs, self.z_dim, device=self.it.device)}
 
-    def gen_rays_at(self, data, prior_info):
-        """generator.py:255-279 + build_rays :317-333 + near_far_from_sphere :336-342 (one kernel)."""
+    def gen_rays_at(self, data, prior_info, with_light=False):
+        """generator.py:255-279 + build_rays :317-333 + near_far_from_sphere :336-342 (one kernel).  `with_light`: the
+        same launch also evaluates prior_info["light"].direction() (lighting.py:115-119) -> "light_dir"."""
         b2w, R = prior_info["b2w"], self.resolution
         xy = getattr(self, "_xy_off", None)
         if xy is None:  # poses given on the device (eval / inference): the reference's tensor arithmetic
@@ -146,25 +173,33 @@ class Generator(nn.Module):
         kinv = getattr(self, "_kinv33", None)
         if kinv is None or kinv.device != b2w.device:
             kinv = self._kinv33 = self.camera.intrinsics_inv[:3, :3].contiguous()
-        ro, rd, near, far = ops.gen_rays(prior_info["c2b"], kinv, xy, R)
-        return {"rays_o": ro, "rays_d": rd, "x_offset": x_off, "y_offset": y_off, "near": near, "far": far}
+        out = {"x_offset": x_off, "y_offset": y_off}
+        if with_light:
+            ro, rd, near, far, out["light_dir"] = ops.gen_rays(prior_info["c2b"], kinv, xy, R, w2b=prior_info["w2b"],
+                                                               light_direction=self.light.param_direction)
+        else:
+            ro, rd, near, far = ops.gen_rays(prior_info["c2b"], kinv, xy, R)
+        out.update({"rays_o": ro, "rays_d": rd, "near": near, "far": far})
+        return out
 
     # -- forward --------------------------------------------------------------------------------
     def forward(self, bs, it, data, return_raw=False):
-        if it is None:
-            it = int(self.it)  # eval / inference callers only (one D2H read); training passes `it`
-        self._it_host = int(it)
-        self.it.fill_(int(it))
+        if it is None:  # eval / inference callers only (one D2H read after a checkpoint load); training passes `it`
+            it = self.iteration()
+        if int(it) != self.iteration():
+            self._it_host, self._it_dirty = int(it), True
         prior = self.sample_prior(bs, data)
         latent = self.sample_latent(bs, data)
-        rays = self.gen_rays_at(data, prior)
+        # the light direction needs the tensor path only when a gradient has to reach param_direction
+        grad_light = torch.is_grad_enabled() and self.light.param_direction.requires_grad
+        rays = self.gen_rays_at(data, prior, with_light=not grad_light)
         h = w = self.resolution
         n_rays = bs * h * w
         cos_anneal_ratio = min(1.0, self._it_host / self.anneal_end)
         # "bg_color": optional (bs, 3) device tensor -- an extension used by the HIP-graph wrapper (oi_amd.graphed), whose
         # inputs must live at fixed device addresses; the reference always draws it from numpy (generator.py:161)
         bg = data["bg_color"] if "bg_color" in data else self._h2d(self.bg_color(bs))
-        ldir = prior["light"].direction()
+        ldir = prior["light"].direction() if grad_light else rays["light_dir"]
         lpk = self.light.packed()
 
         ro_all, rd_all = rays["rays_o"].view(bs, h * w, 3), rays["rays_d"].view(bs, h * w, 3)
@@ -222,20 +257,19 @@ class Generator(nn.Module):
         # logging scalars (generator.py:208-223).  Four per-ray means in two launches instead of four; the light colours
         # are `expand(3)` of one scalar in the reference, so their means are that scalar: three launches instead of
         # nine.  All stay device tensors (the reference calls .item() on the light terms: four host syncs per forward).
-        ray_stats = torch.cat([render_out["s_val"], render_out["cdf_fine"][:, :1], render_out["weight_max"],
-                               render_out["weight_sum"]], 1).mean(0)
-        amb = torch.sigmoid(self.light.param_ambient.detach())
+        ray_stats = torch.cat([render_out["cdf_fine"][:, :1], render_out["weight_max"], render_out["weight_sum"]], 1).mean(0)
+        amb, diff, spec = self.light.stats()
         blob = {
             "loss": {"eikonal": render_out["gradient_error"]},
             "stats": {
                 "surface": render_out["surface_loss"],
-                "s_val": ray_stats[0],
-                "cdf": ray_stats[1],
-                "weight_max": ray_stats[2],
-                "weight_sum": ray_stats[3],
+                "s_val": render_out["s_val"].detach()[0, 0],  # the mean of N copies of one scalar
+                "cdf": ray_stats[0],
+                "weight_max": ray_stats[1],
+                "weight_sum": ray_stats[2],
                 "light/ambient": amb,
-                "light/diffuse": 1 - amb,
-                "light/specular": self.light.param_specular.detach().clamp(min=0),
+                "light/diffuse": diff,
+                "light/specular": spec,
                 "material/shininess": self.light.shininess.detach(),
             },
             "render_out": new,

@@ -59,7 +59,7 @@ def render_frames(gen, zs, b2ws, keys=("image", "mask", "normal_map", "shading_m
         if max_ray_batch is not None:
             G.MAX_RAY_BATCH_SIZE = max_ray_batch
         try:
-            gf = GraphedForward(gen, bs=1, it=int(gen.it), return_raw=True, keys=keys).recapture()
+            gf = GraphedForward(gen, bs=1, it=gen.iteration(), return_raw=True, keys=keys).recapture()
             dev = gen.it.device
             frames = {k: [] for k in keys}
             for z, b2w in zip(zs, b2ws):

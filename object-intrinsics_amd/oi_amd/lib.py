@@ -36,13 +36,6 @@ class CompositeGrads(ctypes.Structure):
                                    "d_sdf", "d_grad", "d_rgb", "d_variance", "d_light", "d_light_dir")]
 
 
-class CompositeGrads(ctypes.Structure):
-    """Mirror of `oi_composite_grads` (include/oi_hip.h)."""
-    _fields_ = [(n, _vp) for n in ("g_weights", "g_weight_sum", "g_color_fine", "g_image_no_bg", "g_image", "g_shading",
-                                   "g_normal", "g_mask", "g_z_map", "g_specular_map", "g_diffuse_map", "g_reduce4",
-                                   "d_sdf", "d_grad", "d_rgb", "d_variance", "d_light", "d_light_dir")]
-
-
 _SIGS = {
     "oi_version": (_i, []),
     "oi_arch": (ctypes.c_char_p, []),
@@ -58,6 +51,7 @@ _SIGS = {
     "oi_sdf_mlp_bwd": (_i, [_vp] * 14 + [_i, _ll, _i, _i, _vp]),
     "oi_composite_bwd": (_i, [ctypes.POINTER(CompositeParams), ctypes.POINTER(CompositeGrads), _vp]),
     "oi_gen_rays": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "oi_gen_rays_light": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "oi_coarse_samples": (_i, [_vp] * 5 + [_ll, _i, _vp, _vp, _vp]),
     "oi_upsample": (_i, [_vp] * 4 + [_ll, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "oi_merge_sorted": (_i, [_vp] * 4 + [_ll, _i, _i, _vp, _vp, _vp]),

@@ -40,7 +40,28 @@ class DirectionalLightWithSpecularFixInit(nn.Module):
 
     def packed(self):
         """[param_ambient, param_specular, param_shininess] as the kernel reads them."""
-        return torch.stack([self.param_ambient, self.param_specular, self.param_shininess])
+        if torch.is_grad_enabled():
+            return torch.stack([self.param_ambient, self.param_specular, self.param_shininess])
+        return self._cached("packed", lambda: torch.stack([self.param_ambient, self.param_specular, self.param_shininess]))
+
+    def stats(self):
+        """(ambient, diffuse, specular) scalars for logging -- detached; lighting.py:50-60 up to the expand(3)."""
+        def build():
+            amb = torch.sigmoid(self.param_ambient.detach())
+            return amb, 1 - amb, self.param_specular.detach().clamp(min=0)
+        return self._cached("stats", build)
+
+    def _cached(self, name, build):
+        """Forward-only scalar glue, rebuilt when a parameter changes (in-place updates bump Tensor._version; the
+        fused optimisers count their writes, oi_amd.optim._written): a handful of 5 us launches per render otherwise."""
+        ps = (self.param_ambient, self.param_specular, self.param_shininess)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        cache = self.__dict__.setdefault("_glue_cache", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = cache[name] = (key, build())
+        return hit[1]
 
     def batch_direction(self, w2b):
         """(B,3) light direction in each box frame (lighting.py:115-119)."""

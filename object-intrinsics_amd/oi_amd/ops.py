@@ -39,6 +39,34 @@ def _new(ref, *shape):
     return torch.empty(shape, dtype=torch.float32, device=ref.device)
 
 
+def _zeros_split(dev, *shapes):
+    """Several zero-initialised fp32 tensors from ONE fill launch (views of one flat buffer, each 16-byte aligned)."""
+    sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (n + 3) // 4 * 4
+    flat = torch.zeros(tot, dtype=torch.float32, device=dev)
+    return [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
+
+
+_ZERO_ROWS = {}
+
+
+def _zero_row4(dev):
+    """A fresh zeroed (4,) accumulator without a fill launch per call: rows of a block zeroed once per 256 calls.  Rows
+    are never handed out twice, so callers may keep them.  Under stream capture the fill has to be part of the graph
+    (a replay accumulates again), so a captured call allocates its own."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(4, dtype=torch.float32, device=dev)
+    st = _ZERO_ROWS.get(dev)
+    if st is None or st[1] >= st[0].shape[0]:
+        st = _ZERO_ROWS[dev] = [torch.zeros(256, 4, dtype=torch.float32, device=dev), 0]
+    row = st[0][st[1]]
+    st[1] += 1
+    return row
+
+
 # ------------------------------------------------------------------------------------------
 # MLP
 # ------------------------------------------------------------------------------------------
@@ -114,10 +142,8 @@ def sdf_mlp_bwd(pts, packed, gamma, beta, grad_fwd, rgb_fwd, g_sdf, g_grad, g_rg
     pts = _c(pts)
     n = pts.shape[0] // B
     dev = pts.device
-    d_small = torch.zeros(L.oi_mlp_bwd_small_floats(), dtype=torch.float32, device=dev)
-    d_wmat = torch.zeros(8, 128, 128, dtype=torch.float32, device=dev)
-    d_gamma = torch.zeros(B, 9, 128, dtype=torch.float32, device=dev)
-    d_beta = torch.zeros(B, 9, 128, dtype=torch.float32, device=dev)
+    d_small, d_wmat, d_gamma, d_beta = _zeros_split(dev, (L.oi_mlp_bwd_small_floats(),), (8, 128, 128), (B, 9, 128),
+                                                    (B, 9, 128))
     scratch = torch.empty(L.oi_mlp_bwd_scratch_bytes(B, n), dtype=torch.uint8, device=dev)
     args = [_c(t) for t in (grad_fwd, rgb_fwd, g_sdf, g_grad, g_rgb)]
     _l.check(L.oi_sdf_mlp_bwd(_p(pts), _p(packed), _p(_c(gamma)), _p(_c(beta)), *[_p(a) for a in args], _p(d_small),
@@ -130,14 +156,20 @@ def sdf_mlp_bwd(pts, packed, gamma, beta, grad_fwd, rgb_fwd, g_sdf, g_grad, g_rg
 # rays / sampling / compositing
 # ------------------------------------------------------------------------------------------
 
-def gen_rays(c2b, kinv3, offs, R):
+def gen_rays(c2b, kinv3, offs, R, w2b=None, light_direction=None):
+    """-> rays_o, rays_d, near, far [, light_dir (B, 3) when `w2b` and the raw `light_direction` parameter are given]"""
     L = _l.load()
     B = c2b.shape[0]
     ro, rd = _new(c2b, B, R, R, 3), _new(c2b, B, R, R, 3)
     near, far = _new(c2b, B * R * R, 1), _new(c2b, B * R * R, 1)
-    _l.check(L.oi_gen_rays(_p(_c(c2b)), _p(_c(kinv3)), _p(_c(offs)), B, R, _p(ro), _p(rd), _p(near), _p(far),
-                           _stream()), "oi_gen_rays")
-    return ro, rd, near, far
+    if w2b is None:
+        _l.check(L.oi_gen_rays(_p(_c(c2b)), _p(_c(kinv3)), _p(_c(offs)), B, R, _p(ro), _p(rd), _p(near), _p(far),
+                               _stream()), "oi_gen_rays")
+        return ro, rd, near, far
+    ldir = _new(c2b, B, 3)
+    _l.check(L.oi_gen_rays_light(_p(_c(c2b)), _p(_c(kinv3)), _p(_c(offs)), B, R, _p(ro), _p(rd), _p(near), _p(far),
+                                 _p(_c(w2b)), _p(_c(light_direction.detach())), _p(ldir), _stream()), "oi_gen_rays_light")
+    return ro, rd, near, far, ldir
 
 
 def coarse_samples(rays_o, rays_d, near, far, S, jitter=None):
@@ -209,7 +241,7 @@ def composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, v
             out[name] = _new(dists, N, c)
         setattr(P, name, _p(out.get(name)))
     if "reduce4" in want:
-        out["reduce4"] = torch.zeros(4, dtype=torch.float32, device=dists.device)
+        out["reduce4"] = _zero_row4(dists.device)
     P.reduce4 = _p(out.get("reduce4"))
     _l.check(L.oi_composite_fwd(ctypes.byref(P), _stream()), "oi_composite_fwd")
     return out
@@ -242,9 +274,7 @@ def composite_bwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, v
         setattr(G, "g_" + name, _p(t))
     dev = dists.device
     d_sdf, d_grad, d_rgb = _new(dists, N, T), _new(dists, N, T, 3), _new(dists, N, T, 3)
-    d_var = torch.zeros(1, dtype=torch.float32, device=dev)
-    d_light = torch.zeros(3, dtype=torch.float32, device=dev)
-    d_ldir = torch.zeros(B, 3, dtype=torch.float32, device=dev)
+    d_var, d_light, d_ldir = _zeros_split(dev, (1,), (3,), (B, 3))
     G.d_sdf, G.d_grad, G.d_rgb = _p(d_sdf), _p(d_grad), _p(d_rgb)
     G.d_variance, G.d_light, G.d_light_dir = _p(d_var), _p(d_light), _p(d_ldir)
     _l.check(L.oi_composite_bwd(ctypes.byref(P), ctypes.byref(G), _stream()), "oi_composite_bwd")

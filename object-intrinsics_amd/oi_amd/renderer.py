@@ -94,16 +94,34 @@ class NeuSRenderer:
         return assemble_render_dict(s, c, self.deviation_network.variance, background_rgb)
 
 
+_INV_S_CACHE = {}
+
+
+def _inv_s(variance):
+    """-> (inv_s, 1 / inv_s), inv_s = exp(10 variance).clamp(1e-6, 1e6) (renderer.py:404): four launches, cached per parameter version when no
+    gradient is being recorded (the compositing kernel computes its own copy from `variance`)."""
+    if torch.is_grad_enabled() and variance.requires_grad:
+        inv = torch.exp(variance * 10.0).clamp(1e-6, 1e6)
+        return inv, 1.0 / inv
+    key = (variance.data_ptr(), variance._version)
+    hit = _INV_S_CACHE.get(variance.device)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            inv = torch.exp(variance * 10.0).clamp(1e-6, 1e6)
+            hit = _INV_S_CACHE[variance.device] = (key, inv, 1.0 / inv)
+    return hit[1], hit[2]
+
+
 def assemble_render_dict(s, c, variance, background_rgb=None):
     """Same keys/shapes as NeuSRenderer.render's return value (renderer.py:448-473)."""
     N, T = s["sdf"].shape
     r4 = c["reduce4"]
-    inv_s = torch.exp(variance * 10.0).clamp(1e-6, 1e6)
+    _, s_val = _inv_s(variance)
     color = c["color_fine"]
     if background_rgb is not None:
         color = color + background_rgb * (1.0 - c["weight_sum"])
     return {
-        "s_val": (1.0 / inv_s).expand(N, 1),
+        "s_val": s_val.expand(N, 1),
         "cdf_fine": c["cdf"],
         "weight_sum": c["weight_sum"],
         "weight_max": c["weight_max"],

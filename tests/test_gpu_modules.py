@@ -326,6 +326,40 @@ def test_fused_step_invalidates_packed_weight_images():
     assert maxdiff(e_cached, before) > 1e-4
 
 
+def test_forward_glue_fast_paths_match_tensor_paths():
+    """The no-grad forward folds scalar glue into existing launches / version-keyed caches: light direction from the
+    ray kernel, cached light + variance scalars, host-side iteration counter.  Each must equal the tensor path."""
+    gen = build_generator(8, 8, 8, 1, "f16x3").eval()
+    with torch.no_grad():
+        gen.light.param_direction.copy_(torch.tensor([0.3, -0.8, 0.5]))
+    prior = gen.sample_prior(3, {})
+    rays = gen.gen_rays_at({}, prior, with_light=True)
+    assert maxdiff(rays["light_dir"], prior["light"].direction()) < 1e-6
+    ref = gen.gen_rays_at({}, prior)
+    for k in ("rays_o", "rays_d", "near", "far"):
+        assert maxdiff(rays[k], ref[k]) == 0.0
+    # iteration counter: host-side between observations, the buffer is right whenever it can be observed
+    with torch.no_grad():
+        blob = gen(bs=1, it=7, data={})["box"]
+    assert int(gen.state_dict()["it"]) == 7 and gen.iteration() == 7
+    gen.it.fill_(3)                      # external write (what load_state_dict / EMA buffer copies do)
+    assert gen.iteration() == 3
+    # cached scalars follow parameter updates
+    for rep in range(2):
+        with torch.no_grad():
+            blob = gen(bs=1, it=None, data={})["box"]
+        v = gen.deviation_network.variance.detach()
+        amb = torch.sigmoid(gen.light.param_ambient.detach())
+        assert abs(float(blob["stats"]["s_val"]) - float(1.0 / torch.exp(10 * v).clamp(1e-6, 1e6))) < 1e-7
+        assert abs(float(blob["stats"]["light/ambient"]) - float(amb)) < 1e-7
+        assert abs(float(blob["stats"]["light/diffuse"]) - float(1 - amb)) < 1e-7
+        assert abs(float(blob["stats"]["light/specular"]) - max(0.0, float(gen.light.param_specular))) < 1e-7
+        with torch.no_grad():
+            gen.deviation_network.variance.add_(0.05)
+            gen.light.param_ambient.add_(0.3)
+            gen.light.param_specular.add_(0.2)
+
+
 def test_fused_ema_matches_reference_formula():
     from oi_amd.ema import EMA
     net = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Linear(53, 5000)).cuda()
