@@ -222,9 +222,20 @@ typedef struct oi_composite_params {
   /* global reductions, accumulated with atomics; caller zeroes them: [0]=sum m*(|g|-1)^2,
    * [1]=sum m, [2]=sum exp(-100|sdf|), [3]=min mid_z is NOT here (see z_min) */
   float* reduce4;
+  /* sums over rays, accumulated with atomics; caller zeroes them: [0]=sum cdf[r][0], [1]=sum weight_max,
+   * [2]=sum weight_sum (the logging means of generator.py:208-213 before the division) */
+  float* ray_sums;
 } oi_composite_params;
 
 int oi_composite_fwd(const oi_composite_params* p, oi_stream_t stream);
+
+/* Scalars the reference derives from a render with ~8 tiny tensor launches, in one:
+ *   out[0] = gradient_error = reduce4[0] / (reduce4[1] + 1e-5)          (renderer.py:306-311)
+ *   out[1] = surface_loss   = reduce4[2] / (N*T)                         (renderer.py:459-461)
+ *   out[2..4] = mean over rays of cdf[:,0], weight_max, weight_sum       (generator.py:208-213)
+ * Forward-only: the host mirror uses it when no gradient is recorded. */
+int oi_render_stats(const float* reduce4, const float* ray_sums, long long N, int T, float* out,
+                    oi_stream_t stream);
 
 /* Backward of oi_composite_fwd (what autograd derives for renderer.py:266-311 + generator.py:107-172 in the
  * reference).  `fwd` repeats the forward inputs (outputs ignored).  Upstream gradients (any may be NULL):

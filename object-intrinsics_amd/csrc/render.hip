@@ -297,7 +297,7 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z, float e
 
 __global__ void __launch_bounds__(256)
 composite_fwd_kernel(const oi_composite_params p) {
-  __shared__ float red[RAYS_PER_BLOCK][3];
+  __shared__ float red[RAYS_PER_BLOCK][6];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long long r = (long long)blockIdx.x * RAYS_PER_BLOCK + wave;
   const bool live = r < p.N;
@@ -317,7 +317,7 @@ composite_fwd_kernel(const oi_composite_params p) {
   float carry = 1.0f;
   float a_wsum = 0.f, a_wmax = 0.f, a_c0 = 0.f, a_c1 = 0.f, a_c2 = 0.f, a_i0 = 0.f, a_i1 = 0.f, a_i2 = 0.f;
   float a_sh = 0.f, a_n0 = 0.f, a_n1 = 0.f, a_n2 = 0.f, a_z = 0.f, a_sp = 0.f, a_df = 0.f;
-  float a_eik = 0.f, a_m = 0.f, a_surf = 0.f;
+  float a_eik = 0.f, a_m = 0.f, a_surf = 0.f, cdf_first = 0.f;
 
   for (int c0 = 0; c0 < T; c0 += 64) {
     const int i = c0 + lane;
@@ -359,6 +359,7 @@ composite_fwd_kernel(const oi_composite_params p) {
     const float spec = l_spec * powf(al, l_shin);
     const float shade = l_amb + diff;
 
+    if (c0 == 0) cdf_first = __shfl(prev_cdf, 0, 64);
     if (on && live) {
       if (p.weights) p.weights[k] = w;
       if (p.cdf) p.cdf[k] = prev_cdf;
@@ -428,6 +429,32 @@ composite_fwd_kernel(const oi_composite_params p) {
       for (int w = 0; w < RAYS_PER_BLOCK; ++w) v += red[w][threadIdx.x];
       atomicAdd(p.reduce4 + threadIdx.x, v);
     }
+  }
+  if (p.ray_sums != nullptr) {  // sums over rays behind the logging means of generator.py:208-213
+    if (lane == 0) {
+      red[wave][3] = live ? cdf_first : 0.f;
+      red[wave][4] = live ? a_wmax : 0.f;
+      red[wave][5] = live ? a_wsum : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      float v = 0.f;
+      for (int w = 0; w < RAYS_PER_BLOCK; ++w) v += red[w][3 + threadIdx.x];
+      atomicAdd(p.ray_sums + threadIdx.x, v);
+    }
+  }
+}
+
+// gradient_error, surface_loss (renderer.py:306-311, 459-461) and the per-ray logging means (generator.py:208-213)
+// from the reductions of composite_fwd_kernel: one launch for five scalar results.
+__global__ void render_stats_kernel(const float* __restrict__ reduce4, const float* __restrict__ ray_sums, float n_rays,
+                                    float n_samples, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    out[0] = reduce4[0] / (reduce4[1] + 1e-5f);
+    out[1] = reduce4[2] / n_samples;
+    out[2] = ray_sums[0] / n_rays;
+    out[3] = ray_sums[1] / n_rays;
+    out[4] = ray_sums[2] / n_rays;
   }
 }
 
@@ -507,6 +534,14 @@ int oi_composite_fwd(const oi_composite_params* p, oi_stream_t stream) {
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(oi::cdiv(p->N, RAYS_PER_BLOCK)), dim3(256), 0, oi::as_stream(stream),
                      *p);
   return oi::check_launch("oi_composite_fwd");
+}
+
+int oi_render_stats(const float* reduce4, const float* ray_sums, long long N, int T, float* out, oi_stream_t stream) {
+  OI_REQUIRE(reduce4 && ray_sums && out, "oi_render_stats: null pointer");
+  OI_REQUIRE(N > 0 && T > 0, "oi_render_stats: N=%lld T=%d", N, T);
+  hipLaunchKernelGGL(render_stats_kernel, dim3(1), dim3(64), 0, oi::as_stream(stream), reduce4, ray_sums, (float)N,
+                     (float)N * (float)T, out);
+  return oi::check_launch("oi_render_stats");
 }
 
 }  // extern "C"

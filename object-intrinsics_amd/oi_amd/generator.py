@@ -124,12 +124,16 @@ class Generator(nn.Module):
             w2b_h[:, 3, 3] = 1.0
             c2b_h = w2b_h @ cam["c2w"]
             xy_h = self._crop_offsets_host(b2w_h, cam)
-            flat = self._h2d(np.concatenate([b2w_h.ravel(), w2b_h.ravel(), c2b_h.ravel(), xy_h.ravel()]))
+            # the background colour is the next numpy draw of the forward (generator.py:161): same order, same upload
+            bg_h = None if "bg_color" in data else np.asarray(self.bg_color(bs), dtype=np.float32)
+            parts = [b2w_h.ravel(), w2b_h.ravel(), c2b_h.ravel(), xy_h.ravel()] + ([] if bg_h is None else [bg_h.ravel()])
+            flat = self._h2d(np.concatenate(parts))
             n = bs * 16
             b2w, w2b, c2b = flat[:n].view(bs, 4, 4), flat[n:2 * n].view(bs, 4, 4), flat[2 * n:3 * n].view(bs, 4, 4)
-            self._xy_off = flat[3 * n:].view(bs, 2)
+            self._xy_off = flat[3 * n:3 * n + 2 * bs].view(bs, 2)
+            self._bg_dev = None if bg_h is None else flat[3 * n + 2 * bs:].view(bs, 3)
             return {"c2b": c2b, "b2w": b2w, "w2b": w2b, "light": self.light.batch_transform(w2b=w2b)}
-        self._xy_off = None
+        self._xy_off = self._bg_dev = None
         w2b = invert_rot_t(b2w)
         c2b = torch.einsum("bij,jk->bik", w2b, self.camera.c2w)
         return {"c2b": c2b, "b2w": b2w, "w2b": w2b, "light": self.light.batch_transform(w2b=w2b)}
@@ -198,7 +202,12 @@ class Generator(nn.Module):
         cos_anneal_ratio = min(1.0, self._it_host / self.anneal_end)
         # "bg_color": optional (bs, 3) device tensor -- an extension used by the HIP-graph wrapper (oi_amd.graphed), whose
         # inputs must live at fixed device addresses; the reference always draws it from numpy (generator.py:161)
-        bg = data["bg_color"] if "bg_color" in data else self._h2d(self.bg_color(bs))
+        if "bg_color" in data:
+            bg = data["bg_color"]
+        else:
+            bg = getattr(self, "_bg_dev", None)
+            if bg is None:
+                bg = self._h2d(self.bg_color(bs))
         ldir = prior["light"].direction() if grad_light else rays["light_dir"]
         lpk = self.light.packed()
 
@@ -218,7 +227,7 @@ class Generator(nn.Module):
             s, c = self.renderer.render_full(flat(ro_all), flat(rd_all), flat(near_all), flat(far_all),
                                              perturb_overwrite=-1 if self.training else 0,
                                              cos_anneal_ratio=cos_anneal_ratio, z=latent["z"], w=latent["w"],
-                                             light=lpk, light_dir=ldir, bg=bg, film=film)
+                                             light=lpk, light_dir=ldir, bg=bg, film=film, ray_sums=n_chunks == 1)
             outs.append((s, c))
         if n_chunks == 1:
             s, c = outs[0]
@@ -227,7 +236,9 @@ class Generator(nn.Module):
             s = {k: cat(k, 0) for k in outs[0][0]}
             c = {k: cat(k, 1) for k in outs[0][1] if k != "reduce4"}
             c["reduce4"] = sum(o[1]["reduce4"] for o in outs)
-        render_out = assemble_render_dict(s, c, self.deviation_network.variance)
+        # no gradient recorded: gradient_error, surface_loss and the three per-ray logging means in ONE launch
+        finals = ops.render_stats(c["reduce4"], c["ray_sums"], s["sdf"].shape[0], s["sdf"].shape[1]) if "ray_sums" in c else None
+        render_out = assemble_render_dict(s, c, self.deviation_network.variance, finals=finals)
         if n_chunks > 1:
             render_out["gradient_error"] = None
             render_out["surface_loss"] = None
@@ -257,7 +268,10 @@ class Generator(nn.Module):
         # logging scalars (generator.py:208-223).  Four per-ray means in two launches instead of four; the light colours
         # are `expand(3)` of one scalar in the reference, so their means are that scalar: three launches instead of
         # nine.  All stay device tensors (the reference calls .item() on the light terms: four host syncs per forward).
-        ray_stats = torch.cat([render_out["cdf_fine"][:, :1], render_out["weight_max"], render_out["weight_sum"]], 1).mean(0)
+        if finals is not None:
+            ray_stats = finals[2:5]
+        else:
+            ray_stats = torch.cat([render_out["cdf_fine"][:, :1], render_out["weight_max"], render_out["weight_sum"]], 1).mean(0)
         amb, diff, spec = self.light.stats()
         blob = {
             "loss": {"eikonal": render_out["gradient_error"]},

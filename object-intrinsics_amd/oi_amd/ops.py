@@ -213,6 +213,7 @@ def midpoints(rays_o, rays_d, z, last_dist):
 PER_SAMPLE_OUT = ("weights", "cdf", "alpha", "inside_sphere", "pts_norm")
 PER_RAY_OUT = {"weight_sum": 1, "weight_max": 1, "color_fine": 3, "image_no_bg": 3, "image": 3, "shading": 1,
                "normal": 3, "mask": 1, "z_map": 1, "specular_map": 1, "diffuse_map": 1}
+ALL_COMPOSITE_OUT = tuple(PER_SAMPLE_OUT) + tuple(PER_RAY_OUT) + ("reduce4",)
 
 
 def composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light, cos_anneal_ratio,
@@ -243,7 +244,17 @@ def composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, v
     if "reduce4" in want:
         out["reduce4"] = _zero_row4(dists.device)
     P.reduce4 = _p(out.get("reduce4"))
+    if "ray_sums" in want:  # forward-only extra (not in the default set): sums behind the logging means
+        out["ray_sums"] = _zero_row4(dists.device)
+    P.ray_sums = _p(out.get("ray_sums"))
     _l.check(L.oi_composite_fwd(ctypes.byref(P), _stream()), "oi_composite_fwd")
+    return out
+
+
+def render_stats(reduce4, ray_sums, N, T):
+    """-> (5,) [gradient_error, surface_loss, mean cdf[:,0], mean weight_max, mean weight_sum] in one launch."""
+    out = _new(reduce4, 5)
+    _l.check(_l.load().oi_render_stats(_p(reduce4), _p(ray_sums), N, T, _p(out), _stream()), "oi_render_stats")
     return out
 
 

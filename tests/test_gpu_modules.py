@@ -344,6 +344,17 @@ def test_forward_glue_fast_paths_match_tensor_paths():
     assert int(gen.state_dict()["it"]) == 7 and gen.iteration() == 7
     gen.it.fill_(3)                      # external write (what load_state_dict / EMA buffer copies do)
     assert gen.iteration() == 3
+    # one-launch render statistics (oi_render_stats) vs the reference's tensor expressions on the raw outputs
+    with torch.no_grad():
+        blob = gen(bs=2, it=None, data={}, return_raw=True)["box"]
+    raw = blob["raw_render_out"]
+    for k, ref in (("cdf", raw["cdf_fine"][:, :1].mean()), ("weight_max", raw["weight_max"].mean()),
+                   ("weight_sum", raw["weight_sum"].mean())):
+        assert abs(float(blob["stats"][k]) - float(ref)) < 1e-6, k
+    inside = (raw["pts_norm"] < 1.2).float()
+    eik = (inside * (torch.linalg.norm(raw["gradients"], dim=-1) - 1.0) ** 2).sum() / (inside.sum() + 1e-5)
+    assert abs(float(blob["loss"]["eikonal"]) - float(eik)) < 1e-5 * max(1.0, float(eik))
+    assert abs(float(blob["stats"]["surface"]) - float(torch.exp(-100.0 * raw["sdf"].abs()).mean())) < 1e-6
     # cached scalars follow parameter updates
     for rep in range(2):
         with torch.no_grad():
