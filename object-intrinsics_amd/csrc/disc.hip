@@ -21,6 +21,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // fragments use the same (half, tap) -> k map, so any K order is valid).
 // Small-M layers (late blocks at batch 1-4) are weight-bandwidth bound: K is split across
 // wavefronts (grid) and partial tiles are combined with fp32 atomics, activation in a second pass.
+// (Measured alternatives for the combine, both slower on this multi-XCD part: a grid-level "last arriver" --
+// device-scope release/acquire between workgroups costs an L2 write-back + invalidate per workgroup, 2-4x the extra
+// launches; and splits as the waves of ONE workgroup with an LDS reduction -- a tile's whole K then streams through
+// a single CU, 16 busy CUs instead of 256.)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 conv4x4_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -52,27 +56,32 @@ conv4x4_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
   const int krows = Cin * 4;  // kernel rows (cin, ky)
   const int r_begin = ks * rows_per_split;
   const int r_end = min(krows, r_begin + rows_per_split);
-  for (int r0 = r_begin; r0 < r_end; r0 += 2) {
-    const int r = r0 + h;  // this lane-half's kernel row
-    const bool r_ok = r < r_end;
-    const int cin = r >> 2, ky = r & 3;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-    if (r_ok && n_ok) {
-      const float4 wv = *reinterpret_cast<const float4*>(wrow + r * 4);
-      a0 = wv.x; a1 = wv.y; a2 = wv.z; a3 = wv.w;
+  // four kernel-row pairs per trip: all 8 loads of a trip are issued before its 16 MFMAs (the loop is latency-bound)
+  for (int r0 = r_begin; r0 < r_end; r0 += 8) {
+    float a[4][4], bv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + 2 * u + h;  // this lane-half's kernel row
+      const bool r_ok = r < r_end;
+      const int cin = r >> 2, ky = r & 3;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[u][k] = bv[u][k] = 0.f;
+      if (r_ok && n_ok) {
+        const float4 wv = *reinterpret_cast<const float4*>(wrow + r * 4);
+        a[u][0] = wv.x; a[u][1] = wv.y; a[u][2] = wv.z; a[u][3] = wv.w;
+      }
+      const int iy = iy0 + ky;
+      if (r_ok && m_ok && iy >= 0 && iy < H) {
+        const float* xr = xb + ((size_t)cin * H + iy) * W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (ix0 + k >= 0 && ix0 + k < W) bv[u][k] = xr[ix0 + k];
+      }
     }
-    const int iy = iy0 + ky;
-    if (r_ok && m_ok && iy >= 0 && iy < H) {
-      const float* xr = xb + ((size_t)cin * H + iy) * W;
-      if (ix0 + 0 >= 0 && ix0 + 0 < W) b0 = xr[ix0 + 0];
-      if (ix0 + 1 >= 0 && ix0 + 1 < W) b1 = xr[ix0 + 1];
-      if (ix0 + 2 >= 0 && ix0 + 2 < W) b2 = xr[ix0 + 2];
-      if (ix0 + 3 >= 0 && ix0 + 3 < W) b3 = xr[ix0 + 3];
-    }
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][k], bv[u][k], acc, 0, 0, 0);
   }
   // D layout: column = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * h (channel)
   if (!m_ok) return;
