@@ -231,16 +231,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   float* hdr = reinterpret_cast<float*>(packed);
   __shared__ float red[256];
-  if (blockIdx.y == NMAT) {  // header
-    if (blockIdx.x == H_WSCALE / 256) {  // the block that owns the image scales (block-uniform branch)
-      for (int m = 0; m < NMAT; ++m) {
-        float inv;
-        image_scale<PREC>(wh, wv, m, red, &inv);
-        if (idx == H_WSCALE + m) hdr[idx] = inv;
-      }
-      if (idx >= H_WSCALE && idx < H_WSCALE + NMAT) return;
-    }
-    if (idx >= H_FLOATS) return;
+  if (blockIdx.y == NMAT) {  // header (the image scales at H_WSCALE are written by block 0 of every matrix)
+    if (idx >= H_FLOATS || (idx >= H_WSCALE && idx < H_WSCALE + NMAT)) return;
     float v = 0.f;
     if (idx < H_SIG) {
       int f = idx >> 2, j = idx & 3;
@@ -262,8 +254,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
     return;
   }
   const int m = blockIdx.y;
-  float inv_unused;
-  const float wscale = image_scale<PREC>(wh, wv, m, red, &inv_unused);
+  float inv;
+  const float wscale = image_scale<PREC>(wh, wv, m, red, &inv);
+  if (idx == 0) hdr[H_WSCALE + m] = inv;  // 2^-k_m for the kernels (1 in the unscaled modes)
   if (idx >= C * C) return;
   char* base = packed + H_BYTES + (size_t)m * layer_bytes(PREC);
   if (PREC == OI_PREC_F32) {
