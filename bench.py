@@ -161,8 +161,42 @@ def bench_training(args, gen, disc, device, world, barrier, distributed):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt)
     it_s = args.train_steps / dt
+
+    # the training render alone (forward + backward incl. the double-backward through the
+    # normals: image, mask and eikonal terms all carry gradient) and one discriminator training step alone
+    def timed(fn, n):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
+
+    g_raw = gen
+    from oi_amd.trainer import toggle_grad
+
+    def render_fwd_bwd():
+        toggle_grad(g_raw, True)
+        for p_ in g_raw.parameters():
+            p_.grad = None
+        blob = g_raw(bs=B, it=tr.it, data={})["box"]
+        ro = blob["render_out"]
+        (ro["image"].square().mean() + ro["mask"].mean() + 10.0 * blob["loss"]["eikonal"]).backward()
+
+    n_sub = max(3, min(10, args.train_steps))
+    t_render = timed(render_fwd_bwd, n_sub)
+    with torch.no_grad():
+        fake = g_raw(bs=B, it=tr.it, data={})["box"]
+    fake_d = {**fake["render_out"], "c2b": fake["prior_info"]["c2b"]}
+    t_dstep = timed(lambda: tr.train_step_discriminator("discriminator", data, fake_d), n_sub)
     return {"it_per_s": it_s, "ms_per_it": 1e3 / it_s, "steps": args.train_steps,
             "rays_per_s": 3 * world * B * R * R * it_s, "d_train_images_per_s": 4 * world * B * it_s,
+            "render_fwd_bwd": {"ms": 1e3 * t_render, "rays_per_s_per_gpu": B * R * R / t_render,
+                               "what": "Generator.forward with gradient + backward (double-backward through d sdf/dx)"},
+            "d_step": {"ms": 1e3 * t_dstep, "images_per_s_per_gpu": 2 * B / t_dstep,
+                       "what": "one ADADiscriminatorView training step: real fwd + R1 double-backward + fake fwd + bwd + RMSprop"},
             "what": "Trainer.train_step: G step (render fwd+bwd incl. double-backward, 2 D fwd+bwd-to-input) + D step "
                     "+ mask-D step (each: real fwd + R1 double-backward + fake fwd + bwd), fused Adam/RMSprop steps"
                     + (", flat-gradient RCCL all-reduce x3" if distributed else ""),
