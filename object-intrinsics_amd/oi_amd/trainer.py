@@ -22,6 +22,29 @@ def toggle_grad(model, requires_grad):
         p.requires_grad_(requires_grad)
 
 
+class _GradToggle:
+    """`toggle_grad` over the three networks, three times per iteration (gan_pose_trainer.py:103-106, 148-151), walks
+    ~100 parameters through nn.Module.parameters() each time: remember each network's state and parameter list and
+    touch a network only when its state changes."""
+
+    def __init__(self):
+        self.state, self.params = {}, {}
+
+    def __call__(self, key, model, requires_grad):
+        cached = self.params.get(key)
+        if cached is None or cached[0] is not model:
+            cached = self.params[key] = (model, list(model.parameters()))
+            self.state.pop(key, None)
+        ps = cached[1]
+        # (first / last parameter probed: somebody else may have toggled the network since)
+        if self.state.get(key) is requires_grad and (not ps or (ps[0].requires_grad is requires_grad
+                                                               and ps[-1].requires_grad is requires_grad)):
+            return
+        for p in cached[1]:
+            p.requires_grad_(requires_grad)
+        self.state[key] = requires_grad
+
+
 def _unwrap(m):
     return m.module if hasattr(m, "module") and isinstance(m.module, torch.nn.Module) else m
 
@@ -47,6 +70,7 @@ class Trainer:
         self.loss_weight = lw
         self.gan, self.aux_pose = GANLoss("bce"), PositionLoss("mse")
         self.it = it
+        self._toggle = _GradToggle()
 
     def train_step(self, data):
         self.it += 1
@@ -65,7 +89,7 @@ class Trainer:
 
     def train_step_generator(self, bs):
         for k in MODULE_KEYS:
-            toggle_grad(self.modules[k], k == "generator")
+            self._toggle(k, self.modules[k], k == "generator")
         _zero_grad(self.generator, self.opt_generator)
         blob = self.generator(bs=bs, it=self.it, data={}, return_raw=False)["box"]
         x_fake = torch.cat([blob["render_out"][k] for k in DATA_KEYS["discriminator"]], dim=-3)
@@ -83,7 +107,7 @@ class Trainer:
 
     def train_step_discriminator(self, key, real, fake):
         for k in MODULE_KEYS:
-            toggle_grad(self.modules[k], k == key)
+            self._toggle(k, self.modules[k], k == key)
         disc, opt = self.modules[key], self.modules[f"opt_{key}"]
         _zero_grad(disc, opt)
         x_real = torch.cat([real[k] for k in DATA_KEYS[key]], dim=-3).detach().clone().requires_grad_()
