@@ -309,7 +309,7 @@ struct FwdScratch {
       for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rs, o.l16 >> 1, slot * 8192 + g * 512, 0);
     } else {
-      oi::buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, o.l16, slot * 16384 + g * 1024);
+      oi::buffer_store_b128<OI_FWD_NT_ST>(__builtin_bit_cast(u32x4, v), rs, o.l16, slot * 16384 + g * 1024);
     }
   }
   __device__ __forceinline__ f32x4 load(int slot, int g, const LaneOff& o) const {
@@ -320,7 +320,7 @@ struct FwdScratch {
       for (int k = 0; k < 4; ++k) v[k] = (float)hv[k];
       return v;
     } else {
-      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o.l16, slot * 16384 + g * 1024, OI_SCRATCH_NT));
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o.l16, slot * 16384 + g * 1024, OI_FWD_NT_LD));
     }
   }
 };

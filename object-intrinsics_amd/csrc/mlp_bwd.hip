@@ -53,10 +53,10 @@ constexpr int L_TOTAL_BWD = L_RACC + 8 * C * 4;
 struct WaveScratchB {
   __amdgpu_buffer_rsrc_t rs;
   __device__ __forceinline__ void store(int slot, int g, int l16, f32x4 v) const {
-    oi::buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024);
+    oi::buffer_store_b128<OI_BWD_NT_ST>(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024);
   }
   __device__ __forceinline__ f32x4 load(int slot, int g, int l16) const {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, l16, slot * 16384 + g * 1024, OI_SCRATCH_NT));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, l16, slot * 16384 + g * 1024, OI_BWD_NT_LD));
   }
 };
 

@@ -99,13 +99,28 @@ __device__ __forceinline__ float wave_scan_add(float v, int lane) {
 // hazard only when the store's soffset is NOT a register (an SI-era exemption in the hazard recogniser that
 // does not hold on this part), so the uniform offset is folded into voffset (one v_add) and soffset stays 0;
 // the compiler then inserts the required s_nop itself.  Loads keep the SGPR soffset (no such hazard).
-// Cache policy of the scratch streams (buffer intrinsic aux operand, bit 1 = nt): every scratch slot is written once
-// and read once or twice much later, so it is marked non-temporal -- measured -1.5 % on the forward kernel, -2.8 % on a
-// training iteration (the 25 GB backward scratch no longer churns L2 / MALL).
-#define OI_SCRATCH_NT 2
+// Cache policy of the scratch streams (buffer intrinsic aux operand, bit 1 = nt), measured A/B on one MI355X:
+//   forward kernel  (9 slots, each written once and read back once, LIFO):  loads nt, stores ordinary  1.130 ms
+//                    both nt 1.180 ms, stores only 1.168 ms, neither 1.204 ms -- a non-temporal STORE makes the line's
+//                    only re-read miss, a non-temporal LOAD tells the caches the line is dead after its last use;
+//   backward sweep  (46 slots, 25 GB, most of it consumed by the NEXT kernel):  both nt 68.0 it/s of training,
+//                    loads only 67.5, stores only 67.5, neither 66.6.
+#ifndef OI_FWD_NT_LD
+#define OI_FWD_NT_LD 2
+#endif
+#ifndef OI_FWD_NT_ST
+#define OI_FWD_NT_ST 0
+#endif
+#ifndef OI_BWD_NT_LD
+#define OI_BWD_NT_LD 2
+#endif
+#ifndef OI_BWD_NT_ST
+#define OI_BWD_NT_ST 2
+#endif
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <int AUX>
 __device__ __forceinline__ void buffer_store_b128(u32x4_t v, __amdgpu_buffer_rsrc_t rs, int voff, int uoff) {
-  __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + uoff, 0, OI_SCRATCH_NT);
+  __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + uoff, 0, AUX);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
