@@ -225,10 +225,19 @@ composite_bwd_kernel(const oi_composite_params p, const oi_composite_grads q) {
     }
   }
 
-  // ---- global accumulations: wave -> block -> atomics
+  // ---- global accumulations
   float v[8] = {acc_amb, acc_cd, acc_cs, acc_sh, acc_l0, acc_l1, acc_l2, acc_invs};
 #pragma unroll
   for (int t = 0; t < 8; ++t) v[t] = wave_sum(v[t]);
+  if (q.ray_partials != nullptr) {  // parked per ray, reduced by composite_bwd_reduce_kernel
+    if (lane == 0 && live) {
+      float4* dst = reinterpret_cast<float4*>(q.ray_partials + r * 8);
+      dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+      dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    return;
+  }
+  // no workspace: wave -> block -> atomics (every block hits the same seven addresses)
   if (lane == 0) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) red[wave][t] = live ? v[t] : 0.f;
@@ -254,6 +263,45 @@ composite_bwd_kernel(const oi_composite_params p, const oi_composite_grads q) {
   }
 }
 
+// One block per batch element: sums the parked per-ray partials in a fixed order; d_light / d_variance (shared by all
+// elements, zeroed by the caller) receive one atomic per element.
+__global__ void __launch_bounds__(256)
+composite_bwd_reduce_kernel(const oi_composite_params p, const oi_composite_grads q) {
+  __shared__ float red[4][8];
+  const int e = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long per = p.N / p.B, r0 = (long long)e * per;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long long i = threadIdx.x; i < per; i += blockDim.x) {
+    const float4* src = reinterpret_cast<const float4*>(q.ray_partials + (r0 + i) * 8);
+    const float4 a = src[0], b = src[1];
+    s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+    s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) s[t] = wave_sum(s[t]);
+  if (lane == 0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) red[wave][t] = s[t];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) s[t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+  if (q.d_light_dir) {
+    q.d_light_dir[e * 3 + 0] = s[4];
+    q.d_light_dir[e * 3 + 1] = s[5];
+    q.d_light_dir[e * 3 + 2] = s[6];
+  }
+  if (q.d_light) {
+    const float l_amb = sigmoidf_(p.light[0]);
+    atomicAdd(q.d_light + 0, (s[0] - s[1]) * l_amb * (1.0f - l_amb));
+    atomicAdd(q.d_light + 1, p.light[1] > 0.f ? s[2] : 0.f);
+    atomicAdd(q.d_light + 2, s[3]);
+  }
+  const float inv_s_raw = expf(p.variance[0] * 10.0f);
+  if (q.d_variance && inv_s_raw > 1e-6f && inv_s_raw < 1e6f) atomicAdd(q.d_variance, s[7] * inv_s_raw * 10.0f);
+}
+
 }  // namespace
 
 extern "C" int oi_composite_bwd(const oi_composite_params* p, const oi_composite_grads* g, oi_stream_t stream) {
@@ -268,5 +316,8 @@ extern "C" int oi_composite_bwd(const oi_composite_params* p, const oi_composite
   OI_REQUIRE(sh <= 60 * 1024, "oi_composite_bwd: T=%d too large", p->T);
   hipLaunchKernelGGL(composite_bwd_kernel, dim3(oi::cdiv(p->N, RAYS_PER_BLOCK)), dim3(256), sh, oi::as_stream(stream),
                      *p, *g);
-  return oi::check_launch("oi_composite_bwd");
+  int rc = oi::check_launch("oi_composite_bwd");
+  if (rc != OI_OK || g->ray_partials == nullptr) return rc;
+  hipLaunchKernelGGL(composite_bwd_reduce_kernel, dim3(p->B), dim3(256), 0, oi::as_stream(stream), *p, *g);
+  return oi::check_launch("oi_composite_bwd(reduce)");
 }

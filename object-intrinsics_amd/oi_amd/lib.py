@@ -33,7 +33,7 @@ class CompositeGrads(ctypes.Structure):
     """Mirror of `oi_composite_grads` (include/oi_hip.h)."""
     _fields_ = [(n, _vp) for n in ("g_weights", "g_weight_sum", "g_color_fine", "g_image_no_bg", "g_image", "g_shading",
                                    "g_normal", "g_mask", "g_z_map", "g_specular_map", "g_diffuse_map", "g_reduce4",
-                                   "d_sdf", "d_grad", "d_rgb", "d_variance", "d_light", "d_light_dir")]
+                                   "d_sdf", "d_grad", "d_rgb", "d_variance", "d_light", "d_light_dir", "ray_partials")]
 
 
 _SIGS = {

@@ -288,6 +288,8 @@ def composite_bwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, v
     d_var, d_light, d_ldir = _zeros_split(dev, (1,), (3,), (B, 3))
     G.d_sdf, G.d_grad, G.d_rgb = _p(d_sdf), _p(d_grad), _p(d_rgb)
     G.d_variance, G.d_light, G.d_light_dir = _p(d_var), _p(d_light), _p(d_ldir)
+    partials = _new(dists, N, 8)  # per-ray partial sums of the global gradients, reduced by a second small kernel
+    G.ray_partials = _p(partials)
     _l.check(L.oi_composite_bwd(ctypes.byref(P), ctypes.byref(G), _stream()), "oi_composite_bwd")
     return d_sdf, d_grad, d_rgb, d_var, d_light, d_ldir
 
