@@ -222,19 +222,24 @@ typedef struct oi_composite_params {
   /* global reductions, accumulated with atomics; caller zeroes them: [0]=sum m*(|g|-1)^2,
    * [1]=sum m, [2]=sum exp(-100|sdf|), [3]=min mid_z is NOT here (see z_min) */
   float* reduce4;
-  /* sums over rays, accumulated with atomics; caller zeroes them: [0]=sum cdf[r][0], [1]=sum weight_max,
-   * [2]=sum weight_sum (the logging means of generator.py:208-213 before the division) */
-  float* ray_sums;
+  /* optional [oi_composite_num_blocks(N)][8] float workspace.  With it the kernel parks, per block and without
+   * atomics, [0..2] = the three reduce4 terms and [4..6] = sum cdf[r][0], sum weight_max, sum weight_sum (the logging
+   * means of generator.py:208-213 before the division); `reduce4` is then ignored and oi_render_stats turns the
+   * workspace into totals + derived scalars.  (1024 blocks adding onto three addresses with atomics cost more than
+   * the rest of the kernel: 37 us vs 16 us at N = 4096.) */
+  float* block_partials;
 } oi_composite_params;
 
 int oi_composite_fwd(const oi_composite_params* p, oi_stream_t stream);
+int oi_composite_num_blocks(long long N);
 
-/* Scalars the reference derives from a render with ~8 tiny tensor launches, in one:
- *   out[0] = gradient_error = reduce4[0] / (reduce4[1] + 1e-5)          (renderer.py:306-311)
- *   out[1] = surface_loss   = reduce4[2] / (N*T)                         (renderer.py:459-461)
- *   out[2..4] = mean over rays of cdf[:,0], weight_max, weight_sum       (generator.py:208-213)
- * Forward-only: the host mirror uses it when no gradient is recorded. */
-int oi_render_stats(const float* reduce4, const float* ray_sums, long long N, int T, float* out,
+/* Reduces `block_partials` (fixed summation order) and derives the scalars the reference gets from ~8 tiny tensor
+ * launches.  out16: [0..3] reduce4 totals, [4..7] ray sums,
+ *   [8]  gradient_error = out[0] / (out[1] + 1e-5)                        (renderer.py:306-311)
+ *   [9]  surface_loss   = out[2] / (N*T)                                  (renderer.py:459-461)
+ *   [10..12] mean over rays of cdf[:,0], weight_max, weight_sum           (generator.py:208-213)
+ * The host mirror feeds [8..12] to callers only when no gradient is recorded (autograd needs the tensor formulas). */
+int oi_render_stats(const float* block_partials, int n_blocks, long long N, int T, float* out16,
                     oi_stream_t stream);
 
 /* Backward of oi_composite_fwd (what autograd derives for renderer.py:266-311 + generator.py:107-172 in the

@@ -417,45 +417,65 @@ composite_fwd_kernel(const oi_composite_params p) {
     if (p.specular_map) p.specular_map[r] = a_sp;
     if (p.diffuse_map) p.diffuse_map[r] = a_df;
   }
-  if (p.reduce4 != nullptr) {
+  if (p.block_partials != nullptr || p.reduce4 != nullptr) {
+    // per-ray terms of the global reductions: [0..2] eikonal numerator / denominator / surface sum (renderer.py:306-311,
+    // 459-461), [4..6] cdf of the first sample, weight_max, weight_sum (the logging means of generator.py:208-213)
     if (lane == 0) {
       red[wave][0] = live ? a_eik : 0.f;
       red[wave][1] = live ? a_m : 0.f;
       red[wave][2] = live ? a_surf : 0.f;
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-      float v = 0.f;
-      for (int w = 0; w < RAYS_PER_BLOCK; ++w) v += red[w][threadIdx.x];
-      atomicAdd(p.reduce4 + threadIdx.x, v);
-    }
-  }
-  if (p.ray_sums != nullptr) {  // sums over rays behind the logging means of generator.py:208-213
-    if (lane == 0) {
       red[wave][3] = live ? cdf_first : 0.f;
       red[wave][4] = live ? a_wmax : 0.f;
       red[wave][5] = live ? a_wsum : 0.f;
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 6) {
       float v = 0.f;
-      for (int w = 0; w < RAYS_PER_BLOCK; ++w) v += red[w][3 + threadIdx.x];
-      atomicAdd(p.ray_sums + threadIdx.x, v);
+      for (int w = 0; w < RAYS_PER_BLOCK; ++w) v += red[w][threadIdx.x];
+      if (p.block_partials != nullptr) {
+        // parked per block and summed by render_stats_kernel: 1024 blocks adding onto the same three addresses with
+        // atomics cost more than the rest of this kernel (37 us vs 16 us at N = 4096)
+        const int slot = threadIdx.x < 3 ? threadIdx.x : threadIdx.x + 1;
+        p.block_partials[(size_t)blockIdx.x * 8 + slot] = v;
+      } else if (threadIdx.x < 3) {
+        atomicAdd(p.reduce4 + threadIdx.x, v);
+      }
     }
   }
 }
 
-// gradient_error, surface_loss (renderer.py:306-311, 459-461) and the per-ray logging means (generator.py:208-213)
-// from the reductions of composite_fwd_kernel: one launch for five scalar results.
-__global__ void render_stats_kernel(const float* __restrict__ reduce4, const float* __restrict__ ray_sums, float n_rays,
-                                    float n_samples, float* __restrict__ out) {
-  if (threadIdx.x == 0) {
-    out[0] = reduce4[0] / (reduce4[1] + 1e-5f);
-    out[1] = reduce4[2] / n_samples;
-    out[2] = ray_sums[0] / n_rays;
-    out[3] = ray_sums[1] / n_rays;
-    out[4] = ray_sums[2] / n_rays;
+// Sums the per-block partials of composite_fwd_kernel in a fixed order and derives the scalars the reference gets from
+// ~8 tiny tensor launches:  out[0..3] = reduce4 totals, out[4..7] = ray sums, out[8] = gradient_error =
+// out[0] / (out[1] + 1e-5), out[9] = surface_loss = out[2] / (N T), out[10..12] = means over rays of cdf[:,0],
+// weight_max, weight_sum.
+__global__ void __launch_bounds__(256)
+render_stats_kernel(const float* __restrict__ block_partials, int n_blocks, float n_rays, float n_samples,
+                    float* __restrict__ out) {
+  __shared__ float red[4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) {
+    const float4* src = reinterpret_cast<const float4*>(block_partials + (size_t)i * 8);
+    const float4 a = src[0], b = src[1];
+    s[0] += a.x; s[1] += a.y; s[2] += a.z;
+    s[4] += b.x; s[5] += b.y; s[6] += b.z;
   }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) s[t] = oi::wave_sum(s[t]);
+  if (lane == 0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) red[wave][t] = s[t];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) out[t] = s[t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+  out[8] = s[0] / (s[1] + 1e-5f);
+  out[9] = s[2] / n_samples;
+  out[10] = s[4] / n_rays;
+  out[11] = s[5] / n_rays;
+  out[12] = s[6] / n_rays;
+  out[13] = out[14] = out[15] = 0.f;
 }
 
 }  // namespace
@@ -536,11 +556,14 @@ int oi_composite_fwd(const oi_composite_params* p, oi_stream_t stream) {
   return oi::check_launch("oi_composite_fwd");
 }
 
-int oi_render_stats(const float* reduce4, const float* ray_sums, long long N, int T, float* out, oi_stream_t stream) {
-  OI_REQUIRE(reduce4 && ray_sums && out, "oi_render_stats: null pointer");
-  OI_REQUIRE(N > 0 && T > 0, "oi_render_stats: N=%lld T=%d", N, T);
-  hipLaunchKernelGGL(render_stats_kernel, dim3(1), dim3(64), 0, oi::as_stream(stream), reduce4, ray_sums, (float)N,
-                     (float)N * (float)T, out);
+int oi_composite_num_blocks(long long N) { return N > 0 ? oi::cdiv(N, RAYS_PER_BLOCK) : 0; }
+
+int oi_render_stats(const float* block_partials, int n_blocks, long long N, int T, float* out16, oi_stream_t stream) {
+  OI_REQUIRE(block_partials && out16, "oi_render_stats: null pointer");
+  OI_REQUIRE(N > 0 && T > 0 && n_blocks == oi::cdiv(N, RAYS_PER_BLOCK), "oi_render_stats: N=%lld T=%d n_blocks=%d", N,
+             T, n_blocks);
+  hipLaunchKernelGGL(render_stats_kernel, dim3(1), dim3(256), 0, oi::as_stream(stream), block_partials, n_blocks,
+                     (float)N, (float)N * (float)T, out16);
   return oi::check_launch("oi_render_stats");
 }
 

@@ -227,17 +227,18 @@ class Generator(nn.Module):
             s, c = self.renderer.render_full(flat(ro_all), flat(rd_all), flat(near_all), flat(far_all),
                                              perturb_overwrite=-1 if self.training else 0,
                                              cos_anneal_ratio=cos_anneal_ratio, z=latent["z"], w=latent["w"],
-                                             light=lpk, light_dir=ldir, bg=bg, film=film, ray_sums=n_chunks == 1)
+                                             light=lpk, light_dir=ldir, bg=bg, film=film)
             outs.append((s, c))
         if n_chunks == 1:
             s, c = outs[0]
         else:  # eval only: (bs, chunk, ...) pieces back to (bs*h*w, ...) rows (generator.py:298-305)
             cat = lambda k, d: torch.cat([o[d][k].unflatten(0, (bs, -1)) for o in outs], 1).flatten(0, 1)
             s = {k: cat(k, 0) for k in outs[0][0]}
-            c = {k: cat(k, 1) for k in outs[0][1] if k != "reduce4"}
+            c = {k: cat(k, 1) for k in outs[0][1] if k not in ("reduce4", "ray_sums", "finals")}
             c["reduce4"] = sum(o[1]["reduce4"] for o in outs)
-        # no gradient recorded: gradient_error, surface_loss and the three per-ray logging means in ONE launch
-        finals = ops.render_stats(c["reduce4"], c["ray_sums"], s["sdf"].shape[0], s["sdf"].shape[1]) if "ray_sums" in c else None
+        # no gradient recorded: gradient_error, surface_loss and the three per-ray logging means come out of the
+        # compositing reduction itself (oi_render_stats); with autograd they are tensor expressions of reduce4
+        finals = c.get("finals") if n_chunks == 1 else None
         render_out = assemble_render_dict(s, c, self.deviation_network.variance, finals=finals)
         if n_chunks > 1:
             render_out["gradient_error"] = None

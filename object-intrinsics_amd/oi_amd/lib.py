@@ -26,7 +26,7 @@ class CompositeParams(ctypes.Structure):
                 [("cos_anneal_ratio", _f), ("N", _ll), ("T", _i), ("B", _i)] +
                 [(n, _vp) for n in ("weights", "cdf", "alpha", "inside_sphere", "pts_norm", "weight_sum", "weight_max",
                                     "color_fine", "image_no_bg", "image", "shading", "normal", "mask", "z_map",
-                                    "specular_map", "diffuse_map", "reduce4", "ray_sums")])
+                                    "specular_map", "diffuse_map", "reduce4", "block_partials")])
 
 
 class CompositeGrads(ctypes.Structure):
@@ -50,7 +50,8 @@ _SIGS = {
     "oi_mlp_bwd_small_floats": (_i, []),
     "oi_sdf_mlp_bwd": (_i, [_vp] * 14 + [_i, _ll, _i, _i, _vp]),
     "oi_composite_bwd": (_i, [ctypes.POINTER(CompositeParams), ctypes.POINTER(CompositeGrads), _vp]),
-    "oi_render_stats": (_i, [_vp, _vp, _ll, _i, _vp, _vp]),
+    "oi_render_stats": (_i, [_vp, _i, _ll, _i, _vp, _vp]),
+    "oi_composite_num_blocks": (_i, [_ll]),
     "oi_gen_rays": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "oi_gen_rays_light": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "oi_coarse_samples": (_i, [_vp] * 5 + [_ll, _i, _vp, _vp, _vp]),

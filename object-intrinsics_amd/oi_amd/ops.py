@@ -50,23 +50,6 @@ def _zeros_split(dev, *shapes):
     return [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
 
 
-_ZERO_ROWS = {}
-
-
-def _zero_row4(dev):
-    """A fresh zeroed (4,) accumulator without a fill launch per call: rows of a block zeroed once per 256 calls.  Rows
-    are never handed out twice, so callers may keep them.  Under stream capture the fill has to be part of the graph
-    (a replay accumulates again), so a captured call allocates its own."""
-    if torch.cuda.is_current_stream_capturing():
-        return torch.zeros(4, dtype=torch.float32, device=dev)
-    st = _ZERO_ROWS.get(dev)
-    if st is None or st[1] >= st[0].shape[0]:
-        st = _ZERO_ROWS[dev] = [torch.zeros(256, 4, dtype=torch.float32, device=dev), 0]
-    row = st[0][st[1]]
-    st[1] += 1
-    return row
-
-
 # ------------------------------------------------------------------------------------------
 # MLP
 # ------------------------------------------------------------------------------------------
@@ -218,7 +201,9 @@ ALL_COMPOSITE_OUT = tuple(PER_SAMPLE_OUT) + tuple(PER_RAY_OUT) + ("reduce4",)
 
 def composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light, cos_anneal_ratio,
                   B, outputs=None):
-    """Returns dict of requested outputs (default: all) + 'reduce4' = [sum m*(|g|-1)^2, sum m, sum exp(-100|sdf|), 0]."""
+    """Returns dict of requested outputs (default: all) + 'reduce4' = [sum m*(|g|-1)^2, sum m, sum exp(-100|sdf|), 0].
+    With 'reduce4' come two forward-only extras from the same reduction launch (oi_render_stats): 'ray_sums'
+    = [sum cdf[:,0], sum weight_max, sum weight_sum, 0] and 'finals' = [gradient_error, surface_loss, the three means]."""
     L = _l.load()
     N, T = dists.shape
     P = _l.CompositeParams()
@@ -241,20 +226,16 @@ def composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, v
         if name in want:
             out[name] = _new(dists, N, c)
         setattr(P, name, _p(out.get(name)))
-    if "reduce4" in want:
-        out["reduce4"] = _zero_row4(dists.device)
-    P.reduce4 = _p(out.get("reduce4"))
-    if "ray_sums" in want:  # forward-only extra (not in the default set): sums behind the logging means
-        out["ray_sums"] = _zero_row4(dists.device)
-    P.ray_sums = _p(out.get("ray_sums"))
+    partials = None
+    if "reduce4" in want:  # per-block partial sums (no atomics), reduced below
+        partials = _new(dists, L.oi_composite_num_blocks(N), 8)
+    P.reduce4 = None
+    P.block_partials = _p(partials)
     _l.check(L.oi_composite_fwd(ctypes.byref(P), _stream()), "oi_composite_fwd")
-    return out
-
-
-def render_stats(reduce4, ray_sums, N, T):
-    """-> (5,) [gradient_error, surface_loss, mean cdf[:,0], mean weight_max, mean weight_sum] in one launch."""
-    out = _new(reduce4, 5)
-    _l.check(_l.load().oi_render_stats(_p(reduce4), _p(ray_sums), N, T, _p(out), _stream()), "oi_render_stats")
+    if partials is not None:
+        out16 = _new(dists, 16)
+        _l.check(L.oi_render_stats(_p(partials), partials.shape[0], N, T, _p(out16), _stream()), "oi_render_stats")
+        out["reduce4"], out["ray_sums"], out["finals"] = out16[0:4], out16[4:8], out16[8:13]
     return out
 
 

@@ -53,7 +53,7 @@ class NeuSRenderer:
         return z
 
     def render_full(self, rays_o, rays_d, near, far, perturb_overwrite=-1, cos_anneal_ratio=0.0, z=None, w=None,
-                    light=None, light_dir=None, bg=None, outputs=None, film=None, ray_sums=False):
+                    light=None, light_dir=None, bg=None, outputs=None, film=None):
         """Shared implementation: returns (per-sample/per-ray dict, composite dict)."""
         from .autograd import composite
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
@@ -76,8 +76,6 @@ class NeuSRenderer:
         if light is None:
             light = torch.tensor([0.0, 0.0, 1.0], device=dev)
             light_dir = torch.tensor([[0.0, 0.0, -1.0]], device=dev).expand(B, 3)
-        if ray_sums and outputs is None:  # forward-only extra: present in the result only on the no-grad path
-            outputs = ops.ALL_COMPOSITE_OUT + ("ray_sums",)
         comp = composite(sdf.view(N, T), grad.view(N, T, 3), rgb.view(N, T, 3), dists, mid_z, rays_o, rays_d,
                          light_dir, bg, self.deviation_network.variance, light, cos_anneal_ratio, B, outputs)
         samples = {"sdf": sdf.view(N, T), "gradients": grad.view(N, T, 3), "raw_color": rgb.view(N, T, 3),
@@ -115,8 +113,8 @@ def _inv_s(variance):
 
 
 def assemble_render_dict(s, c, variance, background_rgb=None, finals=None):
-    """Same keys/shapes as NeuSRenderer.render's return value (renderer.py:448-473).  `finals`: the output of
-    ops.render_stats (gradient_error and surface_loss already divided: one launch instead of three)."""
+    """Same keys/shapes as NeuSRenderer.render's return value (renderer.py:448-473).  `finals`: the derived scalars
+    of ops.composite_fwd (gradient_error and surface_loss already divided, no extra launches; no-grad callers only)."""
     N, T = s["sdf"].shape
     r4 = c["reduce4"]
     _, s_val = _inv_s(variance)
