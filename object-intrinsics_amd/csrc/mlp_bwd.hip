@@ -50,13 +50,30 @@ constexpr int DS_TOTAL = 2440;
 constexpr int L_RACC = L_WBUF + 65536;  // per-workgroup reduction scratch: [8][128] floats
 constexpr int L_TOTAL_BWD = L_RACC + 8 * C * 4;
 
+// Cache policy per slot family (aux operand of the buffer instructions; measured in oi_common.h's table):
+//   LOCAL  slots are re-read later in THIS kernel (phi, g, cbar, the colour-head pair),
+//   WGRAD  slots are only written here and consumed by the weight-gradient GEMM (v, gbar, ubar).
+#ifndef OI_BWD_ST_LOCAL
+#define OI_BWD_ST_LOCAL OI_BWD_NT_ST
+#endif
+#ifndef OI_BWD_ST_WGRAD
+#define OI_BWD_ST_WGRAD OI_BWD_NT_ST
+#endif
+#ifndef OI_BWD_LD_EARLY
+#define OI_BWD_LD_EARLY 0  // phi read in phases B and C is read again in phase D: 8.59 vs 8.66 ms per training render
+#endif
+#ifndef OI_BWD_LD_LAST
+#define OI_BWD_LD_LAST OI_BWD_NT_LD
+#endif
 struct WaveScratchB {
   __amdgpu_buffer_rsrc_t rs;
+  template <int AUX = OI_BWD_ST_LOCAL>
   __device__ __forceinline__ void store(int slot, int g, int l16, f32x4 v) const {
-    oi::buffer_store_b128<OI_BWD_NT_ST>(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024);
+    oi::buffer_store_b128<AUX>(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024);
   }
+  template <int AUX = OI_BWD_LD_LAST>
   __device__ __forceinline__ f32x4 load(int slot, int g, int l16) const {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, l16, slot * 16384 + g * 1024, OI_BWD_NT_LD));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, l16, slot * 16384 + g * 1024, AUX));
   }
 };
 
@@ -315,7 +332,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     // the two barriers instead of being paid once per group of four features (the sweep is latency-, not math-bound)
     f32x4 phv[16];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) phv[g] = ws.load(S_PHI + l, g, o.l16);
+    for (int g = 0; g < 16; ++g) phv[g] = ws.load<OI_BWD_LD_EARLY>(S_PHI + l, g, o.l16);
     __syncthreads();
     stage_layer_dma<PREC>(lds, mats + (size_t)(7 + l - 1) * layer_bytes(PREC), wave, lane);
     stage_film(lds, gamma, beta, hdr, e, l, tid);
@@ -334,7 +351,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         act[4 * g + k] = vv[k];
       }
       if (l < NL_SDF - 1) ws.store(S_G + l, g, o.l16, gsv);  // g_{l+1}; g_8 is the constant w_sigma
-      ws.store(S_V + l - 1, g, o.l16, vv);
+      ws.store<OI_BWD_ST_WGRAD>(S_V + l - 1, g, o.l16, vv);
       __builtin_amdgcn_sched_barrier(0);
     }
     acc_zero(acc);
@@ -359,7 +376,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   __syncthreads();
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
-    const f32x4 ph = ws.load(S_PHI + 0, g, o.l16);
+    const f32x4 ph = ws.load<OI_BWD_LD_EARLY>(S_PHI + 0, g, o.l16);
     const f32x4 g1 = ws.load(S_G + 0, g, o.l16);
     const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
     f32x4 cb, v0;
@@ -395,14 +412,14 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       f32x4 v;
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = act[4 * g + k];
-      ws.store(S_GB + l - 1, g, o.l16, v);
+      ws.store<OI_BWD_ST_WGRAD>(S_GB + l - 1, g, o.l16, v);
     }
     acc_zero(acc);
     const float fC = gemm_scaled<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + l - 1] : 1.f);  // vbar_l = W_l gbar_l
     f32x4 phc[16], gnc[16];
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      phc[g] = ws.load(S_PHI + l, g, o.l16);
+      phc[g] = ws.load<OI_BWD_LD_EARLY>(S_PHI + l, g, o.l16);
       if (l < NL_SDF - 1) gnc[g] = ws.load(S_G + l, g, o.l16);
     }
 #pragma unroll
@@ -494,7 +511,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       reduce_group(lds, 1, g, h, j, r_b);
       reduce_group(lds, 2, g, h, j, ub);
       if (l >= 1) {
-        ws.store(S_U + l - 1, g, o.l16, ub);
+        ws.store<OI_BWD_ST_WGRAD>(S_U + l - 1, g, o.l16, ub);
       } else {  // d W0 += ubar_0 x^T
         reduce_group(lds, 3, g, h, j, ub * px);
         reduce_group(lds, 4, g, h, j, ub * py);
