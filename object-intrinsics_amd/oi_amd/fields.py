@@ -6,7 +6,6 @@ with identical constructor kwargs, method names and state_dict keys (SURVEY.md 8
     sigma_linear.{weight,bias}; views_linears.{...}; rgb_linear.{weight,bias}; variance.
 The modules only *hold* parameters; evaluation happens in the HIP MLP kernel (csrc/mlp.hip) through
 `FieldPack`, which caches the MFMA weight images per parameter version."""
-import os
 
 import numpy as np
 import torch

@@ -1,7 +1,6 @@
 """GAN losses of the path (host-side glue over D outputs): src/loss/gan.py:5-22, 39-49 and
 src/loss/position.py:4-18.  The R1 term differentiates through oi_amd's discriminator, whose
 autograd Functions supply the double-backward from HIP kernels."""
-import torch
 import torch.nn.functional as F
 from torch import autograd
 

@@ -4,7 +4,6 @@ Every function allocates its outputs with the torch caching allocator, passes ra
 pointers + the *current* HIP stream to liboi_hip.so, and returns immediately (stream ordered).
 Autograd structure lives in `oi_amd.autograd`."""
 import ctypes
-import math
 
 import torch
 
@@ -196,7 +195,6 @@ def midpoints(rays_o, rays_d, z, last_dist):
 PER_SAMPLE_OUT = ("weights", "cdf", "alpha", "inside_sphere", "pts_norm")
 PER_RAY_OUT = {"weight_sum": 1, "weight_max": 1, "color_fine": 3, "image_no_bg": 3, "image": 3, "shading": 1,
                "normal": 3, "mask": 1, "z_map": 1, "specular_map": 1, "diffuse_map": 1}
-ALL_COMPOSITE_OUT = tuple(PER_SAMPLE_OUT) + tuple(PER_RAY_OUT) + ("reduce4",)
 
 
 def composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light, cos_anneal_ratio,
