@@ -235,6 +235,11 @@ extern "C" {
 
 int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
                    int stride, int pad, float slope, oi_stream_t stream) {
+  return oi_conv4x4_fwd_into(x, w, bias, y, B, Cin, H, W, Cout, stride, pad, slope, 0, stream);
+}
+
+int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
+                        int Cout, int stride, int pad, float slope, int y_is_zero, oi_stream_t stream) {
   OI_REQUIRE(x && w && y, "oi_conv4x4_fwd: null pointer");
   OI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && stride > 0 && pad >= 0, "oi_conv4x4_fwd: bad shape");
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
@@ -251,7 +256,7 @@ int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, 
   k_splits = oi::cdiv(krows, rows_per_split);
   hipStream_t st = oi::as_stream(stream);
   const long long total = (long long)B * Cout * Ho * Wo;
-  if (k_splits > 1) {
+  if (k_splits > 1 && !y_is_zero) {
     hipError_t e = hipMemsetAsync(y, 0, total * sizeof(float), st);
     if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_fwd: memset: %s", hipGetErrorString(e));
   }

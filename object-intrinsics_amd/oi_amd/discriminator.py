@@ -34,9 +34,27 @@ class DCDiscriminator(nn.Module):
         self.blocks = nn.ModuleList([_ConvParam(chans[i], chans[i + 1]) for i in range(n_layers)])
         self.conv_out = _ConvParam(n_feat, out_dim, bias=last_bias)
 
+    def _forward_nograd(self, x):
+        """All layer outputs in ONE zero-filled arena: a single fill launch instead of one per split-K layer."""
+        from . import ops
+        layers = [(l.weight, None, 2, 1, 0.2) for l in self.blocks] + [(self.conv_out.weight, self.conv_out.bias, 1, 0, 1.0)]
+        shapes, shp = [], tuple(x.shape)
+        for w, _, stride, pad, _ in layers:
+            shp = ops.conv4x4_out_shape(shp, w.shape[0], stride, pad)
+            shapes.append(shp)
+        sizes = [(s[0] * s[1] * s[2] * s[3] + 3) // 4 * 4 for s in shapes]
+        arena = torch.zeros(sum(sizes), dtype=torch.float32, device=x.device)
+        off = 0
+        for (w, b, stride, pad, slope), s, n in zip(layers, shapes, sizes):
+            x = ops.conv4x4_fwd(x, w, b, stride, pad, slope, out=arena[off:off + s[0] * s[1] * s[2] * s[3]].view(s))
+            off += n
+        return x
+
     def forward(self, x, **kwargs):
         batch_size = x.shape[0]
         assert x.shape[1] == self.in_dim, x.shape
+        if not torch.is_grad_enabled():
+            return self._forward_nograd(x.float()).reshape(batch_size, self.out_dim)
         for layer in self.blocks:
             x = conv4x4_lrelu(x, layer.weight, None, stride=2, pad=1, slope=0.2)
         out = conv4x4_lrelu(x, self.conv_out.weight, self.conv_out.bias, stride=1, pad=0, slope=1.0)

@@ -277,16 +277,27 @@ def composite_bwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, v
 # discriminator side
 # ------------------------------------------------------------------------------------------
 
-def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2):
+def conv4x4_out_shape(x_shape, Cout, stride, pad):
+    B, _, H, W = x_shape
+    return B, Cout, (H + 2 * pad - 4) // stride + 1, (W + 2 * pad - 4) // stride + 1
+
+
+def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2, out=None):
+    """`out`: optional ZERO-FILLED contiguous output (e.g. a view of an arena shared by a chain of layers): the
+    split-K path then needs no fill launch of its own."""
     L = _l.load()
     x, w = _c(x), _c(w)
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
     assert w.shape[1:] == (Cin, 4, 4)
-    Ho, Wo = (H + 2 * pad - 4) // stride + 1, (W + 2 * pad - 4) // stride + 1
-    y = _new(x, B, Cout, Ho, Wo)
-    _l.check(L.oi_conv4x4_fwd(_p(x), _p(w), _p(_c(bias)), _p(y), B, Cin, H, W, Cout, stride, pad, float(slope),
-                              _stream()), "oi_conv4x4_fwd")
+    shape = conv4x4_out_shape(x.shape, Cout, stride, pad)
+    if out is None:
+        y = _new(x, *shape)
+    else:
+        assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.float32, (out.shape, shape)
+        y = out
+    _l.check(L.oi_conv4x4_fwd_into(_p(x), _p(w), _p(_c(bias)), _p(y), B, Cin, H, W, Cout, stride, pad, float(slope),
+                                   int(out is not None), _stream()), "oi_conv4x4_fwd")
     return y
 
 
