@@ -283,11 +283,14 @@ int oi_composite_bwd(const oi_composite_params* fwd, const oi_composite_grads* g
  */
 int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin,
                    int H, int W, int Cout, int stride, int pad, float slope, oi_stream_t stream);
-/* The same with the caller's promise that y already holds zeros (y_is_zero != 0): the split-K path then skips its own
- * zero-fill, so a chain of layers can share ONE fill of an arena holding all their outputs. */
+/* Chain form for forward-only passes:  y = lrelu_slope( conv( lrelu_x_slope(x) ) + bias ).
+ *   x_slope != 1: the LeakyReLU of the PRODUCING layer is applied while x is loaded, so a split-K producer can hand
+ *     over its pre-activation sums (slope = 1, no bias) and needs no activation pass of its own;
+ *   y_is_zero != 0: the caller promises that y already holds zeros; the split-K path then skips its zero-fill, so a
+ *     chain of layers shares ONE fill of an arena holding all their outputs. */
 int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float* y, int B, int Cin,
-                        int H, int W, int Cout, int stride, int pad, float slope, int y_is_zero,
-                        oi_stream_t stream);
+                        int H, int W, int Cout, int stride, int pad, float slope, float x_slope,
+                        int y_is_zero, oi_stream_t stream);
 
 /* Backward of the convolution (cuDNN bwd-data / bwd-filter in the reference, issued by autograd for
  * discriminator.py:80-83).  g = dL/d(conv output, pre-activation) [B][Cout][Ho][Wo].

@@ -29,7 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ void __launch_bounds__(256)
 conv4x4_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                    float* __restrict__ y, int B, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride,
-                   int pad, float slope, int m_tiles, int n_tiles, int k_splits, int rows_per_split) {
+                   int pad, float slope, int m_tiles, int n_tiles, int k_splits, int rows_per_split, float x_slope) {
   const int lane = threadIdx.x & 63;
   const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long n_items = (long long)m_tiles * n_tiles * k_splits;
@@ -77,6 +77,12 @@ conv4x4_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
         for (int k = 0; k < 4; ++k)
           if (ix0 + k >= 0 && ix0 + k < W) bv[u][k] = xr[ix0 + k];
       }
+    }
+    if (x_slope != 1.0f) {  // the producer left its LeakyReLU to this layer's loads (wave-uniform branch)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bv[u][k] = bv[u][k] > 0.f ? bv[u][k] : bv[u][k] * x_slope;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -235,11 +241,12 @@ extern "C" {
 
 int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
                    int stride, int pad, float slope, oi_stream_t stream) {
-  return oi_conv4x4_fwd_into(x, w, bias, y, B, Cin, H, W, Cout, stride, pad, slope, 0, stream);
+  return oi_conv4x4_fwd_into(x, w, bias, y, B, Cin, H, W, Cout, stride, pad, slope, 1.0f, 0, stream);
 }
 
 int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
-                        int Cout, int stride, int pad, float slope, int y_is_zero, oi_stream_t stream) {
+                        int Cout, int stride, int pad, float slope, float x_slope, int y_is_zero,
+                        oi_stream_t stream) {
   OI_REQUIRE(x && w && y, "oi_conv4x4_fwd: null pointer");
   OI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && stride > 0 && pad >= 0, "oi_conv4x4_fwd: bad shape");
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
@@ -262,7 +269,7 @@ int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float
   }
   const long long items = tiles * k_splits;
   hipLaunchKernelGGL(conv4x4_fwd_kernel, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, x, w, bias, y, B, Cin, H, W,
-                     Cout, Ho, Wo, stride, pad, slope, m_tiles, n_tiles, k_splits, rows_per_split);
+                     Cout, Ho, Wo, stride, pad, slope, m_tiles, n_tiles, k_splits, rows_per_split, x_slope);
   int rc = oi::check_launch("oi_conv4x4_fwd");
   if (rc != OI_OK) return rc;
   if (k_splits > 1 && (slope != 1.0f || bias != nullptr)) {

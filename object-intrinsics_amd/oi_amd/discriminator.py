@@ -35,7 +35,9 @@ class DCDiscriminator(nn.Module):
         self.conv_out = _ConvParam(n_feat, out_dim, bias=last_bias)
 
     def _forward_nograd(self, x):
-        """All layer outputs in ONE zero-filled arena: a single fill launch instead of one per split-K layer."""
+        """Forward-only chain: all layer outputs live in ONE zero-filled arena (a single fill launch instead of one per
+        split-K layer) and every block hands over its pre-activation sums -- the LeakyReLU is applied by the next
+        layer while it loads them, so the split-K layers need no activation pass: 6 launches instead of 13."""
         from . import ops
         layers = [(l.weight, None, 2, 1, 0.2) for l in self.blocks] + [(self.conv_out.weight, self.conv_out.bias, 1, 0, 1.0)]
         shapes, shp = [], tuple(x.shape)
@@ -45,8 +47,12 @@ class DCDiscriminator(nn.Module):
         sizes = [(s[0] * s[1] * s[2] * s[3] + 3) // 4 * 4 for s in shapes]
         arena = torch.zeros(sum(sizes), dtype=torch.float32, device=x.device)
         off = 0
-        for (w, b, stride, pad, slope), s, n in zip(layers, shapes, sizes):
-            x = ops.conv4x4_fwd(x, w, b, stride, pad, slope, out=arena[off:off + s[0] * s[1] * s[2] * s[3]].view(s))
+        x_slope = 1.0
+        for i, ((w, b, stride, pad, slope), s, n) in enumerate(zip(layers, shapes, sizes)):
+            last = i == len(layers) - 1
+            x = ops.conv4x4_fwd(x, w, b, stride, pad, slope if last else 1.0, x_slope=x_slope,
+                                out=arena[off:off + s[0] * s[1] * s[2] * s[3]].view(s))
+            x_slope = slope  # this block's activation, deferred to the next layer's loads
             off += n
         return x
 

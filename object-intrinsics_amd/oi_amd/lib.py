@@ -60,7 +60,7 @@ _SIGS = {
     "oi_midpoints": (_i, [_vp] * 3 + [_ll, _i, _f, _vp, _vp, _vp, _vp]),
     "oi_composite_fwd": (_i, [ctypes.POINTER(CompositeParams), _vp]),
     "oi_conv4x4_fwd": (_i, [_vp] * 4 + [_i] * 7 + [_f, _vp]),
-    "oi_conv4x4_fwd_into": (_i, [_vp] * 4 + [_i] * 7 + [_f, _i, _vp]),
+    "oi_conv4x4_fwd_into": (_i, [_vp] * 4 + [_i] * 7 + [_f, _f, _i, _vp]),
     "oi_conv4x4_dgrad": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
     "oi_conv4x4_wgrad": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
     "oi_lrelu_mask_mul": (_i, [_vp] * 3 + [_ll, _f, _vp]),

@@ -282,9 +282,10 @@ def conv4x4_out_shape(x_shape, Cout, stride, pad):
     return B, Cout, (H + 2 * pad - 4) // stride + 1, (W + 2 * pad - 4) // stride + 1
 
 
-def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2, out=None):
-    """`out`: optional ZERO-FILLED contiguous output (e.g. a view of an arena shared by a chain of layers): the
-    split-K path then needs no fill launch of its own."""
+def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2, out=None, x_slope=1.0):
+    """y = lrelu_slope(conv(lrelu_x_slope(x)) + bias).  `out`: optional ZERO-FILLED contiguous output (e.g. a view of an
+    arena shared by a chain of layers): the split-K path then needs no fill launch of its own.  `x_slope`: LeakyReLU
+    applied to x while it is loaded (the producing layer handed over pre-activations)."""
     L = _l.load()
     x, w = _c(x), _c(w)
     B, Cin, H, W = x.shape
@@ -297,7 +298,7 @@ def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2, out=None):
         assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.float32, (out.shape, shape)
         y = out
     _l.check(L.oi_conv4x4_fwd_into(_p(x), _p(w), _p(_c(bias)), _p(y), B, Cin, H, W, Cout, stride, pad, float(slope),
-                                   int(out is not None), _stream()), "oi_conv4x4_fwd")
+                                   float(x_slope), int(out is not None), _stream()), "oi_conv4x4_fwd")
     return y
 
 
