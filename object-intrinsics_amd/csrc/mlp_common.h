@@ -206,23 +206,47 @@ __device__ __forceinline__ void gemm_layer(const char* lds, const LaneOff& o, co
   }
 }
 
-// sin and cos of one fp32 phase.  Accurate form: phi = n*pi + r with n = round(phi/pi) taken from the low mantissa
-// bit of a magic-number FMA (no cvt / rint), 2-constant Cody-Waite reduction with FMA (|phi| stays below a few
-// hundred radians: gamma ~ 30 +- 15, |u| of order one), then sin r and cos r from weighted-minimax polynomials on
-// [-pi/2, pi/2] (1.4e-8 / 7e-9 approximation error with the fp32 coefficients) and ONE shared sign (-1)^n applied
-// by xor -- no quadrant swap, no selects: 19 VALU ops for the pair, all but 3 of them packable (v_pk_fma_f32).
-// Fast form: v_sin_f32 / v_cos_f32 on phi/(2 pi) (used by the bf16 throughput mode).
+// sin and cos of one fp32 phase.  Three accurate forms (OI_TRIG_HW), measured A/B on one MI355X (full f16x3 kernel):
+//   2 (default)  whole-period reduction in revolutions + v_sin_f32 / v_cos_f32                      1.03 ms
+//   1            n = round(phi/pi) by magic-number FMA, 2-constant Cody-Waite, then v_sin / v_cos     1.08 ms
+//   0            the same reduction, weighted-minimax polynomials on [-pi/2, pi/2] (1.4e-8 / 7e-9), shared sign by
+//                xor: 19 VALU ops per pair, all FP                                                     1.12 ms
+// All three are 1e-7-class (hardware: 1.3e-7 absolute on [-1/2, 1/2] revolutions, tools/dbg/trans_acc.hip) and give the
+// same parity margins; the transcendental instructions issue beside the FP VALU / MFMA work, the polynomial adds to it.
+// Fast form (FAST = true, bf16 throughput mode): v_sin / v_cos on phi/(2 pi) with no reduction (error ~ |phi| * 6e-8).
+#ifndef OI_TRIG_HW
+#define OI_TRIG_HW 2
+#endif
 template <bool FAST>
 __device__ __forceinline__ void sincos_(float x, float& s, float& c) {
   if constexpr (FAST) {
     s = __sinf(x);
     c = __cosf(x);
   } else {
+#if OI_TRIG_HW == 2
+    // Whole-period reduction in REVOLUTIONS, then the transcendental unit: n = round(x / 2pi); the fractional part
+    // x/(2pi) - n comes out of ONE fma (exact product, single rounding of a value <= 1/2) plus the low word of 1/(2pi),
+    // so it is good to ~3e-8 revolutions for the |phi| <= a few hundred radians of this network; v_sin / v_cos are
+    // accurate to 1.3e-7 absolute on [-1/2, 1/2] (tools/dbg/trans_acc.hip).  No sign fix-up, four FP VALU operations,
+    // and the two transcendental instructions issue beside the FP VALU / MFMA work instead of adding to it.
+    const float q = x * 0.15915494309189533577f;
+    const float n = __builtin_rintf(q);
+    float r = fmaf(x, 0.15915494309189533577f, -n);
+    r = fmaf(x, 6.4206383266e-09f, r);  // 1/(2 pi) - float(1/(2 pi)) = 0.15915494309189535 - 0.15915493667125702
+    s = __builtin_amdgcn_sinf(r);
+    c = __builtin_amdgcn_cosf(r);
+#else
     constexpr float MAGIC = 12582912.f;  // 1.5 * 2^23: nf = MAGIC + round(x / pi), parity of n in mantissa bit 0
     const float nf = fmaf(x, 0.318309886183790671538f, MAGIC);
     const float n = nf - MAGIC;
     float r = fmaf(n, -3.1415927410125732f, x);
     r = fmaf(n, 8.742278000372485e-08f, r);  // float(pi) - pi
+#if OI_TRIG_HW == 1
+    // the transcendental unit on the exactly reduced argument (|r| <= pi/2 -> |t| <= 1/4 revolution)
+    const float t = r * 0.15915494309189533577f;
+    const float ps = __builtin_amdgcn_sinf(t);
+    const float pc = __builtin_amdgcn_cosf(t);
+#else
     const float t = r * r;
     float ps = fmaf(t, 2.5999420359e-06f, -1.9806565251e-04f);
     ps = fmaf(t, ps, 8.3330161870e-03f);
@@ -232,9 +256,11 @@ __device__ __forceinline__ void sincos_(float x, float& s, float& c) {
     pc = fmaf(t, pc, -1.3888567919e-03f);
     pc = fmaf(t, pc, 4.1666656733e-02f);
     pc = fmaf(t * t, pc, fmaf(t, -0.5f, 1.0f));
+#endif
     const unsigned sign = __builtin_bit_cast(unsigned, nf) << 31;
     s = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, ps) ^ sign);
     c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, pc) ^ sign);
+#endif
   }
 }
 

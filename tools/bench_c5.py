@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--points", type=int, default=1 << 21, help="total points (BASELINE configs[4]: 2^20 rays x 512 = 2^29)")
 ap.add_argument("--chunk", type=int, default=1 << 24, help="points per launch (bounds the 4.6 KB/point scratch of the full pass)")
 ap.add_argument("--iters", type=int, default=10)
-ap.add_argument("--modes", default="f16x3,bf16x6,f32,bf16x3,bf16")
+ap.add_argument("--modes", default="f16x3,bf16x6,f32,bf16x3,bf16", help="comma list; append :poly / :fast to force the sincos flavour")
 args = ap.parse_args()
 kw = dict(D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64)
 sdf = ShapeNetwork(os.path.join(ROOT, "tests", "golden", "weights_sdf.npz"), **kw).cuda()
@@ -24,7 +24,11 @@ n = min(args.points, args.chunk)
 launches = max(1, args.points // n)
 pts = (torch.rand(n, 3, device="cuda") * 2 - 1) * 0.9
 for mode in args.modes.split(","):
+    mode, _, trig = mode.partition(":")
     pack = FieldPack(sdf, col, mode)
+    if trig:
+        pack.set_precision(mode, fast_trig=(trig == "fast"))
+        mode = f"{mode}:{trig}"
     with torch.no_grad():
         _, gamma, beta = pack.film(z=torch.randn(1, 64, device="cuda"))
         scratch = None
