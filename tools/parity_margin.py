@@ -12,7 +12,11 @@ from test_gpu_modules import make_renderer, KEYS
 g = load_golden("f4_render")
 col_sd = load_golden("weights_color")
 for prec in sys.argv[1:] or ["f32", "bf16x6", "f16x3", "bf16x3"]:
+    prec, _, trig = prec.partition(":")  # "f16x3:fast" forces the unreduced hardware sin/cos
     r = make_renderer(col_sd, 16, 16, 1, prec)
+    if trig:
+        r.pack.set_precision(prec, fast_trig=(trig == "fast"))
+        prec = f"{prec}:{trig}"
     worst = {}
     for tag, car in (("c0p0", 0.0), ("c0p5", 0.5), ("c1p0", 1.0)):
         with torch.no_grad():
@@ -22,4 +26,4 @@ for prec in sys.argv[1:] or ["f32", "bf16x6", "f16x3", "bf16x3"]:
             ref = g[f"{tag}_{k}"]
             scale = max(1.0, float(ref.abs().max())) if k == "gradients" else 1.0
             worst[k] = max(worst.get(k, 0.0), float((out[k].cpu() - ref).abs().max()) / scale)
-    print(f"{prec:7s} max {max(worst.values()):.2e}  " + "  ".join(f"{k}={v:.1e}" for k, v in worst.items()))
+    print(f"{prec:10s} max {max(worst.values()):.2e}  " + "  ".join(f"{k}={v:.1e}" for k, v in worst.items()))
