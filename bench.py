@@ -411,9 +411,9 @@ def build_line(args, value, dt, world, timer, d_img_s, train, distributed, bf16_
                          # HBM bytes/launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
                          # WRITE_SIZE, KiB -> bytes), measured on this workload in f32 mode and committed under profiles/;
                          # it cannot be collected from inside the timed process.
-                         "traffic": 4.93e9 if (args.precision in ("f32", "bf16x6", "f16x3", "bf16x3") and (B, R, S, I) == (1, 64, 64, 64)) else None,
+                         "traffic": 4.95e9 if (args.precision in ("f32", "bf16x6", "f16x3", "bf16x3") and (B, R, S, I) == (1, 64, 64, 64)) else None,
                          "traffic_source": "profiles/r1_pmc_fetch*.txt + profiles/r1_pmc_write*.txt (the fp32 gamma*cos(phi) "
-                                           "scratch: 2.43 GB written (WRITE_SIZE) + 2.50 GB read (FETCH_SIZE x2, the gfx950 correction) per launch in the fp32-scratch modes)",
+                                           "scratch: 2.43 GB written (WRITE_SIZE) + 2.52 GB read (FETCH_SIZE x2, the gfx950 correction) per launch in the fp32-scratch modes)",
                          "algorithmic_flops_per_launch": flops, "kernel_ms": kern_ms,
                          "executed_mfma_frac_of_peak": (achieved * MFMA_PER_MAC[args.precision] / peak) if achieved else None,
                          "vs_native_fp32_mfma_peak": (achieved / 157.3) if achieved else None,
