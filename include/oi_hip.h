@@ -120,6 +120,10 @@ int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, con
  * scratch: oi_mlp_bwd_scratch_bytes(B, n) bytes. */
 size_t oi_mlp_bwd_scratch_bytes(int B, long long n_per_elem);
 int oi_mlp_bwd_small_floats(void);
+/* Test hook: the sin / cos the MLP kernels apply to a FiLM phase (fast != 0: the unreduced form of the bf16 throughput
+ * mode).  x, s, c: n floats. */
+int oi_selftest_sincos(const float* x, float* s, float* c, long long n, int fast, oi_stream_t stream);
+
 int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, const float* beta,
                    const float* grad_fwd, const float* rgb_fwd, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* d_small, float* d_wmat, float* d_gamma, float* d_beta,

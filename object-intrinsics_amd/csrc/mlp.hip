@@ -885,6 +885,18 @@ int launch_mlp(const float* pts, const void* packed, const float* gamma, const f
   return launch_mlp_variant<PREC, FAST, false>(pts, pk, gamma, beta, sdf, nullptr, nullptr, feat, nullptr, B, n, st);
 }
 
+// the device sin/cos of the MLP kernels, exposed for tests (include/oi_hip.h: oi_selftest_sincos)
+template <bool FAST>
+__global__ void selftest_sincos_kernel(const float* __restrict__ x, float* __restrict__ s, float* __restrict__ c,
+                                       long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float sv, cv;
+  sincos_<FAST>(x[i], sv, cv);
+  s[i] = sv;
+  c[i] = cv;
+}
+
 }  // namespace
 
 extern "C" {
@@ -964,6 +976,15 @@ int oi_mlp_pack_weights(const float* w0, const float* b0, const float* wh, const
       return oi::fail(OI_ERR_INVALID_ARG, "oi_mlp_pack_weights: bad precision %d", prec);
   }
   return oi::check_launch("oi_mlp_pack_weights");
+}
+
+int oi_selftest_sincos(const float* x, float* s, float* c, long long n, int fast, oi_stream_t stream) {
+  OI_REQUIRE(x && s && c && n > 0, "oi_selftest_sincos: bad argument");
+  if (fast)
+    hipLaunchKernelGGL(selftest_sincos_kernel<true>, dim3(oi::cdiv(n, 256)), dim3(256), 0, oi::as_stream(stream), x, s, c, n);
+  else
+    hipLaunchKernelGGL(selftest_sincos_kernel<false>, dim3(oi::cdiv(n, 256)), dim3(256), 0, oi::as_stream(stream), x, s, c, n);
+  return oi::check_launch("oi_selftest_sincos");
 }
 
 size_t oi_mlp_scratch_bytes(int B, long long n_per_elem) {

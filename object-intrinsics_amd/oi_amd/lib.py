@@ -46,6 +46,7 @@ _SIGS = {
     "oi_mlp_pack_weights": (_i, [_vp] * 11 + [_i, _vp]),
     "oi_mlp_scratch_bytes": (_sz, [_i, _ll]),
     "oi_sdf_mlp_fwd": (_i, [_vp] * 9 + [_i, _ll, _i, _i, _vp]),
+    "oi_selftest_sincos": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
     "oi_mlp_bwd_scratch_bytes": (_sz, [_i, _ll]),
     "oi_mlp_bwd_small_floats": (_i, []),
     "oi_sdf_mlp_bwd": (_i, [_vp] * 14 + [_i, _ll, _i, _i, _vp]),

@@ -341,3 +341,24 @@ def test_f16x3_tracks_native_fp32_off_distribution(ops, sdf_sd, col_sd, wscale, 
     assert all(bool(torch.isfinite(t).all()) for t in b)
     gs = max(1.0, float(a[1].abs().max()))
     assert maxdiff(a[0], b[0]) < 2e-5 and maxdiff(a[1], b[1]) / gs < 2e-5 and maxdiff(a[2], b[2]) < 2e-5
+
+
+def test_device_sincos_accuracy(ops):
+    """The sin / cos of the MLP kernels (whole-period reduction in revolutions + v_sin_f32 / v_cos_f32) against float64
+    on the fp32 phase, over the phase range of FiLM-SIREN layers and far beyond it; torch.sin of the reference is
+    0.5-ulp accurate, so this error adds directly to the parity budget."""
+    import ctypes
+    from oi_amd import lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(11)
+    x = torch.cat([(torch.rand(1 << 20, generator=g) * 2 - 1) * 100.0, (torch.rand(1 << 20, generator=g) * 2 - 1) * 1000.0,
+                   torch.linspace(-8.0, 8.0, 1 << 16), torch.tensor([0.0, 1e-8, -1e-8, 3.14159274, -3.14159274, 1.57079637])])
+    xd = x.cuda()
+    s, c = torch.empty_like(xd), torch.empty_like(xd)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    lib.check(L.oi_selftest_sincos(p(xd), p(s), p(c), x.numel(), 0, ops._stream()), "oi_selftest_sincos")
+    es = (s.cpu().double() - torch.sin(x.double())).abs()
+    ec = (c.cpu().double() - torch.cos(x.double())).abs()
+    assert float(es.max()) < 3e-7 and float(ec.max()) < 3e-7, (float(es.max()), float(ec.max()))
+    small = x.abs() <= 100.0
+    assert float(es[small].max()) < 2.5e-7 and float(ec[small].max()) < 2.5e-7
