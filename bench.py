@@ -415,6 +415,11 @@ def build_line(args, value, dt, world, timer, d_img_s, train, distributed, bf16_
                          "traffic_source": "profiles/r1_pmc_fetch*.txt + profiles/r1_pmc_write*.txt (the fp32 gamma*cos(phi) "
                                            "scratch: 2.43 GB written (WRITE_SIZE) + 2.52 GB read (FETCH_SIZE x2, the gfx950 correction) per launch in the fp32-scratch modes)",
                          "algorithmic_flops_per_launch": flops, "kernel_ms": kern_ms,
+                         # the same launch against the HBM roofline (8 TB/s, MI355X_MICROARCH.md): PMC traffic / live duration
+                         "hbm": ({"achieved": 4.95e9 / (kern_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                  "frac": 4.95e9 / (kern_ms * 1e-3) / 8e12}
+                                 if (kern_ms and args.precision in ("f32", "bf16x6", "f16x3", "bf16x3")
+                                     and (B, R, S, I) == (1, 64, 64, 64)) else None),
                          "executed_mfma_frac_of_peak": (achieved * MFMA_PER_MAC[args.precision] / peak) if achieved else None,
                          "vs_native_fp32_mfma_peak": (achieved / 157.3) if achieved else None,
                          "note": "algorithmic = GEMM MACs x2 of sdf fwd + analytic gradient sweep + colour head per "
