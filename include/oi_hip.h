@@ -100,10 +100,13 @@ int oi_mlp_pack_weights(const float* w0, const float* b0, const float* wh, const
  *   pts [B*n][3]; gamma/beta from oi_film_params ([B][9][128]).
  *   sdf [B*n] (always).  If grad != NULL: grad [B*n][3] (raw d sdf/dx) and, if rgb != NULL,
  *   rgb [B*n][3] = colour head on [feat, grad].  feat [B*n][128] optional (NULL to skip).
- *   scratch: oi_mlp_scratch_bytes(B, n) bytes, needed when grad != NULL (stores the per-layer
- *   gamma*cos(phase) for the reverse sweep, and is what the backward kernels re-read).
+ *   scratch: oi_mlp_scratch_bytes_prec(B, n, prec) bytes, needed when grad != NULL.  OI_PREC_F16X3 (the default mode)
+ *   runs the register-resident kernel (csrc/mlp_fwd3.hip): the phases the reverse sweep needs stay in the register
+ *   file and only the 128 features per point cross HBM (512 B/point); the other modes park gamma*cos(phase) of every
+ *   layer (4.6 KB/point).  oi_mlp_scratch_bytes(B, n) is an upper bound over all modes.
  */
 size_t oi_mlp_scratch_bytes(int B, long long n_per_elem);
+size_t oi_mlp_scratch_bytes_prec(int B, long long n_per_elem, int prec);
 int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, const float* beta,
                    float* sdf, float* grad, float* rgb, float* feat, void* scratch,
                    int B, long long n_per_elem, int prec, int fast_trig, oi_stream_t stream);
@@ -120,6 +123,12 @@ int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, con
  * scratch: oi_mlp_bwd_scratch_bytes(B, n) bytes. */
 size_t oi_mlp_bwd_scratch_bytes(int B, long long n_per_elem);
 int oi_mlp_bwd_small_floats(void);
+/* Test hook for the CU-indexed feature scratch of the register-resident forward kernel: launches n_workgroups
+ * workgroups with that kernel's LDS footprint; each marks busy[slot] (slot = XCC id x 256 + SE/SH/CU bits of HW_ID, < 4096)
+ * on entry and clears it on exit.  *clashes counts workgroups that found their slot already busy (must stay 0);
+ * used[slot] != 0 for every slot seen.  busy / used: 4096 zeroed ints. */
+int oi_selftest_cu_slots(int* busy, int* clashes, int* used, int n_workgroups, int spin, oi_stream_t stream);
+
 /* Test hook: the sin / cos the MLP kernels apply to a FiLM phase (fast != 0: the unreduced form of the bf16 throughput
  * mode).  x, s, c: n floats. */
 int oi_selftest_sincos(const float* x, float* s, float* c, long long n, int fast, oi_stream_t stream);

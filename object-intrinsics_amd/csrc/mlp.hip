@@ -20,6 +20,8 @@
 //    the write and the read by the same wave) instead of re-running the network as autograd does.
 //  * MFMA operand precision is a template mode (oi_precision); accumulation, the FiLM phase and
 //    sin/cos are always fp32.
+#include <cstdlib>
+
 #include "mlp_common.h"
 
 namespace {
@@ -232,7 +234,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
   float* hdr = reinterpret_cast<float*>(packed);
   __shared__ float red[256];
   if (blockIdx.y == NMAT) {  // header (the image scales at H_WSCALE are written by block 0 of every matrix)
-    if (idx >= H_FLOATS || (idx >= H_WSCALE && idx < H_WSCALE + NMAT)) return;
+    if (idx >= H_FLOATS || (idx >= H_WSCALE && idx < H_WSCALE + NMAT) || (idx >= H_BOUND && idx < H_BOUND + NMAT)) return;
     float v = 0.f;
     if (idx < H_SIG) {
       int f = idx >> 2, j = idx & 3;
@@ -257,6 +259,21 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
   float inv;
   const float wscale = image_scale<PREC>(wh, wv, m, red, &inv);
   if (idx == 0) hdr[H_WSCALE + m] = inv;  // 2^-k_m for the kernels (1 in the unscaled modes)
+  if (blockIdx.x == 0) {
+    // largest absolute row sum of the scaled image (induced infinity norm): an a-priori bound on the growth of a vector
+    // through this layer product, used by mlp_fwd3.hip to pick the fp16 scale of an adjoint vector BEFORE it is complete
+    float rs = 0.f;
+    if (threadIdx.x < C)
+      for (int k = 0; k < C; ++k) rs += fabsf(mat_elem(wh, wv, m, threadIdx.x, k));
+    red[threadIdx.x] = rs;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) hdr[H_BOUND + m] = red[0] * wscale;
+    __syncthreads();
+  }
   if (idx >= C * C) return;
   char* base = packed + H_BYTES + (size_t)m * layer_bytes(PREC);
   if (PREC == OI_PREC_F32) {
@@ -294,92 +311,6 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
 // 9 layers are staged once.  (v1 staged synchronously with two barriers per layer: 56 % of the fp32
 // MFMA peak, matrix pipe 64 % busy -- profiles/r1_*.)
 // ------------------------------------------------------------------------------------------
-// Scratch accessor of the forward kernel.  In the bf16 throughput mode the parked gamma*cos(phi) / feature
-// fragments are stored as fp16 (|c| < 64, 2^-11 relative: far below the bf16 operand rounding), halving the
-// one HBM stream that bounds that mode (profiles/r1_*: 4.9 GB per launch in fp32).
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-template <bool HALF>
-struct FwdScratch {
-  __amdgpu_buffer_rsrc_t rs;
-  __device__ __forceinline__ void store(int slot, int g, const LaneOff& o, f32x4 v) const {
-    if constexpr (HALF) {
-      f16x4 hv;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rs, o.l16 >> 1, slot * 8192 + g * 512, 0);
-    } else {
-      oi::buffer_store_b128<OI_FWD_NT_ST>(__builtin_bit_cast(u32x4, v), rs, o.l16, slot * 16384 + g * 1024);
-    }
-  }
-  __device__ __forceinline__ f32x4 load(int slot, int g, const LaneOff& o) const {
-    if constexpr (HALF) {
-      const f16x4 hv = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, o.l16 >> 1, slot * 8192 + g * 512, 0));
-      f32x4 v;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = (float)hv[k];
-      return v;
-    } else {
-      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o.l16, slot * 16384 + g * 1024, OI_FWD_NT_LD));
-    }
-  }
-};
-
-constexpr int V2_WAVES = 8;                   // scratch is sized for 8-wave tiles (an upper bound for 4-wave tiles)
-constexpr int V2_TILE = V2_WAVES * WAVE_PTS;  // 256 points
-constexpr int V2_FILM = 0;                    // [9][gamma 128 | beta' 128],  beta' = gamma * bias + beta
-constexpr int V2_TABS = 9 * 1024;             // 9216
-constexpr int V2_WBUF = V2_TABS + H_TABS_END * 4;  // 15488
-// Workgroup shape.  Every mode runs 8 wavefronts (256 points) per workgroup and CU with a double-buffered image
-// ring, except BF16X6 (96 KiB images: one slot).  F16X3 can alternatively be built with 4-wave workgroups and ONE
-// 64 KiB slot (79 KiB LDS, two independent workgroups per CU): measured 1.5 % slower (tools/bench_c5.py) -- on
-// gfx950 FP VALU and MFMA time of co-resident waves add up, so running the two workgroups out of phase buys nothing.
-#ifndef OI_F16X3_FULL_WAVES
-#define OI_F16X3_FULL_WAVES 8
-#endif
-#ifndef OI_F16X3_SDF_WAVES
-#define OI_F16X3_SDF_WAVES 8
-#endif
-__host__ __device__ constexpr int v2_waves(int prec, bool full) {
-  return prec == OI_PREC_F16X3 ? (full ? OI_F16X3_FULL_WAVES : OI_F16X3_SDF_WAVES) : 8;
-}
-// BF16X6 images are 96 KiB: a single ring slot, refilled behind a barrier while the VALU phase runs
-__host__ __device__ constexpr bool v2_two_slots(int prec, bool full) {
-  return prec != OI_PREC_BF16X6 && !(prec == OI_PREC_F16X3 && v2_waves(prec, full) == 4);
-}
-__host__ __device__ constexpr int v2_lds_total(int prec, bool full) {
-  return V2_WBUF + (v2_two_slots(prec, full) ? 2 : 1) * layer_bytes(prec);
-}
-
-struct LayOff {  // per-layer runtime VGPR bases (everything else is an immediate)
-  int wl;   // 16*lane + ring slot base
-  int wh;   // wl + 32768
-  int wq;   // wl + 65536
-  int f16;  // 16*h + 1024*layer  (FiLM rows of this layer)
-};
-
-template <int PREC, int NWAVES>
-__device__ __forceinline__ void prefetch_image(char* lds, const char* __restrict__ src, int slot, int wave, int lane) {
-  constexpr int NCHUNK = layer_bytes(PREC) / 1024;
-#pragma unroll
-  for (int c0 = 0; c0 < NCHUNK / NWAVES; ++c0) {
-    const int c = c0 * NWAVES + wave;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src + c * 1024 + lane * 16),
-        (__attribute__((address_space(3))) void*)(lds + V2_WBUF + slot * layer_bytes(PREC) + c * 1024), 16, 0, 0);
-  }
-}
-
-template <int PREC>
-__device__ __forceinline__ LayOff lay_off(const LaneOff& o, int slot, int layer) {
-  LayOff r;
-  r.wl = o.l16 + V2_WBUF + slot * layer_bytes(PREC);
-  r.wh = r.wl + 32768;
-  r.wq = r.wl + 65536;
-  r.f16 = o.h16 + V2_FILM + layer * 1024;
-  return r;
-}
-
 struct NoHook {
   __device__ __forceinline__ void operator()(int) const {}
 };
@@ -637,16 +568,6 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-}
-
-// wait for this wave's LDS-DMA, then rendezvous: next image resident, previous ring slot free
-// TRAILING > 0 would let that many younger VMEM operations (the FiLM phase's scratch stores) stay in flight; it relies
-// on in-order vmcnt retirement between LDS-DMA loads and stores and measured no gain (the wait is for the slowest
-// wave, not for write acknowledgements), so every call site waits for vmcnt(0).
-template <int TRAILING = 0>
-__device__ __forceinline__ void ring_sync() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TRAILING) : "memory");
-  __syncthreads();
 }
 
 // 1: F16X3 forward layers run layer_fwd_pipelined (FiLM / sin of block t-1 between block t's MFMAs): same-box A/B
@@ -1077,9 +998,15 @@ int oi_selftest_sincos(const float* x, float* s, float* c, long long n, int fast
   return oi::check_launch("oi_selftest_sincos");
 }
 
-size_t oi_mlp_scratch_bytes(int B, long long n_per_elem) {
+size_t oi_mlp_scratch_bytes(int B, long long n_per_elem) {  // upper bound over every precision / kernel
   const long long tiles = (n_per_elem + V2_TILE - 1) / V2_TILE;
   return (size_t)B * tiles * V2_WAVES * NSLOT * 16 * 64 * 16;
+}
+
+size_t oi_mlp_scratch_bytes_prec(int B, long long n_per_elem, int prec) {
+  static const bool use_v2 = [] { const char* v = getenv("OI_FWD_V2"); return v && v[0] == '1'; }();
+  if (prec == OI_PREC_F16X3 && !use_v2) return oimlp::full3_scratch_bytes(B, n_per_elem);  // 512 B/point
+  return oi_mlp_scratch_bytes(B, n_per_elem);                                               // 4.6 KB/point
 }
 
 int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf,
@@ -1090,6 +1017,10 @@ int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, con
   OI_REQUIRE(grad != nullptr || rgb == nullptr, "oi_sdf_mlp_fwd: rgb requires grad");
   OI_REQUIRE(grad == nullptr || scratch != nullptr, "oi_sdf_mlp_fwd: grad requires scratch");
   hipStream_t st = oi::as_stream(stream);
+  // F16X3 with the gradient: the register-resident kernel (mlp_fwd3.hip); OI_FWD_V2=1 keeps the scratch-streaming v2
+  static const bool use_v2 = [] { const char* v = getenv("OI_FWD_V2"); return v && v[0] == '1'; }();
+  if (prec == OI_PREC_F16X3 && grad != nullptr && !use_v2)
+    return oimlp::launch_full3_f16x3(pts, packed, gamma, beta, sdf, grad, rgb, feat, scratch, B, n_per_elem, fast_trig, st);
 #define OI_MLP_CASE(P)                                                                                        \
   case P:                                                                                                     \
     return fast_trig ? launch_mlp<P, true>(pts, packed, gamma, beta, sdf, grad, rgb, feat, scratch, B, n_per_elem, st) \

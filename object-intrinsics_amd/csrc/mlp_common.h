@@ -24,6 +24,7 @@ constexpr int H_RGB = 1168;      // [3][128] wrgb, then brgb[3]
 constexpr int H_TABS_END = 1568; // tab0..rgb are copied to LDS as one block
 constexpr int H_BIAS = 1568;     // [9][128]  b0, b1..b7, bv
 constexpr int H_WSCALE = 2720;   // [16] 2^-k_m: inverse of the power-of-two scale baked into image m (1 unless F16X3)
+constexpr int H_BOUND = 2736;    // [16] max_i sum_k |image_m[i][k]| of the (scaled) image m: |W_img x| <= bound * max|x|
 constexpr int H_FLOATS = 2816;
 constexpr size_t H_BYTES = H_FLOATS * 4;
 
@@ -363,5 +364,111 @@ __device__ __forceinline__ void init_bias(const char* lds, const LaneOff& o, f32
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// forward-kernel plumbing shared by mlp.hip (v2 kernels, all precisions) and mlp_fwd3.hip (register-resident F16X3)
+// ------------------------------------------------------------------------------------------
+// Scratch accessor of the forward kernel.  In the bf16 throughput mode the parked gamma*cos(phi) / feature
+// fragments are stored as fp16 (|c| < 64, 2^-11 relative: far below the bf16 operand rounding), halving the
+// one HBM stream that bounds that mode (profiles/r1_*: 4.9 GB per launch in fp32).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <bool HALF>
+struct FwdScratch {
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ void store(int slot, int g, const LaneOff& o, f32x4 v) const {
+    if constexpr (HALF) {
+      f16x4 hv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hv[k] = (_Float16)v[k];
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hv), rs, o.l16 >> 1, slot * 8192 + g * 512, 0);
+    } else {
+      oi::buffer_store_b128<OI_FWD_NT_ST>(__builtin_bit_cast(u32x4, v), rs, o.l16, slot * 16384 + g * 1024);
+    }
+  }
+  __device__ __forceinline__ f32x4 load(int slot, int g, const LaneOff& o) const {
+    if constexpr (HALF) {
+      const f16x4 hv = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rs, o.l16 >> 1, slot * 8192 + g * 512, 0));
+      f32x4 v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (float)hv[k];
+      return v;
+    } else {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o.l16, slot * 16384 + g * 1024, OI_FWD_NT_LD));
+    }
+  }
+};
+
+constexpr int V2_WAVES = 8;                   // scratch is sized for 8-wave tiles (an upper bound for 4-wave tiles)
+constexpr int V2_TILE = V2_WAVES * WAVE_PTS;  // 256 points
+constexpr int V2_FILM = 0;                    // [9][gamma 128 | beta' 128],  beta' = gamma * bias + beta
+constexpr int V2_TABS = 9 * 1024;             // 9216
+constexpr int V2_WBUF = V2_TABS + H_TABS_END * 4;  // 15488
+// Workgroup shape.  Every mode runs 8 wavefronts (256 points) per workgroup and CU with a double-buffered image
+// ring, except BF16X6 (96 KiB images: one slot).  F16X3 can alternatively be built with 4-wave workgroups and ONE
+// 64 KiB slot (79 KiB LDS, two independent workgroups per CU): measured 1.5 % slower (tools/bench_c5.py) -- on
+// gfx950 FP VALU and MFMA time of co-resident waves add up, so running the two workgroups out of phase buys nothing.
+#ifndef OI_F16X3_FULL_WAVES
+#define OI_F16X3_FULL_WAVES 8
+#endif
+#ifndef OI_F16X3_SDF_WAVES
+#define OI_F16X3_SDF_WAVES 8
+#endif
+__host__ __device__ constexpr int v2_waves(int prec, bool full) {
+  return prec == OI_PREC_F16X3 ? (full ? OI_F16X3_FULL_WAVES : OI_F16X3_SDF_WAVES) : 8;
+}
+// BF16X6 images are 96 KiB: a single ring slot, refilled behind a barrier while the VALU phase runs
+__host__ __device__ constexpr bool v2_two_slots(int prec, bool full) {
+  return prec != OI_PREC_BF16X6 && !(prec == OI_PREC_F16X3 && v2_waves(prec, full) == 4);
+}
+__host__ __device__ constexpr int v2_lds_total(int prec, bool full) {
+  return V2_WBUF + (v2_two_slots(prec, full) ? 2 : 1) * layer_bytes(prec);
+}
+
+struct LayOff {  // per-layer runtime VGPR bases (everything else is an immediate)
+  int wl;   // 16*lane + ring slot base
+  int wh;   // wl + 32768
+  int wq;   // wl + 65536
+  int f16;  // 16*h + 1024*layer  (FiLM rows of this layer)
+};
+
+template <int PREC, int NWAVES>
+__device__ __forceinline__ void prefetch_image(char* lds, const char* __restrict__ src, int slot, int wave, int lane) {
+  constexpr int NCHUNK = layer_bytes(PREC) / 1024;
+#pragma unroll
+  for (int c0 = 0; c0 < NCHUNK / NWAVES; ++c0) {
+    const int c = c0 * NWAVES + wave;
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(src + c * 1024 + lane * 16),
+        (__attribute__((address_space(3))) void*)(lds + V2_WBUF + slot * layer_bytes(PREC) + c * 1024), 16, 0, 0);
+  }
+}
+
+template <int PREC>
+__device__ __forceinline__ LayOff lay_off(const LaneOff& o, int slot, int layer) {
+  LayOff r;
+  r.wl = o.l16 + V2_WBUF + slot * layer_bytes(PREC);
+  r.wh = r.wl + 32768;
+  r.wq = r.wl + 65536;
+  r.f16 = o.h16 + V2_FILM + layer * 1024;
+  return r;
+}
+
+// wait for this wave's LDS-DMA, then rendezvous: next image resident, previous ring slot free
+// TRAILING > 0 would let that many younger VMEM operations (the FiLM phase's scratch stores) stay in flight; it relies
+// on in-order vmcnt retirement between LDS-DMA loads and stores and measured no gain (the wait is for the slowest
+// wave, not for write acknowledgements), so every call site waits for vmcnt(0).
+template <int TRAILING = 0>
+__device__ __forceinline__ void ring_sync() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TRAILING) : "memory");
+  __syncthreads();
+}
+
+
+// mlp_fwd3.hip: register-resident F16X3 forward with gradient (+ albedo); scratch = one 16 KiB slot per wave tile
+size_t full3_scratch_bytes(int B, long long n_per_elem);
+int launch_full3_f16x3(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf,
+                       float* grad, float* rgb, float* feat, void* scratch, int B, long long n, int fast_trig,
+                       hipStream_t st);
 
 }  // namespace oimlp

@@ -8,7 +8,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboi_hip.so")
+# OI_LIB: an alternative build of the same library (A/B experiments, tools/dbg/build_variants.sh); default = the in-tree build
+LIB_PATH = os.environ.get("OI_LIB") or os.path.join(_HERE, "liboi_hip.so")
 _lock = threading.Lock()
 _lib = None
 
@@ -45,8 +46,10 @@ _SIGS = {
     "oi_mlp_packed_bytes": (_sz, [_i]),
     "oi_mlp_pack_weights": (_i, [_vp] * 11 + [_i, _vp]),
     "oi_mlp_scratch_bytes": (_sz, [_i, _ll]),
+    "oi_mlp_scratch_bytes_prec": (_sz, [_i, _ll, _i]),
     "oi_sdf_mlp_fwd": (_i, [_vp] * 9 + [_i, _ll, _i, _i, _vp]),
     "oi_selftest_sincos": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
+    "oi_selftest_cu_slots": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "oi_mlp_bwd_scratch_bytes": (_sz, [_i, _ll]),
     "oi_mlp_bwd_small_floats": (_i, []),
     "oi_sdf_mlp_bwd": (_i, [_vp] * 14 + [_i, _ll, _i, _i, _vp]),

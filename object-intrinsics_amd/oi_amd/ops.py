@@ -93,8 +93,9 @@ def mlp_pack_weights(w0, b0, wh, bh, wsig, bsig, wv, bv, wrgb, brgb, prec):
     return packed
 
 
-def mlp_scratch_bytes(B, n_per_elem):
-    return _l.load().oi_mlp_scratch_bytes(B, n_per_elem)
+def mlp_scratch_bytes(B, n_per_elem, prec=None):
+    L = _l.load()
+    return L.oi_mlp_scratch_bytes(B, n_per_elem) if prec is None else L.oi_mlp_scratch_bytes_prec(B, n_per_elem, prec)
 
 
 def sdf_mlp_fwd(pts, packed, gamma, beta, B, prec, fast_trig=False, want_grad=False, want_rgb=False,
@@ -110,7 +111,7 @@ def sdf_mlp_fwd(pts, packed, gamma, beta, B, prec, fast_trig=False, want_grad=Fa
     rgb = _new(pts, n_tot, 3) if want_rgb else None
     feat = _new(pts, n_tot, 128) if want_feat else None
     if want_grad and scratch is None:
-        scratch = torch.empty(L.oi_mlp_scratch_bytes(B, n), dtype=torch.uint8, device=pts.device)
+        scratch = torch.empty(L.oi_mlp_scratch_bytes_prec(B, n, prec), dtype=torch.uint8, device=pts.device)
     assert not want_rgb or want_grad
     _l.check(L.oi_sdf_mlp_fwd(_p(pts), _p(packed), _p(gamma), _p(beta), _p(sdf), _p(grad), _p(rgb), _p(feat),
                               _p(scratch) if want_grad else None, B, n, prec, int(bool(fast_trig)), _stream()),

@@ -74,9 +74,10 @@ def test_sdf_mlp_golden(ops, packed_all, col_sd, mode, tol_sdf, tol_grad, tol_rg
     # intermediate 128-d features (not a renderer output): bf16x3 drops the lo*lo product terms
     # (2^-16 relative per product, amplified by the gamma ~ 30 FiLM phases over 8 layers)
     assert e_feat < {"f32": 1e-4, "bf16x6": 1e-4, "f16x3": 1e-4, "bf16x3": 3e-4, "bf16": 1e-1}[mode]
-    # sdf-only variant agrees with the full variant
+    # sdf-only variant agrees with the full variant (f16x3: two kernels, the register-resident one forms the FiLM phase
+    # in revolutions: two valid fp32 roundings of the same phase, both within tol_sdf of the reference)
     sdf2, _, _, _, _ = ops.sdf_mlp_fwd(g1["pts"].cuda(), packs[mode], gamma, beta, 2, prec, fast_trig=(mode == "bf16"))
-    assert maxdiff(sdf2, sdf) < 1e-6
+    assert maxdiff(sdf2, sdf) < (5e-6 if mode == "f16x3" else 1e-6)
 
 
 @pytest.mark.parametrize("n", [1, 37, 128, 1000])
@@ -362,3 +363,40 @@ def test_device_sincos_accuracy(ops):
     assert float(es.max()) < 3e-7 and float(ec.max()) < 3e-7, (float(es.max()), float(ec.max()))
     small = x.abs() <= 100.0
     assert float(es[small].max()) < 2.5e-7 and float(ec[small].max()) < 2.5e-7
+
+
+def test_cu_slot_exclusive(ops):
+    """The register-resident forward kernel parks features in a scratch slot indexed by the physical CU (XCC id + SE/SH/CU
+    bits of HW_ID) when a launch has more than 4096 workgroups.  On the device: many more workgroups than CUs, each with
+    that kernel's LDS footprint, must never find their slot busy, and the ids must spread over many distinct slots."""
+    from oi_amd import lib
+    L = lib.load()
+    busy = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    used = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    clashes = torch.zeros(1, dtype=torch.int32, device="cuda")
+    stream = ops._stream()
+    for _ in range(3):
+        lib.check(L.oi_selftest_cu_slots(busy.data_ptr(), clashes.data_ptr(), used.data_ptr(), 20000, 200, stream),
+                  "oi_selftest_cu_slots")
+    torch.cuda.synchronize()
+    assert int(clashes) == 0, int(clashes)
+    assert int(busy.abs().sum()) == 0
+    n_slots = int((used != 0).sum())
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert n_cu // 2 <= n_slots <= n_cu, (n_slots, n_cu)
+
+
+def test_sdf_mlp_large_launch_uses_cu_slots(ops, packed_all):
+    """> 4096 workgroups (CU-indexed scratch) gives the same result as the same points in small launches."""
+    P, packs = packed_all
+    g1 = load_golden("f1_film_siren")
+    w, gamma, beta = ops.film_params(P["style_w"], P["style_b"], P["gw"], P["gb"], P["bw"], P["bb"], w=g1["w"][:1].cuda())
+    n = 128 * 6000 + 37
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    pts = (torch.rand(n, 3, device="cuda", generator=gen) * 2 - 1) * 1.1
+    sdf, grad, rgb, _, _ = ops.sdf_mlp_fwd(pts, packs["f16x3"], gamma, beta, 1, 4, want_grad=True, want_rgb=True)
+    for lo in (0, 128 * 3000 + 5, n - 4096):
+        sl = slice(lo, lo + 4096)
+        s2, g2, r2, _, _ = ops.sdf_mlp_fwd(pts[sl].contiguous(), packs["f16x3"], gamma, beta, 1, 4, want_grad=True, want_rgb=True)
+        # different tile alignment -> different point-to-lane mapping only; per-point arithmetic is identical
+        assert maxdiff(s2, sdf[sl]) == 0 and maxdiff(g2, grad[sl]) == 0 and maxdiff(r2, rgb[sl]) == 0
