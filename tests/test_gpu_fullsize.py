@@ -98,3 +98,80 @@ def test_c5_mlp_only_microbench_size(sdf_sd, col_sd):
     s = torch.cat([c[1] for c in checks])
     ref = O.sdf_forward(sdf_sd, p, w)[0].squeeze(-1)
     assert maxdiff(s, ref) < 2e-5
+
+
+def test_c2_size_mlp_backward_vs_oracle(sdf_sd, col_sd):
+    """Backward of the MLP op at the full C2 launch size (524,288 points = 4,096 rays x 128 samples; the real grid of the
+    sweep kernel, its scratch indexing, the split weight-gradient GEMM and every atomics-accumulated output): the
+    cotangents are non-zero on 2,048 points scattered over the launch, so the parameter gradients equal those of the
+    subset alone, which the fp64 oracle differentiates with autograd (points are independent in this op)."""
+    from oi_amd.fields import ShapeNetwork, ColorNetwork, FieldPack
+    from oi_amd.autograd import sdf_mlp
+    from test_gpu_backward import _oracle_mlp_grads, rel_err
+    n, B, n_sub = 4096 * 128, 1, 2048
+    g = torch.Generator().manual_seed(42)
+    pts = torch.rand(n, 3, generator=g) * 2.0 - 1.0
+    w = O.style_mlp(sdf_sd, torch.randn(B, 64, generator=g))
+    idx = torch.randperm(n, generator=g)[:n_sub]
+    cs, cg, cr = torch.zeros(n), torch.zeros(n, 3), torch.zeros(n, 3)
+    cs[idx] = torch.randn(n_sub, generator=g)
+    cg[idx] = 0.1 * torch.randn(n_sub, 3, generator=g)
+    cr[idx] = torch.randn(n_sub, 3, generator=g)
+    loss_o, g_o = _oracle_mlp_grads(sdf_sd, col_sd, pts[idx], w, cs[idx], cg[idx], cr[idx])
+    sdf_net = ShapeNetwork(SDF_NPZ, **NET_KW).cuda()
+    col_net = ColorNetwork(**NET_KW)
+    col_net.load_state_dict(col_sd)
+    col_net = col_net.cuda()
+    pack = FieldPack(sdf_net, col_net, "f16x3")
+    wh = w.cuda().requires_grad_(True)
+    _, gamma, beta = pack.film(w=wh)
+    sdf, grad, rgb, _ = sdf_mlp(pack, pts.cuda(), gamma, beta, B, True, True, False)
+    loss = (sdf * cs.cuda()).sum() + (grad * cg.cuda()).sum() + (rgb * cr.cuda()).sum()
+    assert abs(float(loss) - loss_o) < 1e-3 * max(1.0, abs(loss_o))
+    named = [("sdf." + k, v) for k, v in sdf_net.named_parameters() if not k.startswith("style.")] + \
+            [("col." + k, v) for k, v in col_net.named_parameters()] + [("w", wh)]
+    gr = torch.autograd.grad(loss, [v for _, v in named])
+    bad = {name: rel_err(a, g_o[name]) for (name, _), a in zip(named, gr) if rel_err(a, g_o[name]) > 2e-3}
+    assert not bad, bad
+
+
+def test_c2_size_render_backward_ray_subset_vs_oracle(sdf_sd, col_sd):
+    """Training render at C2 size (4,096 rays x 64+64 samples, gradient enabled): loss = <c, color_fine> + <c', weight_sum>
+    with cotangents on a 128-ray subset.  Rays are independent, so the parameter gradients equal those of the subset
+    alone, which the fp64 oracle differentiates with autograd (render_core on the HIP path's own samples of those rays:
+    the sampling itself carries no gradient, renderer.py:390).  The global eikonal mean is pinned by F6 / F9 and
+    tests/test_gpu_backward.py::test_composite_backward_vs_oracle."""
+    from test_gpu_backward import rel_err
+    N, S, I = 4096, 64, 64
+    ro, rd, near, far = _rays(N, 23)
+    w = O.style_mlp(sdf_sd, torch.randn(1, 64, generator=torch.Generator().manual_seed(6)))
+    r = _renderer(col_sd, S, I, 1, "f16x3")
+    g = torch.Generator().manual_seed(7)
+    idx = torch.sort(torch.randperm(N, generator=g)[:128]).values
+    c_col, c_ws = torch.zeros(N, 3), torch.zeros(N, 1)
+    c_col[idx] = torch.randn(128, 3, generator=g)
+    c_ws[idx] = torch.randn(128, 1, generator=g)
+    named = [("sdf." + k, v) for k, v in r.sdf_network.named_parameters()] + \
+            [("col." + k, v) for k, v in r.color_network.named_parameters()]
+    smp, comp = r.render_full(ro.cuda(), rd.cuda(), near.cuda(), far.cuda(), 0, 0.5, None, w.cuda(),
+                              outputs=("weights", "weight_sum", "color_fine", "reduce4"))
+    loss = (comp["color_fine"] * c_col.cuda()).sum() + (comp["weight_sum"] * c_ws.cuda()).sum()
+    gr = torch.autograd.grad(loss, [v for _, v in named], allow_unused=True)
+    sd = {k: v.double().clone().requires_grad_(True) for k, v in sdf_sd.items()}
+    csd = {k: v.double().clone().requires_grad_(True) for k, v in col_sd.items()}
+    z = smp["z_vals"].detach().cpu()[idx].double()
+    ref = O.render_core(sd, csd, torch.tensor(0.3, dtype=torch.float64), ro[idx].double(), rd[idx].double(), z,
+                        w.double(), S, 0.5)
+    loss_o = (ref["color_fine"] * c_col[idx].double()).sum() + (ref["weight_sum"] * c_ws[idx].double()).sum()
+    assert abs(float(loss) - float(loss_o)) < 1e-3 * max(1.0, abs(float(loss_o)))
+    leaves = [("sdf." + k, v) for k, v in sd.items()] + [("col." + k, v) for k, v in csd.items()]
+    g_o = dict(zip([n_ for n_, _ in leaves], torch.autograd.grad(loss_o, [v for _, v in leaves], allow_unused=True)))
+    bad, checked = {}, 0
+    for (name, _), a in zip(named, gr):
+        b = g_o.get(name)
+        if a is None or b is None or name.startswith("sdf.style."):
+            continue
+        checked += 1
+        if rel_err(a, b) > 3e-3:
+            bad[name] = rel_err(a, b)
+    assert checked > 50 and not bad, bad

@@ -450,3 +450,66 @@ def test_graphed_forward_matches_eager():
             ref = gen(bs=1, it=1000, data={"b2w": b2w, "z": z, "bg_color": bg}, return_raw=True)["box"]["render_out"]
         for k in ("image", "mask", "normal_map", "shading_map", "z_map"):
             assert torch.equal(out[k], ref[k]), (frame, k, maxdiff(out[k], ref[k]))
+
+
+# ------------------------------------------------------------------ round-2 fixtures (oracle/gen_golden_r2.py)
+@pytest.mark.parametrize("S", [16, 32])
+def test_k4_sampling_stage_by_stage_golden_f10(col_sd, S):
+    """up_sample_steps = 4 against the reference's own intermediates: every stage is fed the REFERENCE's previous
+    z / sdf, so a discontinuous bin switch cannot hide a difference -- 100 % of the rays within 1e-4 at every stage,
+    then every key of render() on the reference's final samples within 1e-4 (renderer.py:137-197, 400-413)."""
+    from oi_amd import ops
+    from oi_amd.autograd import sdf_mlp
+    g = load_golden("f10_render_k4")
+    t = f"s{S}_"
+    r = make_renderer(col_sd, S, S, 4, "f16x3")
+    ro, rd = g["rays_o"].cuda(), g["rays_d"].cuda()
+    w = g["w"].cuda()
+    _, gamma, beta = r.pack.film(w=w)
+    N = ro.shape[0]
+    with torch.no_grad():
+        for i in range(4):
+            zb, sb = g[f"{t}z_before{i}"].cuda(), g[f"{t}sdf_before{i}"].cuda()
+            last = i == 3
+            z_new, pts_new, z_m = ops.upsample(ro, rd, zb, sb, S // 4, 64.0 * 2 ** i, merge=last)
+            assert maxdiff(z_new.cpu(), g[f"{t}z_new{i}"]) < 1e-4, (i, maxdiff(z_new.cpu(), g[f"{t}z_new{i}"]))
+            if last:
+                assert maxdiff(z_m.cpu(), g[f"{t}z_after{i}"]) < 1e-4
+            else:  # merge the REFERENCE's new samples (with this implementation's sdf at them)
+                zn = g[f"{t}z_new{i}"].cuda()
+                p = (ro[:, None, :] + rd[:, None, :] * zn[..., None]).reshape(-1, 3)
+                sdf_new = sdf_mlp(r.pack, p, gamma, beta, 1, False, False, False)[0].view(N, -1)
+                zo, so = ops.merge_sorted(zb, sb, zn, sdf_new)
+                assert maxdiff(zo.cpu(), g[f"{t}z_after{i}"]) == 0.0
+                assert maxdiff(so.cpu(), g[f"{t}sdf_after{i}"]) < 2e-5
+        z_fin = g[f"{t}z_after3"].cuda()
+        r.sample_z = lambda *a, **k: z_fin          # the final stage on the reference's own samples
+        out = r.render(ro, rd, g["near"].cuda(), g["far"].cuda(), perturb_overwrite=0,
+                       cos_anneal_ratio=float(g["cos_anneal_ratio"]), w=w)
+    for k in KEYS:
+        ref = g[f"{t}render_{k}"]
+        scale = max(1.0, float(ref.abs().max())) if k == "gradients" else 1.0
+        assert maxdiff(out[k].cpu(), ref) < 1e-4 * scale, (k, maxdiff(out[k].cpu(), ref))
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_inference_frame_golden_f11(graphed):
+    """One frame of the inference driver against the reference: Generator.forward(return_raw=True) in eval mode with given
+    z / b2w at 32 x 32, 16+16 samples (depth x2 of an 8+8 config), rendered in four ray chunks
+    (scripts/test.py:274-281, src/utils/test.py:131-155, generator.py:286-305)."""
+    from oi_amd import inference
+    g = load_golden("f11_inference")
+    gen = build_generator(32, 16, 16, 1, "f16x3").eval()
+    gen.color_network.load_state_dict(sub_sd(g, "color."))
+    gen.light.load_state_dict(sub_sd(g, "light."))
+    gen.it.fill_(int(g["it"]))
+    keys = ("image", "mask", "normal_map", "shading_map")
+    np.random.seed(22)  # the background colour is the first numpy draw of the forward (prior.py:15)
+    fr = inference.render_frames(gen, [g["z"][0]], [g["b2w"][0]], keys=keys, max_ray_batch=int(g["max_ray_batch"]),
+                                 graphed=graphed)
+    for k in keys:
+        if graphed and k == "image":
+            continue  # the captured graph composites over a fixed black background
+        ref = g["map_" + k][0]
+        assert tuple(fr[k][0].shape) == tuple(ref.shape), (k, fr[k][0].shape, ref.shape)
+        assert maxdiff(fr[k][0].cpu(), ref) < 1e-4, (k, maxdiff(fr[k][0].cpu(), ref))

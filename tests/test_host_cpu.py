@@ -123,3 +123,28 @@ def test_config_seam_redirects_dataset_and_ema():
     from oi_amd.ema import EMA
     assert get_obj_from_str("src.datasets.eval_dataset.Dataset") is Dataset
     assert get_obj_from_str("src.utils.ema.EMA") is EMA
+
+
+def small_generator_cfg(R, S, I, K):
+    """Reference-named generator config (configs/train.yaml layout) at a small size; shared with the fixture tests."""
+    fov, img, img_scene = 10.0, 256, 1588
+    cam_dist = float(1 / np.tan(0.5 * fov * np.pi / 180))
+    scene_fov = float(2 * np.arctan(img_scene / img * np.tan(0.5 * fov * np.pi / 180)) * 180 / np.pi)
+    scene_res = int(R * img_scene / img)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kw = dict(D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64)
+    net = lambda t, **k: {"__target__": t, "kwargs": k}
+    return net("src.models.generator.Generator",
+               color_network=net("src.models.fields.ColorNetwork", **kw),
+               sdf_network=net("src.models.fields.ShapeNetwork",
+                               checkpoint_path=os.path.join(root, "tests", "golden", "weights_sdf.npz"), **kw),
+               deviation_network=net("src.third_party.neus.models.fields.SingleVarianceNetwork", init_val=0.3),
+               light_network=net("src.utils.prior.build_directional_light_optimizable", cam_loc=None, light_loc=None,
+                                 ambient_color=0.33, diffuse_color=0.66, specular_color=0, shininess=10),
+               camera=net("src.models.camera_network.Camera", cam_dist=cam_dist, resolution=scene_res, fov=scene_fov),
+               z_dim=64, resolution=R, scene_resolution=scene_res,
+               renderer=net("src.third_party.neus.models.renderer.NeuSRenderer", n_importance=I, n_outside=0,
+                            n_samples=S, perturb=1, up_sample_steps=K),
+               anneal_end=50000,
+               pose_prior=net("src.utils.pose_sampler.Plane", cam_loc=[0, -1, 0], rot_degree_range_scale=360,
+                              rot_roll_degree_range_scale=20, xy_range_scale=[6, 3.5]))

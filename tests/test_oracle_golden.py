@@ -211,3 +211,76 @@ def test_f9_scripted_train_step_discriminator_side():
         for (k, _), gr in zip(sd.items(), gw):
             ref = g[f"{tag}_g." + k]
             assert maxdiff(gr, ref) < 1e-4 * max(1e-3, float(ref.abs().max())), (tag, k)
+
+
+# ------------------------------------------------------------------ round-2 fixtures (oracle/gen_golden_r2.py)
+@pytest.mark.parametrize("S", [16, 32])
+def test_f10_k4_stages(sdf_sd, col_sd, S):
+    """K = 4 hierarchical sampling, stage by stage on the reference's own intermediate z / sdf, then the full render
+    dict on the reference's final samples (renderer.py:137-197, 400-413)."""
+    g = load_golden("f10_render_k4")
+    ro, rd, t = g["rays_o"], g["rays_d"], f"s{S}_"
+    for i in range(4):
+        zb, sb = g[f"{t}z_before{i}"], g[f"{t}sdf_before{i}"]
+        z_new = O.sample_pdf_det(zb, O.up_sample_weights(ro, rd, zb, sb, 64.0 * 2 ** i), S // 4)
+        assert maxdiff(z_new, g[f"{t}z_new{i}"]) < 2e-5, i
+        zm, _ = O.merge_sorted(zb, g[f"{t}z_new{i}"])
+        assert maxdiff(zm, g[f"{t}z_after{i}"]) == 0.0
+    z_fin = g[f"{t}z_after3"]
+    out = O.render_core(sdf_sd, col_sd, g["variance"], ro, rd, z_fin, g["w"], S, float(g["cos_anneal_ratio"]))
+    for k in ("cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error", "mid_z_vals",
+              "surface_loss", "sdf", "color_fine", "raw_color"):
+        assert maxdiff(out[k], g[f"{t}render_{k}"]) < 1e-4, (k, maxdiff(out[k], g[f"{t}render_{k}"]))
+
+
+def test_k4_end_to_end_flip_fraction_fp32_vs_fp64(sdf_sd, col_sd):
+    """Importance sampling is discontinuous in its inputs, so two CORRECT evaluations differ in a few rays: the oracle
+    itself, run in fp32 and in fp64 on the inputs of tests/test_gpu_modules.py::test_render_vs_oracle_hierarchical
+    (K = 4), places the samples of a measurable fraction of rays differently.  That fraction is what the ray-wise
+    threshold of the GPU end-to-end test (>= 97 % of rays sample-for-sample within 1e-4) has to leave room for."""
+    K, S, I = 4, 64, 64
+    g = torch.Generator().manual_seed(K)
+    N = 2 * 150
+    ro = torch.tensor([0.0, 0.0, -3.0]).expand(N, 3) + 0.05 * torch.randn(N, 3, generator=g)
+    rd = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + 0.2 * torch.randn(N, 3, generator=g), dim=-1)
+    near, far = O.near_far_from_sphere(ro, rd)
+    w = O.style_mlp(sdf_sd, torch.randn(2, 64, generator=g))
+    z32 = O.hierarchical_z(sdf_sd, ro, rd, near, far, w, S, I, K)
+    sd64 = {k: v.double() for k, v in sdf_sd.items()}
+    z64 = O.hierarchical_z(sd64, ro.double(), rd.double(), near.double(), far.double(), w.double(), S, I, K)
+    flipped = ((z32.double() - z64).abs().max(-1).values >= 1e-4).float().mean()
+    print(f"fp32-vs-fp64 oracle: {100 * float(flipped):.2f} % of rays place a sample differently by >= 1e-4")
+    # measured 11.7 %: fp32 round-off alone moves the samples of more rays than the 3 % the GPU test tolerates between
+    # two fp32-class implementations -- the allowance is not hiding an implementation difference
+    assert 0.03 <= float(flipped) <= 0.25
+
+
+def test_f12_reference_checkpoint_loads_into_dropin_modules():
+    """A model.pt written by the reference's CheckpointIO.save from reference modules (src/utils/checkpoint.py:36-48)
+    loads, strictly, into the drop-in modules through oi_amd.checkpoint; the opposite direction (written here, read by
+    the reference's CheckpointIO.load into reference modules) was checked when the fixture was generated."""
+    import os
+    from conftest import GOLDEN
+    from oi_amd.checkpoint import CheckpointIO
+    from oi_amd.config import build_from_config
+    from test_host_cpu import small_generator_cfg
+    g = load_golden("f12_checkpoint")
+    assert int(g["reverse_direction_ok"]) == 1
+    gen = build_from_config(small_generator_cfg(8, 8, 8, 1))
+    net = lambda t, **kw: {"__target__": t, "kwargs": kw}
+    disc = build_from_config(net("src.models.discriminator.ADADiscriminatorView",
+                                 aug=net("src.third_party.ada.augment.AugmentPipe", scale=1, xint=1), aug_p=0.5,
+                                 img_size=8, in_dim=3, last_bias=False, n_feat=16, out_dim=7, out_dim_latent=0,
+                                 out_dim_position=6))
+    opt = torch.optim.RMSprop(disc.parameters(), lr=1e-4)
+    io = CheckpointIO(checkpoint_dir=None, generator=gen, discriminator=disc, opt_discriminator=opt)
+    scal = io.load(os.path.join(GOLDEN, "ref_model.pt"), strict=True)
+    assert scal["it"] == 4321 and scal["epoch"] == 7 and scal["loss_val_best"] == 0.125
+    for k, v in gen.state_dict().items():
+        assert torch.equal(v.cpu(), g["gen." + k]), k
+    for k, v in disc.state_dict().items():
+        assert torch.equal(v.cpu(), g["disc." + k]), k
+    st = opt.state_dict()["state"]
+    assert len(st) > 0
+    for i in st:
+        assert torch.equal(st[i]["square_avg"].cpu(), g[f"opt.{i}.square_avg"])
