@@ -13,6 +13,11 @@ per GPU with inputs generated on the device, followed by one ADA-discriminator f
 (`ADADiscriminatorView`, 64^2) on the rendered images.  Timing: W warm-up steps, then exactly K
 steps bracketed by barrier + torch.cuda.synchronize(), max over ranks; rank 0 prints ONE JSON line.
 
+`--gpus N` with N > 1 launched from a bare shell (no WORLD_SIZE in the environment) re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU over RCCL.
+The timed region is repeated (each repeat = exactly K steps between barrier + synchronize) until >= 2 s have been
+measured; `value` / `ms_per_step` are over all repeats, `repeats` and the per-repeat spread are reported.
+
 Extra objects in that line:
   roofline      dominant kernel (sdf_mlp_kernel, full variant): algorithmic FLOPs / launch divided by
                 its mean duration measured with HIP events on the launch stream inside the timed region
@@ -21,7 +26,10 @@ Extra objects in that line:
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -133,7 +141,7 @@ def cpu_baseline(R, S, I, K, B):
                       f"{len(times)} runs ({sum(times):.1f} s of CPU work, torch CPU fp32, {cores} threads)"}
 
 
-def bench_training(args, gen, disc, device, world, barrier, distributed):
+def bench_training(args, gen, disc, device, world, barrier, distributed, sub_legs=True):
     from oi_amd.config import build_from_config
     from oi_amd.ddp import FlatGradDDP
     from oi_amd.trainer import Trainer
@@ -144,7 +152,7 @@ def bench_training(args, gen, disc, device, world, barrier, distributed):
                                   img_size=R, in_dim=1, last_bias=False, n_feat=512, out_dim=1)).to(device)
     nets = {"generator": gen, "discriminator": disc, "mask_discriminator": mdisc}
     if distributed:
-        nets = {k: FlatGradDDP(v) for k, v in nets.items()}
+        nets = {k: FlatGradDDP(v, comm_stream=True) for k, v in nets.items()}
     mods = dict(nets)
     from oi_amd.optim import FusedAdam, FusedRMSprop  # configs/train.yaml:133-147, one launch per step each
     mods["opt_generator"] = FusedAdam(nets["generator"].parameters(), lr=2e-5, betas=(0.0, 0.9))
@@ -165,6 +173,9 @@ def bench_training(args, gen, disc, device, world, barrier, distributed):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt)
     it_s = args.train_steps / dt
+
+    if not sub_legs:
+        return {"it_per_s": it_s, "ms_per_it": 1e3 / it_s, "steps": args.train_steps}
 
     # the training render alone (forward + backward incl. the double-backward through the
     # normals: image, mask and eikonal terms all carry gradient) and one discriminator training step alone
@@ -225,7 +236,19 @@ def main():
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-mode measurement")
     ap.add_argument("--train-timeout", type=int, default=300, help="watchdog (s) for the secondary training leg")
     ap.add_argument("--no-disc", action="store_true")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step timed region until this much has been measured")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (C5, D batch sweep, shipped-config training, inference)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher (one process per GPU, RCCL over xGMI)
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -288,15 +311,28 @@ def main():
         barrier()
         d_img_s = B * args.steps / (time.perf_counter() - t0)
 
-    timer_on[0] = True
+    # how many repeats of the K-step region make >= --min-seconds (same number on every rank: decided from the slowest)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(min(5, args.steps)):
         step(args.warmup + i)
     barrier()
-    dt = time.perf_counter() - t0
+    probe = torch.tensor([(time.perf_counter() - t0) / min(5, args.steps)], device=device, dtype=torch.float64)
+    if distributed:
+        dist.all_reduce(probe, op=dist.ReduceOp.MAX)
+    repeats = int(max(1, min(500, math.ceil(1.3 * args.min_seconds / max(1e-6, float(probe) * args.steps)))))
+    timer_on[0] = True
+    dts = []
+    for r_ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        barrier()
+        dts.append(time.perf_counter() - t0)
     timer_on[0] = False
     main_kernel_ms = timer.mean_ms()
+    timer.pairs = []  # the events are no longer needed (thousands of them after the repeats)
 
     # ---- secondary: the same step in the bf16 operand mode that BASELINE.json's configs[1] names (one bf16 MFMA per
     #      product, v_sin/v_cos, fp16 scratch: 1e-2-class, NOT the parity path) -- reported beside the headline
@@ -326,14 +362,18 @@ def main():
     timer.override = main_kernel_ms
 
     # headline reductions first: nothing after this point can take the timed result away
-    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    t = torch.tensor(dts, device=device, dtype=torch.float64)
     dd = torch.tensor([d_img_s or 0.0], device=device, dtype=torch.float64)
     if distributed:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # per repeat: the slowest rank
         dist.all_reduce(dd, op=dist.ReduceOp.SUM)
-    dt = float(t)
+    dts = [float(x) for x in t]
+    dt = sum(dts) / repeats                       # mean duration of one K-step region
     rays_per_step = world * B * R * R
     value = rays_per_step * args.steps / dt
+    spread = {"repeats": repeats, "timed_seconds": sum(dts),
+              "ms_per_step_min": min(dts) / args.steps * 1e3, "ms_per_step_median": float(np.median(dts)) / args.steps * 1e3,
+              "ms_per_step_max": max(dts) / args.steps * 1e3}
     line = None
 
     # ---- full training iteration (3 renders, 6 D forwards, 3 backward + optimiser steps, flat-gradient
@@ -346,7 +386,7 @@ def main():
 
         line_ref = []
         if rank == 0:
-            line_ref.append(build_line(args, value, dt, world, timer, float(dd) if d_img_s else None, None, distributed, bf16_mode))
+            line_ref.append(build_line(args, value, dt, world, timer, float(dd) if d_img_s else None, None, distributed, bf16_mode, spread))
 
         def _watchdog():  # a thread, not SIGALRM: the main thread would be blocked inside a collective / synchronize
             if rank == 0 and line_ref:
@@ -364,7 +404,12 @@ def main():
         dog.cancel()
 
     if rank == 0:
-        line = build_line(args, value, dt, world, timer, float(dd) if d_img_s else None, train, distributed, bf16_mode)
+        line = build_line(args, value, dt, world, timer, float(dd) if d_img_s else None, train, distributed, bf16_mode, spread)
+        if world == 1 and not args.no_extras and not args.no_disc:
+            try:
+                line["extras"] = extras(args, gen, device)
+            except Exception as ex:  # never lose the headline line because of a secondary measurement
+                line["extras"] = {"error": f"{type(ex).__name__}: {ex}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.res, args.samples, args.importance, args.up_steps, args.batch)
     if distributed:
@@ -378,7 +423,131 @@ def main():
         print(json.dumps(line), flush=True)
 
 
-def build_line(args, value, dt, world, timer, d_img_s, train, distributed, bf16_mode=None):
+def _ev_time(fn, n, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n  # ms, GPU side (includes launch gaps when the host cannot keep up)
+
+
+def extras(args, gen, device):
+    """Secondary legs (N = 1 only; each a few hundred ms): driver-observed copies of what tools/ measures.
+    c5_mlp          SURVEY 8d(iii): FiLM-SIREN MLP points/s at 2^21 points, sdf-only and full pass
+    discriminator   SURVEY 8d(ii): ADADiscriminatorView forward at B in {1, 4, 64} (64^2) with its roofline: fp32-MFMA
+                    FLOPs at B = 64, the 11.25 MB weight read at B = 1
+    training_shipped_config  the reference's shipped training configuration (configs/train.yaml:70-76, 86, 102, 131:
+                    128^2 crop, 16 + 4 samples, K = 1, discriminators at 128^2, batch 1 per GPU) -- the only configuration
+                    the reference publishes a speed for (README.md:49: ~2.31 it/s on 2 x RTX 3090)
+    inference       scripts/test.py -res 128 -depth 16 (256 + 64 samples per ray, multi-chunk), frames/s"""
+    from oi_amd import ops
+    from oi_amd.config import build_from_config
+    out = {}
+    net = lambda t, **kw: {"__target__": t, "kwargs": kw}
+    # ---- C5
+    pack = gen.renderer.pack
+    n = 1 << 21
+    pts = (torch.rand(n, 3, device=device) * 2 - 1) * 0.9
+    with torch.no_grad():
+        _, gamma, beta = pack.film(z=torch.randn(1, 64, device=device))
+        full = ops.sdf_mlp_fwd(pts, pack.packed(), gamma, beta, 1, pack.prec, pack.fast_trig, True, True, False, None)
+        scratch = full[-1]
+        ms_sdf = _ev_time(lambda: ops.sdf_mlp_fwd(pts, pack.packed(), gamma, beta, 1, pack.prec, pack.fast_trig), 10)
+        ms_full = _ev_time(lambda: ops.sdf_mlp_fwd(pts, pack.packed(), gamma, beta, 1, pack.prec, pack.fast_trig, True, True,
+                                                   False, scratch), 10)
+    peak = PEAK_TFLOPS[args.precision]
+    out["c5_mlp"] = {"points": n, "precision": args.precision,
+                     "sdf_only": {"ms": ms_sdf, "points_per_s": n / ms_sdf * 1e3, "algorithmic_TFLOP_per_s": n * F_SDF / ms_sdf / 1e9,
+                                  "frac_of_mfma_peak": n * F_SDF / ms_sdf / 1e9 / peak},
+                     "full": {"ms": ms_full, "points_per_s": n / ms_full * 1e3,
+                              "algorithmic_TFLOP_per_s": n * (F_SDF + F_GRAD + F_COL) / ms_full / 1e9,
+                              "frac_of_mfma_peak": n * (F_SDF + F_GRAD + F_COL) / ms_full / 1e9 / peak}}
+    del pts, full, scratch
+    # ---- discriminator batch sweep (forward, eval, no grad)
+    disc = build_from_config(net("src.models.discriminator.ADADiscriminatorView",
+                                 aug=net("src.third_party.ada.augment.AugmentPipe", scale=1, xint=1), aug_p=1, img_size=64,
+                                 in_dim=3, last_bias=False, n_feat=512, out_dim=7, out_dim_latent=0, out_dim_position=6)).to(device).eval()
+    d_flops, d_wbytes = 207.7e6, 11.25e6   # SURVEY.md 8(d): per image forward, fp32 weight bytes
+    sweep = {}
+    for bsz in (1, 4, 64):
+        x = torch.rand(bsz, 3, 64, 64, device=device)
+        with torch.no_grad():
+            ms = _ev_time(lambda: disc(x, it=0), 30 if bsz < 64 else 10)
+        sweep[f"B{bsz}"] = {"ms": ms, "images_per_s": bsz / ms * 1e3,
+                            "roofline": {"mfma_fp32": {"achieved_TFLOP_per_s": bsz * d_flops / ms / 1e9, "peak": 157.3,
+                                                       "frac": bsz * d_flops / ms / 1e9 / 157.3},
+                                         "weight_read_hbm": {"achieved_GB_per_s": d_wbytes / ms / 1e6, "peak": 8000.0,
+                                                             "frac": d_wbytes / ms / 1e6 / 8000.0}}}
+    out["discriminator"] = {"what": "ADADiscriminatorView forward (ADA xint + scale, 5 conv4x4 s2 + head), 64^2, fp32; bound: "
+                                    "weight read at B = 1, fp32 MFMA at B = 64", **sweep}
+    del disc
+    # ---- shipped training configuration
+    import copy
+    a2 = copy.copy(args)
+    a2.res, a2.samples, a2.importance, a2.up_steps, a2.batch = 128, 16, 4, 1, 1
+    a2.train_steps = max(5, min(20, args.train_steps or 10))
+    g2, d2 = build_models(128, 16, 4, 1, args.precision, device)
+    g2.train()
+    tr = bench_training(a2, g2, d2, device, 1, torch.cuda.synchronize, False, sub_legs=False)
+    out["training_shipped_config"] = {
+        "config": "configs/train.yaml: 128x128 crop, 16 + 4 samples/ray, 1 up-sampling step, batch 1 per GPU, RGB-D + mask "
+                  "discriminators at 128^2 (n_feat 512), Adam 2e-5 / RMSprop 1e-4",
+        "it_per_s": tr["it_per_s"], "ms_per_it": tr["ms_per_it"], "steps": tr["steps"],
+        "published": {"it_per_s": 2.31, "hardware": "2 x GeForce RTX 3090, DDP x2 (README.md:49: 100k iterations in ~12 h)"},
+        "vs_baseline": tr["it_per_s"] / 2.31,
+        "note": "per-GPU iteration rate on ONE MI355X (batch 1) against the reference's two-GPU DDP run (batch 1 per GPU, same "
+                "per-GPU work, all-reduce included there): different hardware, context only"}
+    del g2, d2
+    # ---- inference driver leg
+    from oi_amd import inference
+    g3, _ = build_models(128, 256, 64, 1, args.precision, device)
+    g3.eval()
+    zs = [torch.randn(64) for _ in range(4)]
+    np.random.seed(0)
+    b2w = torch.tensor(g3.pose_prior(1), dtype=torch.float32)[0]
+    inference.render_frames(g3, zs[:1], [b2w], keys=("image",))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inference.render_frames(g3, zs, [b2w] * 4, keys=("image", "normal_map", "shading_map"))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 4
+    out["inference"] = {"what": "scripts/test.py -res 128 -depth 16: 128x128 frame, 256 + 64 samples per ray, eval, ray chunks "
+                                "of MAX_RAY_BATCH_SIZE / bs (generator.py:286-305)", "frames": 4, "s_per_frame": dt,
+                        "rays_per_s": 128 * 128 / dt, "points_per_frame": 128 * 128 * 320}
+    return out
+
+
+def csrc_digest():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("oi_build", os.path.join(ROOT, "object-intrinsics_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod._digest()
+
+
+def measured_traffic(args):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r2_traffic.json,
+    written by tools/traffic_json.py: FETCH_SIZE x2 -- the gfx950 correction of MI355X_MICROARCH.md -- + WRITE_SIZE).
+    Counters cannot be collected from inside the timed process, so the figure is tied to the kernel sources by digest:
+    a build whose csrc/ differs from the profiled one reports traffic = null instead of a stale number."""
+    path = os.path.join(ROOT, "profiles", "r2_traffic.json")
+    if not os.path.exists(path):
+        return None, "profiles/r2_traffic.json missing"
+    rec = json.load(open(path))
+    key = f"{args.precision}:{args.batch}x{args.res}x{args.res}:{args.samples}+{args.importance}"
+    ent = rec.get("entries", {}).get(key)
+    if ent is None:
+        return None, f"no PMC record for {key}"
+    if rec.get("csrc_digest") != csrc_digest():
+        return None, "csrc/ changed since the PMC passes of profiles/r2_traffic.json were taken (re-run tools/refresh_profiles.sh)"
+    return float(ent["bytes_per_launch"]), ent["source"]
+
+
+def build_line(args, value, dt, world, timer, d_img_s, train, distributed, bf16_mode=None, spread=None):
     R, S, I, K, B = args.res, args.samples, args.importance, args.up_steps, args.batch
     if True:
         n_pts = B * R * R * (S + I)
@@ -386,10 +555,12 @@ def build_line(args, value, dt, world, timer, d_img_s, train, distributed, bf16_
         flops = n_pts * (F_SDF + F_GRAD + F_COL)
         achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms else None
         peak = PEAK_TFLOPS[args.precision]
+        traffic, traffic_src = measured_traffic(args)
         line = {
             "metric": "rendered rays/sec (64x64 img, 128 samples/ray) + D-images/sec",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "timing": spread,
             "dtype": {"f32": "f32", "bf16x3": "bf16x3 (fp32 split into 2 bf16 MFMA operands, fp32 accumulate)",
                       "bf16x6": "f32 via bf16x6 (fp32 operands split 3-way, 6 bf16 MFMAs per product, fp32 accumulate: "
                                 "fp32-exact contractions, 1e-4 parity path)",
@@ -405,21 +576,17 @@ def build_line(args, value, dt, world, timer, d_img_s, train, distributed, bf16_
             "d_images_per_s": d_img_s,
             "training": train,
             "bf16_mode": bf16_mode,
-            "roofline": {"bound": "mfma", "kernel": "sdf_mlp_kernel<full> (sdf + d sdf/dx + albedo at the fine samples)",
+            "roofline": {"bound": "mfma",
+                         "kernel": ("sdf_mlp_full3_kernel (register-resident: sdf + d sdf/dx + albedo at the fine samples)"
+                                    if args.precision == "f16x3" else "sdf_mlp_kernel<full> (sdf + d sdf/dx + albedo at the fine samples)"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None,
-                         # HBM bytes/launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
-                         # WRITE_SIZE, KiB -> bytes), measured on this workload in f32 mode and committed under profiles/;
-                         # it cannot be collected from inside the timed process.
-                         "traffic": 4.95e9 if (args.precision in ("f32", "bf16x6", "f16x3", "bf16x3") and (B, R, S, I) == (1, 64, 64, 64)) else None,
-                         "traffic_source": "profiles/r1_pmc_fetch*.txt + profiles/r1_pmc_write*.txt (the fp32 gamma*cos(phi) "
-                                           "scratch: 2.43 GB written (WRITE_SIZE) + 2.52 GB read (FETCH_SIZE x2, the gfx950 correction) per launch in the fp32-scratch modes)",
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_flops_per_launch": flops, "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": n_pts * 40,  # 12 B point in, 28 B sdf + gradient + albedo out
                          # the same launch against the HBM roofline (8 TB/s, MI355X_MICROARCH.md): PMC traffic / live duration
-                         "hbm": ({"achieved": 4.95e9 / (kern_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                  "frac": 4.95e9 / (kern_ms * 1e-3) / 8e12}
-                                 if (kern_ms and args.precision in ("f32", "bf16x6", "f16x3", "bf16x3")
-                                     and (B, R, S, I) == (1, 64, 64, 64)) else None),
+                         "hbm": ({"achieved": traffic / (kern_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                  "frac": traffic / (kern_ms * 1e-3) / 8e12} if (kern_ms and traffic) else None),
                          "executed_mfma_frac_of_peak": (achieved * MFMA_PER_MAC[args.precision] / peak) if achieved else None,
                          "vs_native_fp32_mfma_peak": (achieved / 157.3) if achieved else None,
                          "note": "algorithmic = GEMM MACs x2 of sdf fwd + analytic gradient sweep + colour head per "

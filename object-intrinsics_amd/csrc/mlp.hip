@@ -877,11 +877,8 @@ int launch_mlp_variant(const float* pts, const char* pk, const float* gamma, con
   constexpr int LDS_BYTES = v2_lds_total(PREC, FULL);
   dim3 grid(oi::cdiv(n, NWV * WAVE_PTS), B), block(64 * NWV);
   auto k = sdf_mlp_kernel<PREC, FAST, FULL>;
-  static thread_local bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr = true;
-  }
+  // per launch: the attribute is per device, and a process may drive several
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   hipLaunchKernelGGL(k, grid, block, LDS_BYTES, st, pts, pk, gamma, beta, sdf, grad, rgb, feat, scratch, n);
   return oi::check_launch("oi_sdf_mlp_fwd");
 }

@@ -769,11 +769,8 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
                float* d_wmat, float* d_gamma, float* d_beta, void* scratch, int B, long long n, hipStream_t st) {
   dim3 grid(oi::cdiv(n, TILE_PTS), B), block(256);
   auto k = mlp_bwd_sweep_kernel<PREC, FAST>;
-  static thread_local bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL_BWD);
-    attr = true;
-  }
+  // per launch: the attribute is per device, and a process may drive several
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL_BWD);
   hipLaunchKernelGGL(k, grid, block, L_TOTAL_BWD, st, pts, reinterpret_cast<const char*>(packed), gamma, beta, grad_fwd,
                      rgb_fwd, g_sdf, g_grad, g_rgb, d_small, d_gamma, d_beta, reinterpret_cast<char*>(scratch), n);
   int rc = oi::check_launch("oi_sdf_mlp_bwd(sweep)");

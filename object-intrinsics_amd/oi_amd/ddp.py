@@ -7,8 +7,15 @@ Replaces torch.nn.parallel.DistributedDataParallel as used by the reference (scr
   * gradients of a network live in ONE contiguous buffer (param.grad are views into it), so the exchange
     is a single collective of 1.2 MB (generator) / 11 MB (each discriminator) instead of bucketed copies;
     at these sizes the ring is latency-bound, so fewer, larger messages are what pays on xGMI;
-  * the collective is enqueued from an end-of-backward callback (same trigger DDP uses), stream-ordered
-    before the optimiser step: drop-in for `loss.backward(); opt.step()` in the unmodified trainer;
+  * the collective is enqueued from an end-of-backward callback (same trigger DDP uses), stream-ordered before
+    the optimiser step: drop-in for `loss.backward(); opt.step()` in the unmodified trainer.  With
+    `comm_stream=True` it runs on a dedicated communication stream that first waits for the backward's kernels, and
+    `wait()` / `sync()` make the current stream wait for it: a trainer that knows what comes next can enqueue
+    independent work (the next no-grad render) between `backward()` and `sync(); opt.step()` and have it overlap
+    the exchange (oi_amd.trainer does);
+  * `sync()` is the explicit form for callers that cannot rely on the hook: it issues the collective if this
+    backward did not (a rank on which no wrapped parameter received a gradient would otherwise skip the
+    collective and hang the others) -- call it on every rank after every backward of this network;
   * parameters are broadcast once from rank 0 at construction; the reference's per-forward buffer
     broadcast (generator `it` + camera matrices, 3x per step) is dropped: those buffers are
     deterministic functions of the step counter / config and identical on every rank.
@@ -19,7 +26,7 @@ import torch.nn as nn
 
 
 class FlatGradDDP(nn.Module):
-    def __init__(self, module, process_group=None, broadcast_parameters=True):
+    def __init__(self, module, process_group=None, broadcast_parameters=True, comm_stream=False):
         super().__init__()
         self.module = module
         self.pg = process_group
@@ -29,11 +36,17 @@ class FlatGradDDP(nn.Module):
         n = sum(p.numel() for p in params)
         dev = params[0].device
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._views = {}
         off = 0
         for p in params:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            v = self.flat_grad[off:off + p.numel()].view_as(p)
+            self._views[id(p)] = v
+            p.grad = v
             off += p.numel()
-        self._pending = False
+        self._pending = False      # an end-of-backward callback is queued
+        self._needs_exchange = True  # set by zero_grad() / an arriving gradient, cleared by the collective
+        self._event = None         # completion of the collective on the communication stream
+        self._stream = torch.cuda.Stream(device=dev) if (comm_stream and dev.type == "cuda") else None
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         if broadcast_parameters and self.world > 1:
             flat = torch.cat([p.detach().reshape(-1) for p in params])
@@ -50,38 +63,57 @@ class FlatGradDDP(nn.Module):
     # -- gradient exchange -------------------------------------------------------------------
     def _on_grad(self, p):
         # autograd may have replaced p.grad with a fresh tensor (first accumulation into a None grad): fold it back
-        if p.grad is not None and p.grad.data_ptr() != self._view_of(p).data_ptr():
-            v = self._view_of(p)
-            v.add_(p.grad) if getattr(self, "_accumulating", False) else v.copy_(p.grad)
+        v = self._views[id(p)]
+        if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+            v.copy_(p.grad)
             p.grad = v
+        self._needs_exchange = True
         if not self._pending:
             self._pending = True
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
 
-    def _view_of(self, p):
-        if not hasattr(self, "_views"):
-            self._views = {}
-            off = 0
-            for q in self._params:
-                self._views[id(q)] = self.flat_grad[off:off + q.numel()].view_as(q)
-                off += q.numel()
-        return self._views[id(p)]
-
     def _finalize(self):
         self._pending = False
-        if self.world > 1:
+        self._exchange()
+
+    def _exchange(self):
+        self._needs_exchange = False
+        if self.world <= 1:
+            return
+        if self._stream is None:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-            self.flat_grad.div_(self.world)
+            self.flat_grad.mul_(1.0 / self.world)
+            return
+        cur = torch.cuda.current_stream(self.flat_grad.device)
+        self._stream.wait_stream(cur)                       # the backward's kernels first
+        with torch.cuda.stream(self._stream):
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+            self.flat_grad.mul_(1.0 / self.world)
+            self._event = torch.cuda.Event()
+            self._event.record(self._stream)
+
+    def sync(self):
+        """Issue the collective now unless this round's end-of-backward callback already did (a round starts at
+        zero_grad(): a rank whose backward produced no gradient for this network still takes part, with zeros), then
+        `wait()`."""
+        if self._needs_exchange:
+            self._exchange()
+        self.wait()
+
+    def wait(self):
+        """Make the current stream wait for the exchange (call before reading the gradients / the optimiser step)."""
+        if self._event is not None:
+            torch.cuda.current_stream(self.flat_grad.device).wait_event(self._event)
+            self._event = None
 
     def zero_grad(self, set_to_none=False):
+        self.wait()
         self.flat_grad.zero_()
+        self._needs_exchange = True
         for p in self._params:
-            p.grad = self._view_of(p)
+            p.grad = self._views[id(p)]
 
 
 def zero_grad(optimizer_or_module):
     """`opt.zero_grad()` replacement that keeps the flat views (set_to_none=False)."""
-    if isinstance(optimizer_or_module, torch.optim.Optimizer):
-        optimizer_or_module.zero_grad(set_to_none=False)
-    else:
-        optimizer_or_module.zero_grad(set_to_none=False)
+    optimizer_or_module.zero_grad(set_to_none=False)

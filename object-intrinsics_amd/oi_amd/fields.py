@@ -131,6 +131,16 @@ class ColorNetwork(nn.Module):
         self.rgb_linear = LinearLayer(W, 3, freq_init=True)
         self.style_dim, self.w_dim = style_dim, W
 
+    def forward(self, points, normals, view_dirs, feature_vectors, z=None, w=None):
+        """The reference evaluates the albedo head on (feature_vectors, normals) handed over from the SDF network
+        (fields.py:89-101; `points`, `view_dirs`, `z` are ignored there).  Here the head is the tail of the fused MLP
+        launch -- features and d sdf/dx never leave the kernel -- so there is no stand-alone evaluation on caller-supplied
+        features: use `oi_amd.autograd.sdf_mlp(pack, points, gamma, beta, B, want_grad=True, want_rgb=True, ...)`
+        (what NeuSRenderer.render_full does) with a FieldPack over the (ShapeNetwork, ColorNetwork) pair."""
+        raise NotImplementedError(
+            "ColorNetwork.forward on caller-supplied features is not part of the HIP path: the albedo head runs fused "
+            "behind the SDF network (oi_amd.autograd.sdf_mlp(..., want_grad=True, want_rgb=True) / NeuSRenderer.render)")
+
 
 class SingleVarianceNetwork(nn.Module):
     def __init__(self, init_val):

@@ -139,9 +139,13 @@ class Generator(nn.Module):
         return {"c2b": c2b, "b2w": b2w, "w2b": w2b, "light": self.light.batch_transform(w2b=w2b)}
 
     def _camera_host(self):
+        # host copies of the camera buffers, keyed on (address, version) of the device buffers: load_state_dict / .to()
+        # overwrite them (the reference's load path does, src/utils/test.py:update_legacy_state_dict) and the host-side
+        # training geometry must follow
+        key = tuple((t.data_ptr(), t._version) for t in (self.camera.c2w, self.camera.w2c))
         cam = getattr(self, "_cam_np", None)
-        if cam is None:
-            cam = self._cam_np = {"c2w": self.camera.c2w.detach().cpu().numpy().astype(np.float32),
+        if cam is None or cam["key"] != key:
+            cam = self._cam_np = {"key": key, "c2w": self.camera.c2w.detach().cpu().numpy().astype(np.float32),
                                   "w2c": self.camera.w2c.detach().cpu().numpy().astype(np.float32)}
         return cam
 
@@ -174,9 +178,12 @@ class Generator(nn.Module):
             cy = self.camera.cam_dist / b2c_t[..., 2] * b2c_t[..., 1] * R / 2 + 0.5 * self.scene_resolution
             xy = torch.stack([cx - R / 2, cy - R / 2], -1)
         x_off, y_off = xy[:, 0], xy[:, 1]
+        ki = self.camera.intrinsics_inv
+        kkey = (ki.data_ptr(), ki._version)
         kinv = getattr(self, "_kinv33", None)
-        if kinv is None or kinv.device != b2w.device:
-            kinv = self._kinv33 = self.camera.intrinsics_inv[:3, :3].contiguous()
+        if kinv is None or kinv.device != b2w.device or getattr(self, "_kinv33_key", None) != kkey:
+            kinv, self._kinv33_key = ki[:3, :3].contiguous(), kkey
+            self._kinv33 = kinv
         out = {"x_offset": x_off, "y_offset": y_off}
         if with_light:
             ro, rd, near, far, out["light_dir"] = ops.gen_rays(prior_info["c2b"], kinv, xy, R, w2b=prior_info["w2b"],

@@ -49,6 +49,13 @@ def _unwrap(m):
     return m.module if hasattr(m, "module") and isinstance(m.module, torch.nn.Module) else m
 
 
+def _sync(net):
+    """Gradient exchange of a FlatGradDDP-wrapped network (issued by its end-of-backward callback, or here if this rank's
+    backward produced no gradient for it) must have completed before the optimiser reads the gradients."""
+    if hasattr(net, "sync"):
+        net.sync()
+
+
 def _zero_grad(net, opt):
     """FlatGradDDP keeps every gradient as a view of one flat buffer: one fill.  Plain modules drop their gradients
     (`set_to_none=True`, the reference's default `opt.zero_grad()`): no fill per parameter now, no `+=` per parameter in
@@ -81,9 +88,16 @@ class Trainer:
         out.update(self.train_step_generator(bs))
         with torch.no_grad():
             blob = self.generator(bs=bs, it=self.it, data={}, return_raw=False)["box"]
-        out.update(self.train_step_discriminator("discriminator", data, {**blob["render_out"], "c2b": blob["prior_info"]["c2b"]}))
+        # The second no-grad render does not depend on the discriminator's update: it is ENQUEUED between the
+        # discriminator's backward and its `sync(); opt.step()` so that, under FlatGradDDP, the 11 MB gradient exchange on
+        # the communication stream overlaps it.  Same arithmetic and same RNG draw order as the reference's sequence
+        # (gan_pose_trainer.py:84-90): the render only reads generator state.
+        ret_d, finish_d = self.train_step_discriminator("discriminator", data, {**blob["render_out"], "c2b": blob["prior_info"]["c2b"]},
+                                                        defer_step=True)
         with torch.no_grad():
             blob = self.generator(bs=bs, it=self.it, data={}, return_raw=False)["box"]
+        finish_d()
+        out.update(ret_d)
         out.update(self.train_step_discriminator("mask_discriminator", data, blob["render_out"]))
         return out
 
@@ -102,10 +116,11 @@ class Trainer:
             loss = loss + self.loss_weight[k] * v
             ret[f"generator/{k}"] = v
         loss.backward()
+        _sync(self.generator)
         self.opt_generator.step()
         return ret
 
-    def train_step_discriminator(self, key, real, fake):
+    def train_step_discriminator(self, key, real, fake, defer_step=False):
         for k in MODULE_KEYS:
             self._toggle(k, self.modules[k], k == key)
         disc, opt = self.modules[key], self.modules[f"opt_{key}"]
@@ -124,6 +139,14 @@ class Trainer:
         loss_fake = self.gan(d_fake, 0)
         loss = loss_real + loss_fake + loss_reg * self.loss_weight["reg"] + loss_aux * self.loss_weight["aux_pose"](self.it)
         loss.backward()
-        opt.step()
-        return {f"{key}/loss": loss_fake + loss_real, f"{key}/reg": loss_reg, f"{key}/fake": loss_fake,
-                f"{key}/real": loss_real, f"{key}/aux_pose": loss_aux}
+        ret = {f"{key}/loss": loss_fake + loss_real, f"{key}/reg": loss_reg, f"{key}/fake": loss_fake,
+               f"{key}/real": loss_real, f"{key}/aux_pose": loss_aux}
+
+        def finish():
+            _sync(disc)
+            opt.step()
+
+        if defer_step:
+            return ret, finish
+        finish()
+        return ret

@@ -70,3 +70,41 @@ def test_flat_grad_ddp_world2():
         opt.step()
     w1 = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     assert torch.allclose(g, ga, atol=1e-6) and torch.allclose(w1, w1a, atol=1e-6)
+
+
+def _worker_asym(rank, world, port, q):
+    """Rank 1's backward produces NO gradient for the wrapped network: `sync()` must still take part in the collective."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "object-intrinsics_amd"))
+    from oi_amd.ddp import FlatGradDDP
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    net = torch.nn.Linear(4, 2)
+    other = torch.nn.Linear(4, 2)
+    ddp = FlatGradDDP(net)
+    x = torch.ones(3, 4)
+    ddp.zero_grad()
+    loss = ddp(x).sum() if rank == 0 else other(x).sum()
+    loss.backward()
+    ddp.sync()
+    q.put((rank, ddp.flat_grad.clone().numpy()))
+    dist.destroy_process_group()
+
+
+def test_flat_grad_ddp_rank_without_gradient_does_not_hang():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_asym, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g0, g1 = torch.from_numpy(res[0]), torch.from_numpy(res[1])
+    assert torch.equal(g0, g1)
+    # d sum(Wx + b) / dW = 3 (three rows of ones), / db = 3; averaged with rank 1's zeros
+    assert torch.allclose(g0, torch.full_like(g0, 1.5))

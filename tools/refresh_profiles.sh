@@ -1,23 +1,25 @@
 #!/bin/bash
 # Runs ON the GPU box (gpurun): regenerates every file profiles/ holds for the default (f16x3) mode into gpurun_out/.
-#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh'
-# then copy gpurun_out/r1_* into profiles/.  Counter passes are separate runs (--pmc never combined with other traces).
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'
+# then copy gpurun_out/r2_* into profiles/.  Counter passes are separate runs (--pmc never combined with other traces).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
+T=${OI_PROFILE_TAG:-r2}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bf16"
-python $R/bench.py 2>/dev/null | tail -1 > $O/r1_bench_f16x3.json
-python $R/bench.py --res 128 --samples 128 --importance 128 --up-steps 4 --steps 10 --warmup 3 --train-steps 0 --no-bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r1_bench_c4_f16x3.json
+BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bf16 --no-extras --min-seconds 0.2"
+python $R/bench.py 2>/dev/null | tail -1 > $O/${T}_bench_f16x3.json
+python $R/bench.py --res 128 --samples 128 --importance 128 --up-steps 4 --steps 10 --warmup 3 --train-steps 0 --no-bf16 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/${T}_bench_c4_f16x3.json
 rm -rf /tmp/p_ks; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_ks -- $BENCH > /dev/null 2>&1
-python $R/tools/prof_summary.py /tmp/p_ks $O/r1_kernel_stats_f16x3.txt > /dev/null
+python $R/tools/prof_summary.py /tmp/p_ks $O/${T}_kernel_stats_f16x3.txt > /dev/null
 rm -rf /tmp/p_tl; rocprofv3 --kernel-trace --output-format csv -d /tmp/p_tl -- $BENCH --train-steps 0 > /dev/null 2>&1
-python $R/tools/dbg/timeline.py /tmp/p_tl $O/r1_timeline_step_f16x3.txt > /dev/null
-for c in "FETCH_SIZE:fetch" "WRITE_SIZE:write" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE:sq"; do
+python $R/tools/dbg/timeline.py /tmp/p_tl $O/${T}_timeline_step_f16x3.txt > /dev/null
+for c in "FETCH_SIZE:fetch" "WRITE_SIZE:write" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE:sq"; do
   ctr=${c%%:*}; tag=${c##*:}
   rm -rf /tmp/p_$tag; rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/p_$tag -- $BENCH --steps 5 --warmup 2 --train-steps 4 > /dev/null 2>&1
-  python $R/tools/prof_summary.py /tmp/p_$tag $O/r1_pmc_${tag}_f16x3.txt > /dev/null
+  python $R/tools/prof_summary.py /tmp/p_$tag $O/${T}_pmc_${tag}_f16x3.txt > /dev/null
 done
-python $R/tools/bench_c5.py > $O/r1_c5_mlp_microbench.jsonl 2>/dev/null
-ls -la $O/r1_*
+python $R/tools/traffic_json.py $O/${T}_pmc_fetch_f16x3.txt $O/${T}_pmc_write_f16x3.txt sdf_mlp_full3_kernel "f16x3:1x64x64:64+64" $O/${T}_traffic.json
+python $R/tools/bench_c5.py > $O/${T}_c5_mlp_microbench.jsonl 2>/dev/null
+ls -la $O/${T}_*
