@@ -114,8 +114,9 @@ int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, con
 /* Backward of oi_sdf_mlp_fwd w.r.t. every parameter and the FiLM vectors -- including the second-order
  * terms that arise because d sdf/dx is a forward output (the reference: autograd with create_graph=True
  * through fields.py:104-122, backward at gan_pose_trainer.py:141).  Upstream gradients g_sdf [B*n],
- * g_grad [B*n][3], g_rgb [B*n][3] may be NULL.  grad_fwd / rgb_fwd are the forward outputs (needed when
- * g_rgb != NULL).  Results are ACCUMULATED (atomics) into caller-zeroed buffers:
+ * g_grad [B*n][3], g_rgb [B*n][3] may be NULL.  grad_fwd / rgb_fwd / feat_fwd ([B*n][128]) are the forward outputs
+ * (needed when g_rgb != NULL: the albedo head is differentiated first, from the features the forward wrote, because its
+ * gradient with respect to d sdf/dx is an INPUT of the sweep that recomputes the network).  Results are ACCUMULATED (atomics) into caller-zeroed buffers:
  *   d_small  oi_mlp_bwd_small_floats() floats: dW0 [128][3] | db [9][128] (b0..b7, bv) | dwsig [128] | dbsig [1]+3 |
  *            dWv[:,128:131] [128][3] | dWrgb [3][128] | dbrgb [3]+1
  *   d_wmat   [8][128][128]: dW_1..dW_7, dWv[:, :128]
@@ -134,7 +135,7 @@ int oi_selftest_cu_slots(int* busy, int* clashes, int* used, int n_workgroups, i
 int oi_selftest_sincos(const float* x, float* s, float* c, long long n, int fast, oi_stream_t stream);
 
 int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, const float* beta,
-                   const float* grad_fwd, const float* rgb_fwd, const float* g_sdf, const float* g_grad,
+                   const float* grad_fwd, const float* rgb_fwd, const float* feat_fwd, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* d_small, float* d_wmat, float* d_gamma, float* d_beta,
                    void* scratch, int B, long long n_per_elem, int prec, int fast_trig, oi_stream_t stream);
 

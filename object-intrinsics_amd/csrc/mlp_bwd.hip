@@ -8,16 +8,20 @@
 //
 // Per point, with a_0 = x, u_l = W_l a_l + b_l, phi_l = gamma_l u_l + beta_l, a_{l+1} = sin phi_l,
 // c_l = gamma_l cos phi_l, g_8 = w_sigma, v_l = g_{l+1} * c_l, g_l = W_l^T v_l (grad = g_0):
-//   phase A  (l up)    recompute phi_l                                  [7 GEMMs]   flash-style recompute
-//   colour             backward of the albedo head                      [2 GEMMs]
-//   phase B  (l down)  g_{l+1}, v_l                                     [7 GEMMs]
-//   phase C  (l up)    gbar_0 = dL/dgrad; vbar_l = W_l gbar_l; gbar_{l+1} = vbar_l * c_l; cbar_l = vbar_l * g_{l+1}
-//   phase D  (l down)  phibar_l = abar_{l+1} cos phi_l - cbar_l gamma_l sin phi_l; ubar_l = phibar_l gamma_l;
-//                      abar_l = W_l^T ubar_l; gamma/beta/bias gradients
-// All four sweeps keep the point on the MFMA column (activations never leave registers inside a sweep);
-// per-layer fragments that a later sweep needs are parked in a global scratch (buffer addressing).
-// The weight gradients  dW_l = sum_p ( v_l gbar_l^T + ubar_l a_l^T )  are a second, split-K GEMM kernel
-// over the parked operands (K = points).
+//   colour             backward of the albedo head (needs a_8: saved by the forward) -> gbar_0 = dL/dgrad   [2 GEMMs]
+//   up sweep   (l up)   TWO products per staged image:  vbar_l = W_l gbar_l  and  u_l = W_l a_l (recompute, flash-style);
+//                       gbar_{l+1} = vbar_l * c_l;  parks phi_l and vbar_l                                    [14 GEMMs]
+//   down sweep (l down) cbar_l = vbar_l * g_{l+1};  v_l = g_{l+1} * c_l;
+//                       phibar_l = abar_{l+1} cos phi_l - cbar_l gamma_l sin phi_l;  ubar_l = phibar_l gamma_l;
+//                       TWO products per staged image:  g_l = W_l^T v_l  and  abar_l = W_l^T ubar_l;
+//                       gamma / beta / bias gradients; parks v_l, ubar_l for the weight-gradient GEMM       [14 GEMMs]
+// (Round 1 ran four sweeps -- phi up, g down, gbar up, abar down -- and parked 46 slots per point; forming g again in the
+// last sweep instead of parking it, and gbar together with the recomputed activations, leaves 32 slots, 16 of which
+// are read back here: 23.5 -> 16 KB written and 22 -> 9 KB read per point.)
+// Both sweeps keep the point on the MFMA column (activations never leave registers inside a sweep);
+// The weight gradients  dW_l = sum_p ( v_l gbar_l^T + ubar_l a_l^T )  are a second, split-K GEMM kernel over the
+// parked operands (K = points); gbar_l = vbar_{l-1} c_{l-1} and a_l = sin phi_{l-1} are re-formed there from the SAME
+// parked phi_{l-1}.
 #include <algorithm>
 
 #include "mlp_common.h"
@@ -28,14 +32,12 @@ using namespace oimlp;
 
 // scratch slots of one wave tile (16 KiB each)
 constexpr int S_PHI = 0;    // 8: phi_l
-constexpr int S_G = 8;      // 7: g_{l+1}, l = 0..6   (g_8 = w_sigma is a constant)
-constexpr int S_CB = 15;    // 8: cbar_l
-constexpr int S_V = 23;     // 7: v_l,    l = 1..7   (wgrad operand)
-constexpr int S_GB = 30;    // 7: gbar_l, l = 1..7   (wgrad operand)
-constexpr int S_U = 37;     // 7: ubar_l, l = 1..7   (wgrad operand)
-constexpr int S_UV = 44;    // 1: uvbar (colour head pre-activation gradient)
-constexpr int S_AC = 45;    // 1: abar_8 contribution of the colour head
-constexpr int NSLOT_BWD = 46;
+constexpr int S_VB = 8;     // 8: vbar_l = W_l gbar_l           (down sweep: cbar_l = vbar_l g_{l+1}; wgrad: gbar_{l+1} = vbar_l c_l)
+constexpr int S_V = 16;     // 7: v_l,    l = 1..7   (wgrad operand)
+constexpr int S_U = 23;     // 7: ubar_l, l = 1..7   (wgrad operand)
+constexpr int S_UV = 30;    // 1: uvbar (colour head pre-activation gradient)
+constexpr int S_AC = 31;    // 1: abar_8 contribution of the colour head
+constexpr int NSLOT_BWD = 32;
 
 // small-gradient buffer (floats)
 constexpr int DS_W0 = 0;       // [128][3]
@@ -47,8 +49,13 @@ constexpr int DS_WRGB = 2052;  // [3][128]
 constexpr int DS_BRGB = 2436;  // [3] (+1 pad)
 constexpr int DS_TOTAL = 2440;
 
-constexpr int L_RACC = L_WBUF + 65536;  // per-workgroup reduction scratch: [8][128] floats
-constexpr int L_TOTAL_BWD = L_RACC + 8 * C * 4;
+// LDS of the sweep kernel: FiLM rows (slot 0) | small tables | image slot 0 | image slot 1 | reduction rows | FiLM slot 1.
+// One workgroup (4 waves, one per SIMD, 512 registers each) per CU: the next layer's image and FiLM rows are requested
+// while the current layer computes, so a layer boundary costs a barrier and not an LDS-DMA round trip + the drain of
+// every scratch store in flight.
+constexpr int L_RACC = L_WBUF + 2 * 65536;  // per-workgroup reduction scratch: [8][128] floats
+constexpr int L_FILM2 = L_RACC + 8 * C * 4;
+constexpr int L_TOTAL_BWD = L_FILM2 + 1536;
 
 // Cache policy per slot family (aux operand of the buffer instructions; measured in oi_common.h's table):
 //   LOCAL  slots are re-read later in THIS kernel (phi, g, cbar, the colour-head pair),
@@ -104,14 +111,62 @@ __device__ __forceinline__ void dma_sync() {
   __syncthreads();
 }
 
+// One layer product of the backward sweeps: acc = W_img . v with only ONE k-step of A fragments (4 output blocks x hi / lo
+// limb = 32 VGPRs) live at a time -- two 64-register point vectors and the accumulators are live around every product of
+// these sweeps, and two waves share a SIMD (256 registers each); the co-resident wave covers the LDS latency.
+template <int PREC>
+__device__ __forceinline__ void gemm_lean(const char* lds, const LaneOff& o, const float (&v)[64], f32x16 (&acc)[4]) {
+  if constexpr (PREC == OI_PREC_F16X3) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      f16x8 bh, bl;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float x = v[8 * s + i];
+        bh[i] = (_Float16)x;
+        bl[i] = (_Float16)(x - (float)bh[i]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f16x8 wh = __builtin_bit_cast(f16x8, lds_f4(lds, L_WBUF + (t * 8 + s) * 1024, o.l16));
+        const f16x8 wl = __builtin_bit_cast(f16x8, lds_f4(lds, L_WBUF + (t * 8 + s) * 1024, o.l16hi));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, acc[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    gemm_layer<PREC>(lds, o, v, acc);
+  }
+}
+// acc = W_img . v (accumulators come in zeroed or holding the bias); returns the factor the accumulators still carry:
+// 1 for the unscaled images, 2^-k_m (x 1 / normalisation of v, which is scaled in place) for F16X3
+template <int PREC, bool NORM>
+__device__ __forceinline__ float gemm2(const char* lds, const LaneOff& o, float (&v)[64], f32x16 (&acc)[4], float inv_img) {
+  float f = 1.f;
+  if constexpr (PREC == OI_PREC_F16X3) {
+    f = inv_img;
+    if constexpr (NORM) f *= pow2_normalise(v);
+  }
+  gemm_lean<PREC>(lds, o, v, acc);
+  return f;
+}
+
+// OI_BWD_WAVES_PER_SIMD = 1: one workgroup per CU with the whole 512-entry register file per wave (two 64-register point
+// vectors, the accumulators and a full layer of prefetched phi / vbar fragments are live at once; with 256 registers hipcc
+// spilled ~370 of them: same-box A/B 4.86 -> 4.29 ms before the double-buffered staging below)
+#ifndef OI_BWD_WAVES_PER_SIMD
+#define OI_BWD_WAVES_PER_SIMD 1
+#endif
 template <int PREC, bool FAST>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, OI_BWD_WAVES_PER_SIMD)
 mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ packed, const float* __restrict__ gamma,
                      const float* __restrict__ beta, const float* __restrict__ grad_fwd,
-                     const float* __restrict__ rgb_fwd, const float* __restrict__ g_sdf,
-                     const float* __restrict__ g_grad, const float* __restrict__ g_rgb, float* __restrict__ d_small,
-                     float* __restrict__ d_gamma, float* __restrict__ d_beta, char* __restrict__ scratch,
-                     long long n_per_elem) {
+                     const float* __restrict__ rgb_fwd, const float* __restrict__ feat_fwd,
+                     const float* __restrict__ g_sdf, const float* __restrict__ g_grad,
+                     const float* __restrict__ g_rgb, float* __restrict__ d_small, float* __restrict__ d_gamma,
+                     float* __restrict__ d_beta, char* __restrict__ scratch, long long n_per_elem) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,7 +174,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   const int e = blockIdx.y;
   const float* hdr = reinterpret_cast<const float*>(packed);
   const char* mats = packed + H_BYTES;
-  const bool has_col = rgb_fwd != nullptr && g_rgb != nullptr;
+  const bool has_col = rgb_fwd != nullptr && g_rgb != nullptr && feat_fwd != nullptr;
 
   LaneOff o;
   o.h16 = 16 * h;
@@ -132,6 +187,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   const bool valid = local < n_per_elem;
   const long long pt = (long long)e * n_per_elem + (valid ? local : n_per_elem - 1);
   const float vmask = valid ? 1.f : 0.f;  // tail points contribute nothing
+  const __amdgpu_buffer_rsrc_t img_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mats), 0, NMAT * layer_bytes(PREC), 0x00020000);
 
   WaveScratchB ws;
   {
@@ -139,10 +196,20 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     ws.rs = __builtin_amdgcn_make_buffer_rsrc(scratch + wt * (long long)(NSLOT_BWD * 16384), 0, NSLOT_BWD * 16384,
                                               0x00020000);
   }
+  // image slot ws_ (0 / 1) and FiLM slot fs_ (0 / 1) as lane bases: every LDS access stays <per-lane VGPR> + immediate
+  auto layer_off = [&](int ws_, int fs_) {
+    LaneOff r = o;
+    r.l16 += ws_ * 65536;
+    r.l16hi += ws_ * 65536;
+    r.h16 += fs_ * (L_FILM2 - L_FILM);
+    return r;
+  };
+  auto stage_img = [&](int image, int ws_) { stage_layer_rs<PREC>(lds + ws_ * 65536, img_rs, image, wave, o.l16); };
+  auto stage_flm = [&](int l_, int fs_) { stage_film(lds + fs_ * (L_FILM2 - L_FILM), gamma, beta, hdr, e, l_, tid); };
   {
     float* tabs = reinterpret_cast<float*>(lds + L_TABS);
     for (int i = tid; i < H_TABS_END; i += 256) tabs[i] = hdr[i];
-    stage_film(lds, gamma, beta, hdr, e, 0, tid);
+    stage_flm(0, 0);
     racc_zero(lds, tid);
   }
   const float px = pts[pt * 3 + 0], py = pts[pt * 3 + 1], pz = pts[pt * 3 + 2];
@@ -151,65 +218,24 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         Gz = (g_grad ? g_grad[pt * 3 + 2] : 0.f) * vmask;
   __syncthreads();
 
-  float act[64];
+  float act[64];  // up sweep: a_l;     down sweep: abar_{l+1} -> ubar_l -> abar_l
+  float gb[64];   // up sweep: gbar_l -> vbar_l -> gbar_{l+1};   down sweep: g_{l+1} -> v_l -> g_l
   f32x16 acc[4];
-  const float* film = reinterpret_cast<const float*>(lds + L_FILM);
-  // F16X3: the images carry a power-of-two scale 2^k_m (header H_WSCALE holds 2^-k_m); every GEMM returns the factor
-  // its accumulators still need (gemm_scaled), adjoint vectors are normalised per point before the fp16 split.
+  // F16X3: the images carry a power-of-two scale 2^k_m (header H_WSCALE holds 2^-k_m); every product returns the factor
+  // its accumulators still need (gemm2), adjoint vectors are normalised per point before the fp16 split.
   constexpr bool SC = PREC == OI_PREC_F16X3;
 
-  // ================= phase A: recompute phi_l (ascending) =================
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
-    const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
-    const f32x4 bs = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
-    f32x4 ph;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const f32x4 w = lds_f4(lds, L_TABS + H_TAB0 * 4 + (grp_f0(g) + k) * 16, o.h64);
-      const float u = fmaf(pz, w[2], fmaf(py, w[1], px * w[0])) + bs[k];
-      ph[k] = fmaf(gm[k], u, bt[k]);
-      float s, c;
-      sincos_<FAST>(ph[k], s, c);
-      act[4 * g + k] = s;
-    }
-    ws.store(S_PHI + 0, g, o.l16, ph);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  for (int l = 1; l < NL_SDF; ++l) {
-    __syncthreads();
-    stage_layer_dma<PREC>(lds, mats + (size_t)(l - 1) * layer_bytes(PREC), wave, lane);
-    stage_film(lds, gamma, beta, hdr, e, l, tid);
-    dma_sync();
-    if constexpr (SC) acc_zero(acc); else init_bias(lds, o, acc);
-    const float fA = gemm_scaled<PREC, false>(lds, o, act, acc, SC ? hdr[H_WSCALE + l - 1] : 1.f);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
-      const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
-      f32x4 bs;
-      if constexpr (SC) bs = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
-      f32x4 ph;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float u = SC ? fmaf(acc[g >> 2][4 * (g & 3) + k], fA, bs[k]) : acc[g >> 2][4 * (g & 3) + k];
-        ph[k] = fmaf(gm[k], u, bt[k]);
-        float s, c;
-        sincos_<FAST>(ph[k], s, c);
-        act[4 * g + k] = s;
-      }
-      ws.store(S_PHI + l, g, o.l16, ph);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  // act = a_8 (features)
-
-  // ================= colour head backward =================
+  // ================= colour head backward (first: its dL/dgrad term is part of gbar_0) =================
   if (has_col) {
     __syncthreads();
-    stage_layer_dma<PREC>(lds, mats + (size_t)14 * layer_bytes(PREC), wave, lane);
-    stage_film(lds, gamma, beta, hdr, e, 8, tid);
+    stage_img(14, 0);
+    stage_flm(8, 0);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {  // a_8, as the forward wrote it (feat output): features grp_f0(g) + 4 h .. + 3
+      const f32x4 v = *reinterpret_cast<const f32x4*>(feat_fwd + pt * C + grp_f0(g) + 4 * h);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) act[4 * g + k] = v[k];
+    }
     dma_sync();
     const float fx = grad_fwd[pt * 3 + 0], fy = grad_fwd[pt * 3 + 1], fz = grad_fwd[pt * 3 + 2];
     float rho[3];
@@ -219,8 +245,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       rho[k] = g_rgb[pt * 3 + k] * rv * (1.0f - rv) * vmask;  // through the sigmoid
     }
     if constexpr (SC) acc_zero(acc); else init_bias(lds, o, acc);
-    const float fV = gemm_scaled<PREC, false>(lds, o, act, acc, SC ? hdr[H_WSCALE + 14] : 1.f);
-    // uv -> phiv -> hv; then uvbar.  Reductions: rows 0 gamma_v, 1 beta_v, 2 bv, 3..5 Wrgb, (6,7 free)
+    const float fV = gemm2<PREC, false>(lds, o, act, acc, SC ? hdr[H_WSCALE + 14] : 1.f);
+    // uv -> phiv -> hv; then uvbar.  Reductions: rows 0 gamma_v, 1 beta_v, 2 bv, 3..5 Wrgb, 6..7 dWv[:, 128 + (0, 1)]
     float dGx = 0.f, dGy = 0.f, dGz = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -258,16 +284,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       reduce_group(lds, 3, g, h, j, r0);
       reduce_group(lds, 4, g, h, j, r1);
       reduce_group(lds, 5, g, h, j, r2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // dWv[:, 128+t] = sum_p uvbar * grad_t  (rows 6,7 then a second round for the third column)
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      f32x4 uvb;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) uvb[k] = act[4 * g + k];
       reduce_group(lds, 6, g, h, j, uvb * fx);
       reduce_group(lds, 7, g, h, j, uvb * fy);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // contribution to dL/dgrad through the colour-head input
     dGx += __shfl_xor(dGx, 32, 64);
@@ -296,7 +315,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     __syncthreads();
     racc_zero(lds, tid);
     // abar_8 from the colour head: Wv[:, :128]^T uvbar   (transposed colour image, matrix 15)
-    stage_layer_dma<PREC>(lds, mats + (size_t)15 * layer_bytes(PREC), wave, lane);
+    stage_img(15, 0);
     dma_sync();
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -306,7 +325,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       reduce_group(lds, 0, g, h, j, uvb * fz);
     }
     acc_zero(acc);
-    const float fT = gemm_scaled<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + 15] : 1.f);
+    const float fT = gemm2<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + 15] : 1.f);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       f32x4 v;
@@ -318,157 +337,90 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     racc_flush_row(lds, 0, d_small + DS_WVX + 2, 3, tid);
     __syncthreads();
     racc_zero(lds, tid);
-  }
-
-  // ================= phase B: reverse sweep g_{l+1}, v_l (descending) =================
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const f32x4 w = lds_f4(lds, L_TABS + (H_SIG + grp_f0(g)) * 4, o.h16);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) act[4 * g + k] = w[k];
-  }
-  for (int l = NL_SDF - 1; l >= 1; --l) {
-    // the layer's phi fragments are requested before the image is staged: their HBM latency overlaps the staging and
-    // the two barriers instead of being paid once per group of four features (the sweep is latency-, not math-bound)
-    f32x4 phv[16];
-#pragma unroll
-    for (int g = 0; g < 16; ++g) phv[g] = ws.load<OI_BWD_LD_EARLY>(S_PHI + l, g, o.l16);
+    stage_flm(0, 0);
     __syncthreads();
-    stage_layer_dma<PREC>(lds, mats + (size_t)(7 + l - 1) * layer_bytes(PREC), wave, lane);
-    stage_film(lds, gamma, beta, hdr, e, l, tid);
-    dma_sync();
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const f32x4 ph = phv[g];
-      const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
-      f32x4 gsv, vv;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float s, c;
-        sincos_<FAST>(ph[k], s, c);
-        gsv[k] = act[4 * g + k];
-        vv[k] = gsv[k] * gm[k] * c;
-        act[4 * g + k] = vv[k];
-      }
-      if (l < NL_SDF - 1) ws.store(S_G + l, g, o.l16, gsv);  // g_{l+1}; g_8 is the constant w_sigma
-      ws.store<OI_BWD_ST_WGRAD>(S_V + l - 1, g, o.l16, vv);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    acc_zero(acc);
-    const float fB = gemm_scaled<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + 7 + l - 1] : 1.f);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) act[16 * t + r] = SC ? acc[t][r] * fB : acc[t][r];
-  }
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {  // g_1
-    f32x4 v;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = act[4 * g + k];
-    ws.store(S_G + 0, g, o.l16, v);
   }
 
-  // ================= phase C: gbar sweep (ascending) =================
-  // layer 0: vbar_0 = W0 gbar_0 (gbar_0 = dL/dgrad, 3-vector); reductions rows 0..2: dW0 += v_0 gbar_0^T
-  __syncthreads();
-  stage_film(lds, gamma, beta, hdr, e, 0, tid);
-  __syncthreads();
+  // ================= up sweep: recompute phi_l, carry gbar_l =================
+  // FiLM rows of layer l live in FiLM slot l & 1, layer l's forward image in image slot (l - 1) & 1: both are requested one
+  // layer ahead
+  stage_img(0, 0);
+  stage_flm(1, 1);
+  // layer 0 on the VALU: phi_0; vbar_0 = W0 gbar_0 (gbar_0 = dL/dgrad, a 3-vector); gbar_1 = vbar_0 c_0
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
-    const f32x4 ph = ws.load<OI_BWD_LD_EARLY>(S_PHI + 0, g, o.l16);
-    const f32x4 g1 = ws.load(S_G + 0, g, o.l16);
     const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
-    f32x4 cb, v0;
+    const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
+    const f32x4 bs = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
+    f32x4 ph, vb;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const f32x4 w = lds_f4(lds, L_TABS + H_TAB0 * 4 + (grp_f0(g) + k) * 16, o.h64);
+      const float u = fmaf(pz, w[2], fmaf(py, w[1], px * w[0])) + bs[k];
+      ph[k] = fmaf(gm[k], u, bt[k]);
       float s, c;
       sincos_<FAST>(ph[k], s, c);
-      const float cl = gm[k] * c;
-      const float vb = fmaf(Gz, w[2], fmaf(Gy, w[1], Gx * w[0]));  // vbar_0
-      act[4 * g + k] = vb * cl;                                   // gbar_1
-      cb[k] = vb * g1[k];                                         // cbar_0
-      v0[k] = g1[k] * cl;                                         // v_0
+      act[4 * g + k] = s;
+      vb[k] = fmaf(Gz, w[2], fmaf(Gy, w[1], Gx * w[0]));
+      gb[4 * g + k] = vb[k] * gm[k] * c;
     }
-    ws.store(S_CB + 0, g, o.l16, cb);
-    reduce_group(lds, 0, g, h, j, v0 * Gx);
-    reduce_group(lds, 1, g, h, j, v0 * Gy);
-    reduce_group(lds, 2, g, h, j, v0 * Gz);
+    ws.store(S_PHI + 0, g, o.l16, ph);
+    ws.store(S_VB + 0, g, o.l16, vb);
     __builtin_amdgcn_sched_barrier(0);
   }
-  __syncthreads();
-  racc_flush_row(lds, 0, d_small + DS_W0 + 0, 3, tid);
-  racc_flush_row(lds, 1, d_small + DS_W0 + 1, 3, tid);
-  racc_flush_row(lds, 2, d_small + DS_W0 + 2, 3, tid);
   for (int l = 1; l < NL_SDF; ++l) {
-    __syncthreads();
-    if (l == 1) racc_zero(lds, tid);
-    stage_layer_dma<PREC>(lds, mats + (size_t)(l - 1) * layer_bytes(PREC), wave, lane);
-    stage_film(lds, gamma, beta, hdr, e, l, tid);
-    dma_sync();
+    dma_sync();  // layer l's image and FiLM rows have landed; every wave is done with layer l - 1
+    if (l < NL_SDF - 1) {
+      stage_img(l, l & 1);
+      stage_flm(l + 1, (l + 1) & 1);
+    } else {
+      stage_img(13, 1);  // the down sweep starts with the transposed image of layer 7 (FiLM rows 7 are resident)
+    }
+    const LaneOff ol = layer_off((l - 1) & 1, l & 1);
+    const float inv_img = SC ? hdr[H_WSCALE + l - 1] : 1.f;
+    // vbar_l = W_l gbar_l
+    acc_zero(acc);
+    const float fA = gemm2<PREC, true>(lds, ol, gb, acc, inv_img);
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {  // park gbar_l for the weight-gradient GEMM
+    for (int g = 0; g < 16; ++g) {
       f32x4 v;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = act[4 * g + k];
-      ws.store<OI_BWD_ST_WGRAD>(S_GB + l - 1, g, o.l16, v);
+      for (int k = 0; k < 4; ++k) {
+        v[k] = SC ? acc[g >> 2][4 * (g & 3) + k] * fA : acc[g >> 2][4 * (g & 3) + k];
+        gb[4 * g + k] = v[k];
+      }
+      ws.store(S_VB + l, g, o.l16, v);
     }
-    acc_zero(acc);
-    const float fC = gemm_scaled<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + l - 1] : 1.f);  // vbar_l = W_l gbar_l
-    f32x4 phc[16], gnc[16];
+    // u_l = W_l a_l + b_l -> phi_l, a_{l+1};  gbar_{l+1} = vbar_l gamma_l cos phi_l
+    if constexpr (SC) acc_zero(acc); else init_bias(lds, ol, acc);
+    const float fB = gemm2<PREC, false>(lds, ol, act, acc, inv_img);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      phc[g] = ws.load<OI_BWD_LD_EARLY>(S_PHI + l, g, o.l16);
-      if (l < NL_SDF - 1) gnc[g] = ws.load(S_G + l, g, o.l16);
-    }
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const f32x4 ph = phc[g];
-      const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
-      f32x4 gn;
-      if (l < NL_SDF - 1) gn = gnc[g];
-      else gn = lds_f4(lds, L_TABS + (H_SIG + grp_f0(g)) * 4, o.h16);
-      f32x4 cb;
+      const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, ol.h16);
+      const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, ol.h16);
+      f32x4 bs;
+      if constexpr (SC) bs = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, ol.h16);
+      f32x4 ph;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
+        const float u = SC ? fmaf(acc[g >> 2][4 * (g & 3) + k], fB, bs[k]) : acc[g >> 2][4 * (g & 3) + k];
+        ph[k] = fmaf(gm[k], u, bt[k]);
         float s, c;
         sincos_<FAST>(ph[k], s, c);
-        const float vb = SC ? acc[g >> 2][4 * (g & 3) + k] * fC : acc[g >> 2][4 * (g & 3) + k];
-        act[4 * g + k] = vb * gm[k] * c;  // gbar_{l+1}
-        cb[k] = vb * gn[k];               // cbar_l
+        act[4 * g + k] = s;
+        gb[4 * g + k] *= gm[k] * c;
       }
-      ws.store(S_CB + l, g, o.l16, cb);
+      ws.store(S_PHI + l, g, o.l16, ph);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  // d w_sigma += sum_p gbar_8   (row 3)
+  // d w_sigma = sum_p (gbar_8 + gs a_8)  (row 3);  d b_sigma = sum_p gs
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     f32x4 v;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = act[4 * g + k];
+    for (int k = 0; k < 4; ++k) v[k] = fmaf(gs, act[4 * g + k], gb[4 * g + k]);
     reduce_group(lds, 3, g, h, j, v);
-  }
-
-  // ================= phase D: abar sweep (descending) =================
-  // abar_8 = gs * w_sigma (+ colour head); also d w_sigma += gs * a_8 (row 3), d b_sigma += gs
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const f32x4 w = lds_f4(lds, L_TABS + (H_SIG + grp_f0(g)) * 4, o.h16);
-    const f32x4 ph = ws.load(S_PHI + 7, g, o.l16);
-    f32x4 ac = {0.f, 0.f, 0.f, 0.f};
-    if (has_col) ac = ws.load(S_AC, g, o.l16);
-    f32x4 a8;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float s, c;
-      sincos_<FAST>(ph[k], s, c);
-      a8[k] = s * gs;
-      act[4 * g + k] = fmaf(gs, w[k], ac[k]);
-    }
-    reduce_group(lds, 3, g, h, j, a8);
-    __builtin_amdgcn_sched_barrier(0);
   }
   {
     float b = (h == 0) ? gs : 0.f;
@@ -477,55 +429,92 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   }
   __syncthreads();
   racc_flush_row(lds, 3, d_small + DS_WSIG, 1, tid);
+
+  // ================= down sweep: g_l and abar_l together =================
+  // g_8 = w_sigma;  abar_8 = gs * w_sigma (+ the colour head's contribution)
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const f32x4 w = lds_f4(lds, L_TABS + (H_SIG + grp_f0(g)) * 4, o.h16);
+    f32x4 ac = {0.f, 0.f, 0.f, 0.f};
+    if (has_col) ac = ws.load(S_AC, g, o.l16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gb[4 * g + k] = w[k];
+      act[4 * g + k] = fmaf(gs, w[k], ac[k]);
+    }
+  }
+  // the transposed image of layer l sits in image slot l & 1, its FiLM rows in FiLM slot l & 1; phi_l / vbar_l of the WHOLE
+  // layer are requested one layer ahead (128 registers: the reason this kernel runs one wave per SIMD)
+  f32x4 phn[16], vbn[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    phn[g] = ws.load(S_PHI + 7, g, o.l16);
+    vbn[g] = ws.load(S_VB + 7, g, o.l16);
+  }
   for (int l = NL_SDF - 1; l >= 0; --l) {
-    f32x4 phd[16];
-#pragma unroll
-    for (int g = 0; g < 16; ++g) phd[g] = ws.load(S_PHI + l, g, o.l16);
-    __syncthreads();
+    dma_sync();  // layer l's transposed image and FiLM rows have landed; the previous layer's row flush is complete
     racc_zero(lds, tid);
-    if (l >= 1) stage_layer_dma<PREC>(lds, mats + (size_t)(7 + l - 1) * layer_bytes(PREC), wave, lane);
-    stage_film(lds, gamma, beta, hdr, e, l, tid);
-    f32x4 cbv[16];
-#pragma unroll
-    for (int g = 0; g < 16; ++g) cbv[g] = ws.load(S_CB + l, g, o.l16);
-    dma_sync();
+    if (l >= 2) stage_img(7 + l - 2, (l - 1) & 1);
+    if (l >= 1) stage_flm(l - 1, (l - 1) & 1);
+    const LaneOff ol = layer_off(l & 1, l & 1);
+    __syncthreads();  // reduction rows zeroed
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const f32x4 ph = phd[g];
-      const f32x4 cb = cbv[g];
-      const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
-      const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
-      f32x4 r_g, r_b, ub;
+      {
+        const f32x4 ph = phn[g], vb = vbn[g];
+        const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, ol.h16);
+        const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, ol.h16);
+        f32x4 r_g, r_b, ub, vv;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float s, c;
-        sincos_<FAST>(ph[k], s, c);
-        const float phb = act[4 * g + k] * c - cb[k] * gm[k] * s;   // phibar_l
-        const float u = (ph[k] - bt[k]) * __builtin_amdgcn_rcpf(gm[k]);  // u_l
-        r_g[k] = fmaf(phb, u, cb[k] * c);                           // d gamma_l
-        r_b[k] = phb;                                               // d beta_l
-        ub[k] = phb * gm[k];                                        // ubar_l
-        act[4 * g + k] = ub[k];
+        for (int k = 0; k < 4; ++k) {
+          float s, c;
+          sincos_<FAST>(ph[k], s, c);
+          const float gn = gb[4 * g + k];                              // g_{l+1}
+          const float cb = vb[k] * gn;                                 // cbar_l
+          vv[k] = gn * gm[k] * c;                                      // v_l
+          const float phb = act[4 * g + k] * c - cb * gm[k] * s;       // phibar_l
+          const float u = (ph[k] - bt[k]) * __builtin_amdgcn_rcpf(gm[k]);  // u_l
+          r_g[k] = fmaf(phb, u, cb * c);                               // d gamma_l
+          r_b[k] = phb;                                                // d beta_l
+          ub[k] = phb * gm[k];                                         // ubar_l
+          gb[4 * g + k] = vv[k];
+          act[4 * g + k] = ub[k];
+        }
+        reduce_group(lds, 0, g, h, j, r_g);
+        reduce_group(lds, 1, g, h, j, r_b);
+        reduce_group(lds, 2, g, h, j, ub);
+        if (l >= 1) {
+          ws.store<OI_BWD_ST_WGRAD>(S_V + l - 1, g, o.l16, vv);
+          ws.store<OI_BWD_ST_WGRAD>(S_U + l - 1, g, o.l16, ub);
+        } else {  // d W0 = sum_p (ubar_0 x^T + v_0 gbar_0^T)
+          reduce_group(lds, 3, g, h, j, ub * px + vv * Gx);
+          reduce_group(lds, 4, g, h, j, ub * py + vv * Gy);
+          reduce_group(lds, 5, g, h, j, ub * pz + vv * Gz);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      reduce_group(lds, 0, g, h, j, r_g);
-      reduce_group(lds, 1, g, h, j, r_b);
-      reduce_group(lds, 2, g, h, j, ub);
-      if (l >= 1) {
-        ws.store<OI_BWD_ST_WGRAD>(S_U + l - 1, g, o.l16, ub);
-      } else {  // d W0 += ubar_0 x^T
-        reduce_group(lds, 3, g, h, j, ub * px);
-        reduce_group(lds, 4, g, h, j, ub * py);
-        reduce_group(lds, 5, g, h, j, ub * pz);
+    }
+    if (l >= 1) {  // the next layer's fragments travel while this layer's two products run
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        phn[g] = ws.load(S_PHI + l - 1, g, o.l16);
+        vbn[g] = ws.load(S_VB + l - 1, g, o.l16);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
     if (l >= 1) {
+      const float inv_t = SC ? hdr[H_WSCALE + 7 + l - 1] : 1.f;
       acc_zero(acc);
-      const float fD = gemm_scaled<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + 7 + l - 1] : 1.f);  // abar_l = W_l^T ubar_l
+      const float f1 = gemm2<PREC, true>(lds, ol, gb, acc, inv_t);   // g_l = W_l^T v_l
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) act[16 * t + r] = SC ? acc[t][r] * fD : acc[t][r];
+        for (int r = 0; r < 16; ++r) gb[16 * t + r] = SC ? acc[t][r] * f1 : acc[t][r];
+      acc_zero(acc);
+      const float f2 = gemm2<PREC, true>(lds, ol, act, acc, inv_t);  // abar_l = W_l^T ubar_l
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) act[16 * t + r] = SC ? acc[t][r] * f2 : acc[t][r];
     }
     __syncthreads();
     racc_flush_row(lds, 0, d_gamma + ((size_t)e * 9 + l) * C, 1, tid);
@@ -542,7 +531,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 // ------------------------------------------------------------------------------------------
 // weight-gradient GEMM:  dW_m[o][i] += sum_p X[o][p] Y[i][p]  (K = points), fp32 MFMA, split over
 // chunks of wave tiles; one workgroup = one (matrix, chunk), wave w owns output rows 32w..32w+31.
-//   matrices m = 0..6  (layer l = m+1):  X1 = v_l, Y1 = gbar_l;  X2 = ubar_l, Y2 = a_l = sin(phi_{l-1})
+//   matrices m = 0..6  (layer l = m+1):  X1 = v_l, Y1 = gbar_l = vbar_{l-1} gamma_{l-1} cos(phi_{l-1});
+//                                        X2 = ubar_l, Y2 = a_l = sin(phi_{l-1})      (both Y from the same parked phi)
 //   matrix   m = 7     (colour head):     X  = uvbar,            Y  = a_8 = sin(phi_7)
 // Operands are read from the sweep kernel's scratch slots (C-fragment order) and transposed via LDS.
 // ------------------------------------------------------------------------------------------
@@ -558,8 +548,8 @@ constexpr int WG_SLOT_FLOATS = 4096 + 8 * 32;
 
 template <bool FAST>
 __global__ void __launch_bounds__(256)
-mlp_wgrad_kernel(const char* __restrict__ scratch, float* __restrict__ d_wmat, long long n_wave_tiles,
-                 int tiles_per_chunk, int has_col) {
+mlp_wgrad_kernel(const char* __restrict__ scratch, const float* __restrict__ gamma, float* __restrict__ d_wmat,
+                 long long n_wave_tiles, long long wt_per_elem, int tiles_per_chunk, int has_col) {
   __shared__ __attribute__((aligned(16))) float sx[WG_SLOT_FLOATS], sy[WG_SLOT_FLOATS];
   const int m = blockIdx.y;
   if (m == 7 && !has_col) return;
@@ -577,13 +567,15 @@ mlp_wgrad_kernel(const char* __restrict__ scratch, float* __restrict__ d_wmat, l
     const char* base = scratch + wt * (long long)(NSLOT_BWD * 16384);
     for (int pr = 0; pr < npair; ++pr) {
       int sxi, syi;
-      bool y_is_phi;
-      if (m == 7) { sxi = S_UV; syi = S_PHI + 7; y_is_phi = true; }
-      else if (pr == 0) { sxi = S_V + m; syi = S_GB + m; y_is_phi = false; }
-      else { sxi = S_U + m; syi = S_PHI + m; y_is_phi = true; }  // a_l = sin(phi_{l-1}), l = m+1
+      bool y_is_gbar;  // pair 0 of a layer matrix: Y = gbar_l, re-formed from vbar_{l-1} and phi_{l-1}
+      if (m == 7) { sxi = S_UV; syi = S_PHI + 7; y_is_gbar = false; }
+      else if (pr == 0) { sxi = S_V + m; syi = S_PHI + m; y_is_gbar = true; }
+      else { sxi = S_U + m; syi = S_PHI + m; y_is_gbar = false; }  // a_l = sin(phi_{l-1}), l = m+1
       __syncthreads();
       const f32x4* gx4 = reinterpret_cast<const f32x4*>(base + (size_t)sxi * 16384);
       const f32x4* gy4 = reinterpret_cast<const f32x4*>(base + (size_t)syi * 16384);
+      const f32x4* gv4 = reinterpret_cast<const f32x4*>(base + (size_t)(S_VB + (m < 7 ? m : 0)) * 16384);
+      const float* grow = gamma + ((wt / wt_per_elem) * 9 + (m < 7 ? m : 0)) * C;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         // f32x4 number q = it*256 + tid of the slot: 32-point block q >> 5 = ((4t + rr) * 2 + hh)
@@ -591,13 +583,16 @@ mlp_wgrad_kernel(const char* __restrict__ scratch, float* __restrict__ d_wmat, l
         const int dq = q + 2 * (q >> 5);  // + 8 floats per 32-point block
         reinterpret_cast<f32x4*>(sx)[dq] = gx4[q];
         f32x4 y = gy4[q];
-        if (y_is_phi) {
+        f32x4 vb = {0.f, 0.f, 0.f, 0.f}, gm = {0.f, 0.f, 0.f, 0.f};
+        if (y_is_gbar) {
+          vb = gv4[q];
+          gm = *reinterpret_cast<const f32x4*>(grow + grp_f0(q >> 6) + 4 * ((q >> 5) & 1));
+        }
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            float s, c;
-            sincos_<FAST>(y[k], s, c);
-            y[k] = s;
-          }
+        for (int k = 0; k < 4; ++k) {
+          float s, c;
+          sincos_<FAST>(y[k], s, c);
+          y[k] = y_is_gbar ? vb[k] * gm[k] * c : s;
         }
         reinterpret_cast<f32x4*>(sy)[dq] = y;
       }
@@ -658,8 +653,8 @@ __device__ __forceinline__ void frag16(const float* sl, int f, int p0, float sc,
 
 template <bool FAST>
 __global__ void __launch_bounds__(256)
-mlp_wgrad_f16_kernel(const char* __restrict__ scratch, float* __restrict__ d_wmat, long long n_wave_tiles,
-                     int tiles_per_chunk, int has_col) {
+mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__ gamma, float* __restrict__ d_wmat,
+                     long long n_wave_tiles, long long wt_per_elem, int tiles_per_chunk, int has_col) {
   __shared__ __attribute__((aligned(16))) float sx[WG16_SLOT_FLOATS], sy[WG16_SLOT_FLOATS];
   __shared__ __attribute__((aligned(16))) f16x8 sb[2][4][2][64];  // [hi|lo][column tile][k-step][lane]
   __shared__ float smax[2][4];
@@ -675,31 +670,52 @@ mlp_wgrad_f16_kernel(const char* __restrict__ scratch, float* __restrict__ d_wma
   const int fo = 32 * wave + i;
   for (long long wt = t_begin; wt < t_end; ++wt) {
     const char* base = scratch + wt * (long long)(NSLOT_BWD * 16384);
+    // both Y operands of a layer matrix come from the SAME parked phi_{l-1}: one read, one sin / cos per element
+    //   pair 0: Y = gbar_l = vbar_{l-1} gamma_{l-1} cos(phi_{l-1})      pair 1: Y = a_l = sin(phi_{l-1})
+    const f32x4* gp4 = reinterpret_cast<const f32x4*>(base + (size_t)(S_PHI + m) * 16384);
+    const f32x4* gv4 = reinterpret_cast<const f32x4*>(base + (size_t)(S_VB + (m < 7 ? m : 0)) * 16384);
+    const float* grow = gamma + ((wt / wt_per_elem) * 9 + (m < 7 ? m : 0)) * C;
+    // every load of the tile is issued before any of it is used: ONE memory round trip per tile (the kernel is a chain of
+    // dependent round trips otherwise -- one per operand pair plus one for phi -- and latency-, not bandwidth-bound)
+    const f32x4* gx0 = reinterpret_cast<const f32x4*>(base + (size_t)(m == 7 ? S_UV : S_V + m) * 16384);
+    const f32x4* gx1 = reinterpret_cast<const f32x4*>(base + (size_t)(S_U + (m < 7 ? m : 0)) * 16384);
+    f32x4 ysin[4], ygb[4], xall[2][4], ph4[4], vb4[4], gm4[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = it * 256 + tid;
+      ph4[it] = gp4[q];
+      xall[0][it] = gx0[q];
+      vb4[it] = gm4[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      xall[1][it] = xall[0][it];
+      if (m < 7) {
+        vb4[it] = gv4[q];
+        gm4[it] = *reinterpret_cast<const f32x4*>(grow + grp_f0(q >> 6) + 4 * ((q >> 5) & 1));
+        xall[1][it] = gx1[q];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float sn, cs;
+        sincos_<FAST>(ph4[it][k], sn, cs);
+        ysin[it][k] = sn;
+        ygb[it][k] = vb4[it][k] * gm4[it][k] * cs;
+      }
+    }
     for (int pr = 0; pr < npair; ++pr) {
-      int sxi, syi;
-      bool y_is_phi;
-      if (m == 7) { sxi = S_UV; syi = S_PHI + 7; y_is_phi = true; }
-      else if (pr == 0) { sxi = S_V + m; syi = S_GB + m; y_is_phi = false; }
-      else { sxi = S_U + m; syi = S_PHI + m; y_is_phi = true; }
-      const f32x4* gx4 = reinterpret_cast<const f32x4*>(base + (size_t)sxi * 16384);
-      const f32x4* gy4 = reinterpret_cast<const f32x4*>(base + (size_t)syi * 16384);
+      const bool y_is_gbar = (m < 7) && pr == 0;
       f32x4 xv[4], yv[4];
       float mx = 0.f, my = 0.f;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int q = it * 256 + tid;
-        xv[it] = gx4[q];
-        yv[it] = gy4[q];
+        xv[it] = xall[pr][it];
+        yv[it] = y_is_gbar ? ygb[it] : ysin[it];
       }
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          if (y_is_phi) {
-            float sn, cs;
-            sincos_<FAST>(yv[it][k], sn, cs);
-            yv[it][k] = sn;
-          }
           mx = fmaxf(mx, fabsf(xv[it][k]));
           my = fmaxf(my, fabsf(yv[it][k]));
         }
@@ -765,25 +781,25 @@ mlp_wgrad_f16_kernel(const char* __restrict__ scratch, float* __restrict__ d_wma
 
 template <int PREC, bool FAST>
 int launch_bwd(const float* pts, const void* packed, const float* gamma, const float* beta, const float* grad_fwd,
-               const float* rgb_fwd, const float* g_sdf, const float* g_grad, const float* g_rgb, float* d_small,
+               const float* rgb_fwd, const float* feat_fwd, const float* g_sdf, const float* g_grad, const float* g_rgb, float* d_small,
                float* d_wmat, float* d_gamma, float* d_beta, void* scratch, int B, long long n, hipStream_t st) {
   dim3 grid(oi::cdiv(n, TILE_PTS), B), block(256);
   auto k = mlp_bwd_sweep_kernel<PREC, FAST>;
   // per launch: the attribute is per device, and a process may drive several
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL_BWD);
   hipLaunchKernelGGL(k, grid, block, L_TOTAL_BWD, st, pts, reinterpret_cast<const char*>(packed), gamma, beta, grad_fwd,
-                     rgb_fwd, g_sdf, g_grad, g_rgb, d_small, d_gamma, d_beta, reinterpret_cast<char*>(scratch), n);
+                     rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, d_gamma, d_beta, reinterpret_cast<char*>(scratch), n);
   int rc = oi::check_launch("oi_sdf_mlp_bwd(sweep)");
   if (rc != OI_OK) return rc;
   const long long n_wt = (long long)B * grid.x * 4;
   int chunk = (int)std::max<long long>(1, (n_wt * 8 + 2047) / 2048);  // ~2048 workgroups in total
   dim3 g2(oi::cdiv(n_wt, chunk), 8);
   if constexpr (PREC == OI_PREC_F16X3) {
-    hipLaunchKernelGGL(mlp_wgrad_f16_kernel<FAST>, g2, block, 0, st, reinterpret_cast<const char*>(scratch), d_wmat,
-                       n_wt, chunk, (rgb_fwd != nullptr && g_rgb != nullptr) ? 1 : 0);
+    hipLaunchKernelGGL(mlp_wgrad_f16_kernel<FAST>, g2, block, 0, st, reinterpret_cast<const char*>(scratch), gamma, d_wmat,
+                       n_wt, (long long)grid.x * 4, chunk, (rgb_fwd != nullptr && g_rgb != nullptr && feat_fwd != nullptr) ? 1 : 0);
   } else {
-    hipLaunchKernelGGL(mlp_wgrad_kernel<FAST>, g2, block, 0, st, reinterpret_cast<const char*>(scratch), d_wmat, n_wt,
-                       chunk, (rgb_fwd != nullptr && g_rgb != nullptr) ? 1 : 0);
+    hipLaunchKernelGGL(mlp_wgrad_kernel<FAST>, g2, block, 0, st, reinterpret_cast<const char*>(scratch), gamma, d_wmat, n_wt,
+                       (long long)grid.x * 4, chunk, (rgb_fwd != nullptr && g_rgb != nullptr && feat_fwd != nullptr) ? 1 : 0);
   }
   return oi::check_launch("oi_sdf_mlp_bwd(wgrad)");
 }
@@ -800,21 +816,22 @@ size_t oi_mlp_bwd_scratch_bytes(int B, long long n_per_elem) {
 int oi_mlp_bwd_small_floats(void) { return DS_TOTAL; }
 
 int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, const float* beta, const float* grad_fwd,
-                   const float* rgb_fwd, const float* g_sdf, const float* g_grad, const float* g_rgb, float* d_small,
+                   const float* rgb_fwd, const float* feat_fwd, const float* g_sdf, const float* g_grad, const float* g_rgb, float* d_small,
                    float* d_wmat, float* d_gamma, float* d_beta, void* scratch, int B, long long n_per_elem, int prec,
                    int fast_trig, oi_stream_t stream) {
   OI_REQUIRE(pts && packed && gamma && beta && d_small && d_wmat && d_gamma && d_beta && scratch,
              "oi_sdf_mlp_bwd: null pointer");
   OI_REQUIRE(B > 0 && n_per_elem > 0, "oi_sdf_mlp_bwd: B=%d n=%lld", B, n_per_elem);
   OI_REQUIRE((rgb_fwd == nullptr) == (g_rgb == nullptr) || g_rgb == nullptr, "oi_sdf_mlp_bwd: g_rgb needs rgb_fwd");
-  OI_REQUIRE(g_rgb == nullptr || grad_fwd != nullptr, "oi_sdf_mlp_bwd: colour backward needs the forward gradient");
+  OI_REQUIRE(g_rgb == nullptr || (grad_fwd != nullptr && feat_fwd != nullptr),
+             "oi_sdf_mlp_bwd: colour backward needs the forward gradient and the forward features");
   OI_REQUIRE(prec != OI_PREC_BF16X6, "oi_sdf_mlp_bwd: pass the OI_PREC_F32 image for the backward of the BF16X6 mode");
   hipStream_t st = oi::as_stream(stream);
 #define OI_BWD_CASE(P)                                                                                              \
   case P:                                                                                                           \
-    return fast_trig ? launch_bwd<P, true>(pts, packed, gamma, beta, grad_fwd, rgb_fwd, g_sdf, g_grad, g_rgb, d_small, \
+    return fast_trig ? launch_bwd<P, true>(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, \
                                            d_wmat, d_gamma, d_beta, scratch, B, n_per_elem, st)                     \
-                     : launch_bwd<P, false>(pts, packed, gamma, beta, grad_fwd, rgb_fwd, g_sdf, g_grad, g_rgb, d_small, \
+                     : launch_bwd<P, false>(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, \
                                             d_wmat, d_gamma, d_beta, scratch, B, n_per_elem, st);
   switch (prec) {
     OI_BWD_CASE(OI_PREC_F32)

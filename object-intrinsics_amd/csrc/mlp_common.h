@@ -81,6 +81,20 @@ __device__ __forceinline__ void stage_layer_dma(char* lds, const char* __restric
   }
 }
 
+// The same LDS-DMA through a buffer descriptor over the 16 images: the image / chunk offset travels in an SGPR and the
+// lane offset (16 * lane) in ONE VGPR.  With flat pointers hipcc keeps a 64-bit address pair per chunk alive across the
+// whole kernel (16 pairs = 32 VGPRs, spilled and reloaded around every layer in the backward sweep).
+template <int PREC>
+__device__ __forceinline__ void stage_layer_rs(char* lds, __amdgpu_buffer_rsrc_t rs, int image, int wave, int l16) {
+  constexpr int NCHUNK = layer_bytes(PREC) / 1024;
+#pragma unroll
+  for (int c0 = 0; c0 < NCHUNK / 4; ++c0) {
+    const int c = c0 * 4 + wave;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + L_WBUF + c * 1024), 16, l16,
+                                             image * layer_bytes(PREC) + c * 1024, 0, 0);
+  }
+}
+
 template <int PREC>
 __device__ __forceinline__ void stage_layer(char* lds, const char* __restrict__ src, int tid) {
   constexpr int N16 = layer_bytes(PREC) / 16;

@@ -22,22 +22,23 @@ class SdfMlpFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pack, pts, gamma, beta, B, want_grad, want_rgb, want_feat, *params):
         packed = pack.packed()
+        # the backward differentiates the albedo head first, from the features (a_8) the forward wrote
         sdf, grad, rgb, feat, _ = ops.sdf_mlp_fwd(pts, packed, gamma, beta, B, pack.prec, pack.fast_trig, want_grad,
-                                                  want_rgb, want_feat)
+                                                  want_rgb, want_feat or want_rgb)
         ctx.pack, ctx.B = pack, B
         # the image of the weights the forward used (parameters may be stepped before backward is called)
         ctx.packed = packed if pack.prec_bwd == pack.prec else pack.packed(for_backward=True)
-        ctx.save_for_backward(pts, gamma, beta, grad, rgb)
+        ctx.save_for_backward(pts, gamma, beta, grad, rgb, feat)
         if feat is not None:
             ctx.mark_non_differentiable(feat)
-        return sdf, grad, rgb, feat
+        return sdf, grad, rgb, (feat if want_feat else None)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_sdf, g_grad, g_rgb, _g_feat):
-        pts, gamma, beta, grad, rgb = ctx.saved_tensors
+        pts, gamma, beta, grad, rgb, feat = ctx.saved_tensors
         pack = ctx.pack
-        d_small, d_wmat, d_gamma, d_beta = ops.sdf_mlp_bwd(pts, ctx.packed, gamma, beta, grad, rgb, g_sdf, g_grad,
+        d_small, d_wmat, d_gamma, d_beta = ops.sdf_mlp_bwd(pts, ctx.packed, gamma, beta, grad, rgb, feat, g_sdf, g_grad,
                                                            g_rgb if rgb is not None else None, ctx.B, pack.prec_bwd,
                                                            pack.fast_trig)
         s = d_small

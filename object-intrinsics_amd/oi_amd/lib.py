@@ -52,7 +52,7 @@ _SIGS = {
     "oi_selftest_cu_slots": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "oi_mlp_bwd_scratch_bytes": (_sz, [_i, _ll]),
     "oi_mlp_bwd_small_floats": (_i, []),
-    "oi_sdf_mlp_bwd": (_i, [_vp] * 14 + [_i, _ll, _i, _i, _vp]),
+    "oi_sdf_mlp_bwd": (_i, [_vp] * 15 + [_i, _ll, _i, _i, _vp]),
     "oi_composite_bwd": (_i, [ctypes.POINTER(CompositeParams), ctypes.POINTER(CompositeGrads), _vp]),
     "oi_render_stats": (_i, [_vp, _i, _ll, _i, _vp, _vp]),
     "oi_composite_num_blocks": (_i, [_ll]),

@@ -119,7 +119,7 @@ def sdf_mlp_fwd(pts, packed, gamma, beta, B, prec, fast_trig=False, want_grad=Fa
     return sdf, grad, rgb, feat, scratch
 
 
-def sdf_mlp_bwd(pts, packed, gamma, beta, grad_fwd, rgb_fwd, g_sdf, g_grad, g_rgb, B, prec, fast_trig=False):
+def sdf_mlp_bwd(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, B, prec, fast_trig=False):
     """-> d_small (flat), d_wmat (8,128,128), d_gamma (B,9,128), d_beta (B,9,128)."""
     L = _l.load()
     pts = _c(pts)
@@ -128,7 +128,7 @@ def sdf_mlp_bwd(pts, packed, gamma, beta, grad_fwd, rgb_fwd, g_sdf, g_grad, g_rg
     d_small, d_wmat, d_gamma, d_beta = _zeros_split(dev, (L.oi_mlp_bwd_small_floats(),), (8, 128, 128), (B, 9, 128),
                                                     (B, 9, 128))
     scratch = torch.empty(L.oi_mlp_bwd_scratch_bytes(B, n), dtype=torch.uint8, device=dev)
-    args = [_c(t) for t in (grad_fwd, rgb_fwd, g_sdf, g_grad, g_rgb)]
+    args = [_c(t) for t in (grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb)]
     _l.check(L.oi_sdf_mlp_bwd(_p(pts), _p(packed), _p(_c(gamma)), _p(_c(beta)), *[_p(a) for a in args], _p(d_small),
                               _p(d_wmat), _p(d_gamma), _p(d_beta), _p(scratch), B, n, prec, int(bool(fast_trig)),
                               _stream()), "oi_sdf_mlp_bwd")
