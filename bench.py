@@ -158,7 +158,7 @@ def bench_training(args, gen, disc, device, world, barrier, distributed, sub_leg
     mods["opt_generator"] = FusedAdam(nets["generator"].parameters(), lr=2e-5, betas=(0.0, 0.9))
     mods["opt_discriminator"] = FusedRMSprop(nets["discriminator"].parameters(), lr=1e-4)
     mods["opt_mask_discriminator"] = FusedRMSprop(nets["mask_discriminator"].parameters(), lr=1e-4)
-    tr = Trainer(mods)
+    tr = Trainer(mods, graph_d_steps=not getattr(args, "eager_d_steps", False))
     data = {"image": torch.rand(B, 3, R, R, device=device), "mask": torch.rand(B, 1, R, R, device=device)}
     for _ in range(2):
         tr.train_step(data)
@@ -206,12 +206,17 @@ def bench_training(args, gen, disc, device, world, barrier, distributed, sub_leg
         fake = g_raw(bs=B, it=tr.it, data={})["box"]
     fake_d = {**fake["render_out"], "c2b": fake["prior_info"]["c2b"]}
     t_dstep = timed(lambda: tr.train_step_discriminator("discriminator", data, fake_d), n_sub)
+    tr_eager = Trainer(mods)
+    tr_eager.it = tr.it
+    t_dstep_eager = timed(lambda: tr_eager.train_step_discriminator("discriminator", data, fake_d), n_sub)
     return {"it_per_s": it_s, "ms_per_it": 1e3 / it_s, "steps": args.train_steps,
             "rays_per_s": 3 * world * B * R * R * it_s, "d_train_images_per_s": 4 * world * B * it_s,
             "render_fwd_bwd": {"ms": 1e3 * t_render, "rays_per_s_per_gpu": B * R * R / t_render,
                                "what": "Generator.forward with gradient + backward (double-backward through d sdf/dx)"},
-            "d_step": {"ms": 1e3 * t_dstep, "images_per_s_per_gpu": 2 * B / t_dstep,
-                       "what": "one ADADiscriminatorView training step: real fwd + R1 double-backward + fake fwd + bwd + RMSprop"},
+            "d_step": {"ms": 1e3 * t_dstep, "images_per_s_per_gpu": 2 * B / t_dstep, "eager_ms": 1e3 * t_dstep_eager,
+                       "what": "one ADADiscriminatorView training step: real fwd + R1 double-backward + fake fwd + bwd + RMSprop"
+                               + (" (forward + backward replayed from one captured hipGraph; eager_ms = the same step "
+                                  "launch by launch)" if not getattr(args, "eager_d_steps", False) else "")},
             "what": "Trainer.train_step: G step (render fwd+bwd incl. double-backward, 2 D fwd+bwd-to-input) + D step "
                     "+ mask-D step (each: real fwd + R1 double-backward + fake fwd + bwd), fused Adam/RMSprop steps"
                     + (", flat-gradient RCCL all-reduce x3" if distributed else ""),
@@ -236,6 +241,7 @@ def main():
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary bf16-mode measurement")
     ap.add_argument("--train-timeout", type=int, default=300, help="watchdog (s) for the secondary training leg")
     ap.add_argument("--no-disc", action="store_true")
+    ap.add_argument("--eager-d-steps", action="store_true", help="training legs: discriminator steps eagerly instead of from captured hipGraphs")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step timed region until this much has been measured")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (C5, D batch sweep, shipped-config training, inference)")
     args = ap.parse_args()

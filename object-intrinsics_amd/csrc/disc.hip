@@ -264,7 +264,7 @@ int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float
   hipStream_t st = oi::as_stream(stream);
   const long long total = (long long)B * Cout * Ho * Wo;
   if (k_splits > 1 && !y_is_zero) {
-    hipError_t e = hipMemsetAsync(y, 0, total * sizeof(float), st);
+    hipError_t e = oi::zero_async(y, total, st);
     if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_fwd: memset: %s", hipGetErrorString(e));
   }
   const long long items = tiles * k_splits;
@@ -312,7 +312,7 @@ int oi_affine_grid_sample_bwd(const float* gy, const float* theta, float* gx, in
   OI_REQUIRE(gy && theta && gx, "oi_affine_grid_sample_bwd: null pointer");
   OI_REQUIRE(B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "oi_affine_grid_sample_bwd: bad shape");
   hipStream_t st = oi::as_stream(stream);
-  hipError_t e = hipMemsetAsync(gx, 0, (size_t)B * C * Hi * Wi * sizeof(float), st);
+  hipError_t e = oi::zero_async(gx, (size_t)B * C * Hi * Wi, st);
   if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_affine_grid_sample_bwd: memset: %s", hipGetErrorString(e));
   const long long n = (long long)B * C * Ho * Wo;
   hipLaunchKernelGGL(affine_grid_sample_bwd_kernel, dim3(oi::cdiv(n, 256)), dim3(256), 0, st, gy, theta, gx, B, C, Hi,
@@ -338,7 +338,7 @@ int oi_reflect_pad_bwd(const float* gy, float* gx, int BC, int H, int W, int px0
   OI_REQUIRE(px0 >= 0 && px1 >= 0 && py0 >= 0 && py1 >= 0 && px0 < W && px1 < W && py0 < H && py1 < H,
              "oi_reflect_pad_bwd: padding must be in [0, size)");
   hipStream_t st = oi::as_stream(stream);
-  hipError_t e = hipMemsetAsync(gx, 0, (size_t)BC * H * W * sizeof(float), st);
+  hipError_t e = oi::zero_async(gx, (size_t)BC * H * W, st);
   if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_reflect_pad_bwd: memset: %s", hipGetErrorString(e));
   const int Ho = H + py0 + py1, Wo = W + px0 + px1;
   const long long n = (long long)BC * Ho * Wo;

@@ -125,4 +125,18 @@ __device__ __forceinline__ void buffer_store_b128(u32x4_t v, __amdgpu_buffer_rsr
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Zero fill as a KERNEL (grid-stride dwords).  The launchers used hipMemsetAsync; captured into a hipGraph (the
+// discriminator step of oi_amd.graphed.GraphedDStep) those memset nodes left split-K / scatter-add outputs partly
+// unfilled on ROCm 7.2 -- replay six of an otherwise bit-identical step summed onto stale memory and overflowed.  A kernel
+// node is replayed like every other launch.
+static __global__ void zero_fill_kernel(float* __restrict__ p, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+inline hipError_t zero_async(float* p, size_t n_floats, hipStream_t st) {
+  if (n_floats == 0) return hipSuccess;
+  const long long blocks = (long long)((n_floats + 255) / 256);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, p, (long long)n_floats);
+  return hipGetLastError();
+}
+
 }  // namespace oi

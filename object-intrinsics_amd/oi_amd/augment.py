@@ -138,14 +138,9 @@ class AugmentPipe(torch.nn.Module):
             G = mul(G, translate2d(-t[:, 0] * f32(W), -t[:, 1] * f32(H), B))
         return G
 
-    def forward(self, images, debug_percentile=None):
-        assert isinstance(images, torch.Tensor) and images.ndim == 4
-        B, C, H, W = images.shape
-        G_inv = self.sample_G_inv(images, debug_percentile)
-        if G_inv is None:
-            return images
+    def margins_for(self, G_inv, H, W):
+        """Padding margins (mx0, my0, mx1, my1) of augment.py:272-283 from the host copy of G_inv."""
         f32 = np.float32
-        # padding margins (augment.py:272-283), on the host copy of G_inv
         cx, cy = (W - 1) / 2, (H - 1) / 2
         cp = np.array([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]], f32)
         cp = G_inv @ cp.T                                     # (B, 3, 4)
@@ -154,17 +149,55 @@ class AugmentPipe(torch.nn.Module):
         m = np.concatenate([-m, m]).max(axis=1)               # [x0, y0, x1, y1]
         m = m + np.array([Hz_pad * 2 - cx, Hz_pad * 2 - cy] * 2, f32)
         m = np.minimum(np.maximum(m, 0), np.array([W - 1, H - 1] * 2, f32))
-        mx0, my0, mx1, my1 = (int(v) for v in np.ceil(m))
+        return tuple(int(v) for v in np.ceil(m))
 
-        x = reflect_pad(images, mx0, mx1, my0, my1)
+    @staticmethod
+    def static_margins(H, W):
+        """The largest margins margins_for() can return (its own clamp): with them every intermediate shape is independent
+        of the sampled transform -- what a captured hipGraph of the discriminator step needs.  The resampled pixels
+        are the same ones (a larger reflect-padded canvas around the same image), up to the rounding of the normalised
+        sampling coordinates."""
+        return (W - 1, H - 1, W - 1, H - 1)
+
+    def theta_for(self, G_inv, margins, H, W):
+        """(B, 2, 3) float32 numpy: the affine sampling grid of augment.py:285-297 for given padding margins."""
+        f32 = np.float32
+        B = G_inv.shape[0]
+        mx0, my0, mx1, my1 = margins
+        Hz_pad = self.Hz_geom.shape[0] // 4
         mm = lambda a, b: (a @ b).astype(f32)
         G_inv = mm(translate2d((mx0 - mx1) / 2, (my0 - my1) / 2, B), G_inv)
-        x = upfirdn2d_separable(x, self.Hz_geom, up=2, pad=(6, 5, 6, 5), flip=False, gain=4.0)  # upsample2d
         G_inv = mm(mm(scale2d(2, 2, B), G_inv), scale2d(0.5, 0.5, B))
         G_inv = mm(mm(translate2d(-0.5, -0.5, B), G_inv), translate2d(0.5, 0.5, B))
         Ho, Wo = (H + Hz_pad * 2) * 2, (W + Hz_pad * 2) * 2
-        G_inv = mm(mm(scale2d(2 / x.shape[3], 2 / x.shape[2], B), G_inv), scale2d(Wo / 2, Ho / 2, B))
-        theta = torch.from_numpy(np.ascontiguousarray(G_inv[:, :2, :])).to(images.device, non_blocking=True)
+        Wp, Hp = (W + mx0 + mx1) * 2, (H + my0 + my1) * 2     # the padded, x2-upsampled canvas
+        G_inv = mm(mm(scale2d(2 / Wp, 2 / Hp, B), G_inv), scale2d(Wo / 2, Ho / 2, B))
+        return np.ascontiguousarray(G_inv[:, :2, :])
+
+    def apply_theta(self, images, theta, margins):
+        """reflect pad -> x2 sym6 upsample -> affine bilinear resample -> /2 sym6 downsample (augment.py:284-301) for a
+        sampling grid `theta` that is already on the device."""
+        B, C, H, W = images.shape
+        mx0, my0, mx1, my1 = margins
+        Hz_pad = self.Hz_geom.shape[0] // 4
+        x = reflect_pad(images, mx0, mx1, my0, my1)
+        x = upfirdn2d_separable(x, self.Hz_geom, up=2, pad=(6, 5, 6, 5), flip=False, gain=4.0)  # upsample2d
+        Ho, Wo = (H + Hz_pad * 2) * 2, (W + Hz_pad * 2) * 2
         x = affine_grid_sample(x, theta, Ho, Wo)
         # downsample2d(padding=-2*Hz_pad, flip_filter=True): pad = -6 + (12-2+1)//2 = -1, -6 + 5 = -1
         return upfirdn2d_separable(x, self.Hz_geom, down=2, pad=(-1, -1, -1, -1), flip=True, gain=1.0)
+
+    def forward(self, images, debug_percentile=None, theta=None):
+        """`theta`: (B, 2, 3) device tensor built by the caller with `theta_for(sample_G_inv(...), static_margins(H, W), H, W)`
+        -- the shape-static form used under hipGraph capture (oi_amd.graphed.GraphedDStep); default: the reference's
+        flow with margins fitted to the sampled transform."""
+        assert isinstance(images, torch.Tensor) and images.ndim == 4
+        B, C, H, W = images.shape
+        if theta is not None:
+            return self.apply_theta(images, theta, self.static_margins(H, W))
+        G_inv = self.sample_G_inv(images, debug_percentile)
+        if G_inv is None:
+            return images
+        margins = self.margins_for(G_inv, H, W)
+        th = torch.from_numpy(self.theta_for(G_inv, margins, H, W)).to(images.device, non_blocking=True)
+        return self.apply_theta(images, th, margins)

@@ -62,6 +62,8 @@ class FlatGradDDP(nn.Module):
 
     # -- gradient exchange -------------------------------------------------------------------
     def _on_grad(self, p):
+        if getattr(self, "_in_graph", False):   # captured steps (oi_amd.graphed.GraphedDStep) exchange explicitly via sync()
+            return
         # autograd may have replaced p.grad with a fresh tensor (first accumulation into a None grad): fold it back
         v = self._views[id(p)]
         if p.grad is not None and p.grad.data_ptr() != v.data_ptr():

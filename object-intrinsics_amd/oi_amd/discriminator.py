@@ -77,8 +77,9 @@ class ADADiscriminator(DCDiscriminator):
     def get_resolution(self):
         return self.resolution
 
-    def forward(self, x, **kwargs):
-        return super().forward(self.aug(x), **kwargs)
+    def forward(self, x, aug_theta=None, **kwargs):
+        """`aug_theta`: precomputed sampling grid for the shape-static augmentation (see AugmentPipe.forward)."""
+        return super().forward(self.aug(x) if aug_theta is None else self.aug(x, theta=aug_theta), **kwargs)
 
 
 class ADADiscriminatorView(ADADiscriminator):

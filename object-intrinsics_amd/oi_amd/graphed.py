@@ -11,6 +11,8 @@ Restrictions: eval mode only (no per-ray jitter: its RNG offset would be frozen)
 iteration counter (`cos_anneal_ratio` is a launch argument and therefore baked in), and parameters must not be
 re-packed between capture and replay (call `recapture()` after an optimiser step or `load_state_dict`).
 """
+import os
+
 import torch
 
 
@@ -56,4 +58,131 @@ class GraphedForward:
         if bg_color is not None:
             self.bg.copy_(bg_color, non_blocking=True)
         self.graph.replay()
+        return self.out
+
+
+class GraphedDStep:
+    """hipGraph of one discriminator training step WITHOUT the optimiser step: zero the gradients, real forward + R1
+    double backward, fake forward (+ auxiliary pose regression), backward (gan_pose_trainer.py:154-200).
+
+    Eagerly that is ~230 launches of a few microseconds each behind Python `autograd.Function`s: 3.1 ms of host time
+    for 0.8 ms of GPU work at batch 1 (bench `training.d_step`).  Captured, the step is one `hipGraphLaunch`.
+    What makes it capturable:
+      * shapes: the ADA augmentation runs with the largest padding margins its own clamp allows
+        (`AugmentPipe.static_margins`), so no intermediate size depends on the sampled transform;
+      * randomness: the augmentation parameters are still drawn by numpy on the host, in the eager order (real batch
+        first, then fake), and reach the graph as two (B, 2, 3) sampling grids in fixed device buffers;
+      * scalars that change per iteration (the pose-loss weight) are device scalars;
+      * the optimiser step stays outside (its chunk table is re-uploaded when pointers change): the gradients come
+        out of the graph at fixed addresses, `opt.step()` follows eagerly (one launch), and under FlatGradDDP the
+        gradient exchange sits between the two as in the eager trainer.
+    Recapture after anything that replaces parameter / gradient tensors (load_state_dict keeps them)."""
+
+    def __init__(self, disc, gan, aux_pose=None, reg_weight=10.0, prior=None):
+        self.disc, self.gan, self.aux_pose, self.reg_weight, self.prior = disc, gan, aux_pose, float(reg_weight), prior
+        self.graph = None
+
+    def _net(self):
+        return self.disc.module if hasattr(self.disc, "flat_grad") else self.disc
+
+    def _alloc(self, x_real, x_fake, c2b):
+        dev = x_real.device
+        B = x_real.shape[0]
+        self.x_real = torch.empty_like(x_real)
+        self.x_fake = torch.empty_like(x_fake)
+        self.th_real = torch.empty(B, 2, 3, device=dev)
+        self.th_fake = torch.empty(B, 2, 3, device=dev)
+        self.c2b = None if c2b is None else torch.empty_like(c2b)
+        self.aux_w = torch.zeros((), device=dev)
+        # ring of pinned staging buffers: the host runs several steps ahead of the stream, and a pinned buffer may only be
+        # rewritten once the copy that reads it has executed
+        self._pins = [torch.empty(2, B, 2, 3, pin_memory=True) for _ in range(8)]
+        self._pin_ev = [None] * 8
+        self._pin_i = 0
+
+    def _step(self):
+        from .losses import compute_grad2
+        disc = self.disc
+        if hasattr(disc, "flat_grad"):
+            disc._in_graph = True  # the wrapper's gradient hooks are Python: they would run at capture time only
+            disc.zero_grad()
+        else:
+            for p in disc.parameters():
+                p.grad = None
+        x_real = self.x_real.detach().clone().requires_grad_()
+        d_real = disc(x_real, aug_theta=self.th_real)[:, :1]
+        loss_real = self.gan(d_real, 1)
+        loss_reg = compute_grad2(d_real, x_real)
+        x_fake = self.x_fake.detach().clone().requires_grad_()
+        d_fake = disc(x_fake, aug_theta=self.th_fake)
+        loss_aux = torch.zeros((), device=x_real.device)
+        if d_fake.size(1) > 1:
+            d_fake, d_aux = torch.split(d_fake, (1, self.prior.repr_dim), dim=1)
+            loss_aux = self.aux_pose(d_aux, self.prior.pose_to_vec_repr(self.c2b))
+        loss_fake = self.gan(d_fake, 0)
+        loss = loss_real + loss_fake + loss_reg * self.reg_weight + loss_aux * self.aux_w
+        loss.backward()
+        return {"loss": loss_fake + loss_real, "reg": loss_reg, "fake": loss_fake, "real": loss_real, "aux_pose": loss_aux}
+
+    def _thetas(self, shape):
+        """Host-side augmentation parameters in the eager draw order: real batch, then fake batch."""
+        aug = self._net().aug
+        B, C, H, W = shape
+        dummy = torch.empty(B, C, H, W, device="meta")
+        m = aug.static_margins(H, W)
+        out = []
+        for _ in range(2):
+            G = aug.sample_G_inv(dummy)
+            if G is None:
+                import numpy as np
+                G = np.tile(np.eye(3, dtype=np.float32), (B, 1, 1))
+            out.append(aug.theta_for(G, m, H, W))
+        return out
+
+    def _upload(self, x_real, x_fake, c2b, aux_w):
+        th = self._thetas(tuple(x_real.shape))
+        i = self._pin_i = (self._pin_i + 1) % len(self._pins)
+        if self._pin_ev[i] is not None:
+            self._pin_ev[i].synchronize()
+        pin = self._pins[i]
+        pin[0].numpy()[:] = th[0]
+        pin[1].numpy()[:] = th[1]
+        self.th_real.copy_(pin[0], non_blocking=True)
+        self.th_fake.copy_(pin[1], non_blocking=True)
+        self._pin_ev[i] = torch.cuda.Event()
+        self._pin_ev[i].record()
+        self.x_real.copy_(x_real, non_blocking=True)
+        self.x_fake.copy_(x_fake, non_blocking=True)
+        if self.c2b is not None:
+            self.c2b.copy_(c2b, non_blocking=True)
+        self.aux_w.fill_(float(aux_w))
+
+    def capture(self, x_real, x_fake, c2b, aux_w):
+        import numpy as np
+        self._alloc(x_real, x_fake, c2b)
+        state = np.random.get_state()       # warm-up / capture must not consume the trainer's random stream
+        self._upload(x_real, x_fake, c2b, aux_w)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._step()
+        np.random.set_state(state)
+        return self
+
+    def __call__(self, x_real, x_fake, c2b=None, aux_w=0.0):
+        if self.graph is None:
+            self.capture(x_real, x_fake, c2b, aux_w)
+        self._upload(x_real, x_fake, c2b, aux_w)
+        if os.environ.get("OI_GRAPH_D_EAGER") == "1":   # debugging aid: the same shape-static step, launch by launch
+            self.out = self._step()
+            return self.out
+        self.graph.replay()
+        if hasattr(self.disc, "flat_grad"):
+            self.disc._needs_exchange = True  # the replayed backward filled the flat buffer: exchange it in sync()
         return self.out

@@ -67,7 +67,9 @@ def _zero_grad(net, opt):
 
 
 class Trainer:
-    def __init__(self, modules, loss_weight=None, it=-1):
+    def __init__(self, modules, loss_weight=None, it=-1, graph_d_steps=False):
+        """graph_d_steps: replay the two discriminator steps from captured hipGraphs (oi_amd.graphed.GraphedDStep); the
+        ADA augmentation then pads with its largest margins (same pixels, shape-static)."""
         self.modules = modules
         for k in MODULE_KEYS:
             setattr(self, k, modules[k])
@@ -78,6 +80,7 @@ class Trainer:
         self.gan, self.aux_pose = GANLoss("bce"), PositionLoss("mse")
         self.it = it
         self._toggle = _GradToggle()
+        self._graphed = {} if graph_d_steps else None
 
     def train_step(self, data):
         self.it += 1
@@ -124,6 +127,8 @@ class Trainer:
         for k in MODULE_KEYS:
             self._toggle(k, self.modules[k], k == key)
         disc, opt = self.modules[key], self.modules[f"opt_{key}"]
+        if self._graphed is not None:
+            return self._graphed_d_step(key, disc, opt, real, fake, defer_step)
         _zero_grad(disc, opt)
         x_real = torch.cat([real[k] for k in DATA_KEYS[key]], dim=-3).detach().clone().requires_grad_()
         d_real = disc(x_real, it=self.it)[:, :1]
@@ -141,6 +146,29 @@ class Trainer:
         loss.backward()
         ret = {f"{key}/loss": loss_fake + loss_real, f"{key}/reg": loss_reg, f"{key}/fake": loss_fake,
                f"{key}/real": loss_real, f"{key}/aux_pose": loss_aux}
+
+        def finish():
+            _sync(disc)
+            opt.step()
+
+        if defer_step:
+            return ret, finish
+        finish()
+        return ret
+
+    def _graphed_d_step(self, key, disc, opt, real, fake, defer_step):
+        from .graphed import GraphedDStep
+        gd = self._graphed.get(key)
+        if gd is None:
+            gd = self._graphed[key] = GraphedDStep(disc, self.gan, self.aux_pose, self.loss_weight["reg"],
+                                                   _unwrap(self.generator).pose_prior)
+        x_real = torch.cat([real[k] for k in DATA_KEYS[key]], dim=-3).detach()
+        x_fake = torch.cat([fake[k] for k in DATA_KEYS[key]], dim=-3).detach()
+        has_aux = _unwrap(disc).out_dim > 1
+        out = gd(x_real, x_fake, fake["c2b"].detach() if has_aux else None,
+                 self.loss_weight["aux_pose"](self.it) if has_aux else 0.0)
+        ret = {f"{key}/loss": out["loss"], f"{key}/reg": out["reg"], f"{key}/fake": out["fake"], f"{key}/real": out["real"],
+               f"{key}/aux_pose": out["aux_pose"] if has_aux else 0}
 
         def finish():
             _sync(disc)

@@ -489,3 +489,42 @@ def test_training_trajectory_f16x3_tracks_native_fp32():
     a, b = run("f32"), run("f16x3")
     assert np.isfinite(a).all() and np.isfinite(b).all()
     assert np.abs(a - b).max() < 1e-4, np.abs(a - b).max(axis=1)
+
+
+def test_graphed_discriminator_steps_match_eager():
+    """oi_amd.graphed.GraphedDStep (one hipGraphLaunch per discriminator step, shape-static ADA margins) against the eager
+    trainer: three training iterations from identical weights / seeds give the same losses and the same weights."""
+    import bench
+    from oi_amd.config import build_from_config
+    from oi_amd.optim import FusedAdam, FusedRMSprop
+    from oi_amd.trainer import Trainer
+    dev = torch.device("cuda")
+    R = 32
+    net = lambda t, **kw: {"__target__": t, "kwargs": kw}
+    res = []
+    for graphed in (False, True):
+        torch.manual_seed(5)
+        np.random.seed(5)
+        gen, disc = bench.build_models(R, 8, 8, 1, "f16x3", dev)
+        mdisc = build_from_config(net("src.models.discriminator.ADADiscriminator",
+                                      aug=net("src.third_party.ada.augment.AugmentPipe", scale=1, xint=1), aug_p=1,
+                                      img_size=R, in_dim=1, last_bias=False, n_feat=512, out_dim=1)).to(dev)
+        mods = {"generator": gen, "discriminator": disc, "mask_discriminator": mdisc,
+                "opt_generator": FusedAdam(gen.parameters(), lr=2e-5, betas=(0.0, 0.9)),
+                "opt_discriminator": FusedRMSprop(disc.parameters(), lr=1e-4),
+                "opt_mask_discriminator": FusedRMSprop(mdisc.parameters(), lr=1e-4)}
+        tr = Trainer(mods, graph_d_steps=graphed)
+        g = torch.Generator(device=dev).manual_seed(9)
+        data = {"image": torch.rand(1, 3, R, R, device=dev, generator=g), "mask": torch.rand(1, 1, R, R, device=dev, generator=g)}
+        out = None
+        for step in range(3):
+            torch.manual_seed(100 + step)
+            np.random.seed(100 + step)
+            out = tr.train_step(data)
+        torch.cuda.synchronize()
+        r = {k: float(v) for k, v in out.items()}
+        r["disc_w"] = float(sum(p.double().abs().sum() for p in disc.parameters()))
+        r["mdisc_w"] = float(sum(p.double().abs().sum() for p in mdisc.parameters()))
+        res.append(r)
+    for k in res[0]:
+        assert abs(res[0][k] - res[1][k]) <= 2e-4 * max(1.0, abs(res[0][k])), (k, res[0][k], res[1][k])
