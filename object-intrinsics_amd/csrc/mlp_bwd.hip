@@ -23,6 +23,7 @@
 // parked operands (K = points); gbar_l = vbar_{l-1} c_{l-1} and a_l = sin phi_{l-1} are re-formed there from the SAME
 // parked phi_{l-1}.
 #include <algorithm>
+#include <type_traits>
 
 #include "mlp_common.h"
 
@@ -84,16 +85,37 @@ struct WaveScratchB {
   }
 };
 
-// sum of v over the 32 points (lanes of one half) -> LDS accumulator row `row` at this lane's feature
-__device__ __forceinline__ void reduce_group(char* lds, int row, int g, int h, int j, f32x4 v) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = oi::half_sum32(v[k]);  // 5 DPP adds; valid in lanes 16..31 of each half
-  if (j == 16) {
-    float* racc = reinterpret_cast<float*>(lds + L_RACC) + row * C + grp_f0(g) + 4 * h;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) atomicAdd(racc + k, v[k]);
-  }
+// Sums over the points of a wave tile (parameter gradients of the FiLM rows, biases and heads).  The point sits on the
+// lane (j = lane & 31), so every value needs a cross-lane sum; done one value at a time (5 DPP adds + a 2-lane LDS atomic
+// behind a branch each) this was half of the instructions of the down sweep.  Instead 16 values (4 groups x 4 features of
+// one 32-feature block) go through ONE transposed butterfly: at every step two registers become one -- each lane keeps
+// the partial sum of the value its lane bit selects (2 selects + 1 DPP add) -- so after 4 steps lane r of every 16-lane
+// row holds the row's sum of value r: 45 instructions per 16 values, no branch, and one full-wave ds_add_f32 (the two rows
+// of a half hit the same address).
+template <int CTRL>
+__device__ __forceinline__ float fold_pair(float a, float b, bool bit) {
+  const float keep = bit ? b : a, give = bit ? a : b;
+  return keep + oi::dpp_mov<CTRL>(give);
 }
+__device__ __forceinline__ float row_transpose_sum16(const float (&v)[16], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+  float a[8], b[4], c[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = fold_pair<0xB1>(v[2 * i], v[2 * i + 1], b0);   // quad_perm [1,0,3,2]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = fold_pair<0x4E>(a[2 * i], a[2 * i + 1], b1);   // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) c[i] = fold_pair<0x124>(b[2 * i], b[2 * i + 1], b2);  // row_ror:4 (adjacent quads)
+  return fold_pair<0x128>(c[0], c[1], b3);                                          // row_ror:8
+}
+// v[4 * rr + k] = value of feature 32 t + 8 rr + 4 h + k at this lane's point -> LDS accumulator row `row`
+struct RowSum {
+  float* lane_base;  // racc + 8 * ((lane & 15) >> 2) + 4 * h + (lane & 3)
+  int lane;
+  __device__ __forceinline__ void add(int row, int t, const float (&v)[16]) const {
+    atomicAdd(lane_base + row * C + 32 * t, row_transpose_sum16(v, lane));
+  }
+};
 
 __device__ __forceinline__ void racc_zero(char* lds, int tid) {
   float* racc = reinterpret_cast<float*>(lds + L_RACC);
@@ -103,6 +125,11 @@ __device__ __forceinline__ void racc_zero(char* lds, int tid) {
 __device__ __forceinline__ void racc_flush_row(char* lds, int row, float* dst, int stride, int tid) {
   const float* racc = reinterpret_cast<const float*>(lds + L_RACC) + row * C;
   if (tid < C) atomicAdd(dst + tid * stride, racc[tid]);
+}
+// the same row times a per-feature factor (sum_p ubar = gamma * sum_p phibar: the bias gradient needs no sum of its own)
+__device__ __forceinline__ void racc_flush_row_scaled(char* lds, int row, const float* factor, float* dst, int tid) {
+  const float* racc = reinterpret_cast<const float*>(lds + L_RACC) + row * C;
+  if (tid < C) atomicAdd(dst + tid, racc[tid] * factor[tid]);
 }
 
 // this wave's LDS-DMA has landed (and so have its outstanding scratch loads), then rendezvous
@@ -159,6 +186,22 @@ __device__ __forceinline__ float gemm2(const char* lds, const LaneOff& o, float 
 #ifndef OI_BWD_WAVES_PER_SIMD
 #define OI_BWD_WAVES_PER_SIMD 1
 #endif
+// timing ablations (results are garbage): -DOI_BWD_ABL=1 no v / ubar stores, 2 no phi / vbar reloads, 4 no up-sweep stores
+#ifndef OI_BWD_ABL
+#define OI_BWD_ABL 0
+#endif
+// -DOI_BWD_PROF: per-phase shader-clock accounting of the sweep (tools/dbg/phase_prof_bwd.py)
+#ifdef OI_BWD_PROF
+__device__ unsigned long long oi_prof_bwd[16];
+#define BW_T(i)                                                  \
+  do {                                                           \
+    const unsigned long long t_ = __builtin_readcyclecounter();  \
+    pacc[i] += t_ - tprev;                                       \
+    tprev = t_;                                                  \
+  } while (0)
+#else
+#define BW_T(i)
+#endif
 template <int PREC, bool FAST>
 __global__ void __launch_bounds__(256, OI_BWD_WAVES_PER_SIMD)
 mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ packed, const float* __restrict__ gamma,
@@ -183,6 +226,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   o.l16hi = 16 * lane + 32768;
   asm volatile("" : "+v"(o.h16), "+v"(o.h64), "+v"(o.l16), "+v"(o.l16hi));
 
+  const RowSum rs{reinterpret_cast<float*>(lds + L_RACC) + 8 * ((lane & 15) >> 2) + 4 * h + (lane & 3), lane};
   const long long local = (long long)blockIdx.x * TILE_PTS + wave * WAVE_PTS + j;
   const bool valid = local < n_per_elem;
   const long long pt = (long long)e * n_per_elem + (valid ? local : n_per_elem - 1);
@@ -212,6 +256,11 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     stage_flm(0, 0);
     racc_zero(lds, tid);
   }
+#ifdef OI_BWD_PROF
+  unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_readcyclecounter();
+  const unsigned long long tstart = tprev;
+#endif
   const float px = pts[pt * 3 + 0], py = pts[pt * 3 + 1], pz = pts[pt * 3 + 2];
   const float gs = (g_sdf ? g_sdf[pt] : 0.f) * vmask;
   float Gx = (g_grad ? g_grad[pt * 3 + 0] : 0.f) * vmask, Gy = (g_grad ? g_grad[pt * 3 + 1] : 0.f) * vmask,
@@ -249,44 +298,48 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     // uv -> phiv -> hv; then uvbar.  Reductions: rows 0 gamma_v, 1 beta_v, 2 bv, 3..5 Wrgb, 6..7 dWv[:, 128 + (0, 1)]
     float dGx = 0.f, dGy = 0.f, dGz = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
-      const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
-      const f32x4 w0 = lds_f4(lds, L_TABS + (H_RGB + 0 * C + grp_f0(g)) * 4, o.h16);
-      const f32x4 w1 = lds_f4(lds, L_TABS + (H_RGB + 1 * C + grp_f0(g)) * 4, o.h16);
-      const f32x4 w2 = lds_f4(lds, L_TABS + (H_RGB + 2 * C + grp_f0(g)) * 4, o.h16);
-      f32x4 uvb, r_g, r_b, r0, r1, r2, bsv;
-      if constexpr (SC) bsv = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
+    for (int t = 0; t < 4; ++t) {
+      float R[8][16];  // rows: 0 gamma_v, 1 beta_v (x gamma_v = bv), 2 dWv[:, 130], 3..5 Wrgb, 6..7 dWv[:, 128 + (0, 1)]
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const f32x4 wx = lds_f4(lds, L_TABS + H_TABV * 4 + (grp_f0(g) + k) * 16, o.h64);
-        const float ua = SC ? fmaf(acc[g >> 2][4 * (g & 3) + k], fV, bsv[k]) : acc[g >> 2][4 * (g & 3) + k];
-        const float uv = ua + fmaf(fz, wx[2], fmaf(fy, wx[1], fx * wx[0]));
-        const float phiv = fmaf(gm[k], uv, bt[k]);
-        float hv, cv;
-        sincos_<FAST>(phiv, hv, cv);
-        const float hvb = w0[k] * rho[0] + w1[k] * rho[1] + w2[k] * rho[2];
-        const float phb = hvb * cv;
-        uvb[k] = phb * gm[k];
-        r_g[k] = phb * uv;
-        r_b[k] = phb;
-        r0[k] = rho[0] * hv; r1[k] = rho[1] * hv; r2[k] = rho[2] * hv;
-        dGx = fmaf(uvb[k], wx[0], dGx);
-        dGy = fmaf(uvb[k], wx[1], dGy);
-        dGz = fmaf(uvb[k], wx[2], dGz);
+      for (int rr = 0; rr < 4; ++rr) {
+        const int g = 4 * t + rr;
+        const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
+        const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
+        const f32x4 w0 = lds_f4(lds, L_TABS + (H_RGB + 0 * C + grp_f0(g)) * 4, o.h16);
+        const f32x4 w1 = lds_f4(lds, L_TABS + (H_RGB + 1 * C + grp_f0(g)) * 4, o.h16);
+        const f32x4 w2 = lds_f4(lds, L_TABS + (H_RGB + 2 * C + grp_f0(g)) * 4, o.h16);
+        f32x4 uvb, bsv;
+        if constexpr (SC) bsv = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const f32x4 wx = lds_f4(lds, L_TABS + H_TABV * 4 + (grp_f0(g) + k) * 16, o.h64);
+          const float ua = SC ? fmaf(acc[t][4 * rr + k], fV, bsv[k]) : acc[t][4 * rr + k];
+          const float uv = ua + fmaf(fz, wx[2], fmaf(fy, wx[1], fx * wx[0]));
+          const float phiv = fmaf(gm[k], uv, bt[k]);
+          float hv, cv;
+          sincos_<FAST>(phiv, hv, cv);
+          const float hvb = w0[k] * rho[0] + w1[k] * rho[1] + w2[k] * rho[2];
+          const float phb = hvb * cv;
+          uvb[k] = phb * gm[k];
+          R[0][4 * rr + k] = phb * uv;
+          R[1][4 * rr + k] = phb;
+          R[2][4 * rr + k] = uvb[k] * fz;
+          R[3][4 * rr + k] = rho[0] * hv;
+          R[4][4 * rr + k] = rho[1] * hv;
+          R[5][4 * rr + k] = rho[2] * hv;
+          R[6][4 * rr + k] = uvb[k] * fx;
+          R[7][4 * rr + k] = uvb[k] * fy;
+          dGx = fmaf(uvb[k], wx[0], dGx);
+          dGy = fmaf(uvb[k], wx[1], dGy);
+          dGz = fmaf(uvb[k], wx[2], dGz);
+        }
+        ws.store(S_UV, g, o.l16, uvb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) act[4 * g + k] = uvb[k];
+        __builtin_amdgcn_sched_barrier(0);
       }
-      ws.store(S_UV, g, o.l16, uvb);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) act[4 * g + k] = uvb[k];
-      reduce_group(lds, 0, g, h, j, r_g);
-      reduce_group(lds, 1, g, h, j, r_b);
-      reduce_group(lds, 2, g, h, j, uvb);
-      reduce_group(lds, 3, g, h, j, r0);
-      reduce_group(lds, 4, g, h, j, r1);
-      reduce_group(lds, 5, g, h, j, r2);
-      reduce_group(lds, 6, g, h, j, uvb * fx);
-      reduce_group(lds, 7, g, h, j, uvb * fy);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int r = 0; r < 8; ++r) rs.add(r, t, R[r]);
     }
     // contribution to dL/dgrad through the colour-head input
     dGx += __shfl_xor(dGx, 32, 64);
@@ -306,7 +359,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     __syncthreads();
     racc_flush_row(lds, 0, d_gamma + ((size_t)e * 9 + 8) * C, 1, tid);
     racc_flush_row(lds, 1, d_beta + ((size_t)e * 9 + 8) * C, 1, tid);
-    racc_flush_row(lds, 2, d_small + DS_B + 8 * C, 1, tid);
+    racc_flush_row_scaled(lds, 1, reinterpret_cast<const float*>(lds + L_FILM), d_small + DS_B + 8 * C, tid);
+    racc_flush_row(lds, 2, d_small + DS_WVX + 2, 3, tid);
     racc_flush_row(lds, 3, d_small + DS_WRGB + 0 * C, 1, tid);
     racc_flush_row(lds, 4, d_small + DS_WRGB + 1 * C, 1, tid);
     racc_flush_row(lds, 5, d_small + DS_WRGB + 2 * C, 1, tid);
@@ -317,13 +371,6 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     // abar_8 from the colour head: Wv[:, :128]^T uvbar   (transposed colour image, matrix 15)
     stage_img(15, 0);
     dma_sync();
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      f32x4 uvb;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) uvb[k] = act[4 * g + k];
-      reduce_group(lds, 0, g, h, j, uvb * fz);
-    }
     acc_zero(acc);
     const float fT = gemm2<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + 15] : 1.f);
 #pragma unroll
@@ -334,13 +381,11 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       ws.store(S_AC, g, o.l16, v);
     }
     __syncthreads();
-    racc_flush_row(lds, 0, d_small + DS_WVX + 2, 3, tid);
-    __syncthreads();
-    racc_zero(lds, tid);
     stage_flm(0, 0);
     __syncthreads();
   }
 
+  BW_T(0);
   // ================= up sweep: recompute phi_l, carry gbar_l =================
   // FiLM rows of layer l live in FiLM slot l & 1, layer l's forward image in image slot (l - 1) & 1: both are requested one
   // layer ahead
@@ -368,8 +413,10 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     ws.store(S_VB + 0, g, o.l16, vb);
     __builtin_amdgcn_sched_barrier(0);
   }
+  BW_T(1);
   for (int l = 1; l < NL_SDF; ++l) {
     dma_sync();  // layer l's image and FiLM rows have landed; every wave is done with layer l - 1
+    BW_T(2);
     if (l < NL_SDF - 1) {
       stage_img(l, l & 1);
       stage_flm(l + 1, (l + 1) & 1);
@@ -380,7 +427,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     const float inv_img = SC ? hdr[H_WSCALE + l - 1] : 1.f;
     // vbar_l = W_l gbar_l
     acc_zero(acc);
+    BW_T(3);
     const float fA = gemm2<PREC, true>(lds, ol, gb, acc, inv_img);
+    BW_T(4);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       f32x4 v;
@@ -389,11 +438,13 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         v[k] = SC ? acc[g >> 2][4 * (g & 3) + k] * fA : acc[g >> 2][4 * (g & 3) + k];
         gb[4 * g + k] = v[k];
       }
-      ws.store(S_VB + l, g, o.l16, v);
+      if (!(OI_BWD_ABL & 4)) ws.store(S_VB + l, g, o.l16, v);
     }
     // u_l = W_l a_l + b_l -> phi_l, a_{l+1};  gbar_{l+1} = vbar_l gamma_l cos phi_l
     if constexpr (SC) acc_zero(acc); else init_bias(lds, ol, acc);
+    BW_T(5);
     const float fB = gemm2<PREC, false>(lds, ol, act, acc, inv_img);
+    BW_T(4);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, ol.h16);
@@ -410,17 +461,18 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         act[4 * g + k] = s;
         gb[4 * g + k] *= gm[k] * c;
       }
-      ws.store(S_PHI + l, g, o.l16, ph);
+      if (!(OI_BWD_ABL & 4)) ws.store(S_PHI + l, g, o.l16, ph);
       __builtin_amdgcn_sched_barrier(0);
     }
+    BW_T(5);
   }
   // d w_sigma = sum_p (gbar_8 + gs a_8)  (row 3);  d b_sigma = sum_p gs
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    f32x4 v;
+  for (int t = 0; t < 4; ++t) {
+    float v[16];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = fmaf(gs, act[4 * g + k], gb[4 * g + k]);
-    reduce_group(lds, 3, g, h, j, v);
+    for (int i = 0; i < 16; ++i) v[i] = fmaf(gs, act[16 * t + i], gb[16 * t + i]);
+    rs.add(3, t, v);
   }
   {
     float b = (h == 0) ? gs : 0.f;
@@ -451,20 +503,27 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     phn[g] = ws.load(S_PHI + 7, g, o.l16);
     vbn[g] = ws.load(S_VB + 7, g, o.l16);
   }
-  for (int l = NL_SDF - 1; l >= 0; --l) {
+  BW_T(6);
+  // layer 0 is peeled (its extra d W0 rows and missing products are compile-time): no branch inside the unrolled epilogue
+  auto down_layer = [&](int l, auto is_layer0) {
+    constexpr bool L0 = decltype(is_layer0)::value;
     dma_sync();  // layer l's transposed image and FiLM rows have landed; the previous layer's row flush is complete
+    BW_T(7);
     racc_zero(lds, tid);
     if (l >= 2) stage_img(7 + l - 2, (l - 1) & 1);
     if (l >= 1) stage_flm(l - 1, (l - 1) & 1);
     const LaneOff ol = layer_off(l & 1, l & 1);
     __syncthreads();  // reduction rows zeroed
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      {
+    for (int t = 0; t < 4; ++t) {
+      float R[2][16], R0[3][16];  // rows 0 d gamma_l, 1 d beta_l (x gamma_l = d b_l); layer 0: rows 3..5 d W0[:, 0..2]
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int g = 4 * t + rr;
         const f32x4 ph = phn[g], vb = vbn[g];
         const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, ol.h16);
         const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, ol.h16);
-        f32x4 r_g, r_b, ub, vv;
+        f32x4 ub, vv;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float s, c;
@@ -474,36 +533,43 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           vv[k] = gn * gm[k] * c;                                      // v_l
           const float phb = act[4 * g + k] * c - cb * gm[k] * s;       // phibar_l
           const float u = (ph[k] - bt[k]) * __builtin_amdgcn_rcpf(gm[k]);  // u_l
-          r_g[k] = fmaf(phb, u, cb * c);                               // d gamma_l
-          r_b[k] = phb;                                                // d beta_l
+          R[0][4 * rr + k] = fmaf(phb, u, cb * c);                     // d gamma_l
+          R[1][4 * rr + k] = phb;                                      // d beta_l
           ub[k] = phb * gm[k];                                         // ubar_l
           gb[4 * g + k] = vv[k];
           act[4 * g + k] = ub[k];
+          if constexpr (L0) {  // d W0 = sum_p (ubar_0 x^T + v_0 gbar_0^T)
+            R0[0][4 * rr + k] = fmaf(ub[k], px, vv[k] * Gx);
+            R0[1][4 * rr + k] = fmaf(ub[k], py, vv[k] * Gy);
+            R0[2][4 * rr + k] = fmaf(ub[k], pz, vv[k] * Gz);
+          }
         }
-        reduce_group(lds, 0, g, h, j, r_g);
-        reduce_group(lds, 1, g, h, j, r_b);
-        reduce_group(lds, 2, g, h, j, ub);
-        if (l >= 1) {
+        if constexpr (!L0 && !(OI_BWD_ABL & 1)) {
           ws.store<OI_BWD_ST_WGRAD>(S_V + l - 1, g, o.l16, vv);
           ws.store<OI_BWD_ST_WGRAD>(S_U + l - 1, g, o.l16, ub);
-        } else {  // d W0 = sum_p (ubar_0 x^T + v_0 gbar_0^T)
-          reduce_group(lds, 3, g, h, j, ub * px + vv * Gx);
-          reduce_group(lds, 4, g, h, j, ub * py + vv * Gy);
-          reduce_group(lds, 5, g, h, j, ub * pz + vv * Gz);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      rs.add(0, t, R[0]);
+      rs.add(1, t, R[1]);
+      if constexpr (L0) {
+        rs.add(3, t, R0[0]);
+        rs.add(4, t, R0[1]);
+        rs.add(5, t, R0[2]);
+      }
     }
-    if (l >= 1) {  // the next layer's fragments travel while this layer's two products run
+    BW_T(8);
+    if constexpr (!L0 && !(OI_BWD_ABL & 2)) {  // the next layer's fragments travel while this layer's two products run
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         phn[g] = ws.load(S_PHI + l - 1, g, o.l16);
         vbn[g] = ws.load(S_VB + l - 1, g, o.l16);
       }
     }
-    if (l >= 1) {
+    if constexpr (!L0) {
       const float inv_t = SC ? hdr[H_WSCALE + 7 + l - 1] : 1.f;
       acc_zero(acc);
+      BW_T(9);
       const float f1 = gemm2<PREC, true>(lds, ol, gb, acc, inv_t);   // g_l = W_l^T v_l
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -516,16 +582,28 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #pragma unroll
         for (int r = 0; r < 16; ++r) act[16 * t + r] = SC ? acc[t][r] * f2 : acc[t][r];
     }
+    BW_T(10);
     __syncthreads();
     racc_flush_row(lds, 0, d_gamma + ((size_t)e * 9 + l) * C, 1, tid);
     racc_flush_row(lds, 1, d_beta + ((size_t)e * 9 + l) * C, 1, tid);
-    racc_flush_row(lds, 2, d_small + DS_B + l * C, 1, tid);
-    if (l == 0) {
+    racc_flush_row_scaled(lds, 1, reinterpret_cast<const float*>(lds + L_FILM + (l & 1) * (L_FILM2 - L_FILM)),
+                          d_small + DS_B + l * C, tid);
+    if constexpr (L0) {
       racc_flush_row(lds, 3, d_small + DS_W0 + 0, 3, tid);
       racc_flush_row(lds, 4, d_small + DS_W0 + 1, 3, tid);
       racc_flush_row(lds, 5, d_small + DS_W0 + 2, 3, tid);
     }
+    BW_T(11);
+  };
+  for (int l = NL_SDF - 1; l >= 1; --l) down_layer(l, std::false_type{});
+  down_layer(0, std::true_type{});
+#ifdef OI_BWD_PROF
+  if (lane == 0) {
+    for (int i = 0; i < 12; ++i) atomicAdd(&oi_prof_bwd[i], pacc[i]);
+    atomicAdd(&oi_prof_bwd[12], __builtin_readcyclecounter() - tstart);
+    atomicAdd(&oi_prof_bwd[13], 1ull);
   }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -805,6 +883,18 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
 }
 
 }  // namespace
+
+#ifdef OI_BWD_PROF
+extern "C" int oi_prof_bwd_read(unsigned long long* out, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(oi_prof_bwd), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(oi_prof_bwd), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 extern "C" {
 
