@@ -49,8 +49,10 @@ enum oi_status {
  * v_cvt and by the MFMA on gfx950) and the three products hi*hi, hi*lo, lo*hi accumulated in fp32: 2^-22 relative
  * per product (fp32-class, inside the 1e-4 parity bar) at HALF the MFMA work and 2/3 of the LDS image of BF16X6.
  * Activations are sin() outputs in [-1,1]; the adjoint vectors of the analytic-gradient sweep are normalised per
- * point by a power of two before the split, so the fp16 range is never exceeded; weights must satisfy |w| < 65504
- * (forward kernel only). */
+ * point by a power of two before the split, so the fp16 range is never exceeded.  The weight images carry a
+ * per-image power-of-two scale chosen from the image's own max |w| (scaled peak in [2^13, 2^14)), so EVERY finite
+ * weight is inside the fp16 range by construction -- there is no |w| bound to respect; an image with an inf / NaN
+ * weight is flagged in the packed header and reported by oi_mlp_pack_status (OI_ERR_UNSUPPORTED). */
 enum oi_precision { OI_PREC_F32 = 0, OI_PREC_BF16X3 = 1, OI_PREC_BF16 = 2, OI_PREC_BF16X6 = 3, OI_PREC_F16X3 = 4 };
 
 int oi_version(void);
@@ -92,6 +94,11 @@ int oi_mlp_pack_weights(const float* w0, const float* b0, const float* wh, const
                         const float* wsig, const float* bsig, const float* wv, const float* bv,
                         const float* wrgb, const float* brgb, void* packed, int prec,
                         oi_stream_t stream);
+/* Range / finiteness report of a packed image (the pre-pack itself stays asynchronous).  Synchronises `stream`, reads the
+ * packed header back and returns OI_ERR_UNSUPPORTED (oi_last_error names the image) when a weight, bias or head value
+ * is inf / NaN -- the only input the F16X3 images cannot represent; OI_OK otherwise.  Call it where a sync is free:
+ * after loading a checkpoint, before an inference run (oi_amd.fields.FieldPack.check does). */
+int oi_mlp_pack_status(const void* packed, oi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a3-a6: FiLM-SIREN SDF network (+ analytic d sdf/dx + colour head) at n points per element.
@@ -121,8 +128,12 @@ int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, con
  *            dWv[:,128:131] [128][3] | dWrgb [3][128] | dbrgb [3]+1
  *   d_wmat   [8][128][128]: dW_1..dW_7, dWv[:, :128]
  *   d_gamma, d_beta [B][9][128]
- * scratch: oi_mlp_bwd_scratch_bytes(B, n) bytes. */
+ * scratch / scratch_bytes: working memory of the launch.  It is a BOUND, not a function of the problem size: the points of
+ * every batch element are processed in chunks of as many 128-point tiles as the buffer holds (16 KiB per point and
+ * 2 MiB x B per tile), chunks accumulate into the same outputs.  oi_mlp_bwd_scratch_bytes(B, n) is the size that takes
+ * one chunk; oi_mlp_bwd_scratch_bytes_capped(B, n, cap) the largest tile multiple <= cap (at least one tile). */
 size_t oi_mlp_bwd_scratch_bytes(int B, long long n_per_elem);
+size_t oi_mlp_bwd_scratch_bytes_capped(int B, long long n_per_elem, size_t cap_bytes);
 int oi_mlp_bwd_small_floats(void);
 /* Test hook for the CU-indexed feature scratch of the register-resident forward kernel: launches n_workgroups
  * workgroups with that kernel's LDS footprint; each marks busy[slot] (slot = XCC id x 256 + SE/SH/CU bits of HW_ID, < 4096)
@@ -137,7 +148,8 @@ int oi_selftest_sincos(const float* x, float* s, float* c, long long n, int fast
 int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, const float* beta,
                    const float* grad_fwd, const float* rgb_fwd, const float* feat_fwd, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* d_small, float* d_wmat, float* d_gamma, float* d_beta,
-                   void* scratch, int B, long long n_per_elem, int prec, int fast_trig, oi_stream_t stream);
+                   void* scratch, size_t scratch_bytes, int B, long long n_per_elem, int prec, int fast_trig,
+                   oi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a13 + a14: crop rays.  Replaces Generator.gen_rays_at + build_rays + near_far_from_sphere

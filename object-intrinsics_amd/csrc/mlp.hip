@@ -202,13 +202,17 @@ __device__ __forceinline__ float mat_elem(const float* wh, const float* wv, int 
 // thereby into the parked gamma*cos(phi)), which cancels against the scaled transposed image in the reverse sweep:
 // exact, and free.  Returns the scale; *inv gets 2^-k_m.  Must be called by all 256 threads of the block.
 template <int PREC>
-__device__ float image_scale(const float* wh, const float* wv, int m, float* red, float* inv) {
+__device__ float image_scale(const float* wh, const float* wv, int m, float* red, float* inv, float* bad) {
+  *bad = 0.f;
   if (PREC != OI_PREC_F16X3) {
     *inv = 1.f;
     return 1.f;
   }
   float mx = 0.f;
-  for (int i = threadIdx.x; i < C * C; i += 256) mx = fmaxf(mx, fabsf(mat_elem(wh, wv, m, i >> 7, i & 127)));
+  for (int i = threadIdx.x; i < C * C; i += 256) {
+    const float a = fabsf(mat_elem(wh, wv, m, i >> 7, i & 127));
+    mx = a <= 3.0e38f ? fmaxf(mx, a) : __builtin_inff();  // fmaxf would drop a NaN: non-finite weights must surface
+  }
   red[threadIdx.x] = mx;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -217,6 +221,7 @@ __device__ float image_scale(const float* wh, const float* wv, int m, float* red
   }
   mx = red[0];
   __syncthreads();
+  *bad = mx <= 3.0e38f ? 0.f : 1.f;
   int eb = (__builtin_bit_cast(int, mx) >> 23) & 0xff;
   eb = eb < 14 ? 14 : (eb > 254 ? 254 : eb);
   *inv = __builtin_bit_cast(float, (eb - 13) << 23);
@@ -234,7 +239,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
   float* hdr = reinterpret_cast<float*>(packed);
   __shared__ float red[256];
   if (blockIdx.y == NMAT) {  // header (the image scales at H_WSCALE are written by block 0 of every matrix)
-    if (idx >= H_FLOATS || (idx >= H_WSCALE && idx < H_WSCALE + NMAT) || (idx >= H_BOUND && idx < H_BOUND + NMAT)) return;
+    if (idx >= H_FLOATS || (idx >= H_WSCALE && idx < H_WSCALE + NMAT) || (idx >= H_BOUND && idx < H_BOUND + NMAT) ||
+        (idx >= H_STATUS && idx < H_STATUS + NMAT))
+      return;
     float v = 0.f;
     if (idx < H_SIG) {
       int f = idx >> 2, j = idx & 3;
@@ -256,9 +263,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
     return;
   }
   const int m = blockIdx.y;
-  float inv;
-  const float wscale = image_scale<PREC>(wh, wv, m, red, &inv);
-  if (idx == 0) hdr[H_WSCALE + m] = inv;  // 2^-k_m for the kernels (1 in the unscaled modes)
+  float inv, bad;
+  const float wscale = image_scale<PREC>(wh, wv, m, red, &inv, &bad);
+  if (idx == 0) {
+    hdr[H_WSCALE + m] = inv;  // 2^-k_m for the kernels (1 in the unscaled modes)
+    // the scaled image peaks in [2^13, 2^14): inside fp16 by construction for every finite weight; only inf / NaN is out
+    hdr[H_STATUS + m] = bad;
+  }
   if (blockIdx.x == 0) {
     // largest absolute row sum of the scaled image (induced infinity norm): an a-priori bound on the growth of a vector
     // through this layer product, used by mlp_fwd3.hip to pick the fp16 scale of an adjoint vector BEFORE it is complete
@@ -311,146 +322,6 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
 // 9 layers are staged once.  (v1 staged synchronously with two barriers per layer: 56 % of the fp32
 // MFMA peak, matrix pipe 64 % busy -- profiles/r1_*.)
 // ------------------------------------------------------------------------------------------
-struct NoHook {
-  __device__ __forceinline__ void operator()(int) const {}
-};
-
-// HOOK(s), s = 0..7, runs after the MFMAs that consumed act[8s .. 8s+7]: the reverse sweep uses it to issue the NEXT
-// layer's scratch loads into registers that have just died, one full GEMM ahead of their use.
-template <int PREC, class HOOK = NoHook>
-__device__ __forceinline__ void gemm_layer2(const char* lds, const LayOff& y, const float (&act)[64], f32x16 (&acc)[4],
-                                            HOOK hook = HOOK()) {
-  if constexpr (PREC == OI_PREC_F32) {
-    f32x4 a[4], an[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a[t] = lds_f4(lds, ((t * 16 + 0) * 1024) & 32767, t < 2 ? y.wl : y.wh);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      if (g < 15) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) an[t] = lds_f4(lds, ((t * 16 + g + 1) * 1024) & 32767, t < 2 ? y.wl : y.wh);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][k], act[4 * g + k], acc[t], 0, 0, 0);
-      }
-      if (g & 1) hook(g >> 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) a[t] = an[t];
-    }
-  } else if constexpr (PREC == OI_PREC_BF16X6) {
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      bf16x8 bh, bm, bl;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float v = act[8 * s + i];
-        bh[i] = (__bf16)v;
-        const float r1 = v - (float)bh[i];
-        bm[i] = (__bf16)r1;
-        bl[i] = (__bf16)(r1 - (float)bm[i]);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, lds_f4(lds, (t * 8 + s) * 1024, y.wl));
-        const bf16x8 wm = __builtin_bit_cast(bf16x8, lds_f4(lds, (t * 8 + s) * 1024, y.wh));
-        const bf16x8 wl = __builtin_bit_cast(bf16x8, lds_f4(lds, (t * 8 + s) * 1024, y.wq));
-        // the six products of weight >= 2^-24, smallest first
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, bm, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, bh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bm, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc[t], 0, 0, 0);
-      }
-      hook(s);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else if constexpr (PREC == OI_PREC_F16X3) {
-    f32x4 ah[4], ahn[4], al[4], aln[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      ah[t] = lds_f4(lds, (t * 8 + 0) * 1024, y.wl);
-      al[t] = lds_f4(lds, (t * 8 + 0) * 1024, y.wh);
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      if (s < 7) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          ahn[t] = lds_f4(lds, (t * 8 + s + 1) * 1024, y.wl);
-          aln[t] = lds_f4(lds, (t * 8 + s + 1) * 1024, y.wh);
-        }
-      }
-      f16x8 bh, bl;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float v = act[8 * s + i];
-        bh[i] = (_Float16)v;
-        bl[i] = (_Float16)(v - (float)bh[i]);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const f16x8 wh = __builtin_bit_cast(f16x8, ah[t]);
-        const f16x8 wl = __builtin_bit_cast(f16x8, al[t]);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, acc[t], 0, 0, 0);
-      }
-      hook(s);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        ah[t] = ahn[t];
-        al[t] = aln[t];
-      }
-    }
-  } else {
-    f32x4 ah[4], ahn[4], al[4], aln[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      ah[t] = lds_f4(lds, (t * 8 + 0) * 1024, y.wl);
-      if constexpr (PREC == OI_PREC_BF16X3) al[t] = lds_f4(lds, (t * 8 + 0) * 1024, y.wh);
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      if (s < 7) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          ahn[t] = lds_f4(lds, (t * 8 + s + 1) * 1024, y.wl);
-          if constexpr (PREC == OI_PREC_BF16X3) aln[t] = lds_f4(lds, (t * 8 + s + 1) * 1024, y.wh);
-        }
-      }
-      bf16x8 bh, bl;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float v = act[8 * s + i];
-        bh[i] = (__bf16)v;
-        if constexpr (PREC == OI_PREC_BF16X3) bl[i] = (__bf16)(v - (float)bh[i]);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, ah[t]);
-        if constexpr (PREC == OI_PREC_BF16X3) {
-          const bf16x8 wl = __builtin_bit_cast(bf16x8, al[t]);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc[t], 0, 0, 0);
-        }
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc[t], 0, 0, 0);
-      }
-      hook(s);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        ah[t] = ahn[t];
-        if constexpr (PREC == OI_PREC_BF16X3) al[t] = aln[t];
-      }
-    }
-  }
-}
 
 template <bool FAST, bool FULL, int SRC, class SCR>
 __device__ __forceinline__ void film_sin2(const char* lds, const LaneOff& o, const LayOff& y, const f32x16 (&acc)[4],
@@ -993,6 +864,21 @@ int oi_selftest_sincos(const float* x, float* s, float* c, long long n, int fast
   else
     hipLaunchKernelGGL(selftest_sincos_kernel<false>, dim3(oi::cdiv(n, 256)), dim3(256), 0, oi::as_stream(stream), x, s, c, n);
   return oi::check_launch("oi_selftest_sincos");
+}
+
+int oi_mlp_pack_status(const void* packed, oi_stream_t stream) {
+  OI_REQUIRE(packed, "oi_mlp_pack_status: null pointer");
+  hipStream_t st = oi::as_stream(stream);
+  static thread_local float host[H_FLOATS];
+  if (hipMemcpyAsync(host, packed, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return oi::fail(OI_ERR_LAUNCH, "oi_mlp_pack_status: reading the packed header failed");
+  for (int m = 0; m < NMAT; ++m)
+    if (host[H_STATUS + m] != 0.f)
+      return oi::fail(OI_ERR_UNSUPPORTED, "oi_mlp_pack_status: weight image %d holds a non-finite value (inf / NaN)", m);
+  for (int i = 0; i < H_BIAS + 9 * C; ++i)
+    if (!(host[i] >= -3.0e38f && host[i] <= 3.0e38f))
+      return oi::fail(OI_ERR_UNSUPPORTED, "oi_mlp_pack_status: non-finite first-layer / head weight or bias (header float %d)", i);
+  return OI_OK;
 }
 
 size_t oi_mlp_scratch_bytes(int B, long long n_per_elem) {  // upper bound over every precision / kernel

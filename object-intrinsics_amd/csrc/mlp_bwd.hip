@@ -209,7 +209,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
                      const float* __restrict__ rgb_fwd, const float* __restrict__ feat_fwd,
                      const float* __restrict__ g_sdf, const float* __restrict__ g_grad,
                      const float* __restrict__ g_rgb, float* __restrict__ d_small, float* __restrict__ d_gamma,
-                     float* __restrict__ d_beta, char* __restrict__ scratch, long long n_per_elem) {
+                     float* __restrict__ d_beta, char* __restrict__ scratch, long long n_per_elem, long long n_stride,
+                     long long pt_off) {
+  // this launch covers points [pt_off, pt_off + n_per_elem) of every batch element; an element holds n_stride points
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -229,7 +231,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   const RowSum rs{reinterpret_cast<float*>(lds + L_RACC) + 8 * ((lane & 15) >> 2) + 4 * h + (lane & 3), lane};
   const long long local = (long long)blockIdx.x * TILE_PTS + wave * WAVE_PTS + j;
   const bool valid = local < n_per_elem;
-  const long long pt = (long long)e * n_per_elem + (valid ? local : n_per_elem - 1);
+  const long long pt = (long long)e * n_stride + pt_off + (valid ? local : n_per_elem - 1);
   const float vmask = valid ? 1.f : 0.f;  // tail points contribute nothing
   const __amdgpu_buffer_rsrc_t img_rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mats), 0, NMAT * layer_bytes(PREC), 0x00020000);
@@ -860,26 +862,44 @@ mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__
 template <int PREC, bool FAST>
 int launch_bwd(const float* pts, const void* packed, const float* gamma, const float* beta, const float* grad_fwd,
                const float* rgb_fwd, const float* feat_fwd, const float* g_sdf, const float* g_grad, const float* g_rgb, float* d_small,
-               float* d_wmat, float* d_gamma, float* d_beta, void* scratch, int B, long long n, hipStream_t st) {
-  dim3 grid(oi::cdiv(n, TILE_PTS), B), block(256);
+               float* d_wmat, float* d_gamma, float* d_beta, void* scratch, size_t scratch_bytes, int B, long long n,
+               hipStream_t st) {
+  // The scratch is a bound, not a function of the problem: the points of every batch element are processed in chunks of
+  // as many 128-point tiles as `scratch_bytes` holds; all outputs are accumulated, so chunks simply add up.
+  const long long tile_bytes = 4LL * NSLOT_BWD * 16384;
+  const long long tiles_all = oi::cdiv(n, TILE_PTS);
+  long long tiles_fit = (long long)(scratch_bytes / (size_t)(tile_bytes * B));
+  if (tiles_fit < 1) return oi::fail(OI_ERR_INVALID_ARG, "oi_sdf_mlp_bwd: scratch of %zu bytes holds no tile (need >= %lld)",
+                                     scratch_bytes, tile_bytes * B);
+  if (tiles_fit > tiles_all) tiles_fit = tiles_all;
+  tiles_fit = oi::cdiv(tiles_all, oi::cdiv(tiles_all, tiles_fit));  // equal chunks: no short last launch
+  const int has_col = (rgb_fwd != nullptr && g_rgb != nullptr && feat_fwd != nullptr) ? 1 : 0;
   auto k = mlp_bwd_sweep_kernel<PREC, FAST>;
   // per launch: the attribute is per device, and a process may drive several
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL_BWD);
-  hipLaunchKernelGGL(k, grid, block, L_TOTAL_BWD, st, pts, reinterpret_cast<const char*>(packed), gamma, beta, grad_fwd,
-                     rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, d_gamma, d_beta, reinterpret_cast<char*>(scratch), n);
-  int rc = oi::check_launch("oi_sdf_mlp_bwd(sweep)");
-  if (rc != OI_OK) return rc;
-  const long long n_wt = (long long)B * grid.x * 4;
-  int chunk = (int)std::max<long long>(1, (n_wt * 8 + 2047) / 2048);  // ~2048 workgroups in total
-  dim3 g2(oi::cdiv(n_wt, chunk), 8);
-  if constexpr (PREC == OI_PREC_F16X3) {
-    hipLaunchKernelGGL(mlp_wgrad_f16_kernel<FAST>, g2, block, 0, st, reinterpret_cast<const char*>(scratch), gamma, d_wmat,
-                       n_wt, (long long)grid.x * 4, chunk, (rgb_fwd != nullptr && g_rgb != nullptr && feat_fwd != nullptr) ? 1 : 0);
-  } else {
-    hipLaunchKernelGGL(mlp_wgrad_kernel<FAST>, g2, block, 0, st, reinterpret_cast<const char*>(scratch), gamma, d_wmat, n_wt,
-                       (long long)grid.x * 4, chunk, (rgb_fwd != nullptr && g_rgb != nullptr && feat_fwd != nullptr) ? 1 : 0);
+  for (long long t0 = 0; t0 < tiles_all; t0 += tiles_fit) {
+    const long long nt = std::min(tiles_fit, tiles_all - t0);
+    const long long off = t0 * TILE_PTS, cn = std::min<long long>(nt * TILE_PTS, n - off);
+    dim3 grid((unsigned)nt, B), block(256);
+    hipLaunchKernelGGL(k, grid, block, L_TOTAL_BWD, st, pts, reinterpret_cast<const char*>(packed), gamma, beta, grad_fwd,
+                       rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, d_gamma, d_beta, reinterpret_cast<char*>(scratch), cn, n,
+                       off);
+    int rc = oi::check_launch("oi_sdf_mlp_bwd(sweep)");
+    if (rc != OI_OK) return rc;
+    const long long n_wt = (long long)B * grid.x * 4;
+    int chunk = (int)std::max<long long>(1, (n_wt * 8 + 2047) / 2048);  // ~2048 workgroups in total
+    dim3 g2(oi::cdiv(n_wt, chunk), 8);
+    if constexpr (PREC == OI_PREC_F16X3) {
+      hipLaunchKernelGGL(mlp_wgrad_f16_kernel<FAST>, g2, block, 0, st, reinterpret_cast<const char*>(scratch), gamma, d_wmat,
+                         n_wt, (long long)grid.x * 4, chunk, has_col);
+    } else {
+      hipLaunchKernelGGL(mlp_wgrad_kernel<FAST>, g2, block, 0, st, reinterpret_cast<const char*>(scratch), gamma, d_wmat, n_wt,
+                         (long long)grid.x * 4, chunk, has_col);
+    }
+    rc = oi::check_launch("oi_sdf_mlp_bwd(wgrad)");
+    if (rc != OI_OK) return rc;
   }
-  return oi::check_launch("oi_sdf_mlp_bwd(wgrad)");
+  return OI_OK;
 }
 
 }  // namespace
@@ -903,12 +923,19 @@ size_t oi_mlp_bwd_scratch_bytes(int B, long long n_per_elem) {
   return (size_t)B * tiles * 4 * NSLOT_BWD * 16384;
 }
 
+size_t oi_mlp_bwd_scratch_bytes_capped(int B, long long n_per_elem, size_t cap_bytes) {
+  const size_t per_tile = (size_t)B * 4 * NSLOT_BWD * 16384, full = oi_mlp_bwd_scratch_bytes(B, n_per_elem);
+  if (full <= cap_bytes) return full;
+  const size_t tiles = cap_bytes / per_tile;
+  return (tiles < 1 ? 1 : tiles) * per_tile;
+}
+
 int oi_mlp_bwd_small_floats(void) { return DS_TOTAL; }
 
 int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, const float* beta, const float* grad_fwd,
                    const float* rgb_fwd, const float* feat_fwd, const float* g_sdf, const float* g_grad, const float* g_rgb, float* d_small,
-                   float* d_wmat, float* d_gamma, float* d_beta, void* scratch, int B, long long n_per_elem, int prec,
-                   int fast_trig, oi_stream_t stream) {
+                   float* d_wmat, float* d_gamma, float* d_beta, void* scratch, size_t scratch_bytes, int B,
+                   long long n_per_elem, int prec, int fast_trig, oi_stream_t stream) {
   OI_REQUIRE(pts && packed && gamma && beta && d_small && d_wmat && d_gamma && d_beta && scratch,
              "oi_sdf_mlp_bwd: null pointer");
   OI_REQUIRE(B > 0 && n_per_elem > 0, "oi_sdf_mlp_bwd: B=%d n=%lld", B, n_per_elem);
@@ -920,9 +947,9 @@ int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, con
 #define OI_BWD_CASE(P)                                                                                              \
   case P:                                                                                                           \
     return fast_trig ? launch_bwd<P, true>(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, \
-                                           d_wmat, d_gamma, d_beta, scratch, B, n_per_elem, st)                     \
+                                           d_wmat, d_gamma, d_beta, scratch, scratch_bytes, B, n_per_elem, st)      \
                      : launch_bwd<P, false>(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, \
-                                            d_wmat, d_gamma, d_beta, scratch, B, n_per_elem, st);
+                                            d_wmat, d_gamma, d_beta, scratch, scratch_bytes, B, n_per_elem, st);
   switch (prec) {
     OI_BWD_CASE(OI_PREC_F32)
     OI_BWD_CASE(OI_PREC_BF16X3)

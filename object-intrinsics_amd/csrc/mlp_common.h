@@ -25,6 +25,7 @@ constexpr int H_TABS_END = 1568; // tab0..rgb are copied to LDS as one block
 constexpr int H_BIAS = 1568;     // [9][128]  b0, b1..b7, bv
 constexpr int H_WSCALE = 2720;   // [16] 2^-k_m: inverse of the power-of-two scale baked into image m (1 unless F16X3)
 constexpr int H_BOUND = 2736;    // [16] max_i sum_k |image_m[i][k]| of the (scaled) image m: |W_img x| <= bound * max|x|
+constexpr int H_STATUS = 2752;   // [16] 1 if image m holds a non-finite weight (F16X3; read by oi_mlp_pack_status)
 constexpr int H_FLOATS = 2816;
 constexpr size_t H_BYTES = H_FLOATS * 4;
 
@@ -115,20 +116,31 @@ __device__ __forceinline__ void stage_film(char* lds, const float* __restrict__ 
   }
 }
 
-// acc[t][r] (+)= sum_k A[32t + row][k] * act[k]   with the packed A image in LDS.
-// The A fragments are prefetched exactly one k-group ahead; sched_barrier pins that window.
-template <int PREC>
-__device__ __forceinline__ void gemm_layer(const char* lds, const LaneOff& o, const float (&act)[64],
-                                           f32x16 (&acc)[4]) {
+struct LayOff {  // per-layer runtime VGPR bases (everything else is an immediate)
+  int wl;   // 16*lane + ring slot base
+  int wh;   // wl + 32768
+  int wq;   // wl + 65536
+  int f16;  // 16*h + 1024*layer  (FiLM rows of this layer)
+};
+
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// HOOK(s), s = 0..7, runs after the MFMAs that consumed act[8s .. 8s+7]: the reverse sweep uses it to issue the NEXT
+// layer's scratch loads into registers that have just died, one full GEMM ahead of their use.
+template <int PREC, class HOOK = NoHook>
+__device__ __forceinline__ void gemm_layer2(const char* lds, const LayOff& y, const float (&act)[64], f32x16 (&acc)[4],
+                                            HOOK hook = HOOK()) {
   if constexpr (PREC == OI_PREC_F32) {
     f32x4 a[4], an[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) a[t] = wimg_f4(lds, o, (t * 16 + 0) * 1024);
+    for (int t = 0; t < 4; ++t) a[t] = lds_f4(lds, ((t * 16 + 0) * 1024) & 32767, t < 2 ? y.wl : y.wh);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       if (g < 15) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) an[t] = wimg_f4(lds, o, (t * 16 + g + 1) * 1024);
+        for (int t = 0; t < 4; ++t) an[t] = lds_f4(lds, ((t * 16 + g + 1) * 1024) & 32767, t < 2 ? y.wl : y.wh);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -136,24 +148,53 @@ __device__ __forceinline__ void gemm_layer(const char* lds, const LaneOff& o, co
         for (int t = 0; t < 4; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][k], act[4 * g + k], acc[t], 0, 0, 0);
       }
+      if (g & 1) hook(g >> 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 4; ++t) a[t] = an[t];
+    }
+  } else if constexpr (PREC == OI_PREC_BF16X6) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      bf16x8 bh, bm, bl;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = act[8 * s + i];
+        bh[i] = (__bf16)v;
+        const float r1 = v - (float)bh[i];
+        bm[i] = (__bf16)r1;
+        bl[i] = (__bf16)(r1 - (float)bm[i]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, lds_f4(lds, (t * 8 + s) * 1024, y.wl));
+        const bf16x8 wm = __builtin_bit_cast(bf16x8, lds_f4(lds, (t * 8 + s) * 1024, y.wh));
+        const bf16x8 wl = __builtin_bit_cast(bf16x8, lds_f4(lds, (t * 8 + s) * 1024, y.wq));
+        // the six products of weight >= 2^-24, smallest first
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc[t], 0, 0, 0);
+      }
+      hook(s);
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else if constexpr (PREC == OI_PREC_F16X3) {
     f32x4 ah[4], ahn[4], al[4], aln[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      ah[t] = lds_f4(lds, L_WBUF + (t * 8 + 0) * 1024, o.l16);
-      al[t] = lds_f4(lds, L_WBUF + (t * 8 + 0) * 1024, o.l16hi);
+      ah[t] = lds_f4(lds, (t * 8 + 0) * 1024, y.wl);
+      al[t] = lds_f4(lds, (t * 8 + 0) * 1024, y.wh);
     }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       if (s < 7) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          ahn[t] = lds_f4(lds, L_WBUF + (t * 8 + s + 1) * 1024, o.l16);
-          aln[t] = lds_f4(lds, L_WBUF + (t * 8 + s + 1) * 1024, o.l16hi);
+          ahn[t] = lds_f4(lds, (t * 8 + s + 1) * 1024, y.wl);
+          aln[t] = lds_f4(lds, (t * 8 + s + 1) * 1024, y.wh);
         }
       }
       f16x8 bh, bl;
@@ -171,6 +212,7 @@ __device__ __forceinline__ void gemm_layer(const char* lds, const LaneOff& o, co
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, acc[t], 0, 0, 0);
       }
+      hook(s);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -182,16 +224,16 @@ __device__ __forceinline__ void gemm_layer(const char* lds, const LaneOff& o, co
     f32x4 ah[4], ahn[4], al[4], aln[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      ah[t] = lds_f4(lds, L_WBUF + (t * 8 + 0) * 1024, o.l16);
-      if constexpr (PREC == OI_PREC_BF16X3) al[t] = lds_f4(lds, L_WBUF + (t * 8 + 0) * 1024, o.l16hi);
+      ah[t] = lds_f4(lds, (t * 8 + 0) * 1024, y.wl);
+      if constexpr (PREC == OI_PREC_BF16X3) al[t] = lds_f4(lds, (t * 8 + 0) * 1024, y.wh);
     }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       if (s < 7) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          ahn[t] = lds_f4(lds, L_WBUF + (t * 8 + s + 1) * 1024, o.l16);
-          if constexpr (PREC == OI_PREC_BF16X3) aln[t] = lds_f4(lds, L_WBUF + (t * 8 + s + 1) * 1024, o.l16hi);
+          ahn[t] = lds_f4(lds, (t * 8 + s + 1) * 1024, y.wl);
+          if constexpr (PREC == OI_PREC_BF16X3) aln[t] = lds_f4(lds, (t * 8 + s + 1) * 1024, y.wh);
         }
       }
       bf16x8 bh, bl;
@@ -211,6 +253,7 @@ __device__ __forceinline__ void gemm_layer(const char* lds, const LaneOff& o, co
         }
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc[t], 0, 0, 0);
       }
+      hook(s);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -219,6 +262,19 @@ __device__ __forceinline__ void gemm_layer(const char* lds, const LaneOff& o, co
       }
     }
   }
+}
+
+// acc[t][r] (+)= sum_k A[32t + row][k] * act[k]  with the packed A image in LDS: ONE implementation for every kernel
+// (gemm_layer2); callers that address the image through a LaneOff go through this adapter.
+template <int PREC>
+__device__ __forceinline__ void gemm_layer(const char* lds, const LaneOff& o, const float (&act)[64],
+                                           f32x16 (&acc)[4]) {
+  LayOff y;
+  y.wl = o.l16 + L_WBUF;
+  y.wh = o.l16hi + L_WBUF;
+  y.wq = y.wl + 65536;
+  y.f16 = 0;
+  gemm_layer2<PREC>(lds, y, act, acc);
 }
 
 // sin and cos of one fp32 phase.  Three accurate forms (OI_TRIG_HW), measured A/B on one MI355X (full f16x3 kernel):
@@ -439,12 +495,6 @@ __host__ __device__ constexpr int v2_lds_total(int prec, bool full) {
   return V2_WBUF + (v2_two_slots(prec, full) ? 2 : 1) * layer_bytes(prec);
 }
 
-struct LayOff {  // per-layer runtime VGPR bases (everything else is an immediate)
-  int wl;   // 16*lane + ring slot base
-  int wh;   // wl + 32768
-  int wq;   // wl + 65536
-  int f16;  // 16*h + 1024*layer  (FiLM rows of this layer)
-};
 
 template <int PREC, int NWAVES>
 __device__ __forceinline__ void prefetch_image(char* lds, const char* __restrict__ src, int slot, int wave, int lane) {

@@ -57,17 +57,6 @@ class FilmParamsFunction(torch.autograd.Function):
         return None, r["d_w"], None, None, r["d_gw"], r["d_gb"], r["d_bw"], r["d_bb"]
 
 
-def _film_params_torch(P, z, w):
-    if w is None:
-        h = z
-        for i in range(3):
-            h = torch.nn.functional.leaky_relu(h @ P["style_w"][i].t() + P["style_b"][i], 0.2)
-        w = h
-    gamma = 15.0 * (torch.einsum("bk,lfk->blf", w, P["gw"]) + P["gb"][None]) + 30.0
-    beta = 0.25 * (torch.einsum("bk,lfk->blf", w, P["bw"]) + P["bb"][None])
-    return w, gamma, beta
-
-
 def style_mlp(style_module, z):
     ws = torch.stack([m.weight for m in style_module])
     bs = torch.stack([m.bias for m in style_module])

@@ -249,6 +249,11 @@ class FieldPack:
                                                          P["wv"], P["bv"], P["wrgb"], P["brgb"], prec)
         return self._packs[prec]
 
+    def check(self):
+        """Finiteness report of the packed images (oi_mlp_pack_status): one stream sync, so call it where that is free --
+        after a checkpoint load, before an inference run -- not inside a training iteration."""
+        ops.mlp_pack_status(self.packed())
+
     def film(self, z=None, w=None):
         from .autograd import film_params
         return film_params(self, z=z, w=w)

@@ -53,6 +53,7 @@ def render_frames(gen, zs, b2ws, keys=("image", "mask", "normal_map", "shading_m
     """One frame per (z, b2w) pair, eval mode (perturb off, multi-chunk allowed: generator.py:286-305).
     graphed=True replays one captured hipGraph per frame (oi_amd.graphed.GraphedForward; background fixed to black)."""
     gen.eval()
+    gen.renderer.pack.check()  # inf / NaN weights (a broken checkpoint) are reported here, once, not as NaN frames
     if graphed:
         from .graphed import GraphedForward
         old = G.MAX_RAY_BATCH_SIZE

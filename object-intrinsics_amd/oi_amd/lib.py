@@ -45,14 +45,16 @@ _SIGS = {
     "oi_film_params_bwd": (_i, [_vp] * 16 + [_i, _i, _vp]),
     "oi_mlp_packed_bytes": (_sz, [_i]),
     "oi_mlp_pack_weights": (_i, [_vp] * 11 + [_i, _vp]),
+    "oi_mlp_pack_status": (_i, [_vp, _vp]),
     "oi_mlp_scratch_bytes": (_sz, [_i, _ll]),
     "oi_mlp_scratch_bytes_prec": (_sz, [_i, _ll, _i]),
     "oi_sdf_mlp_fwd": (_i, [_vp] * 9 + [_i, _ll, _i, _i, _vp]),
     "oi_selftest_sincos": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
     "oi_selftest_cu_slots": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "oi_mlp_bwd_scratch_bytes": (_sz, [_i, _ll]),
+    "oi_mlp_bwd_scratch_bytes_capped": (_sz, [_i, _ll, _sz]),
     "oi_mlp_bwd_small_floats": (_i, []),
-    "oi_sdf_mlp_bwd": (_i, [_vp] * 15 + [_i, _ll, _i, _i, _vp]),
+    "oi_sdf_mlp_bwd": (_i, [_vp] * 15 + [_sz, _i, _ll, _i, _i, _vp]),
     "oi_composite_bwd": (_i, [ctypes.POINTER(CompositeParams), ctypes.POINTER(CompositeGrads), _vp]),
     "oi_render_stats": (_i, [_vp, _i, _ll, _i, _vp, _vp]),
     "oi_composite_num_blocks": (_i, [_ll]),

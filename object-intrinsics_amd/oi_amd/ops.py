@@ -4,6 +4,7 @@ Every function allocates its outputs with the torch caching allocator, passes ra
 pointers + the *current* HIP stream to liboi_hip.so, and returns immediately (stream ordered).
 Autograd structure lives in `oi_amd.autograd`."""
 import ctypes
+import os
 
 import torch
 
@@ -93,6 +94,11 @@ def mlp_pack_weights(w0, b0, wh, bh, wsig, bsig, wv, bv, wrgb, brgb, prec):
     return packed
 
 
+def mlp_pack_status(packed):
+    """Raises (OI_ERR_UNSUPPORTED) if the packed image was built from an inf / NaN weight; synchronises the stream."""
+    _l.check(_l.load().oi_mlp_pack_status(_p(packed), _stream()), "oi_mlp_pack_status")
+
+
 def mlp_scratch_bytes(B, n_per_elem, prec=None):
     L = _l.load()
     return L.oi_mlp_scratch_bytes(B, n_per_elem) if prec is None else L.oi_mlp_scratch_bytes_prec(B, n_per_elem, prec)
@@ -119,18 +125,26 @@ def sdf_mlp_fwd(pts, packed, gamma, beta, B, prec, fast_trig=False, want_grad=Fa
     return sdf, grad, rgb, feat, scratch
 
 
-def sdf_mlp_bwd(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, B, prec, fast_trig=False):
-    """-> d_small (flat), d_wmat (8,128,128), d_gamma (B,9,128), d_beta (B,9,128)."""
+def bwd_scratch_cap_bytes():
+    """Upper bound of the MLP backward's working memory (OI_BWD_SCRATCH_MB, default 8192): larger problems run in chunks."""
+    return int(float(os.environ.get("OI_BWD_SCRATCH_MB", "8192")) * (1 << 20))
+
+
+def sdf_mlp_bwd(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, B, prec, fast_trig=False,
+                scratch_cap=None):
+    """-> d_small (flat), d_wmat (8,128,128), d_gamma (B,9,128), d_beta (B,9,128).  Working memory is bounded by
+    `scratch_cap` bytes (default bwd_scratch_cap_bytes()); the library processes the points in chunks that fit."""
     L = _l.load()
     pts = _c(pts)
     n = pts.shape[0] // B
     dev = pts.device
     d_small, d_wmat, d_gamma, d_beta = _zeros_split(dev, (L.oi_mlp_bwd_small_floats(),), (8, 128, 128), (B, 9, 128),
                                                     (B, 9, 128))
-    scratch = torch.empty(L.oi_mlp_bwd_scratch_bytes(B, n), dtype=torch.uint8, device=dev)
+    nbytes = L.oi_mlp_bwd_scratch_bytes_capped(B, n, bwd_scratch_cap_bytes() if scratch_cap is None else int(scratch_cap))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     args = [_c(t) for t in (grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb)]
     _l.check(L.oi_sdf_mlp_bwd(_p(pts), _p(packed), _p(_c(gamma)), _p(_c(beta)), *[_p(a) for a in args], _p(d_small),
-                              _p(d_wmat), _p(d_gamma), _p(d_beta), _p(scratch), B, n, prec, int(bool(fast_trig)),
+                              _p(d_wmat), _p(d_gamma), _p(d_beta), _p(scratch), nbytes, B, n, prec, int(bool(fast_trig)),
                               _stream()), "oi_sdf_mlp_bwd")
     return d_small, d_wmat, d_gamma, d_beta
 

@@ -528,3 +528,65 @@ def test_graphed_discriminator_steps_match_eager():
         res.append(r)
     for k in res[0]:
         assert abs(res[0][k] - res[1][k]) <= 2e-4 * max(1.0, abs(res[0][k])), (k, res[0][k], res[1][k])
+
+
+@pytest.mark.parametrize("n,B", [(700, 1), (300, 2)])
+def test_mlp_backward_bounded_scratch_chunks_match_single_launch(sdf_sd, col_sd, n, B, monkeypatch):
+    """the backward's working memory is a bound (OI_BWD_SCRATCH_MB), not a function of the problem size.  With
+    a cap of ONE 128-point tile per batch element the library walks the points in ceil(n / 128) chunks (ragged last chunk,
+    per-element offsets); every parameter / FiLM gradient must equal the single-launch result up to the order of the fp32
+    atomics."""
+    from oi_amd import ops
+    from oi_amd.fields import ShapeNetwork, ColorNetwork, FieldPack
+    from oi_amd.autograd import sdf_mlp
+    g = torch.Generator().manual_seed(n + B)
+    pts = (torch.rand(B * n, 3, generator=g) * 2.0 - 1.0).cuda()
+    cs, cg, cr = torch.randn(B * n, generator=g).cuda(), 0.1 * torch.randn(B * n, 3, generator=g).cuda(), torch.randn(B * n, 3, generator=g).cuda()
+    sdf_net = ShapeNetwork(SDF_NPZ, **NET_KW).cuda()
+    col_net = ColorNetwork(**NET_KW)
+    col_net.load_state_dict(col_sd)
+    col_net = col_net.cuda()
+    pack = FieldPack(sdf_net, col_net, "f16x3")
+    named = [v for k, v in sdf_net.named_parameters() if not k.startswith("style.")] + list(col_net.parameters())
+
+    def grads():
+        wh = O.style_mlp(sdf_sd, torch.randn(B, 64, generator=torch.Generator().manual_seed(3))).cuda().requires_grad_(True)
+        _, gamma, beta = pack.film(w=wh)
+        sdf, grad, rgb, _ = sdf_mlp(pack, pts, gamma, beta, B, True, True, False)
+        loss = (sdf * cs).sum() + (grad * cg).sum() + (rgb * cr).sum()
+        return torch.autograd.grad(loss, named + [wh])
+
+    full = grads()
+    tile_bytes = ops._l.load().oi_mlp_bwd_scratch_bytes(B, 128)
+    assert ops._l.load().oi_mlp_bwd_scratch_bytes_capped(B, n, tile_bytes) == tile_bytes
+    assert ops._l.load().oi_mlp_bwd_scratch_bytes_capped(B, n, 1) == tile_bytes          # never below one tile
+    monkeypatch.setenv("OI_BWD_SCRATCH_MB", str(tile_bytes / (1 << 20)))
+    chunked = grads()
+    for a, b in zip(full, chunked):
+        assert rel_err(b, a) < 2e-5, rel_err(b, a)
+
+
+def test_pack_status_reports_non_finite_weights(col_sd):
+    """the F16X3 images carry a per-image power-of-two scale taken from the image's own max, so every
+    finite weight is representable; what cannot be represented (inf / NaN, e.g. a diverged checkpoint) is flagged in the
+    packed header and reported by oi_mlp_pack_status instead of silently producing NaN frames."""
+    from oi_amd.fields import ShapeNetwork, ColorNetwork, FieldPack
+    sdf_net = ShapeNetwork(SDF_NPZ, **NET_KW).cuda()
+    col_net = ColorNetwork(**NET_KW)
+    col_net.load_state_dict(col_sd)
+    col_net = col_net.cuda()
+    pack = FieldPack(sdf_net, col_net, "f16x3")
+    pack.check()                                     # healthy weights, including a 1e4 outlier below
+    with torch.no_grad():
+        lin = [m for m in sdf_net.modules() if type(m).__name__ == "FiLMSiren" and tuple(m.weight.shape) == (128, 128)][2]
+        lin.weight[5, 7] = 3.0e4
+    pack.check()
+    with torch.no_grad():
+        lin.weight[5, 7] = float("nan")
+    with pytest.raises(RuntimeError, match="non-finite"):
+        pack.check()
+    with torch.no_grad():
+        lin.weight[5, 7] = 0.0
+        col_net.rgb_linear.bias[1] = float("inf")
+    with pytest.raises(RuntimeError, match="non-finite"):
+        pack.check()

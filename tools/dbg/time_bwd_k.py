@@ -12,7 +12,7 @@ col_sd = load_golden("weights_color")
 sdf_net = ShapeNetwork(SDF_NPZ, **NET_KW).cuda(); col_net = ColorNetwork(**NET_KW); col_net.load_state_dict(col_sd); col_net = col_net.cuda()
 pack = FieldPack(sdf_net, col_net, "f16x3")
 if os.environ.get("OI_DBG_FAST"): pack.fast_trig = True
-B, n = 1, 524288
+B, n = 1, int(os.environ.get('OI_DBG_N', 524288))
 pts = (torch.rand(B * n, 3, device="cuda") * 2 - 1)
 w = torch.randn(B, 64, device="cuda").requires_grad_(True)
 ts = []
