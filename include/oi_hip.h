@@ -355,6 +355,23 @@ int oi_affine_grid_sample_fwd(const float* x, const float* theta, float* y, int 
 int oi_affine_grid_sample_bwd(const float* gy, const float* theta, float* gx, int B, int C, int Hi,
                               int Wi, int Ho, int Wo, oi_stream_t stream);
 
+/* Stand-alone plugin ops, for a caller that keeps the reference's own Python layers and only swaps the compiled ops
+ * (INTEGRATION.md 3).
+ * oi_fused_bias_act = fused_bias_act(input, bias, refer, act, grad, alpha, scale) of stylesdf/op/fused_bias_act.cpp:11-20
+ * (kernel fused_bias_act_kernel.cu:18-49): out[i] = f(x[i] + bias[(i / step_b) % size_b]) * scale with act 1 = linear,
+ * 3 = leaky relu (slope alpha); grad 0 = value, 1 = first derivative gated by sign(refer), 2 = second derivative (0).
+ * bias / refer may be NULL (the reference passes empty tensors); step_b = product of the dimensions after the channel. */
+int oi_fused_bias_act(float* out, const float* x, const float* bias, const float* refer, int act, int grad, float alpha,
+                      float scale, long long size_x, long long step_b, int size_b, oi_stream_t stream);
+/* grid_sample(input, grid) of ada/torch_utils/ops/grid_sample_gradfix.py:33-66: bilinear, zeros padding,
+ * align_corners = False.  x [N][C][Hi][Wi], grid [N][Ho][Wo][2] (x, y in [-1, 1]), y [N][C][Ho][Wo].
+ * oi_grid_sample_bwd is the aten::grid_sampler_2d_backward that wrapper calls: gx [N][C][Hi][Wi] (assigned; NULL to
+ * skip) and ggrid [N][Ho][Wo][2] (assigned; NULL to skip: the output_mask of the reference call). */
+int oi_grid_sample_fwd(const float* x, const float* grid, float* y, int N, int C, int Hi, int Wi, int Ho, int Wo,
+                       oi_stream_t stream);
+int oi_grid_sample_bwd(const float* gy, const float* x, const float* grid, float* gx, float* ggrid, int N, int C, int Hi,
+                       int Wi, int Ho, int Wo, oi_stream_t stream);
+
 /* Reflect padding (torch.nn.functional.pad(mode='reflect'), augment.py:286) and its adjoint. */
 int oi_reflect_pad_fwd(const float* x, float* y, int BC, int H, int W, int px0, int px1, int py0,
                        int py1, oi_stream_t stream);

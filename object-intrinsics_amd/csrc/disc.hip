@@ -116,6 +116,103 @@ __global__ void bias_lrelu_kernel(float* __restrict__ y, const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// Stand-alone plugin ops for a caller that keeps the reference's own Python layers:
+//   fused_bias_act(input, bias, refer, act, grad, alpha, scale)   stylesdf/op/fused_bias_act.cpp:11-20, kernel .cu:18-49
+//   grid_sample(input, grid)  (bilinear, zeros padding, align_corners=False) + the aten::grid_sampler_2d_backward the
+//   reference's autograd wrapper calls                             ada/torch_utils/ops/grid_sample_gradfix.py:33-66
+// Both are HBM-bound elementwise / gather kernels: coalesced along the innermost dimension, nothing staged.
+// ------------------------------------------------------------------------------------------
+__global__ void fused_bias_act_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ b,
+                                      const float* __restrict__ ref, int act, int grad, float alpha, float scale,
+                                      long long size_x, long long step_b, int size_b) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= size_x) return;
+  float v = x[i];
+  if (b != nullptr) v += b[(i / step_b) % size_b];
+  const float r = ref != nullptr ? ref[i] : 0.f;
+  float y;
+  switch (act * 10 + grad) {
+    default:
+    case 10:
+    case 11: y = v; break;
+    case 12:
+    case 32: y = 0.f; break;
+    case 30: y = v > 0.f ? v : v * alpha; break;
+    case 31: y = r > 0.f ? v : v * alpha; break;
+  }
+  out[i] = y * scale;
+}
+
+// unnormalise (align_corners = False): [-1, 1] -> [-0.5, size - 0.5]
+__device__ __forceinline__ float gs_src(float g, int size) { return ((g + 1.f) * size - 1.f) * 0.5f; }
+
+__global__ void grid_sample_fwd_kernel(const float* __restrict__ x, const float* __restrict__ grid, float* __restrict__ y,
+                                       int N, int C, int Hi, int Wi, int Ho, int Wo) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)N * C * Ho * Wo;
+  if (idx >= n) return;
+  const int ox = idx % Wo, oy = (idx / Wo) % Ho, c = (idx / ((long long)Wo * Ho)) % C;
+  const int b = idx / ((long long)Wo * Ho * C);
+  const float* gp = grid + (((size_t)b * Ho + oy) * Wo + ox) * 2;
+  const float ix = gs_src(gp[0], Wi), iy = gs_src(gp[1], Hi);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float tx = ix - fx, ty = iy - fy;
+  const float* xp = x + ((size_t)b * C + c) * Hi * Wi;
+  float v = 0.f;
+  if (y0 >= 0 && y0 < Hi) {
+    if (x0 >= 0 && x0 < Wi) v += xp[y0 * Wi + x0] * (1.f - tx) * (1.f - ty);
+    if (x0 + 1 >= 0 && x0 + 1 < Wi) v += xp[y0 * Wi + x0 + 1] * tx * (1.f - ty);
+  }
+  if (y0 + 1 >= 0 && y0 + 1 < Hi) {
+    if (x0 >= 0 && x0 < Wi) v += xp[(y0 + 1) * Wi + x0] * (1.f - tx) * ty;
+    if (x0 + 1 >= 0 && x0 + 1 < Wi) v += xp[(y0 + 1) * Wi + x0 + 1] * tx * ty;
+  }
+  y[idx] = v;
+}
+
+// one thread per output pixel, looping over the channels: the grid gradient is a sum over channels (no atomics for it)
+__global__ void grid_sample_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                       const float* __restrict__ grid, float* __restrict__ gx, float* __restrict__ ggrid,
+                                       int N, int C, int Hi, int Wi, int Ho, int Wo) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)N * Ho * Wo;
+  if (idx >= n) return;
+  const int ox = idx % Wo, oy = (idx / Wo) % Ho;
+  const int b = idx / ((long long)Wo * Ho);
+  const float* gp = grid + (size_t)idx * 2;
+  const float ix = gs_src(gp[0], Wi), iy = gs_src(gp[1], Hi);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float tx = ix - fx, ty = iy - fy;
+  const bool vx0 = x0 >= 0 && x0 < Wi, vx1 = x0 + 1 >= 0 && x0 + 1 < Wi;
+  const bool vy0 = y0 >= 0 && y0 < Hi, vy1 = y0 + 1 >= 0 && y0 + 1 < Hi;
+  float dix = 0.f, diy = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float g = gy[(((size_t)b * C + c) * Ho + oy) * Wo + ox];
+    const size_t plane = ((size_t)b * C + c) * Hi * Wi;
+    if (gx != nullptr) {
+      float* q = gx + plane;
+      if (vy0 && vx0) atomicAdd(q + y0 * Wi + x0, g * (1.f - tx) * (1.f - ty));
+      if (vy0 && vx1) atomicAdd(q + y0 * Wi + x0 + 1, g * tx * (1.f - ty));
+      if (vy1 && vx0) atomicAdd(q + (y0 + 1) * Wi + x0, g * (1.f - tx) * ty);
+      if (vy1 && vx1) atomicAdd(q + (y0 + 1) * Wi + x0 + 1, g * tx * ty);
+    }
+    if (ggrid != nullptr) {
+      const float* xp = x + plane;
+      const float v00 = vy0 && vx0 ? xp[y0 * Wi + x0] : 0.f, v01 = vy0 && vx1 ? xp[y0 * Wi + x0 + 1] : 0.f;
+      const float v10 = vy1 && vx0 ? xp[(y0 + 1) * Wi + x0] : 0.f, v11 = vy1 && vx1 ? xp[(y0 + 1) * Wi + x0 + 1] : 0.f;
+      dix += g * ((v01 - v00) * (1.f - ty) + (v11 - v10) * ty);
+      diy += g * ((v10 - v00) * (1.f - tx) + (v11 - v01) * tx);
+    }
+  }
+  if (ggrid != nullptr) {
+    ggrid[(size_t)idx * 2 + 0] = dix * (0.5f * Wi);
+    ggrid[(size_t)idx * 2 + 1] = diy * (0.5f * Hi);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // upfirdn2d: zero-insert upsample -> pad/crop -> FIR -> decimate, direct form.
 // ------------------------------------------------------------------------------------------
 __global__ void upfirdn2d_kernel(const float* __restrict__ x, const float* __restrict__ f, float* __restrict__ y,
@@ -318,6 +415,43 @@ int oi_affine_grid_sample_bwd(const float* gy, const float* theta, float* gx, in
   hipLaunchKernelGGL(affine_grid_sample_bwd_kernel, dim3(oi::cdiv(n, 256)), dim3(256), 0, st, gy, theta, gx, B, C, Hi,
                      Wi, Ho, Wo);
   return oi::check_launch("oi_affine_grid_sample_bwd");
+}
+
+int oi_fused_bias_act(float* out, const float* x, const float* bias, const float* refer, int act, int grad, float alpha,
+                      float scale, long long size_x, long long step_b, int size_b, oi_stream_t stream) {
+  OI_REQUIRE(out && x, "oi_fused_bias_act: null pointer");
+  OI_REQUIRE(size_x > 0 && (bias == nullptr || (step_b > 0 && size_b > 0)), "oi_fused_bias_act: bad shape");
+  OI_REQUIRE((act == 1 || act == 3) && grad >= 0 && grad <= 2, "oi_fused_bias_act: act %d grad %d (linear = 1, lrelu = 3)", act,
+             grad);
+  hipLaunchKernelGGL(fused_bias_act_kernel, dim3(oi::cdiv(size_x, 256)), dim3(256), 0, oi::as_stream(stream), out, x, bias,
+                     refer, act, grad, alpha, scale, size_x, step_b, size_b);
+  return oi::check_launch("oi_fused_bias_act");
+}
+
+int oi_grid_sample_fwd(const float* x, const float* grid, float* y, int N, int C, int Hi, int Wi, int Ho, int Wo,
+                       oi_stream_t stream) {
+  OI_REQUIRE(x && grid && y, "oi_grid_sample_fwd: null pointer");
+  OI_REQUIRE(N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "oi_grid_sample_fwd: bad shape");
+  const long long n = (long long)N * C * Ho * Wo;
+  hipLaunchKernelGGL(grid_sample_fwd_kernel, dim3(oi::cdiv(n, 256)), dim3(256), 0, oi::as_stream(stream), x, grid, y, N, C, Hi,
+                     Wi, Ho, Wo);
+  return oi::check_launch("oi_grid_sample_fwd");
+}
+
+int oi_grid_sample_bwd(const float* gy, const float* x, const float* grid, float* gx, float* ggrid, int N, int C, int Hi,
+                       int Wi, int Ho, int Wo, oi_stream_t stream) {
+  OI_REQUIRE(gy && grid && (gx || ggrid), "oi_grid_sample_bwd: null pointer");
+  OI_REQUIRE(ggrid == nullptr || x != nullptr, "oi_grid_sample_bwd: the grid gradient needs the input");
+  OI_REQUIRE(N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "oi_grid_sample_bwd: bad shape");
+  hipStream_t st = oi::as_stream(stream);
+  if (gx != nullptr) {
+    hipError_t e = oi::zero_async(gx, (size_t)N * C * Hi * Wi, st);
+    if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_grid_sample_bwd: zero fill: %s", hipGetErrorString(e));
+  }
+  const long long n = (long long)N * Ho * Wo;
+  hipLaunchKernelGGL(grid_sample_bwd_kernel, dim3(oi::cdiv(n, 256)), dim3(256), 0, st, gy, x, grid, gx, ggrid, N, C, Hi, Wi, Ho,
+                     Wo);
+  return oi::check_launch("oi_grid_sample_bwd");
 }
 
 int oi_reflect_pad_fwd(const float* x, float* y, int BC, int H, int W, int px0, int px1, int py0, int py1,

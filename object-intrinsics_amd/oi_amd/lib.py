@@ -74,6 +74,9 @@ _SIGS = {
     "oi_upfirdn2d": (_i, [_vp] * 3 + [_i] * 14 + [_f, _vp]),
     "oi_affine_grid_sample_fwd": (_i, [_vp] * 3 + [_i] * 6 + [_vp]),
     "oi_affine_grid_sample_bwd": (_i, [_vp] * 3 + [_i] * 6 + [_vp]),
+    "oi_fused_bias_act": (_i, [_vp] * 4 + [_i, _i, _f, _f, _ll, _ll, _i, _vp]),
+    "oi_grid_sample_fwd": (_i, [_vp] * 3 + [_i] * 6 + [_vp]),
+    "oi_grid_sample_bwd": (_i, [_vp] * 5 + [_i] * 6 + [_vp]),
     "oi_reflect_pad_fwd": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
     "oi_reflect_pad_bwd": (_i, [_vp, _vp] + [_i] * 7 + [_vp]),
     "oi_mt_chunk_elems": (_i, []),

@@ -1,5 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
 {
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8
+timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "plugin" 2>&1 | tail -30
 } > gpurun_out/t.log 2>&1 < /dev/null
