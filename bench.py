@@ -488,8 +488,10 @@ def extras(args, gen, device):
                                                        "frac": bsz * d_flops / ms / 1e9 / 157.3},
                                          "weight_read_hbm": {"achieved_GB_per_s": d_wbytes / ms / 1e6, "peak": 8000.0,
                                                              "frac": d_wbytes / ms / 1e6 / 8000.0}}}
-    out["discriminator"] = {"what": "ADADiscriminatorView forward (ADA xint + scale, 5 conv4x4 s2 + head), 64^2, fp32; bound: "
-                                    "weight read at B = 1, fp32 MFMA at B = 64", **sweep}
+    out["discriminator"] = {"what": "ADADiscriminatorView forward (ADA xint + scale, 5 conv4x4 s2 + head), 64^2; convolutions: fp32 MFMA "
+                                    "per-wave gather below 512 output pixels per layer, LDS-tiled f16x3 (22-bit operands, fp32 "
+                                    "accumulate, fixed summation order) above; wall time per forward incl. host launches; bound: "
+                                    "weight read at B = 1, fp32-MFMA peak as the yardstick at B = 64", **sweep}
     del disc
     # ---- shipped training configuration
     import copy

@@ -6,6 +6,8 @@
 //   upfirdn2d plugin (src/third_party/ada/torch_utils/ops/upfirdn2d.cu:29-200, upfirdn2d.cpp:16-94)
 //   F.affine_grid + grid_sample (ada/augment.py:297-298, grid_sample_gradfix.py:33-97), reflect pad
 //     (augment.py:286)
+#include <cstdlib>
+
 #include "oi_common.h"
 
 namespace {
@@ -102,6 +104,187 @@ conv4x4_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
       *dst = v > 0.f ? v : v * slope;
     } else {
       atomicAdd(dst, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Large-batch form of the same convolution (M = B * Ho * Wo >= 2048 pixels: discriminator batches of 16+, e.g. the
+// B = 64 row of SURVEY.md 8d): an LDS-tiled implicit GEMM on the fp16 matrix cores with fp32 operands split into two
+// fp16 limbs (hi + lo = 22 mantissa bits, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate -- the F16X3 mode of
+// the MLP kernels; conv inputs are images / LeakyReLU activations of O(1), weights O(0.1): no scaling needed, and an
+// |x| >= 65504 would surface as inf, not as a silent error).
+//   workgroup tile   64 channels x TM pixels (TM = 128, or 64 when that is what fills the chip) x 64 taps per K chunk
+//   wave (4)         32 channels x TM/2 pixels: TM/64 accumulator blocks, 3 MFMAs per block and 16-tap step
+//   LDS              both operands in MFMA-fragment order [block][k-step][lane][8 x fp16], hi plane | lo plane: every
+//                    operand read is one conflict-free ds_read_b128; every staged octet (8 consecutive taps = two kernel
+//                    rows of one input channel) is one ds_write_b128 per plane
+//   global           a thread gathers its octet's 2 x 4 input pixels (bounds-checked, LeakyReLU of the producer applied on
+//                    the fly) / reads its 2 x float4 of weights, splits to limbs once, and every limb is then used by 32
+//                    (weights: TM) MFMA columns: 16x (TM x) fewer global loads and conversions per MAC than the per-wave
+//                    gather of conv4x4_fwd_kernel.  K is never split: summation order is fixed (reproducible).
+// ------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split8(const float (&v)[8], f32x4& hi, f32x4& lo) {
+  f16x8 h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    h[i] = (_Float16)v[i];
+    l[i] = (_Float16)(v[i] - (float)h[i]);
+  }
+  hi = __builtin_bit_cast(f32x4, h);
+  lo = __builtin_bit_cast(f32x4, l);
+}
+
+template <int TM>
+__global__ void __launch_bounds__(256)
+conv4x4_tiled_f16x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                           float* __restrict__ y, int B, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride,
+                           int pad, float slope, float x_slope, int k_per_split) {
+  constexpr int TN = 64, TK = 64, MB = TM / 32;        // MB pixel blocks per workgroup, MB / 2 per wave
+  constexpr int A_PLANE = (TN / 32) * (TK / 16) * 1024;  // 8 KiB
+  constexpr int B_PLANE = MB * (TK / 16) * 1024;         // 16 / 8 KiB
+  __shared__ __attribute__((aligned(16))) char lds[2 * A_PLANE + 2 * B_PLANE];
+  char* sa = lds;
+  char* sb = lds + 2 * A_PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int n0 = blockIdx.y * TN;
+  const long long m0 = (long long)blockIdx.x * TM;
+  const long long M = (long long)B * Ho * Wo;
+  const int K = Cin * 16;
+  const int k_begin = blockIdx.z * k_per_split, k_end = min(K, k_begin + k_per_split);
+
+  // ---- staging roles ----
+  // weights: octet (n, q), q = 8-tap group of the chunk: 64 x 8 = 512 octets, 2 per thread (o = tid + 256 i: n = o & 63)
+  // pixels:  octet (m, q): TM x 8 octets, TM / 32 per thread (o = tid + 256 i: pixel o % TM, octet o / TM); consecutive
+  //          threads take consecutive pixels (coalesced input rows)
+  int piy0[MB], pix0[MB];
+  const float* pxb[MB];
+  bool pok[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const long long m = m0 + (tid + 256 * i) % TM;
+    pok[i] = m < M;
+    const long long mm = pok[i] ? m : 0;
+    const int ox = mm % Wo, oy = (mm / Wo) % Ho;
+    pxb[i] = x + (size_t)(mm / ((long long)Wo * Ho)) * Cin * H * W;
+    piy0[i] = oy * stride - pad;
+    pix0[i] = ox * stride - pad;
+  }
+  f32x16 acc[MB / 2];
+#pragma unroll
+  for (int i = 0; i < MB / 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // raw fp32 octets of one chunk in registers: requested one chunk ahead, so the gather's latency runs under the MFMAs
+  float wv[2][8], xv[MB][8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = tid + 256 * i;
+      const int n = n0 + (o & 63), k = k0 + 8 * (o >> 6);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wv[i][e] = 0.f;
+      if (n < Cout && k < k_end) {
+        const float4 a = *reinterpret_cast<const float4*>(w + (size_t)n * K + k);
+        const float4 c = *reinterpret_cast<const float4*>(w + (size_t)n * K + k + 4);
+        wv[i][0] = a.x; wv[i][1] = a.y; wv[i][2] = a.z; wv[i][3] = a.w;
+        wv[i][4] = c.x; wv[i][5] = c.y; wv[i][6] = c.z; wv[i][7] = c.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const int k = k0 + 8 * ((tid + 256 * i) / TM);
+      const int cin = k >> 4, ky0 = (k >> 2) & 3;  // ky0 = 0 or 2: the octet is kernel rows ky0, ky0 + 1 of channel cin
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xv[i][e] = 0.f;
+      if (pok[i] && k < k_end) {
+        const float* xc = pxb[i] + (size_t)cin * H * W;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int iy = piy0[i] + ky0 + r;
+          if (iy >= 0 && iy < H) {
+            const float* xr = xc + (size_t)iy * W;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int ix = pix0[i] + c;
+              if (ix >= 0 && ix < W) xv[i][4 * r + c] = xr[ix];
+            }
+          }
+        }
+      }
+    }
+  };
+  fetch(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += TK) {
+    __syncthreads();  // the previous chunk's readers are done
+    // ---- registers -> limbs -> LDS, fragment order [block][k-step][lane = (row & 31) + 32 * (octet & 1)][8] ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = tid + 256 * i;
+      const int nl = o & 63, q = o >> 6;
+      f32x4 hi, lo;
+      split8(wv[i], hi, lo);
+      const int off = (((nl >> 5) * (TK / 16) + (q >> 1)) * 64 + (nl & 31) + 32 * (q & 1)) * 16;
+      *reinterpret_cast<f32x4*>(sa + off) = hi;
+      *reinterpret_cast<f32x4*>(sa + A_PLANE + off) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+      const int o = tid + 256 * i;
+      const int ml = o % TM, q = o / TM;
+      if (x_slope != 1.0f) {  // the producer left its LeakyReLU to this layer's loads
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[i][e] = xv[i][e] > 0.f ? xv[i][e] : xv[i][e] * x_slope;
+      }
+      f32x4 hi, lo;
+      split8(xv[i], hi, lo);
+      const int off = (((ml >> 5) * (TK / 16) + (q >> 1)) * 64 + (ml & 31) + 32 * (q & 1)) * 16;
+      *reinterpret_cast<f32x4*>(sb + off) = hi;
+      *reinterpret_cast<f32x4*>(sb + B_PLANE + off) = lo;
+    }
+    __syncthreads();
+    if (k0 + TK < k_end) fetch(k0 + TK);
+    // ---- MFMAs: this wave's 32 channels x TM / 2 pixels ----
+#pragma unroll
+    for (int ks = 0; ks < TK / 16; ++ks) {
+      const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(sa + ((wn * (TK / 16) + ks) * 64 + lane) * 16));
+      const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(sa + A_PLANE + ((wn * (TK / 16) + ks) * 64 + lane) * 16));
+#pragma unroll
+      for (int j = 0; j < MB / 2; ++j) {
+        const int mb = wm * (MB / 2) + j;
+        const f16x8 bh = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(sb + ((mb * (TK / 16) + ks) * 64 + lane) * 16));
+        const f16x8 bl = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(sb + B_PLANE + ((mb * (TK / 16) + ks) * 64 + lane) * 16));
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // ---- store: D column = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 h (channel) ----
+  const int h = lane >> 5, jl = lane & 31;
+  const bool split = gridDim.z > 1;  // exactly two K halves add into a zeroed output: a + b is order-independent
+#pragma unroll
+  for (int j = 0; j < MB / 2; ++j) {
+    const long long m = m0 + (wm * (MB / 2) + j) * 32 + jl;
+    if (m >= M) continue;
+    const int ox = m % Wo, oy = (m / Wo) % Ho, b = m / ((long long)Wo * Ho);
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int nn = n0 + wn * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * h;
+      if (nn >= Cout) continue;
+      float* dst = y + (((size_t)b * Cout + nn) * Ho + oy) * Wo + ox;
+      float v = acc[j][rg];
+      if (split) {
+        atomicAdd(dst, v);
+      } else {
+        if (bias != nullptr) v += bias[nn];
+        *dst = v > 0.f ? v : v * slope;
+      }
     }
   }
 }
@@ -231,19 +414,20 @@ __global__ void upfirdn2d_kernel(const float* __restrict__ x, const float* __res
   const int ox = idx % Wo, oy = (idx / Wo) % Ho;
   const long long bc = idx / ((long long)Wo * Ho);
   const float* xp = x + bc * H * W;
+  // polyphase walk: only the taps that land on a real sample (every up-th one) are visited, input index + 1 per step; one
+  // integer division per axis and OUTPUT instead of a modulo and a division per TAP (the ADA chain's four passes at B = 64:
+  // 62.6 -> 36.3 us per call on average)
+  const int ty = oy * downy - pady0, tx = ox * downx - padx0;  // zero-inserted coordinate of tap 0
+  int fy0 = ty >= 0 ? (upy - ty % upy) % upy : -ty;            // first tap on a sample with input index >= 0
+  int fx0 = tx >= 0 ? (upx - tx % upx) % upx : -tx;
+  int iy = (ty + fy0) / upy;
+  const int ix0 = (tx + fx0) / upx;
   float acc = 0.f;
-  for (int fy = 0; fy < fh; ++fy) {
-    const int uy = oy * downy + fy - pady0;
-    if (uy < 0 || uy % upy != 0) continue;
-    const int iy = uy / upy;
-    if (iy >= H) continue;
-    for (int fx = 0; fx < fw; ++fx) {
-      const int ux = ox * downx + fx - padx0;
-      if (ux < 0 || ux % upx != 0) continue;
-      const int ix = ux / upx;
-      if (ix >= W) continue;
-      acc = fmaf(xp[iy * W + ix], fs[fy * fw + fx], acc);
-    }
+  for (int fy = fy0; fy < fh && iy < H; fy += upy, ++iy) {
+    const float* xr = xp + (size_t)iy * W;
+    const float* fr = fs + fy * fw;
+    int ix = ix0;
+    for (int fx = fx0; fx < fw && ix < W; fx += upx, ++ix) acc = fmaf(xr[ix], fr[fx], acc);
   }
   y[idx] = acc;
 }
@@ -349,6 +533,35 @@ int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
   OI_REQUIRE(Ho > 0 && Wo > 0, "oi_conv4x4_fwd: input %dx%d too small", H, W);
   const long long M = (long long)B * Ho * Wo;
+  hipStream_t st = oi::as_stream(stream);
+  // large batches: LDS-tiled F16X3 implicit GEMM, K never split (OI_CONV_TILED=0 keeps the per-wave fp32-MFMA path)
+  static const bool tiled_on = [] { const char* e = getenv("OI_CONV_TILED"); return e == nullptr || e[0] != '0'; }();
+  if (tiled_on && M >= 512 && Cout % 64 == 0 && (Cin * 16) % 64 == 0) {
+    const int K = Cin * 16;
+    const bool small = (long long)oi::cdiv(M, 128) * (Cout / 64) < 256;  // fewer workgroups than CUs: halve the pixel tile
+    // still short of the CUs and a long K: two K halves.  Exactly two addends into a zeroed output commute, so the result
+    // stays reproducible; the activation then needs its own pass (none when the caller defers it: slope 1, no bias)
+    const int splits = (small && (long long)oi::cdiv(M, 64) * (Cout / 64) < 192 && K >= 1024) ? 2 : 1;
+    const int k_per_split = splits == 2 ? ((K / 2 + 63) / 64) * 64 : K;
+    const long long total = (long long)B * Cout * Ho * Wo;
+    if (splits == 2 && !y_is_zero) {
+      hipError_t e = oi::zero_async(y, total, st);
+      if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_fwd: zero fill: %s", hipGetErrorString(e));
+    }
+    dim3 grid(oi::cdiv(M, small ? 64 : 128), Cout / 64, splits), block(256);
+    if (small)
+      hipLaunchKernelGGL(conv4x4_tiled_f16x3_kernel<64>, grid, block, 0, st, x, w, bias, y, B, Cin, H, W, Cout, Ho, Wo, stride,
+                         pad, slope, x_slope, k_per_split);
+    else
+      hipLaunchKernelGGL(conv4x4_tiled_f16x3_kernel<128>, grid, block, 0, st, x, w, bias, y, B, Cin, H, W, Cout, Ho, Wo, stride,
+                         pad, slope, x_slope, k_per_split);
+    int rc = oi::check_launch("oi_conv4x4_fwd(tiled)");
+    if (rc == OI_OK && splits == 2 && (slope != 1.0f || bias != nullptr)) {
+      hipLaunchKernelGGL(bias_lrelu_kernel, dim3(oi::cdiv(total, 256)), dim3(256), 0, st, y, bias, total, Cout, Ho * Wo, slope);
+      rc = oi::check_launch("oi_conv4x4_fwd(bias_lrelu)");
+    }
+    return rc;
+  }
   const int m_tiles = oi::cdiv(M, 32), n_tiles = oi::cdiv(Cout, 32);
   const int krows = Cin * 4;
   // split K until ~2 waves per SIMD are in flight, at least 16 kernel rows (64 taps) per split
@@ -358,7 +571,6 @@ int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float
   int rows_per_split = oi::cdiv(krows, k_splits);
   rows_per_split += rows_per_split & 1;  // whole lane-half pairs
   k_splits = oi::cdiv(krows, rows_per_split);
-  hipStream_t st = oi::as_stream(stream);
   const long long total = (long long)B * Cout * Ho * Wo;
   if (k_splits > 1 && !y_is_zero) {
     hipError_t e = oi::zero_async(y, total, st);

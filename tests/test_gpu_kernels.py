@@ -458,3 +458,23 @@ def test_grid_sample_plugin_vs_aten_fwd_bwd_double_bwd():
     da, = torch.autograd.grad((ga1 * v).sum(), ca)
     db = F.grid_sample(v, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
     assert maxdiff(da, db) < 2e-6
+
+
+@pytest.mark.parametrize("B,Cin,H,Cout,x_slope,tile", [(16, 64, 32, 128, 1.0, 64), (9, 128, 32, 64, 0.2, 64), (64, 64, 32, 128, 0.2, 128),
+                                                       (37, 16, 20, 64, 1.0, 64)])
+def test_conv4x4_tiled_f16x3_vs_fp64(ops, B, Cin, H, Cout, x_slope, tile):
+    """The LDS-tiled F16X3 convolution (M = B * Ho * Wo >= 2048 pixels; both pixel-tile widths, ragged last tile, odd
+    image size, LeakyReLU-on-load) against an fp64 convolution: operands carry 22 mantissa bits, accumulation is fp32 with a
+    fixed summation order -- bit-identical between runs."""
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) / math.sqrt(Cin * 16)
+    b = torch.randn(Cout, generator=g)
+    Ho = (H + 2 - 4) // 2 + 1
+    assert B * Ho * Ho >= 2048 and (math.ceil(B * Ho * Ho / 128) * (Cout // 64) < 256) == (tile == 64)
+    xin = torch.nn.functional.leaky_relu(x.double(), x_slope) if x_slope != 1.0 else x.double()
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xin, w.double(), b.double(), stride=2, padding=1), 0.2)
+    y = ops.conv4x4_fwd(x.cuda(), w.cuda(), b.cuda(), 2, 1, 0.2, x_slope=x_slope)
+    assert maxdiff(y.cpu(), ref) < 5e-6 * max(1.0, float(ref.abs().max()))
+    y2 = ops.conv4x4_fwd(x.cuda(), w.cuda(), b.cuda(), 2, 1, 0.2, x_slope=x_slope)
+    assert torch.equal(y, y2)
