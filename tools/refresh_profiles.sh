@@ -20,6 +20,13 @@ for c in "FETCH_SIZE:fetch" "WRITE_SIZE:write" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY
   rm -rf /tmp/p_$tag; rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/p_$tag -- $BENCH --steps 5 --warmup 2 --train-steps 4 > /dev/null 2>&1
   python $R/tools/prof_summary.py /tmp/p_$tag $O/${T}_pmc_${tag}_f16x3.txt > /dev/null
 done
+# training iteration: kernel stats, and launches per iteration from the difference of two runs (10 vs 30 iterations)
+TRAIN="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bf16 --no-extras --min-seconds 0.01"
+rm -rf /tmp/p_t10 /tmp/p_t30
+rocprofv3 --kernel-trace --output-format csv -d /tmp/p_t10 -- $TRAIN --train-steps 10 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/p_t30 -- $TRAIN --train-steps 30 > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/p_t30 $O/${T}_kernel_stats_train.txt > /dev/null
+python $R/tools/train_launches.py /tmp/p_t10 10 /tmp/p_t30 30 > $O/${T}_timeline_train.txt
 python $R/tools/traffic_json.py $O/${T}_pmc_fetch_f16x3.txt $O/${T}_pmc_write_f16x3.txt sdf_mlp_full3_kernel "f16x3:1x64x64:64+64" $O/${T}_traffic.json
 python $R/tools/bench_c5.py > $O/${T}_c5_mlp_microbench.jsonl 2>/dev/null
 ls -la $O/${T}_*
