@@ -42,7 +42,7 @@ def _digest():
     files.append(os.path.join(os.path.dirname(HERE), "include", "oi_hip.h"))
     for f in files:
         with open(f, "rb") as fh:
-            h.update(f.encode())
+            h.update(os.path.basename(f).encode())  # content + name, not the checkout's location
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
     h.update(repr(EXTRA).encode())

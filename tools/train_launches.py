@@ -14,7 +14,7 @@ def load(d):
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                k = r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[:70]
+                k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
                 calls[k] += 1
                 busy[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return calls, busy
