@@ -5,10 +5,10 @@ weights of the reference trainer (src/trainers/gan_pose_trainer.py:77-202; confi
     D step:   render (no grad) -> BCE(D(real),1) + BCE(D(fake)[:, :1],0) + 10*R1(real) + w(it)*MSE(D(fake)[:,1:7], pose)
     maskD:    render (no grad) -> same without the pose term
 i.e. 3 renders, 3+3 discriminator forwards, 3 backward passes (each followed by the flat-gradient
-all-reduce when wrapped in oi_amd.ddp.FlatGradDDP) per iteration.  The reference's own Trainer class
-also runs unmodified on these modules (they keep its interfaces); this compact restatement exists so
-that bench.py / tests can drive a full iteration without the reference's logging/visualisation stack
-(tu.*, tensorboard, torchvision: absent from this image)."""
+all-reduce when wrapped in oi_amd.ddp.FlatGradDDP) per iteration.  The modules keep the interfaces the
+reference's own Trainer class uses, but that class cannot be imported in this image (tu.*, tensorboard,
+torchvision are absent), so running it on top is untested; this compact restatement is what bench.py and
+the tests drive (pinned by the F9 fixture)."""
 import torch
 
 from .losses import GANLoss, PositionLoss, compute_grad2, linear_increase

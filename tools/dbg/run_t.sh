@@ -1,11 +1,10 @@
 #!/bin/bash
 mkdir -p gpurun_out
-R=$GRAFT_REPO_ROOT
-cd /tmp; export TMPDIR=/tmp
 {
-rm -rf /tmp/pd; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/pd -- python $R/tools/dbg/prof_disc64.py > /dev/null 2>&1 < /dev/null
-python $R/tools/prof_summary.py /tmp/pd /tmp/pd.txt < /dev/null > /dev/null 2>&1; head -9 /tmp/pd.txt | cut -c1-150
-rm -rf /tmp/pd1; OI_DBG_B=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/pd1 -- python $R/tools/dbg/prof_disc64.py > /dev/null 2>&1 < /dev/null
-python $R/tools/prof_summary.py /tmp/pd1 /tmp/pd1.txt < /dev/null > /dev/null 2>&1; head -12 /tmp/pd1.txt | cut -c1-150
-cd $R; timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_modules.py tests/test_gpu_backward.py -m gpu -x -q -k "conv4x4 or disc or upfirdn or augment or ada" 2>&1 | tail -3
-} > $R/gpurun_out/t.log 2>&1 < /dev/null
+timeout 900 python -m pytest tests/test_gpu_backward.py tests/test_gpu_ddp.py -m gpu -x -q -k "graphed or train or ddp or iteration" 2>&1 | tail -3
+for v in 0 1 0 1; do echo "== side stream $v"; OI_D_SIDE_STREAM=$v timeout 600 python bench.py --steps 5 --warmup 2 --min-seconds 0.2 --no-cpu-baseline --no-bf16 --no-extras --train-steps 40 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); t = d['training']
+print(t['it_per_s'], t['ms_per_it'], t['d_step']['ms'], t['finite'])
+"; done
+} > gpurun_out/t.log 2>&1 < /dev/null
