@@ -536,12 +536,14 @@ int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float
   hipStream_t st = oi::as_stream(stream);
   // large batches: LDS-tiled F16X3 implicit GEMM, K never split (OI_CONV_TILED=0 keeps the per-wave fp32-MFMA path)
   static const bool tiled_on = [] { const char* e = getenv("OI_CONV_TILED"); return e == nullptr || e[0] != '0'; }();
-  if (tiled_on && M >= 512 && Cout % 64 == 0 && (Cin * 16) % 64 == 0) {
-    const int K = Cin * 16;
-    const bool small = (long long)oi::cdiv(M, 128) * (Cout / 64) < 256;  // fewer workgroups than CUs: halve the pixel tile
-    // still short of the CUs and a long K: two K halves.  Exactly two addends into a zeroed output commute, so the result
-    // stays reproducible; the activation then needs its own pass (none when the caller defers it: slope 1, no bias)
-    const int splits = (small && (long long)oi::cdiv(M, 64) * (Cout / 64) < 192 && K >= 1024) ? 2 : 1;
+  const int K = Cin * 16;
+  const bool small = (long long)oi::cdiv(M, 128) * (Cout / 64) < 256;  // fewer workgroups than CUs: halve the pixel tile
+  // still short of the CUs and a long K: two K halves.  Exactly two addends into a zeroed output commute, so the result
+  // stays reproducible; the activation then needs its own pass (none when the caller defers it: slope 1, no bias)
+  const int splits = (small && (long long)oi::cdiv(M, 64) * (Cout / 64) < 192 && K >= 1024) ? 2 : 1;
+  // worth it from ~half a chip of workgroups; below that the per-wave split-K kernel spreads the K loop over more CUs
+  const bool enough = (long long)oi::cdiv(M, small ? 64 : 128) * (Cout / 64) * splits >= 128;
+  if (tiled_on && M >= 512 && enough && Cout % 64 == 0 && K % 64 == 0) {
     const int k_per_split = splits == 2 ? ((K / 2 + 63) / 64) * 64 : K;
     const long long total = (long long)B * Cout * Ho * Wo;
     if (splits == 2 && !y_is_zero) {
