@@ -408,26 +408,57 @@ __global__ void upfirdn2d_kernel(const float* __restrict__ x, const float* __res
     fs[i] = (flip ? f[fy * fw + fx] : f[(fh - 1 - fy) * fw + (fw - 1 - fx)]) * gain;
   }
   __syncthreads();
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long n = (long long)BC * Ho * Wo;
-  if (idx >= n) return;
-  const int ox = idx % Wo, oy = (idx / Wo) % Ho;
-  const long long bc = idx / ((long long)Wo * Ho);
+  // grid = (row segments, output rows, planes): no integer division to find (plane, oy, ox) -- the three 64-bit
+  // divisions of a flat index cost more than the six taps of an ADA pass
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y;
+  const long long bc = blockIdx.z;
+  if (ox >= Wo) return;
+  const long long idx = (bc * Ho + oy) * Wo + ox;
   const float* xp = x + bc * H * W;
   // polyphase walk: only the taps that land on a real sample (every up-th one) are visited, input index + 1 per step; one
   // integer division per axis and OUTPUT instead of a modulo and a division per TAP (the ADA chain's four passes at B = 64:
   // 62.6 -> 36.3 us per call on average)
   const int ty = oy * downy - pady0, tx = ox * downx - padx0;  // zero-inserted coordinate of tap 0
-  int fy0 = ty >= 0 ? (upy - ty % upy) % upy : -ty;            // first tap on a sample with input index >= 0
-  int fx0 = tx >= 0 ? (upx - tx % upx) % upx : -tx;
-  int iy = (ty + fy0) / upy;
-  const int ix0 = (tx + fx0) / upx;
+  // first tap on a sample with input index >= 0, and that index (up = 1 and 2 -- every ADA pass -- without a division)
+  auto first = [](int t, int up, int& f0, int& i0) {
+    if (up == 1) {
+      f0 = t < 0 ? -t : 0;
+      i0 = t + f0;
+    } else if (up == 2) {
+      f0 = t >= 0 ? (t & 1) : -t;
+      i0 = (t + f0) >> 1;
+    } else {
+      f0 = t >= 0 ? (up - t % up) % up : -t;
+      i0 = (t + f0) / up;
+    }
+  };
+  int fy0, fx0, iy, ix0;
+  first(ty, upy, fy0, iy);
+  first(tx, upx, fx0, ix0);
   float acc = 0.f;
-  for (int fy = fy0; fy < fh && iy < H; fy += upy, ++iy) {
-    const float* xr = xp + (size_t)iy * W;
-    const float* fr = fs + fy * fw;
-    int ix = ix0;
-    for (int fx = fx0; fx < fw && ix < W; fx += upx, ++ix) acc = fmaf(xr[ix], fr[fx], acc);
+  // separable passes with at most 12 visited taps (every ADA pass: 12-tap filters, up or down by 2): all loads of the
+  // output are issued before the first FMA -- the rolled loop below waits out one memory round trip per tap
+  if (fh == 1 && fy0 == 0 && iy < H && (fw - fx0 + upx - 1) / upx <= 12) {
+    const float* xr = xp + (size_t)iy * W + ix0;
+    float v[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) v[t] = (fx0 + t * upx < fw && ix0 + t < W) ? xr[t] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 12; ++t) acc = fmaf(v[t], fx0 + t * upx < fw ? fs[fx0 + t * upx] : 0.f, acc);
+  } else if (fw == 1 && fx0 == 0 && ix0 < W && (fh - fy0 + upy - 1) / upy <= 12) {
+    const float* xc = xp + (size_t)iy * W + ix0;
+    float v[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) v[t] = (fy0 + t * upy < fh && iy + t < H) ? xc[(size_t)t * W] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 12; ++t) acc = fmaf(v[t], fy0 + t * upy < fh ? fs[fy0 + t * upy] : 0.f, acc);
+  } else {
+    for (int fy = fy0; fy < fh && iy < H; fy += upy, ++iy) {
+      const float* xr = xp + (size_t)iy * W;
+      const float* fr = fs + fy * fw;
+      int ix = ix0;
+      for (int fx = fx0; fx < fw && ix < W; fx += upx, ++ix) acc = fmaf(xr[ix], fr[fx], acc);
+    }
   }
   y[idx] = acc;
 }
@@ -601,8 +632,11 @@ int oi_upfirdn2d(const float* x, const float* f, float* y, int BC, int H, int W,
   const int Wo = (W * upx + padx0 + padx1 - fw + downx) / downx;
   const int Ho = (H * upy + pady0 + pady1 - fh + downy) / downy;
   OI_REQUIRE(Wo >= 1 && Ho >= 1, "oi_upfirdn2d: output size %dx%d", Ho, Wo);
-  const long long n = (long long)BC * Ho * Wo;
-  hipLaunchKernelGGL(upfirdn2d_kernel, dim3(oi::cdiv(n, 256)), dim3(256), fh * fw * sizeof(float),
+  OI_REQUIRE(Ho <= 65535 && BC <= 65535, "oi_upfirdn2d: %d rows x %d planes exceed the launch grid", Ho, BC);
+  int bx = 64;  // row segment width with the least padding (ties: the wider one)
+  for (int c = 128; c <= 256; c *= 2)
+    if (oi::cdiv(Wo, c) * c <= oi::cdiv(Wo, bx) * bx) bx = c;
+  hipLaunchKernelGGL(upfirdn2d_kernel, dim3(oi::cdiv(Wo, bx), Ho, BC), dim3(bx), fh * fw * sizeof(float),
                      oi::as_stream(stream), x, f, y, BC, H, W, Ho, Wo, fh, fw, upx, upy, downx, downy, padx0, pady0,
                      flip, gain);
   return oi::check_launch("oi_upfirdn2d");
