@@ -41,12 +41,24 @@ constexpr int F3_LDS = F3_WBUF + 2 * 65536;                 // 152,768 of the CU
 // scratch memory (-Rpass-analysis=kernel-resource-usage); as AGPR-class values they cost one v_accvgpr_write and one
 // v_accvgpr_read each and never compete with the VALU operands.
 typedef float Bank[16][4];
+// timing ablations of single epilogue pieces (results garbage): -DOI_F3_ABL_PIECE bit 1 = no v_sin / v_cos (a multiply
+// instead), 2 = no v_fract, 4 = no AGPR parks, 8 = fp16 split without the residual (hi limb twice)
+#ifndef OI_F3_ABL_PIECE
+#define OI_F3_ABL_PIECE 0
+#endif
+__device__ __forceinline__ float f3_sin(float r) { return (OI_F3_ABL_PIECE & 1) ? r * 0.75f : __builtin_amdgcn_sinf(r); }
+__device__ __forceinline__ float f3_cos(float r) { return (OI_F3_ABL_PIECE & 1) ? r * 0.85f : __builtin_amdgcn_cosf(r); }
 __device__ __forceinline__ float to_acc(float v) {
+  if (OI_F3_ABL_PIECE & 4) {
+    asm volatile("" ::"v"(v));
+    return 0.25f;
+  }
   float a;
   asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
   return a;
 }
 __device__ __forceinline__ float from_acc(float a) {
+  if (OI_F3_ABL_PIECE & 4) return a;
   float v;
   asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
   return v;
@@ -70,6 +82,10 @@ typedef unsigned Limbs[8][4];  // one fp16 limb plane of a B operand: [k-step][d
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
   const f16x2 hv = {(_Float16)a, (_Float16)b};
   hi = __builtin_bit_cast(unsigned, hv);
+  if (OI_F3_ABL_PIECE & 8) {
+    lo = hi;
+    return;
+  }
   float ra, rb;
   asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
@@ -206,6 +222,7 @@ __device__ __forceinline__ void stream_layer(const char* lds, const LayOff& y, c
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (OI_F3_ABL_PIECE & 16) asm volatile("" ::"v"(acc[t]));  // keeps the MFMAs alive when nothing reads them
     if (t == 0) {
       mid();  // the previous layer's output vector is complete here (its block-3 pairs ran above): scale decisions
       __builtin_amdgcn_sched_barrier(0);
@@ -375,6 +392,13 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #endif
   float act[64];                 // fp32 staging of an adjoint vector before its normalisation (reverse layers only)
   f32x16 acc[4];
+#if OI_F3_ABL_PIECE & 16  // timing ablation: the epilogues read a plain VGPR instead of the accumulators
+  float acc_dummy = 0.37f * lane;
+  asm volatile("" : "+v"(acc_dummy));
+#define F3_ACC(TB, I) acc_dummy
+#else
+#define F3_ACC(TB, I) acc[TB][I]
+#endif
   Limbs AH, AL, BH, BL;          // two B-operand limb sets: a layer reads one and its epilogue fills the other
 #if OI_F3_ABL_EPI
   for (int s_ = 0; s_ < 8; ++s_)
@@ -395,7 +419,7 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   // phi (revolutions) -> reduced phase; v_sin_f32 / v_cos_f32 take revolutions and are specified on [-256, 256]: v_fract
   // (exact) keeps any phase inside that domain.  (Feeding the unreduced phase differs by at most 1 ulp inside the
   // domain, tools/dbg/sin_rev_probe.hip: the FAST flavour does that.)
-  auto reduce = [&](float phi) { return FAST ? phi : __builtin_amdgcn_fractf(phi); };
+  auto reduce = [&](float phi) { return (FAST || (OI_F3_ABL_PIECE & 2)) ? phi : __builtin_amdgcn_fractf(phi); };
   auto ld = [&](int imm, int base) { return lds_f4(lds, imm, base); };
 #define ROW_A(FB, G) ld(grp_f0(G) * 4, FB)
 #define ROW_B(FB, G) ld((C + grp_f0(G)) * 4, FB)
@@ -417,7 +441,7 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         const f32x4 w = lds_f4(lds, F3_TABS + H_TAB0 * 4 + (grp_f0(g) + k) * 16, o.h64);
         const float u = fmaf(pz, w[2], fmaf(py, w[1], px * w[0]));
         const float r = reduce(fmaf(a4[k], u, b4[k]));
-        sn[k] = __builtin_amdgcn_sinf(r);
+        sn[k] = f3_sin(r);
         park(g, k, r);
       }
       split_pair(sn[0], sn[1], NH[g >> 1][2 * (g & 1)], NL[g >> 1][2 * (g & 1)]);
@@ -441,11 +465,11 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         NEXT;                                                                                              \
       }                                                                                                    \
     }                                                                                                      \
-    const float r0 = reduce(fmaf(R.a[k], acc[tb][2 * rp], R.b[k]));                                        \
-    const float r1 = reduce(fmaf(R.a[k + 1], acc[tb][2 * rp + 1], R.b[k + 1]));                            \
+    const float r0 = reduce(fmaf(R.a[k], F3_ACC(tb, 2 * rp), R.b[k]));                                        \
+    const float r1 = reduce(fmaf(R.a[k + 1], F3_ACC(tb, 2 * rp + 1), R.b[k + 1]));                            \
     PARK(g, k, r0);                                                                                        \
     PARK(g, k + 1, r1);                                                                                    \
-    split_pair(__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1), NH[2 * tb + (rp >> 2)][rp & 3],       \
+    split_pair(f3_sin(r0), f3_sin(r1), NH[2 * tb + (rp >> 2)][rp & 3],       \
                NL[2 * tb + (rp >> 2)][rp & 3]);                                                            \
   }
   // Reverse sweep bookkeeping.  A reverse layer's input V_l = v_l * S_l is held as fp16 limbs with a power-of-two scale
@@ -482,8 +506,8 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         NEXT;                                                                                              \
       }                                                                                                    \
     }                                                                                                      \
-    const float v0 = (acc[tb][2 * rp] * sg) * (R.c[k] * __builtin_amdgcn_cosf(from_acc(BANK[g][k])));     \
-    const float v1 = (acc[tb][2 * rp + 1] * sg) * (R.c[k + 1] * __builtin_amdgcn_cosf(from_acc(BANK[g][k + 1]))); \
+    const float v0 = (F3_ACC(tb, 2 * rp) * sg) * (R.c[k] * f3_cos(from_acc(BANK[g][k])));     \
+    const float v1 = (F3_ACC(tb, 2 * rp + 1) * sg) * (R.c[k + 1] * f3_cos(from_acc(BANK[g][k + 1]))); \
     vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));                                                       \
     split_pair(v0, v1, NH[2 * tb + (rp >> 2)][rp & 3], NL[2 * tb + (rp >> 2)][rp & 3]);                    \
   }
@@ -564,11 +588,11 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     float v[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const float r = reduce(fmaf(R.a[k + i], acc[tb][2 * rp + i], R.b[k + i]));
-      const float sn = __builtin_amdgcn_sinf(r);
+      const float r = reduce(fmaf(R.a[k + i], F3_ACC(tb, 2 * rp + i), R.b[k + i]));
+      const float sn = f3_sin(r);
       fv[k + i] = sn;
       sdf_part = fmaf(sn, R.d[k + i], sdf_part);
-      v[i] = (R.c[k + i] * sg7) * __builtin_amdgcn_cosf(r);
+      v[i] = (R.c[k + i] * sg7) * f3_cos(r);
     }
     vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
     split_pair(v[0], v[1], BH[2 * tb + (rp >> 2)][rp & 3], BL[2 * tb + (rp >> 2)][rp & 3]);
@@ -623,7 +647,7 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   asm volatile("" : "+v"(one));
   auto pg3 = [&](int tb, int rp) {
     const int g = tb * 4 + (rp >> 1), k = 2 * (rp & 1);
-    const float a0 = acc[tb][2 * rp] * one, a1 = acc[tb][2 * rp + 1] * one;
+    const float a0 = F3_ACC(tb, 2 * rp) * one, a1 = F3_ACC(tb, 2 * rp + 1) * one;
     vmax = fmaxf(vmax, fmaxf(fabsf(a0), fabsf(a1)));
     P0[g][k] = to_acc(a0);
     P0[g][k + 1] = to_acc(a1);
@@ -667,8 +691,8 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     float v[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const float r = reduce(fmaf(R.a[k + i], acc[tb][2 * rp + i], R.b[k + i]));
-      v[i] = (from_acc(P0[g][k + i]) * sg2) * (R.c[k + i] * __builtin_amdgcn_cosf(r));
+      const float r = reduce(fmaf(R.a[k + i], F3_ACC(tb, 2 * rp + i), R.b[k + i]));
+      v[i] = (from_acc(P0[g][k + i]) * sg2) * (R.c[k + i] * f3_cos(r));
     }
     vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
     split_pair(v[0], v[1], AH[2 * tb + (rp >> 2)][rp & 3], AL[2 * tb + (rp >> 2)][rp & 3]);
@@ -693,7 +717,7 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     if (k == 0 && g < 15) rw[(g + 1) & 1].c = ROW_G(F0, g + 1);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      act[4 * g + k + i] = acc[tb][2 * rp + i] * (R.c[k + i] * __builtin_amdgcn_cosf(from_acc(P1[g][k + i])));
+      act[4 * g + k + i] = F3_ACC(tb, 2 * rp + i) * (R.c[k + i] * f3_cos(from_acc(P1[g][k + i])));
   };
   stream_layer(lds, lay(15), BH, BL, acc, r2, [&]() {}, r1);
   F3_T(1);
@@ -762,8 +786,8 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const f32x4 w = lds_f4(lds, F3_TABS + H_TABV * 4 + (grp_f0(g) + k + i) * 16, o.h64);
-        const float u = acc[tb][2 * rp + i] + fmaf(vz, w[2], fmaf(vy, w[1], vx * w[0]));
-        const float sn = __builtin_amdgcn_sinf(reduce(fmaf(R.a[k + i], u, R.b[k + i])));
+        const float u = F3_ACC(tb, 2 * rp + i) + fmaf(vz, w[2], fmaf(vy, w[1], vx * w[0]));
+        const float sn = f3_sin(reduce(fmaf(R.a[k + i], u, R.b[k + i])));
         r0 = fmaf(sn, w0[k + i], r0);
         r1 = fmaf(sn, w1[k + i], r1);
         r2 = fmaf(sn, w2[k + i], r2);

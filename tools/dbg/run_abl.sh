@@ -4,6 +4,6 @@ mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 {
 for v in "$@"; do echo == $v; OI_LIB=$R/object-intrinsics_amd/build/ab/liboi_$v.so timeout 300 python $R/tools/bench_c5.py --modes f16x3 2>&1 < /dev/null | grep f16x3 | sed 's/.*"full"/full/' ; done
-echo == parity p1
-OI_LIB=$R/object-intrinsics_amd/build/ab/liboi_p1.so timeout 600 python -m pytest $R/tests/test_gpu_kernels.py -m gpu -x -q -k "sdf_mlp" 2>&1 < /dev/null | tail -3
+true
+true
 } > $R/gpurun_out/abl.log 2>&1
