@@ -147,12 +147,7 @@ __device__ __forceinline__ void gemm_lean(const char* lds, const LaneOff& o, con
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       f16x8 bh, bl;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float x = v[8 * s + i];
-        bh[i] = (_Float16)x;
-        bl[i] = (_Float16)(x - (float)bh[i]);
-      }
+      split8_pairs(&v[8 * s], bh, bl);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const f16x8 wh = __builtin_bit_cast(f16x8, lds_f4(lds, L_WBUF + (t * 8 + s) * 1024, o.l16));
@@ -723,12 +718,10 @@ __device__ __forceinline__ void pow2_scale_of(float m, float& sc, float& inv) {
 
 // 8 consecutive points of feature f (points p0 .. p0+7) from the skewed fp32 LDS copy -> scaled fp16 hi / lo limbs
 __device__ __forceinline__ void frag16(const float* sl, int f, int p0, float sc, f16x8& hi, f16x8& lo) {
+  float v[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const float v = sl[slot_index4(f, p0 + q)] * sc;
-    hi[q] = (_Float16)v;
-    lo[q] = (_Float16)(v - (float)hi[q]);
-  }
+  for (int q = 0; q < 8; ++q) v[q] = sl[slot_index4(f, p0 + q)] * sc;
+  split8_pairs(v, hi, lo);
 }
 
 template <bool FAST>

@@ -48,6 +48,37 @@ __host__ __device__ __forceinline__ int feat_of(int q, int h) {
 // the MLP kernel
 // ------------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// two fp32 values -> one dword of the hi plane and one of the lo plane: hi = v_cvt_pk_f16_f32 (round to nearest even),
+// residual a - float(hi) in ONE v_fma_mix_f32 per value (fp16 operand read straight from the packed dword; bit-identical
+// to the cvt-back / subtract form, tools/dbg/sin_rev_probe.hip), lo = v_cvt_pk_f16_f32 of the residuals.  Every
+// instruction of this single-wave stream costs ~4.75 issue cycles (tools/dbg/valu_cost.hip): 4 instead of 6 per pair.
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  const f16x2 hv = {(_Float16)a, (_Float16)b};
+  hi = __builtin_bit_cast(unsigned, hv);
+#ifdef OI_F3_ABL_PIECE
+  if (OI_F3_ABL_PIECE & 8) {
+    lo = hi;
+    return;
+  }
+#endif
+  float ra, rb;
+  asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(ra), "=&v"(rb)
+      : "v"(hi), "v"(a), "v"(b));
+  const f16x2 lv = {(_Float16)ra, (_Float16)rb};
+  lo = __builtin_bit_cast(unsigned, lv);
+}
+// eight fp32 values -> the hi and lo fp16 limb fragments (8 x fp16 each) of an MFMA operand: 16 instructions
+__device__ __forceinline__ void split8_pairs(const float* v, f16x8& hi, f16x8& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) split_pair(v[2 * d], v[2 * d + 1], h[d], l[d]);
+  hi = __builtin_bit_cast(f16x8, u32x4{h[0], h[1], h[2], h[3]});
+  lo = __builtin_bit_cast(f16x8, u32x4{l[0], l[1], l[2], l[3]});
+}
+
 
 // All LDS accesses are "<laundered per-lane VGPR> + compile-time immediate" so that hipcc emits
 // ds_read_b128 v, vbase offset:imm and cannot hoist 60+ loop-invariant address registers out of the
@@ -198,12 +229,7 @@ __device__ __forceinline__ void gemm_layer2(const char* lds, const LayOff& y, co
         }
       }
       f16x8 bh, bl;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float v = act[8 * s + i];
-        bh[i] = (_Float16)v;
-        bl[i] = (_Float16)(v - (float)bh[i]);
-      }
+      split8_pairs(&act[8 * s], bh, bl);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const f16x8 wh = __builtin_bit_cast(f16x8, ah[t]);

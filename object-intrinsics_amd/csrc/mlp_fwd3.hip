@@ -72,28 +72,8 @@ __device__ __forceinline__ int cu_slot_id() {
   return (int)(xcc * 256 + cu);
 }
 
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned Limbs[8][4];  // one fp16 limb plane of a B operand: [k-step][dword d] = act indices 8 s + 2 d, 8 s + 2 d + 1
 
-// two fp32 values -> one dword of the hi plane and one of the lo plane: hi = v_cvt_pk_f16_f32 (round to nearest even),
-// residual a - float(hi) in ONE v_fma_mix_f32 per value (fp16 operand read straight from the packed dword; bit-identical
-// to the cvt-back / subtract form, tools/dbg/sin_rev_probe.hip), lo = v_cvt_pk_f16_f32 of the residuals.  Every
-// instruction of this single-wave stream costs ~4.75 issue cycles (tools/dbg/valu_cost.hip): 4 instead of 6 per pair.
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
-  const f16x2 hv = {(_Float16)a, (_Float16)b};
-  hi = __builtin_bit_cast(unsigned, hv);
-  if (OI_F3_ABL_PIECE & 8) {
-    lo = hi;
-    return;
-  }
-  float ra, rb;
-  asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-      : "=&v"(ra), "=&v"(rb)
-      : "v"(hi), "v"(a), "v"(b));
-  const f16x2 lv = {(_Float16)ra, (_Float16)rb};
-  lo = __builtin_bit_cast(unsigned, lv);
-}
 
 // Adjoint vectors have no a-priori range: bring this point's 128-vector (64 entries here, 64 in lane ^ 32) to
 // max |.| in [2^13, 2^14) with an exact power-of-two scale before the fp16 split; `run` accumulates the inverse scales
