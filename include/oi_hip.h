@@ -130,7 +130,8 @@ int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, con
  *   d_gamma, d_beta [B][9][128]
  * scratch / scratch_bytes: working memory of the launch.  It is a BOUND, not a function of the problem size: the points of
  * every batch element are processed in chunks of as many 128-point tiles as the buffer holds (16 KiB per point and
- * 2 MiB x B per tile), chunks accumulate into the same outputs.  oi_mlp_bwd_scratch_bytes(B, n) is the size that takes
+ * 2 MiB x B per tile, behind an 8 KiB header that carries the launch-wide operand maxima from the sweep to the
+ * weight-gradient GEMM), chunks accumulate into the same outputs.  oi_mlp_bwd_scratch_bytes(B, n) is the size that takes
  * one chunk; oi_mlp_bwd_scratch_bytes_capped(B, n, cap) the largest tile multiple <= cap (at least one tile). */
 size_t oi_mlp_bwd_scratch_bytes(int B, long long n_per_elem);
 size_t oi_mlp_bwd_scratch_bytes_capped(int B, long long n_per_elem, size_t cap_bytes);

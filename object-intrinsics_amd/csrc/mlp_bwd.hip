@@ -165,14 +165,34 @@ __device__ __forceinline__ void gemm_lean(const char* lds, const LaneOff& o, con
 // acc = W_img . v (accumulators come in zeroed or holding the bias); returns the factor the accumulators still carry:
 // 1 for the unscaled images, 2^-k_m (x 1 / normalisation of v, which is scaled in place) for F16X3
 template <int PREC, bool NORM>
-__device__ __forceinline__ float gemm2(const char* lds, const LaneOff& o, float (&v)[64], f32x16 (&acc)[4], float inv_img) {
+__device__ __forceinline__ float gemm2(const char* lds, const LaneOff& o, float (&v)[64], f32x16 (&acc)[4], float inv_img,
+                                       float* lane_max = nullptr) {
   float f = 1.f;
   if constexpr (PREC == OI_PREC_F16X3) {
     f = inv_img;
-    if constexpr (NORM) f *= pow2_normalise(v);
+    if constexpr (NORM) f *= pow2_normalise(v, lane_max);
   }
   gemm_lean<PREC>(lds, o, v, acc);
   return f;
+}
+
+// Launch-wide maxima of the weight-gradient operands (header of the scratch buffer, zeroed per launch).  The sweep
+// already takes the per-point maximum of every adjoint vector it feeds to a product; the wave maximum of those is
+// published here (one atomic per wave, layer and operand: non-negative floats order like their bit patterns), so that the
+// weight-gradient GEMM can run on ONE power-of-two scale per operand instead of normalising every 32-point tile.
+constexpr int OM_V = 0;    // 7: max |v_l|,    l = 1..7
+constexpr int OM_U = 7;    // 7: max |ubar_l|, l = 1..7
+constexpr int OM_G = 14;   // 7: max |gbar_l|, l = 1..7
+constexpr int OM_UV = 21;  // 1: max |uvbar|
+// same-address atomics serialise in the L2 (16,384 waves x 22 slots on 22 addresses cost 0.7 ms): 64 replicas of the
+// table, chosen by workgroup; the GEMM takes the maximum over the replicas
+constexpr int OM_STRIDE = 32, OM_REPLICAS = 64;
+constexpr int OM_FLOATS = OM_STRIDE * OM_REPLICAS;  // 8 KiB header: the tiles behind it stay 256-byte aligned
+__device__ __forceinline__ void publish_max(float* op_max, int slot, float lane_max) {
+  const float m = oi::wave_max(lane_max);
+  const int rep = (blockIdx.x + blockIdx.y * gridDim.x) & (OM_REPLICAS - 1);
+  if ((threadIdx.x & 63) == 0)
+    atomicMax(reinterpret_cast<unsigned*>(op_max) + rep * OM_STRIDE + slot, __builtin_bit_cast(unsigned, m));
 }
 
 // OI_BWD_WAVES_PER_SIMD = 1: one workgroup per CU with the whole 512-entry register file per wave (two 64-register point
@@ -204,8 +224,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
                      const float* __restrict__ rgb_fwd, const float* __restrict__ feat_fwd,
                      const float* __restrict__ g_sdf, const float* __restrict__ g_grad,
                      const float* __restrict__ g_rgb, float* __restrict__ d_small, float* __restrict__ d_gamma,
-                     float* __restrict__ d_beta, char* __restrict__ scratch, long long n_per_elem, long long n_stride,
-                     long long pt_off) {
+                     float* __restrict__ d_beta, char* __restrict__ scratch, float* __restrict__ op_max,
+                     long long n_per_elem, long long n_stride, long long pt_off) {
   // this launch covers points [pt_off, pt_off + n_per_elem) of every batch element; an element holds n_stride points
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -369,7 +389,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     stage_img(15, 0);
     dma_sync();
     acc_zero(acc);
-    const float fT = gemm2<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + 15] : 1.f);
+    float mx_uv = 0.f;
+    const float fT = gemm2<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + 15] : 1.f, &mx_uv);
+    if constexpr (SC) publish_max(op_max, OM_UV, mx_uv);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       f32x4 v;
@@ -425,7 +447,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     // vbar_l = W_l gbar_l
     acc_zero(acc);
     BW_T(3);
-    const float fA = gemm2<PREC, true>(lds, ol, gb, acc, inv_img);
+    float mx_g = 0.f;
+    const float fA = gemm2<PREC, true>(lds, ol, gb, acc, inv_img, &mx_g);
+    if constexpr (SC) publish_max(op_max, OM_G + l - 1, mx_g);
     BW_T(4);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -567,13 +591,18 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       const float inv_t = SC ? hdr[H_WSCALE + 7 + l - 1] : 1.f;
       acc_zero(acc);
       BW_T(9);
-      const float f1 = gemm2<PREC, true>(lds, ol, gb, acc, inv_t);   // g_l = W_l^T v_l
+      float mx_v = 0.f, mx_u = 0.f;
+      const float f1 = gemm2<PREC, true>(lds, ol, gb, acc, inv_t, &mx_v);   // g_l = W_l^T v_l
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gb[16 * t + r] = SC ? acc[t][r] * f1 : acc[t][r];
       acc_zero(acc);
-      const float f2 = gemm2<PREC, true>(lds, ol, act, acc, inv_t);  // abar_l = W_l^T ubar_l
+      const float f2 = gemm2<PREC, true>(lds, ol, act, acc, inv_t, &mx_u);  // abar_l = W_l^T ubar_l
+      if constexpr (SC) {
+        publish_max(op_max, OM_V + l - 1, mx_v);
+        publish_max(op_max, OM_U + l - 1, mx_u);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -697,9 +726,8 @@ mlp_wgrad_kernel(const char* __restrict__ scratch, const float* __restrict__ gam
 }
 
 // ---- F16X3 variant of the weight-gradient GEMM (3 fp16 MFMAs per product instead of 8 fp32-MFMA k-steps per 16
-// points).  Both operands are data with no a-priori range, so every staged 32-point tile is normalised by the power
-// of two of its own max (block-wide), multiplied into a per-tile accumulator and merged into the running sum with the
-// exact inverse scale.  The fp32 slot copies sit in LDS with a 4-float skew per 32-point block: the 8 consecutive
+// points).  The operands are data with no a-priori range: they are scaled (exactly, by a power of two) with the launch-wide
+// maximum the sweep published, before the split.  The fp32 slot copies sit in LDS with a 4-float skew per 32-point block: the 8 consecutive
 // points of one feature that a lane needs for its MFMA operand are then conflict-free dword reads.  The B fragments
 // (Y, all 128 columns) are the same for the four waves: each wave converts one column tile and shares it through LDS.
 __device__ __forceinline__ int slot_index4(int f, int p) {
@@ -717,29 +745,48 @@ __device__ __forceinline__ void pow2_scale_of(float m, float& sc, float& inv) {
 }
 
 // 8 consecutive points of feature f (points p0 .. p0+7) from the skewed fp32 LDS copy -> scaled fp16 hi / lo limbs
-__device__ __forceinline__ void frag16(const float* sl, int f, int p0, float sc, f16x8& hi, f16x8& lo) {
+__device__ __forceinline__ void frag16(const float* sl, int f, int p0, f16x8& hi, f16x8& lo) {
   float v[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) v[q] = sl[slot_index4(f, p0 + q)] * sc;
+  for (int q = 0; q < 8; ++q) v[q] = sl[slot_index4(f, p0 + q)];
   split8_pairs(v, hi, lo);
 }
 
 template <bool FAST>
 __global__ void __launch_bounds__(256)
-mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__ gamma, float* __restrict__ d_wmat,
-                     long long n_wave_tiles, long long wt_per_elem, int tiles_per_chunk, int has_col) {
+mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__ op_max, const float* __restrict__ gamma,
+                     float* __restrict__ d_wmat, long long n_wave_tiles, long long wt_per_elem, int tiles_per_chunk,
+                     int has_col) {
   __shared__ __attribute__((aligned(16))) float sx[WG16_SLOT_FLOATS], sy[WG16_SLOT_FLOATS];
   __shared__ __attribute__((aligned(16))) f16x8 sb[2][4][2][64];  // [hi|lo][column tile][k-step][lane]
-  __shared__ float smax[2][4];
   const int m = blockIdx.y;
   if (m == 7 && !has_col) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, i = lane & 31;
   const long long t_begin = (long long)blockIdx.x * tiles_per_chunk;
   const long long t_end = min(n_wave_tiles, t_begin + tiles_per_chunk);
-  f32x16 acc[4];
-  acc_zero(acc);
   const int npair = (m == 7) ? 1 : 2;
+  // ONE power-of-two scale per operand for the whole launch (maxima published by the sweep): the products of all tiles
+  // then share a scale and accumulate straight in the MFMA accumulators -- no per-tile maximum, no per-tile merge.
+  // pair 0: X = v_l (uvbar for the colour head), Y = gbar_l (a_8 = sin, |.| <= 1);  pair 1: X = ubar_l, Y = a_l = sin
+  float scx[2], scy[2], inv[2];
+  {
+    // maximum over the replicas: lane r of every wave reads replica r (the table is 8 KiB and L2-resident)
+    const float* rep = op_max + lane * OM_STRIDE;
+    const float mx0 = oi::wave_max(rep[m == 7 ? OM_UV : OM_V + m]);
+    const float my0 = m == 7 ? 1.0f : oi::wave_max(rep[OM_G + m]);
+    const float mx1 = oi::wave_max(rep[OM_U + (m < 7 ? m : 0)]);
+    float ivx, ivy;
+    pow2_scale_of(mx0, scx[0], ivx);
+    pow2_scale_of(my0, scy[0], ivy);
+    inv[0] = ivx * ivy;
+    pow2_scale_of(mx1, scx[1], ivx);
+    pow2_scale_of(1.0f, scy[1], ivy);
+    inv[1] = ivx * ivy;
+  }
+  f32x16 acc[2][4];
+  acc_zero(acc[0]);
+  acc_zero(acc[1]);
   const int fo = 32 * wave + i;
   for (long long wt = t_begin; wt < t_end; ++wt) {
     const char* base = scratch + wt * (long long)(NSLOT_BWD * 16384);
@@ -748,8 +795,7 @@ mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__
     const f32x4* gp4 = reinterpret_cast<const f32x4*>(base + (size_t)(S_PHI + m) * 16384);
     const f32x4* gv4 = reinterpret_cast<const f32x4*>(base + (size_t)(S_VB + (m < 7 ? m : 0)) * 16384);
     const float* grow = gamma + ((wt / wt_per_elem) * 9 + (m < 7 ? m : 0)) * C;
-    // every load of the tile is issued before any of it is used: ONE memory round trip per tile (the kernel is a chain of
-    // dependent round trips otherwise -- one per operand pair plus one for phi -- and latency-, not bandwidth-bound)
+    // every load of the tile is issued before any of it is used: ONE memory round trip per tile
     const f32x4* gx0 = reinterpret_cast<const f32x4*>(base + (size_t)(m == 7 ? S_UV : S_V + m) * 16384);
     const f32x4* gx1 = reinterpret_cast<const f32x4*>(base + (size_t)(S_U + (m < 7 ? m : 0)) * 16384);
     f32x4 ysin[4], ygb[4], xall[2][4], ph4[4], vb4[4], gm4[4];
@@ -773,73 +819,42 @@ mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__
         float sn, cs;
         sincos_<FAST>(ph4[it][k], sn, cs);
         ysin[it][k] = sn;
-        ygb[it][k] = vb4[it][k] * gm4[it][k] * cs;
+        ygb[it][k] = vb4[it][k] * (gm4[it][k] * scy[0]) * cs;
       }
     }
     for (int pr = 0; pr < npair; ++pr) {
       const bool y_is_gbar = (m < 7) && pr == 0;
-      f32x4 xv[4], yv[4];
-      float mx = 0.f, my = 0.f;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        xv[it] = xall[pr][it];
-        yv[it] = y_is_gbar ? ygb[it] : ysin[it];
-      }
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          mx = fmaxf(mx, fabsf(xv[it][k]));
-          my = fmaxf(my, fabsf(yv[it][k]));
-        }
-      }
-      mx = oi::wave_max(mx);
-      my = oi::wave_max(my);
-      __syncthreads();  // previous tile's readers of sx / sy / sb are done
+      __syncthreads();  // previous pair's readers of sx / sy / sb are done
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int q = it * 256 + tid;
         const int dq = q + (q >> 5);  // + 4 floats per 32-point block
-        reinterpret_cast<f32x4*>(sx)[dq] = xv[it];
-        reinterpret_cast<f32x4*>(sy)[dq] = yv[it];
-      }
-      if (lane == 0) {
-        smax[0][wave] = mx;
-        smax[1][wave] = my;
+        reinterpret_cast<f32x4*>(sx)[dq] = xall[pr][it] * scx[pr];
+        reinterpret_cast<f32x4*>(sy)[dq] = y_is_gbar ? ygb[it] : ysin[it] * scy[pr];
       }
       __syncthreads();
-      float scx, ivx, scy, ivy;
-      pow2_scale_of(fmaxf(fmaxf(smax[0][0], smax[0][1]), fmaxf(smax[0][2], smax[0][3])), scx, ivx);
-      pow2_scale_of(fmaxf(fmaxf(smax[1][0], smax[1][1]), fmaxf(smax[1][2], smax[1][3])), scy, ivy);
       // this wave's column tile of Y -> shared fp16 fragments
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         f16x8 bh, bl;
-        frag16(sy, fo, 16 * ks + 8 * h, scy, bh, bl);
+        frag16(sy, fo, 16 * ks + 8 * h, bh, bl);
         sb[0][wave][ks][lane] = bh;
         sb[1][wave][ks][lane] = bl;
       }
       f16x8 ah[2], al[2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) frag16(sx, fo, 16 * ks + 8 * h, scx, ah[ks], al[ks]);
+      for (int ks = 0; ks < 2; ++ks) frag16(sx, fo, 16 * ks + 8 * h, ah[ks], al[ks]);
       __syncthreads();
-      f32x16 tacc[4];
-      acc_zero(tacc);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const f16x8 bh = sb[0][t][ks][lane], bl = sb[1][t][ks][lane];
-          tacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, tacc[t], 0, 0, 0);
-          tacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, tacc[t], 0, 0, 0);
-          tacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, tacc[t], 0, 0, 0);
+          acc[pr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, acc[pr][t], 0, 0, 0);
+          acc[pr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, acc[pr][t], 0, 0, 0);
+          acc[pr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, acc[pr][t], 0, 0, 0);
         }
       }
-      const float inv = ivx * ivy;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = fmaf(tacc[t][r], inv, acc[t][r]);
     }
   }
   float* dst = d_wmat + (size_t)m * C * C;
@@ -848,7 +863,8 @@ mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) {
       const int oo = 32 * wave + (rg & 3) + 8 * (rg >> 2) + 4 * h;
-      atomicAdd(dst + (size_t)oo * C + 32 * t + i, acc[t][rg]);
+      const float v = npair == 2 ? fmaf(acc[1][t][rg], inv[1], acc[0][t][rg] * inv[0]) : acc[0][t][rg] * inv[0];
+      atomicAdd(dst + (size_t)oo * C + 32 * t + i, v);
     }
 }
 
@@ -861,6 +877,10 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
   // as many 128-point tiles as `scratch_bytes` holds; all outputs are accumulated, so chunks simply add up.
   const long long tile_bytes = 4LL * NSLOT_BWD * 16384;
   const long long tiles_all = oi::cdiv(n, TILE_PTS);
+  OI_REQUIRE(scratch_bytes > OM_FLOATS * sizeof(float), "oi_sdf_mlp_bwd: scratch of %zu bytes", scratch_bytes);
+  float* op_max = reinterpret_cast<float*>(scratch);             // header: launch-wide operand maxima
+  char* tiles = reinterpret_cast<char*>(scratch) + OM_FLOATS * sizeof(float);
+  scratch_bytes -= OM_FLOATS * sizeof(float);
   long long tiles_fit = (long long)(scratch_bytes / (size_t)(tile_bytes * B));
   if (tiles_fit < 1) return oi::fail(OI_ERR_INVALID_ARG, "oi_sdf_mlp_bwd: scratch of %zu bytes holds no tile (need >= %lld)",
                                      scratch_bytes, tile_bytes * B);
@@ -874,20 +894,23 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
     const long long nt = std::min(tiles_fit, tiles_all - t0);
     const long long off = t0 * TILE_PTS, cn = std::min<long long>(nt * TILE_PTS, n - off);
     dim3 grid((unsigned)nt, B), block(256);
+    if constexpr (PREC == OI_PREC_F16X3) {
+      hipError_t e = oi::zero_async(op_max, OM_FLOATS, st);
+      if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_sdf_mlp_bwd: zero fill: %s", hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(k, grid, block, L_TOTAL_BWD, st, pts, reinterpret_cast<const char*>(packed), gamma, beta, grad_fwd,
-                       rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, d_gamma, d_beta, reinterpret_cast<char*>(scratch), cn, n,
-                       off);
+                       rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, d_gamma, d_beta, tiles, op_max, cn, n, off);
     int rc = oi::check_launch("oi_sdf_mlp_bwd(sweep)");
     if (rc != OI_OK) return rc;
     const long long n_wt = (long long)B * grid.x * 4;
     int chunk = (int)std::max<long long>(1, (n_wt * 8 + 2047) / 2048);  // ~2048 workgroups in total
     dim3 g2(oi::cdiv(n_wt, chunk), 8);
     if constexpr (PREC == OI_PREC_F16X3) {
-      hipLaunchKernelGGL(mlp_wgrad_f16_kernel<FAST>, g2, block, 0, st, reinterpret_cast<const char*>(scratch), gamma, d_wmat,
-                         n_wt, (long long)grid.x * 4, chunk, has_col);
-    } else {
-      hipLaunchKernelGGL(mlp_wgrad_kernel<FAST>, g2, block, 0, st, reinterpret_cast<const char*>(scratch), gamma, d_wmat, n_wt,
+      hipLaunchKernelGGL(mlp_wgrad_f16_kernel<FAST>, g2, block, 0, st, tiles, op_max, gamma, d_wmat, n_wt,
                          (long long)grid.x * 4, chunk, has_col);
+    } else {
+      hipLaunchKernelGGL(mlp_wgrad_kernel<FAST>, g2, block, 0, st, tiles, gamma, d_wmat, n_wt, (long long)grid.x * 4, chunk,
+                         has_col);
     }
     rc = oi::check_launch("oi_sdf_mlp_bwd(wgrad)");
     if (rc != OI_OK) return rc;
@@ -913,14 +936,15 @@ extern "C" {
 
 size_t oi_mlp_bwd_scratch_bytes(int B, long long n_per_elem) {
   const long long tiles = (n_per_elem + TILE_PTS - 1) / TILE_PTS;
-  return (size_t)B * tiles * 4 * NSLOT_BWD * 16384;
+  return (size_t)B * tiles * 4 * NSLOT_BWD * 16384 + OM_FLOATS * sizeof(float);
 }
 
 size_t oi_mlp_bwd_scratch_bytes_capped(int B, long long n_per_elem, size_t cap_bytes) {
-  const size_t per_tile = (size_t)B * 4 * NSLOT_BWD * 16384, full = oi_mlp_bwd_scratch_bytes(B, n_per_elem);
+  const size_t per_tile = (size_t)B * 4 * NSLOT_BWD * 16384, head = OM_FLOATS * sizeof(float);
+  const size_t full = oi_mlp_bwd_scratch_bytes(B, n_per_elem);
   if (full <= cap_bytes) return full;
-  const size_t tiles = cap_bytes / per_tile;
-  return (tiles < 1 ? 1 : tiles) * per_tile;
+  const size_t tiles = cap_bytes > head ? (cap_bytes - head) / per_tile : 0;
+  return (tiles < 1 ? 1 : tiles) * per_tile + head;
 }
 
 int oi_mlp_bwd_small_floats(void) { return DS_TOTAL; }

@@ -415,10 +415,11 @@ __device__ __forceinline__ void film_sin(const char* lds, const LaneOff& o, cons
 // Power-of-two normalisation of one point's 128-vector (64 entries in this lane, 64 in lane ^ 32) to max |.| in
 // [2^13, 2^14): the fp16 split of the F16X3 mode then never leaves the normal range of its hi limb and keeps 22
 // mantissa bits.  Scales `act` in place and returns 1/scale (exact).
-__device__ __forceinline__ float pow2_normalise(float (&act)[64]) {
+__device__ __forceinline__ float pow2_normalise(float (&act)[64], float* lane_max = nullptr) {
   float m = 0.f;
 #pragma unroll
   for (int k = 0; k < 64; k += 2) m = fmaxf(m, fmaxf(fabsf(act[k]), fabsf(act[k + 1])));
+  if (lane_max != nullptr) *lane_max = m;  // max |.| of this lane's 64 entries, before the scaling
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   int eb = (__builtin_bit_cast(int, m) >> 23) & 0xff;
   eb = eb < 14 ? 14 : (eb > 254 ? 254 : eb);

@@ -126,8 +126,8 @@ def sdf_mlp_fwd(pts, packed, gamma, beta, B, prec, fast_trig=False, want_grad=Fa
 
 
 def bwd_scratch_cap_bytes():
-    """Upper bound of the MLP backward's working memory (OI_BWD_SCRATCH_MB, default 8192): larger problems run in chunks."""
-    return int(float(os.environ.get("OI_BWD_SCRATCH_MB", "8192")) * (1 << 20))
+    """Upper bound of the MLP backward's working memory (OI_BWD_SCRATCH_MB, default 9216: the C2 training render fits one chunk): larger problems run in chunks."""
+    return int(float(os.environ.get("OI_BWD_SCRATCH_MB", "9216")) * (1 << 20))
 
 
 def sdf_mlp_bwd(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, B, prec, fast_trig=False,
