@@ -205,6 +205,9 @@ __device__ __forceinline__ void publish_max(float* op_max, int slot, float lane_
 #ifndef OI_BWD_ABL
 #define OI_BWD_ABL 0
 #endif
+#ifndef OI_BWD_EARLY_RELOAD
+#define OI_BWD_EARLY_RELOAD 1
+#endif
 // -DOI_BWD_PROF: per-phase shader-clock accounting of the sweep (tools/dbg/phase_prof_bwd.py)
 #ifdef OI_BWD_PROF
 __device__ unsigned long long oi_prof_bwd[16];
@@ -569,6 +572,14 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           ws.store<OI_BWD_ST_WGRAD>(S_V + l - 1, g, o.l16, vv);
           ws.store<OI_BWD_ST_WGRAD>(S_U + l - 1, g, o.l16, ub);
         }
+#if OI_BWD_EARLY_RELOAD
+        // this group's fragments are consumed: request the same group of the NEXT layer into the same registers -- the loads
+        // travel under the rest of the epilogue and both products, and there is no separate issue phase
+        if constexpr (!L0 && !(OI_BWD_ABL & 2)) {
+          phn[g] = ws.load(S_PHI + l - 1, g, o.l16);
+          vbn[g] = ws.load(S_VB + l - 1, g, o.l16);
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       rs.add(0, t, R[0]);
@@ -580,7 +591,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       }
     }
     BW_T(8);
-    if constexpr (!L0 && !(OI_BWD_ABL & 2)) {  // the next layer's fragments travel while this layer's two products run
+    if constexpr (!OI_BWD_EARLY_RELOAD && !L0 && !(OI_BWD_ABL & 2)) {  // the next layer's fragments travel while this layer's two products run
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         phn[g] = ws.load(S_PHI + l - 1, g, o.l16);
