@@ -763,6 +763,13 @@ __device__ __forceinline__ void frag16(const float* sl, int f, int p0, f16x8& hi
   split8_pairs(v, hi, lo);
 }
 
+// the scratch operands are read exactly once by this kernel: non-temporal loads (streaming-read ceiling of the box
+// 5.8 TB/s ordinary, 6.5-7.0 non-temporal: tools/dbg/hbm_read.hip)
+#ifndef OI_WGRAD_NT
+#define OI_WGRAD_NT 1
+#endif
+__device__ __forceinline__ f32x4 ld_once(const f32x4* p) { return OI_WGRAD_NT ? __builtin_nontemporal_load(p) : *p; }
+
 template <bool FAST>
 __global__ void __launch_bounds__(256)
 mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__ op_max, const float* __restrict__ gamma,
@@ -813,14 +820,14 @@ mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int q = it * 256 + tid;
-      ph4[it] = gp4[q];
-      xall[0][it] = gx0[q];
+      ph4[it] = ld_once(gp4 + q);
+      xall[0][it] = ld_once(gx0 + q);
       vb4[it] = gm4[it] = f32x4{0.f, 0.f, 0.f, 0.f};
       xall[1][it] = xall[0][it];
       if (m < 7) {
-        vb4[it] = gv4[q];
+        vb4[it] = ld_once(gv4 + q);
         gm4[it] = *reinterpret_cast<const f32x4*>(grow + grp_f0(q >> 6) + 4 * ((q >> 5) & 1));
-        xall[1][it] = gx1[q];
+        xall[1][it] = ld_once(gx1 + q);
       }
     }
 #pragma unroll
