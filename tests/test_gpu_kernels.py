@@ -478,3 +478,29 @@ def test_conv4x4_tiled_f16x3_vs_fp64(ops, B, Cin, H, Cout, x_slope, tile):
     assert maxdiff(y.cpu(), ref) < 5e-6 * max(1.0, float(ref.abs().max()))
     y2 = ops.conv4x4_fwd(x.cuda(), w.cuda(), b.cuda(), 2, 1, 0.2, x_slope=x_slope)
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("up,down,taps,pad", [((3, 1), (2, 1), (7, 1), (4, 3, 0, 0)), ((1, 3), (1, 2), (1, 5), (0, 0, 2, 5)),
+                                               ((2, 3), (3, 2), (5, 4), (3, 1, 2, 4)), ((1, 1), (1, 1), (13, 1), (6, 6, 0, 0)),
+                                               ((2, 1), (1, 1), (12, 1), (-2, 7, 0, 0))])
+def test_upfirdn2d_general_factors_vs_dense_restatement(ops, up, down, taps, pad):
+    """upfirdn2d beyond the ADA shapes (up / down factors of 3, 2-D filters, a 13-tap filter that leaves the 12-tap fast
+    path, negative padding = cropping): zero-insert upsample -> pad / crop -> correlate with the flipped filter -> decimate,
+    restated densely with torch ops (upfirdn2d.py:160-200 of the reference's ADA copy)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(sum(up) * 7 + sum(taps))
+    B, C, H, W = 2, 3, 11, 13
+    x = torch.randn(B, C, H, W, generator=g)
+    f = torch.randn(taps[1], taps[0], generator=g)             # [fh, fw]
+    upx, upy = up
+    dx, dy = down
+    px0, px1, py0, py1 = pad
+    u = torch.zeros(B, C, H * upy, W * upx, dtype=torch.float64)
+    u[:, :, ::upy, ::upx] = x.double()
+    u = F.pad(u, [max(px0, 0), max(px1, 0), max(py0, 0), max(py1, 0)])
+    u = u[:, :, max(-py0, 0):u.shape[2] - max(-py1, 0), max(-px0, 0):u.shape[3] - max(-px1, 0)]
+    w = f.double().flip([0, 1])[None, None].repeat(C, 1, 1, 1)
+    ref = F.conv2d(u, w, groups=C)[:, :, ::dy, ::dx]
+    y = ops.upfirdn2d(x.cuda(), f.cuda(), upx, upy, dx, dy, px0, px1, py0, py1)
+    assert tuple(y.shape) == tuple(ref.shape), (y.shape, ref.shape)
+    assert maxdiff(y.cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max()))
