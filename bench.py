@@ -19,7 +19,7 @@ The timed region is repeated (each repeat = exactly K steps between barrier + sy
 measured; `value` / `ms_per_step` are over all repeats, `repeats` and the per-repeat spread are reported.
 
 Extra objects in that line:
-  roofline      dominant kernel (sdf_mlp_kernel, full variant): algorithmic FLOPs / launch divided by
+  roofline      dominant kernel (sdf_mlp_full3_kernel: sdf + d sdf/dx + albedo): algorithmic FLOPs / launch divided by
                 its mean duration measured with HIP events on the launch stream inside the timed region
   cpu_baseline  the oracle (CPU restatement, oracle/oi_oracle.py) timed on the host cores on the same
                 workload (N=1, rank 0 only) -- a reported baseline, not the target

@@ -590,3 +590,34 @@ def test_pack_status_reports_non_finite_weights(col_sd):
         col_net.rgb_linear.bias[1] = float("inf")
     with pytest.raises(RuntimeError, match="non-finite"):
         pack.check()
+
+
+def test_mlp_backward_wide_dynamic_range_cotangents(sdf_sd, col_sd):
+    """The weight-gradient GEMM scales every operand by ONE power of two per launch (the launch-wide maximum published by
+    the sweep).  Cotangents spread over 8 decades between points -- a few surface samples carrying almost all of the loss,
+    many far samples carrying very little -- must still give parameter gradients at the fp64 oracle's level."""
+    from oi_amd.fields import ShapeNetwork, ColorNetwork, FieldPack
+    from oi_amd.autograd import sdf_mlp
+    n, B = 1536, 1
+    g = torch.Generator().manual_seed(99)
+    pts = torch.rand(B * n, 3, generator=g) * 2.0 - 1.0
+    w = O.style_mlp(sdf_sd, torch.randn(B, 64, generator=g))
+    mag = 10.0 ** (torch.rand(B * n, generator=g) * 8.0 - 6.0)           # 1e-6 .. 1e2 per point
+    cs = torch.randn(B * n, generator=g) * mag
+    cg = 0.1 * torch.randn(B * n, 3, generator=g) * mag[:, None]
+    cr = torch.randn(B * n, 3, generator=g) * mag[:, None]
+    loss_o, g_o = _oracle_mlp_grads(sdf_sd, col_sd, pts, w, cs, cg, cr)
+    sdf_net = ShapeNetwork(SDF_NPZ, **NET_KW).cuda()
+    col_net = ColorNetwork(**NET_KW)
+    col_net.load_state_dict(col_sd)
+    col_net = col_net.cuda()
+    pack = FieldPack(sdf_net, col_net, "f16x3")
+    wh = w.cuda().requires_grad_(True)
+    _, gamma, beta = pack.film(w=wh)
+    sdf, grad, rgb, _ = sdf_mlp(pack, pts.cuda(), gamma, beta, B, True, True, False)
+    loss = (sdf * cs.cuda()).sum() + (grad * cg.cuda()).sum() + (rgb * cr.cuda()).sum()
+    named = [("sdf." + k, v) for k, v in sdf_net.named_parameters() if not k.startswith("style.")] + \
+            [("col." + k, v) for k, v in col_net.named_parameters()] + [("w", wh)]
+    gr = torch.autograd.grad(loss, [v for _, v in named])
+    bad = {name: rel_err(a, g_o[name]) for (name, _), a in zip(named, gr) if rel_err(a, g_o[name]) > 2e-3}
+    assert not bad, bad
