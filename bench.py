@@ -306,8 +306,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     # discriminator-only timing (images/s), untimed with respect to the main region
-    d_img_s = None
+    d_img_s = d_img_s_eager = None
     if not args.no_disc:
+        from oi_amd.graphed import GraphedDForward
         x = torch.rand(B, 3, R, R, device=device)
         barrier()
         t0 = time.perf_counter()
@@ -315,7 +316,18 @@ def main():
             for _ in range(args.steps):
                 disc(x, it=0)
         barrier()
-        d_img_s = B * args.steps / (time.perf_counter() - t0)
+        d_img_s_eager = B * args.steps / (time.perf_counter() - t0)
+        # the same forward replayed from one captured hipGraph (augmentation parameters still drawn per call on the host)
+        gd = GraphedDForward(disc)
+        for _ in range(3):
+            gd(x)
+        n_d = max(args.steps, 100)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_d):
+            gd(x)
+        barrier()
+        d_img_s = B * n_d / (time.perf_counter() - t0)
 
     # how many repeats of the K-step region make >= --min-seconds (same number on every rank: decided from the slowest)
     barrier()
@@ -369,6 +381,10 @@ def main():
 
     # headline reductions first: nothing after this point can take the timed result away
     t = torch.tensor(dts, device=device, dtype=torch.float64)
+    de = torch.tensor([d_img_s_eager or 0.0], device=device, dtype=torch.float64)
+    if distributed:
+        dist.all_reduce(de, op=dist.ReduceOp.SUM)
+    args._d_images_per_s_eager = float(de) if d_img_s_eager else None
     dd = torch.tensor([d_img_s or 0.0], device=device, dtype=torch.float64)
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)   # per repeat: the slowest rank
@@ -582,6 +598,9 @@ def build_line(args, value, dt, world, timer, d_img_s, train, distributed, bf16_
                        "rays_per_step_per_gpu": B * R * R, "points_per_step_per_gpu": n_pts,
                        "parallelism": f"dp{world} (independent renders, no data-path collective)"},
             "d_images_per_s": d_img_s,
+            "d_images_per_s_what": "ADADiscriminatorView forward, batch 1 per GPU, replayed from a captured hipGraph "
+                                   "(oi_amd.graphed.GraphedDForward); d_images_per_s_eager = the same launch by launch",
+            "d_images_per_s_eager": getattr(args, "_d_images_per_s_eager", None),
             "training": train,
             "bf16_mode": bf16_mode,
             "roofline": {"bound": "mfma",

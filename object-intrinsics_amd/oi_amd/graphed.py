@@ -186,3 +186,63 @@ class GraphedDStep:
         if hasattr(self.disc, "flat_grad"):
             self.disc._needs_exchange = True  # the replayed backward filled the flat buffer: exchange it in sync()
         return self.out
+
+
+class GraphedDForward:
+    """hipGraph of the no-grad ADA-discriminator forward (augmentation chain + convolution chain: ~20 launches of ~5 us,
+    i.e. host-bound at batch 1).  Same recipe as GraphedDStep: static padding margins, augmentation parameters drawn by
+    numpy on the host in the eager order and uploaded through a ring of pinned buffers, the input copied into a fixed
+    buffer.  The returned tensor is the graph's output buffer: read it (or clone it) before the next call."""
+
+    def __init__(self, disc):
+        self.disc, self.graph = disc, None
+
+    def _thetas(self, shape):
+        import numpy as np
+        aug = self.disc.aug
+        B, C, H, W = shape
+        G = aug.sample_G_inv(torch.empty(B, C, H, W, device="meta"))
+        if G is None:
+            G = np.tile(np.eye(3, dtype=np.float32), (B, 1, 1))
+        return aug.theta_for(G, aug.static_margins(H, W), H, W)
+
+    def _upload(self, x):
+        th = self._thetas(tuple(x.shape))
+        i = self._pin_i = (self._pin_i + 1) % len(self._pins)
+        if self._pin_ev[i] is not None:
+            self._pin_ev[i].synchronize()
+        self._pins[i].numpy()[:] = th
+        self.theta.copy_(self._pins[i], non_blocking=True)
+        self._pin_ev[i] = torch.cuda.Event()
+        self._pin_ev[i].record()
+        self.x.copy_(x, non_blocking=True)
+
+    def capture(self, x):
+        import numpy as np
+        B = x.shape[0]
+        self.x = torch.empty_like(x)
+        self.theta = torch.empty(B, 2, 3, device=x.device)
+        self._pins = [torch.empty(B, 2, 3, pin_memory=True) for _ in range(8)]
+        self._pin_ev = [None] * 8
+        self._pin_i = 0
+        state = np.random.get_state()   # warm-up / capture must not consume the caller's random stream
+        self._upload(x)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                self.disc(self.x, aug_theta=self.theta)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = self.disc(self.x, aug_theta=self.theta)
+        np.random.set_state(state)
+        return self
+
+    def __call__(self, x):
+        if self.graph is None or tuple(x.shape) != tuple(self.x.shape):
+            self.capture(x)
+        self._upload(x)
+        self.graph.replay()
+        return self.out

@@ -513,3 +513,26 @@ def test_inference_frame_golden_f11(graphed):
         ref = g["map_" + k][0]
         assert tuple(fr[k][0].shape) == tuple(ref.shape), (k, fr[k][0].shape, ref.shape)
         assert maxdiff(fr[k][0].cpu(), ref) < 1e-4, (k, maxdiff(fr[k][0].cpu(), ref))
+
+
+def test_graphed_discriminator_forward_matches_eager():
+    """oi_amd.graphed.GraphedDForward: the no-grad ADA-discriminator forward replayed from a hipGraph (static padding
+    margins, augmentation parameters drawn on the host in the eager order) against the eager forward from the same
+    numpy state, over several replays with different inputs."""
+    from oi_amd.config import build_from_config
+    from oi_amd.graphed import GraphedDForward
+    net = lambda t, **kw: {"__target__": t, "kwargs": kw}
+    torch.manual_seed(3)
+    disc = build_from_config(net("src.models.discriminator.ADADiscriminatorView",
+                                 aug=net("src.third_party.ada.augment.AugmentPipe", scale=1, xint=1), aug_p=1, img_size=32,
+                                 in_dim=3, last_bias=False, n_feat=64, out_dim=7, out_dim_latent=0, out_dim_position=6)).cuda().eval()
+    gd = GraphedDForward(disc)
+    g = torch.Generator().manual_seed(5)
+    for i in range(4):
+        x = torch.rand(2, 3, 32, 32, generator=g).cuda()
+        np.random.seed(100 + i)
+        with torch.no_grad():
+            want = disc(x, it=0).clone()
+        np.random.seed(100 + i)
+        got = gd(x).clone()
+        assert maxdiff(got, want) < 2e-4 * max(1.0, float(want.abs().max())), (i, maxdiff(got, want))
