@@ -87,7 +87,8 @@ int oi_film_params_bwd(const float* d_gamma, const float* d_beta, const float* w
  * through LDS (DESIGN.md "MLP kernel").  Inputs carry the reference's shapes
  * (SURVEY.md 8b state_dict): w0 [128][3], b0 [128]; wh [7][128][128], bh [7][128] (layers 1..7);
  * wsig [128], bsig [1]; wv [128][131], bv [128]; wrgb [3][128], brgb [3].
- * `packed` must hold oi_mlp_packed_bytes(prec) bytes.
+ * `packed` must hold oi_mlp_packed_bytes(prec) bytes: header, 16 MFMA images (7 forward, 7 transposed, colour head both
+ * ways) and the 8 forward matrices once more as plain fp32 (read by the backward for the FiLM-scale identity).
  */
 size_t oi_mlp_packed_bytes(int prec);
 int oi_mlp_pack_weights(const float* w0, const float* b0, const float* wh, const float* bh,

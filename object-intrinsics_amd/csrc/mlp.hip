@@ -286,6 +286,9 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
     __syncthreads();
   }
   if (idx >= C * C) return;
+  if (m < 7 || m == 14)  // plain fp32 copy [out][in] for the backward's FiLM-scale identity
+    reinterpret_cast<float*>(packed + plain_off(PREC))[(size_t)(m < 7 ? m : 7) * C * C + idx] =
+        mat_elem(wh, wv, m, idx >> 7, idx & 127);
   char* base = packed + H_BYTES + (size_t)m * layer_bytes(PREC);
   if (PREC == OI_PREC_F32) {
     // image [t(4)][g(16)][lane(64)][k(4)] fp32, q = 4g + k
@@ -820,7 +823,7 @@ int oi_film_params_bwd(const float* d_gamma, const float* d_beta, const float* w
   return oi::check_launch("oi_film_params_bwd(style)");
 }
 
-size_t oi_mlp_packed_bytes(int prec) { return H_BYTES + (size_t)NMAT * layer_bytes(prec); }
+size_t oi_mlp_packed_bytes(int prec) { return packed_total_bytes(prec); }
 
 int oi_mlp_pack_weights(const float* w0, const float* b0, const float* wh, const float* bh, const float* wsig,
                         const float* bsig, const float* wv, const float* bv, const float* wrgb, const float* brgb,

@@ -14,7 +14,16 @@
 //   down sweep (l down) cbar_l = vbar_l * g_{l+1};  v_l = g_{l+1} * c_l;
 //                       phibar_l = abar_{l+1} cos phi_l - cbar_l gamma_l sin phi_l;  ubar_l = phibar_l gamma_l;
 //                       TWO products per staged image:  g_l = W_l^T v_l  and  abar_l = W_l^T ubar_l;
-//                       gamma / beta / bias gradients; parks v_l, ubar_l for the weight-gradient GEMM       [14 GEMMs]
+//                       parks v_l, ubar_l for the weight-gradient GEMM                                        [14 GEMMs]
+// Round 3: the FiLM / bias gradients of the MFMA layers are NOT summed in the sweep any more.  phi_l = gamma_l (W_l a + b_l)
+// + beta_l -- and with it every first- and second-order term -- depends on gamma_l, W_l, b_l only through gamma_l W_l and
+// gamma_l b_l, hence per batch element
+//       gamma_l[f] d gamma_l[f] = sum_i W_l[f][i] dW_l[f][i] + b_l[f] db_l[f],     d beta_l[f] = db_l[f] / gamma_l[f],
+// and db_l = sum_p ubar_l is a by-product of the weight-gradient GEMM (which reads ubar_l anyway).  That removes 72 of the
+// 112 cross-lane point sums of a tile and the recomputation of u_l (one v_rcp + 4 VALU per element); the parked phase is
+// the REDUCED phase in revolutions (FiLM rows staged pre-multiplied by 1/2pi, as in the forward kernel), so the down sweep
+// and the GEMM feed it to v_sin / v_cos without a range reduction.  (Requires gamma_l[f] != 0; the reference initialises
+// gamma = 15 (...) + 30.)
 // (Round 1 ran four sweeps -- phi up, g down, gbar up, abar down -- and parked 46 slots per point; forming g again in the
 // last sweep instead of parking it, and gbar together with the recomputed activations, leaves 32 slots, 16 of which
 // are read back here: 23.5 -> 16 KB written and 22 -> 9 KB read per point.)
@@ -33,7 +42,7 @@ using namespace oimlp;
 
 // scratch slots of one wave tile (16 KiB each)
 constexpr int S_PHI = 0;    // 8: phi_l
-constexpr int S_VB = 8;     // 8: vbar_l = W_l gbar_l           (down sweep: cbar_l = vbar_l g_{l+1}; wgrad: gbar_{l+1} = vbar_l c_l)
+constexpr int S_VB = 8;     // 8: gamma_l vbar_l, vbar_l = W_l gbar_l   (down sweep: gamma_l cbar_l = . g_{l+1}; wgrad: gbar_{l+1} = . cos phi_l)
 constexpr int S_V = 16;     // 7: v_l,    l = 1..7   (wgrad operand)
 constexpr int S_U = 23;     // 7: ubar_l, l = 1..7   (wgrad operand)
 constexpr int S_UV = 30;    // 1: uvbar (colour head pre-activation gradient)
@@ -132,6 +141,31 @@ __device__ __forceinline__ void racc_flush_row_scaled(char* lds, int row, const 
   if (tid < C) atomicAdd(dst + tid, racc[tid] * factor[tid]);
 }
 
+// FiLM rows of the backward kernels (one 1536-byte slot): [gamma | G | B2] with the phase in REVOLUTIONS,
+//   phi_l / 2pi = G * acc + B2,   G = gamma / 2pi * 2^-k_img (acc = scaled-image product without bias),
+//   B2 = gamma / 2pi * b_l + beta / 2pi
+constexpr float INV_2PI = 0.15915494309189533577f;
+__device__ __forceinline__ void stage_film_bwd(char* lds, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                               const float* __restrict__ hdr, int e, int l, float inv_img, int tid) {
+  float* film = reinterpret_cast<float*>(lds + L_FILM);
+  if (tid < C) {
+    const float g = gamma[((size_t)e * 9 + l) * C + tid];
+    const float gr = g * INV_2PI;
+    film[tid] = g;
+    film[C + tid] = gr * inv_img;
+    film[2 * C + tid] = fmaf(gr, hdr[H_BIAS + l * C + tid], beta[((size_t)e * 9 + l) * C + tid] * INV_2PI);
+  }
+}
+// sin / cos of a phase in revolutions.  REDUCED: the value is already in [0, 1) (parked by the up sweep)
+template <bool FAST, bool REDUCED>
+__device__ __forceinline__ float rev_reduce(float x) {
+  return (FAST || REDUCED) ? x : __builtin_amdgcn_fractf(x);
+}
+__device__ __forceinline__ void sincos_rev(float r, float& s, float& c) {
+  s = __builtin_amdgcn_sinf(r);
+  c = __builtin_amdgcn_cosf(r);
+}
+
 // this wave's LDS-DMA has landed (and so have its outstanding scratch loads), then rendezvous
 __device__ __forceinline__ void dma_sync() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -220,6 +254,9 @@ __device__ unsigned long long oi_prof_bwd[16];
 #else
 #define BW_T(i)
 #endif
+// section markers in the assembly listing (comments only): tools/isa_mix.py --sections splits the instruction mix on them,
+// the up / down layer bodies are run-time loops and execute 7 times per tile
+#define OI_MARK(name) asm volatile("; OI_MARK " name)
 template <int PREC, bool FAST>
 __global__ void __launch_bounds__(256, OI_BWD_WAVES_PER_SIMD)
 mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ packed, const float* __restrict__ gamma,
@@ -269,7 +306,11 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     return r;
   };
   auto stage_img = [&](int image, int ws_) { stage_layer_rs<PREC>(lds + ws_ * 65536, img_rs, image, wave, o.l16); };
-  auto stage_flm = [&](int l_, int fs_) { stage_film(lds + fs_ * (L_FILM2 - L_FILM), gamma, beta, hdr, e, l_, tid); };
+  // FiLM rows of layer l_; the scale of the forward image that produces u_l (layer 0 runs on the VALU, colour head = image 14)
+  auto stage_flm = [&](int l_, int fs_) {
+    const float inv_img = (PREC == OI_PREC_F16X3 && l_ >= 1) ? hdr[H_WSCALE + (l_ == 8 ? 14 : l_ - 1)] : 1.f;
+    stage_film_bwd(lds + fs_ * (L_FILM2 - L_FILM), gamma, beta, hdr, e, l_, inv_img, tid);
+  };
   {
     float* tabs = reinterpret_cast<float*>(lds + L_TABS);
     for (int i = tid; i < H_TABS_END; i += 256) tabs[i] = hdr[i];
@@ -295,6 +336,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   constexpr bool SC = PREC == OI_PREC_F16X3;
 
   // ================= colour head backward (first: its dL/dgrad term is part of gbar_0) =================
+  OI_MARK("colour x1");
   if (has_col) {
     __syncthreads();
     stage_img(14, 0);
@@ -313,36 +355,35 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       const float rv = rgb_fwd[pt * 3 + k];
       rho[k] = g_rgb[pt * 3 + k] * rv * (1.0f - rv) * vmask;  // through the sigmoid
     }
-    if constexpr (SC) acc_zero(acc); else init_bias(lds, o, acc);
-    const float fV = gemm2<PREC, false>(lds, o, act, acc, SC ? hdr[H_WSCALE + 14] : 1.f);
-    // uv -> phiv -> hv; then uvbar.  Reductions: rows 0 gamma_v, 1 beta_v, 2 bv, 3..5 Wrgb, 6..7 dWv[:, 128 + (0, 1)]
+    acc_zero(acc);
+    (void)gemm2<PREC, false>(lds, o, act, acc, 1.f);
+    // uv -> phiv -> hv; then uvbar.  Point sums kept here: rows 3..5 dWrgb, rows 2 / 6 / 7 dWv[:, 130 / 128 / 129]; the FiLM and
+    // bias gradients of the head come out of the weight-gradient GEMM (FiLM-scale identity), the part of it that belongs to
+    // the three extra input columns is added at the flush below
     float dGx = 0.f, dGy = 0.f, dGz = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      float R[8][16];  // rows: 0 gamma_v, 1 beta_v (x gamma_v = bv), 2 dWv[:, 130], 3..5 Wrgb, 6..7 dWv[:, 128 + (0, 1)]
+      float R[8][16];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int g = 4 * t + rr;
         const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
-        const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
+        const f32x4 gr = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
+        const f32x4 b2 = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
         const f32x4 w0 = lds_f4(lds, L_TABS + (H_RGB + 0 * C + grp_f0(g)) * 4, o.h16);
         const f32x4 w1 = lds_f4(lds, L_TABS + (H_RGB + 1 * C + grp_f0(g)) * 4, o.h16);
         const f32x4 w2 = lds_f4(lds, L_TABS + (H_RGB + 2 * C + grp_f0(g)) * 4, o.h16);
-        f32x4 uvb, bsv;
-        if constexpr (SC) bsv = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
+        f32x4 uvb;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const f32x4 wx = lds_f4(lds, L_TABS + H_TABV * 4 + (grp_f0(g) + k) * 16, o.h64);
-          const float ua = SC ? fmaf(acc[t][4 * rr + k], fV, bsv[k]) : acc[t][4 * rr + k];
-          const float uv = ua + fmaf(fz, wx[2], fmaf(fy, wx[1], fx * wx[0]));
-          const float phiv = fmaf(gm[k], uv, bt[k]);
+          // phase in revolutions: gamma/2pi (W a_8 + Wx grad + b) + beta/2pi
+          const float dx = fmaf(fz, wx[2], fmaf(fy, wx[1], fx * wx[0]));
+          const float ph = fmaf(gr[k], acc[t][4 * rr + k], fmaf(gm[k] * INV_2PI, dx, b2[k]));
           float hv, cv;
-          sincos_<FAST>(phiv, hv, cv);
+          sincos_rev(rev_reduce<FAST, false>(ph), hv, cv);
           const float hvb = w0[k] * rho[0] + w1[k] * rho[1] + w2[k] * rho[2];
-          const float phb = hvb * cv;
-          uvb[k] = phb * gm[k];
-          R[0][4 * rr + k] = phb * uv;
-          R[1][4 * rr + k] = phb;
+          uvb[k] = hvb * cv * gm[k];
           R[2][4 * rr + k] = uvb[k] * fz;
           R[3][4 * rr + k] = rho[0] * hv;
           R[4][4 * rr + k] = rho[1] * hv;
@@ -359,7 +400,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int r = 0; r < 8; ++r) rs.add(r, t, R[r]);
+      for (int r = 2; r < 8; ++r) rs.add(r, t, R[r]);
     }
     // contribution to dL/dgrad through the colour-head input
     dGx += __shfl_xor(dGx, 32, 64);
@@ -377,9 +418,13 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       }
     }
     __syncthreads();
-    racc_flush_row(lds, 0, d_gamma + ((size_t)e * 9 + 8) * C, 1, tid);
-    racc_flush_row(lds, 1, d_beta + ((size_t)e * 9 + 8) * C, 1, tid);
-    racc_flush_row_scaled(lds, 1, reinterpret_cast<const float*>(lds + L_FILM), d_small + DS_B + 8 * C, tid);
+    if (tid < C) {  // gamma_v d gamma_v += sum_{j < 3} Wv[f][128 + j] dWv[f][128 + j]  (the GEMM adds the other 128 columns and bv)
+      const float* racc = reinterpret_cast<const float*>(lds + L_RACC);
+      const f32x4 wx = *reinterpret_cast<const f32x4*>(lds + L_TABS + H_TABV * 4 + tid * 16);
+      const float gv = reinterpret_cast<const float*>(lds + L_FILM)[tid];
+      atomicAdd(d_gamma + ((size_t)e * 9 + 8) * C + tid,
+                fmaf(wx[0], racc[6 * C + tid], fmaf(wx[1], racc[7 * C + tid], wx[2] * racc[2 * C + tid])) / gv);
+    }
     racc_flush_row(lds, 2, d_small + DS_WVX + 2, 3, tid);
     racc_flush_row(lds, 3, d_small + DS_WRGB + 0 * C, 1, tid);
     racc_flush_row(lds, 4, d_small + DS_WRGB + 1 * C, 1, tid);
@@ -408,6 +453,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   }
 
   BW_T(0);
+  OI_MARK("up0 x1");
   // ================= up sweep: recompute phi_l, carry gbar_l =================
   // FiLM rows of layer l live in FiLM slot l & 1, layer l's forward image in image slot (l - 1) & 1: both are requested one
   // layer ahead
@@ -417,19 +463,19 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
-    const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
-    const f32x4 bs = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
+    const f32x4 gr = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
+    const f32x4 b2 = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
     f32x4 ph, vb;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const f32x4 w = lds_f4(lds, L_TABS + H_TAB0 * 4 + (grp_f0(g) + k) * 16, o.h64);
-      const float u = fmaf(pz, w[2], fmaf(py, w[1], px * w[0])) + bs[k];
-      ph[k] = fmaf(gm[k], u, bt[k]);
+      const float u = fmaf(pz, w[2], fmaf(py, w[1], px * w[0]));
+      ph[k] = rev_reduce<FAST, false>(fmaf(gr[k], u, b2[k]));
       float s, c;
-      sincos_<FAST>(ph[k], s, c);
+      sincos_rev(ph[k], s, c);
       act[4 * g + k] = s;
-      vb[k] = fmaf(Gz, w[2], fmaf(Gy, w[1], Gx * w[0]));
-      gb[4 * g + k] = vb[k] * gm[k] * c;
+      vb[k] = fmaf(Gz, w[2], fmaf(Gy, w[1], Gx * w[0])) * gm[k];  // parked with gamma folded in
+      gb[4 * g + k] = vb[k] * c;
     }
     ws.store(S_PHI + 0, g, o.l16, ph);
     ws.store(S_VB + 0, g, o.l16, vb);
@@ -437,6 +483,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   }
   BW_T(1);
   for (int l = 1; l < NL_SDF; ++l) {
+    OI_MARK("up_body x7");
     dma_sync();  // layer l's image and FiLM rows have landed; every wave is done with layer l - 1
     BW_T(2);
     if (l < NL_SDF - 1) {
@@ -455,41 +502,41 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     if constexpr (SC) publish_max(op_max, OM_G + l - 1, mx_g);
     BW_T(4);
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
+    for (int g = 0; g < 16; ++g) {  // gamma_l vbar_l (gamma folded in: what both the down sweep and the GEMM consume)
+      const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, ol.h16);
       f32x4 v;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        v[k] = SC ? acc[g >> 2][4 * (g & 3) + k] * fA : acc[g >> 2][4 * (g & 3) + k];
+        v[k] = SC ? acc[g >> 2][4 * (g & 3) + k] * (fA * gm[k]) : acc[g >> 2][4 * (g & 3) + k] * gm[k];
         gb[4 * g + k] = v[k];
       }
       if (!(OI_BWD_ABL & 4)) ws.store(S_VB + l, g, o.l16, v);
     }
-    // u_l = W_l a_l + b_l -> phi_l, a_{l+1};  gbar_{l+1} = vbar_l gamma_l cos phi_l
-    if constexpr (SC) acc_zero(acc); else init_bias(lds, ol, acc);
+    // phi_l / 2pi = G (W_img a_l) + B2 (image scale and bias folded into the staged rows) -> a_{l+1};
+    // gbar_{l+1} = vbar_l gamma_l cos phi_l
+    acc_zero(acc);
     BW_T(5);
-    const float fB = gemm2<PREC, false>(lds, ol, act, acc, inv_img);
+    (void)gemm2<PREC, false>(lds, ol, act, acc, 1.f);
     BW_T(4);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, ol.h16);
-      const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, ol.h16);
-      f32x4 bs;
-      if constexpr (SC) bs = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, ol.h16);
+      const f32x4 gr = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, ol.h16);
+      const f32x4 b2 = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, ol.h16);
       f32x4 ph;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float u = SC ? fmaf(acc[g >> 2][4 * (g & 3) + k], fB, bs[k]) : acc[g >> 2][4 * (g & 3) + k];
-        ph[k] = fmaf(gm[k], u, bt[k]);
+        ph[k] = rev_reduce<FAST, false>(fmaf(gr[k], acc[g >> 2][4 * (g & 3) + k], b2[k]));
         float s, c;
-        sincos_<FAST>(ph[k], s, c);
+        sincos_rev(ph[k], s, c);
         act[4 * g + k] = s;
-        gb[4 * g + k] *= gm[k] * c;
+        gb[4 * g + k] *= c;
       }
       if (!(OI_BWD_ABL & 4)) ws.store(S_PHI + l, g, o.l16, ph);
       __builtin_amdgcn_sched_barrier(0);
     }
     BW_T(5);
   }
+  OI_MARK("mid x1");
   // d w_sigma = sum_p (gbar_8 + gs a_8)  (row 3);  d b_sigma = sum_p gs
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -531,41 +578,43 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   // layer 0 is peeled (its extra d W0 rows and missing products are compile-time): no branch inside the unrolled epilogue
   auto down_layer = [&](int l, auto is_layer0) {
     constexpr bool L0 = decltype(is_layer0)::value;
-    dma_sync();  // layer l's transposed image and FiLM rows have landed; the previous layer's row flush is complete
+    if constexpr (L0) OI_MARK("down0 x1"); else OI_MARK("down_body x7");
+    dma_sync();  // layer l's transposed image and FiLM rows have landed
     BW_T(7);
-    racc_zero(lds, tid);
+    if constexpr (L0) {  // the reduction rows still hold the w_sigma sums of the up sweep (flushed many barriers ago)
+      racc_zero(lds, tid);
+      __syncthreads();
+    }
     if (l >= 2) stage_img(7 + l - 2, (l - 1) & 1);
     if (l >= 1) stage_flm(l - 1, (l - 1) & 1);
     const LaneOff ol = layer_off(l & 1, l & 1);
-    __syncthreads();  // reduction rows zeroed
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      float R[2][16], R0[3][16];  // rows 0 d gamma_l, 1 d beta_l (x gamma_l = d b_l); layer 0: rows 3..5 d W0[:, 0..2]
+      // layer 0 only (its "weight gradient" is three columns, summed here): rows 1 d b_0 = sum ubar_0, 3..5 d W0[:, 0..2].
+      // Layers 1..7 need NO point sum in this kernel (FiLM-scale identity, see the header comment).
+      float R0[4][16];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int g = 4 * t + rr;
         const f32x4 ph = phn[g], vb = vbn[g];
         const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, ol.h16);
-        const f32x4 bt = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, ol.h16);
         f32x4 ub, vv;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float s, c;
-          sincos_<FAST>(ph[k], s, c);
+          sincos_rev(ph[k], s, c);                                     // parked reduced phase (revolutions)
           const float gn = gb[4 * g + k];                              // g_{l+1}
-          const float cb = vb[k] * gn;                                 // cbar_l
-          vv[k] = gn * gm[k] * c;                                      // v_l
-          const float phb = act[4 * g + k] * c - cb * gm[k] * s;       // phibar_l
-          const float u = (ph[k] - bt[k]) * __builtin_amdgcn_rcpf(gm[k]);  // u_l
-          R[0][4 * rr + k] = fmaf(phb, u, cb * c);                     // d gamma_l
-          R[1][4 * rr + k] = phb;                                      // d beta_l
+          const float cb = vb[k] * gn;                                 // gamma_l cbar_l (gamma folded into the parked vbar)
+          vv[k] = gn * c * gm[k];                                      // v_l
+          const float phb = fmaf(act[4 * g + k], c, -cb * s);          // phibar_l
           ub[k] = phb * gm[k];                                         // ubar_l
           gb[4 * g + k] = vv[k];
           act[4 * g + k] = ub[k];
           if constexpr (L0) {  // d W0 = sum_p (ubar_0 x^T + v_0 gbar_0^T)
-            R0[0][4 * rr + k] = fmaf(ub[k], px, vv[k] * Gx);
-            R0[1][4 * rr + k] = fmaf(ub[k], py, vv[k] * Gy);
-            R0[2][4 * rr + k] = fmaf(ub[k], pz, vv[k] * Gz);
+            R0[0][4 * rr + k] = ub[k];
+            R0[1][4 * rr + k] = fmaf(ub[k], px, vv[k] * Gx);
+            R0[2][4 * rr + k] = fmaf(ub[k], py, vv[k] * Gy);
+            R0[3][4 * rr + k] = fmaf(ub[k], pz, vv[k] * Gz);
           }
         }
         if constexpr (!L0 && !(OI_BWD_ABL & 1)) {
@@ -582,12 +631,11 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #endif
         __builtin_amdgcn_sched_barrier(0);
       }
-      rs.add(0, t, R[0]);
-      rs.add(1, t, R[1]);
       if constexpr (L0) {
-        rs.add(3, t, R0[0]);
-        rs.add(4, t, R0[1]);
-        rs.add(5, t, R0[2]);
+        rs.add(1, t, R0[0]);
+        rs.add(3, t, R0[1]);
+        rs.add(4, t, R0[2]);
+        rs.add(5, t, R0[3]);
       }
     }
     BW_T(8);
@@ -620,15 +668,21 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         for (int r = 0; r < 16; ++r) act[16 * t + r] = SC ? acc[t][r] * f2 : acc[t][r];
     }
     BW_T(10);
-    __syncthreads();
-    racc_flush_row(lds, 0, d_gamma + ((size_t)e * 9 + l) * C, 1, tid);
-    racc_flush_row(lds, 1, d_beta + ((size_t)e * 9 + l) * C, 1, tid);
-    racc_flush_row_scaled(lds, 1, reinterpret_cast<const float*>(lds + L_FILM + (l & 1) * (L_FILM2 - L_FILM)),
-                          d_small + DS_B + l * C, tid);
     if constexpr (L0) {
+      __syncthreads();
+      racc_flush_row(lds, 1, d_small + DS_B, 1, tid);
       racc_flush_row(lds, 3, d_small + DS_W0 + 0, 3, tid);
       racc_flush_row(lds, 4, d_small + DS_W0 + 1, 3, tid);
       racc_flush_row(lds, 5, d_small + DS_W0 + 2, 3, tid);
+      if (tid < C) {  // d beta_0 = d b_0 / gamma_0;  gamma_0 d gamma_0 = sum_j W0[f][j] dW0[f][j] + b_0[f] d b_0[f]
+        const float* racc = reinterpret_cast<const float*>(lds + L_RACC);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(lds + L_TABS + H_TAB0 * 4 + tid * 16);
+        const float ig = 1.0f / reinterpret_cast<const float*>(lds + L_FILM)[tid];  // layer 0's rows sit in FiLM slot 0
+        const float db = racc[1 * C + tid];
+        atomicAdd(d_beta + (size_t)e * 9 * C + tid, db * ig);
+        atomicAdd(d_gamma + (size_t)e * 9 * C + tid,
+                  fmaf(w[0], racc[3 * C + tid], fmaf(w[1], racc[4 * C + tid], fmaf(w[2], racc[5 * C + tid], hdr[H_BIAS + tid] * db))) * ig);
+      }
     }
     BW_T(11);
   };
@@ -661,22 +715,70 @@ __device__ __forceinline__ int slot_index(int f, int p) {
 }
 constexpr int WG_SLOT_FLOATS = 4096 + 8 * 32;
 
+// FiLM / bias gradients of layer `lrow` (1..7, 8 = colour head) of one batch element from a workgroup's partial results
+// (everything is linear in the partial sums, so every workgroup adds its share):
+//   dwv[t][rg]  partial dW[oo][32 t + i], oo = 32 wave + (rg & 3) + 8 (rg >> 2) + 4 h   (MFMA accumulator layout)
+//   sub         this lane's partial sum of ubar[fo] over the points its MFMA A-fragments cover (the other lane half holds
+//               the other points), fo = 32 wave + i
+//   gamma d gamma = sum_i W[f][i] dW[f][i] + b[f] db[f];   d beta = db / gamma;   db = sum_p ubar
+// DW(t, rg) returns the workgroup's partial dW[oo][32 t + i]; it is also what this function adds to the global dW.
+template <class DW>
+__device__ __forceinline__ void film_identity_epilogue(DW dw, float* __restrict__ dst, float sub,
+                                                       const float* __restrict__ wplain, const float* __restrict__ bias_row,
+                                                       const float* __restrict__ gamma_row, float* __restrict__ d_gamma_row,
+                                                       float* __restrict__ d_beta_row, float* __restrict__ d_bias_row, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, h = lane >> 5, i = lane & 31;
+  float s[16];
+#pragma unroll
+  for (int rg = 0; rg < 16; ++rg) {
+    const size_t row = (size_t)(32 * wave + (rg & 3) + 8 * (rg >> 2) + 4 * h) * C + i;
+    float a = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float v = dw(t, rg);
+      atomicAdd(dst + row + 32 * t, v);
+      a = fmaf(v, wplain[row + 32 * t], a);
+    }
+    s[rg] = a;
+    __builtin_amdgcn_sched_barrier(0);  // one row at a time: keeps the 64 weight loads from being hoisted into live registers
+  }
+  float v = row_transpose_sum16(s, lane);  // lane r of every 16-lane row: the row's sum of value r
+  v += __shfl_xor(v, 16, 64);              // both rows of the 32 columns
+  const float w = sub + __shfl_xor(sub, 32, 64);
+  if ((lane & 16) == 0) {
+    const int r = lane & 15;
+    const int oo = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+    atomicAdd(d_gamma_row + oo, v / gamma_row[oo]);
+  }
+  if (h == 0) {
+    const int f = 32 * wave + i;
+    const float ig = 1.0f / gamma_row[f];
+    atomicAdd(d_bias_row + f, w);
+    atomicAdd(d_beta_row + f, w * ig);
+    atomicAdd(d_gamma_row + f, bias_row[f] * w * ig);
+  }
+}
+
 template <bool FAST>
 __global__ void __launch_bounds__(256)
-mlp_wgrad_kernel(const char* __restrict__ scratch, const float* __restrict__ gamma, float* __restrict__ d_wmat,
-                 long long n_wave_tiles, long long wt_per_elem, int tiles_per_chunk, int has_col) {
+mlp_wgrad_kernel(const char* __restrict__ scratch, const char* __restrict__ packed, size_t plain_offset,
+                 const float* __restrict__ gamma, float* __restrict__ d_wmat, float* __restrict__ d_gamma,
+                 float* __restrict__ d_beta, float* __restrict__ d_small, long long wt_per_elem, int tiles_per_chunk,
+                 int has_col) {
   __shared__ __attribute__((aligned(16))) float sx[WG_SLOT_FLOATS], sy[WG_SLOT_FLOATS];
   const int m = blockIdx.y;
   if (m == 7 && !has_col) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, i = lane & 31;
-  const long long t_begin = (long long)blockIdx.x * tiles_per_chunk;
-  const long long t_end = min(n_wave_tiles, t_begin + tiles_per_chunk);
+  const int e = blockIdx.z;  // chunks never straddle batch elements: the FiLM gradients are per element
+  const long long t_begin = e * wt_per_elem + (long long)blockIdx.x * tiles_per_chunk;
+  const long long t_end = min((e + 1) * wt_per_elem, t_begin + tiles_per_chunk);
   f32x16 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float sub = 0.f;  // sum over this lane's points of ubar_l[fo] (uvbar for the colour head): d b_l
   const int npair = (m == 7) ? 1 : 2;
   for (long long wt = t_begin; wt < t_end; ++wt) {
     const char* base = scratch + wt * (long long)(NSLOT_BWD * 16384);
@@ -690,7 +792,7 @@ mlp_wgrad_kernel(const char* __restrict__ scratch, const float* __restrict__ gam
       const f32x4* gx4 = reinterpret_cast<const f32x4*>(base + (size_t)sxi * 16384);
       const f32x4* gy4 = reinterpret_cast<const f32x4*>(base + (size_t)syi * 16384);
       const f32x4* gv4 = reinterpret_cast<const f32x4*>(base + (size_t)(S_VB + (m < 7 ? m : 0)) * 16384);
-      const float* grow = gamma + ((wt / wt_per_elem) * 9 + (m < 7 ? m : 0)) * C;
+      const bool x_is_ubar = m == 7 || pr == 1;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         // f32x4 number q = it*256 + tid of the slot: 32-point block q >> 5 = ((4t + rr) * 2 + hh)
@@ -698,16 +800,13 @@ mlp_wgrad_kernel(const char* __restrict__ scratch, const float* __restrict__ gam
         const int dq = q + 2 * (q >> 5);  // + 8 floats per 32-point block
         reinterpret_cast<f32x4*>(sx)[dq] = gx4[q];
         f32x4 y = gy4[q];
-        f32x4 vb = {0.f, 0.f, 0.f, 0.f}, gm = {0.f, 0.f, 0.f, 0.f};
-        if (y_is_gbar) {
-          vb = gv4[q];
-          gm = *reinterpret_cast<const f32x4*>(grow + grp_f0(q >> 6) + 4 * ((q >> 5) & 1));
-        }
+        f32x4 vb = {0.f, 0.f, 0.f, 0.f};
+        if (y_is_gbar) vb = gv4[q];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float s, c;
-          sincos_<FAST>(y[k], s, c);
-          y[k] = y_is_gbar ? vb[k] * gm[k] * c : s;
+          sincos_rev(y[k], s, c);  // parked reduced phase (revolutions)
+          y[k] = y_is_gbar ? vb[k] * c : s;  // gamma_{l-1} is folded into the parked vbar
         }
         reinterpret_cast<f32x4*>(sy)[dq] = y;
       }
@@ -717,6 +816,7 @@ mlp_wgrad_kernel(const char* __restrict__ scratch, const float* __restrict__ gam
       for (int s = 0; s < 16; ++s) {
         const int p = 2 * s + h;
         const float a = sx[slot_index(fo, p)];
+        if (x_is_ubar) sub += a;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const float b = sy[slot_index(32 * t + i, p)];
@@ -726,14 +826,11 @@ mlp_wgrad_kernel(const char* __restrict__ scratch, const float* __restrict__ gam
     }
   }
   // D[o][i]: column = lane & 31 (input feature i within tile t), row = (reg&3) + 8*(reg>>2) + 4h (o within the wave's strip)
-  float* dst = d_wmat + (size_t)m * C * C;
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int rg = 0; rg < 16; ++rg) {
-      const int oo = 32 * wave + (rg & 3) + 8 * (rg >> 2) + 4 * h;
-      atomicAdd(dst + (size_t)oo * C + 32 * t + i, acc[t][rg]);
-    }
+  const int lrow = m + 1;
+  film_identity_epilogue([&](int t, int rg) { return acc[t][rg]; }, d_wmat + (size_t)m * C * C, sub, reinterpret_cast<const float*>(packed + plain_offset) + (size_t)m * C * C,
+                         reinterpret_cast<const float*>(packed) + H_BIAS + lrow * C, gamma + ((size_t)e * 9 + lrow) * C,
+                         d_gamma + ((size_t)e * 9 + lrow) * C, d_beta + ((size_t)e * 9 + lrow) * C,
+                         d_small + DS_B + lrow * C, tid);
 }
 
 // ---- F16X3 variant of the weight-gradient GEMM (3 fp16 MFMAs per product instead of 8 fp32-MFMA k-steps per 16
@@ -756,11 +853,12 @@ __device__ __forceinline__ void pow2_scale_of(float m, float& sc, float& inv) {
 }
 
 // 8 consecutive points of feature f (points p0 .. p0+7) from the skewed fp32 LDS copy -> scaled fp16 hi / lo limbs
-__device__ __forceinline__ void frag16(const float* sl, int f, int p0, f16x8& hi, f16x8& lo) {
+__device__ __forceinline__ float frag16(const float* sl, int f, int p0, f16x8& hi, f16x8& lo) {
   float v[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) v[q] = sl[slot_index4(f, p0 + q)];
   split8_pairs(v, hi, lo);
+  return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));  // used for the bias gradient (sum over points)
 }
 
 // the scratch operands are read exactly once by this kernel: non-temporal loads (streaming-read ceiling of the box
@@ -768,122 +866,249 @@ __device__ __forceinline__ void frag16(const float* sl, int f, int p0, f16x8& hi
 #ifndef OI_WGRAD_NT
 #define OI_WGRAD_NT 1
 #endif
+#ifndef OI_WG_ABL
+#define OI_WG_ABL 0
+#endif
 __device__ __forceinline__ f32x4 ld_once(const f32x4* p) { return OI_WGRAD_NT ? __builtin_nontemporal_load(p) : *p; }
 
-template <bool FAST>
-__global__ void __launch_bounds__(256)
-mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__ op_max, const float* __restrict__ gamma,
-                     float* __restrict__ d_wmat, long long n_wave_tiles, long long wt_per_elem, int tiles_per_chunk,
-                     int has_col) {
-  __shared__ __attribute__((aligned(16))) float sx[WG16_SLOT_FLOATS], sy[WG16_SLOT_FLOATS];
-  __shared__ __attribute__((aligned(16))) f16x8 sb[2][4][2][64];  // [hi|lo][column tile][k-step][lane]
-  const int m = blockIdx.y;
-  if (m == 7 && !has_col) return;
+// -DOI_WG_PROF: per-phase shader-clock accounting of the weight-gradient GEMM (read with oi_prof_bwd_read, slots 0..7)
+#ifdef OI_WG_PROF
+#ifndef OI_BWD_PROF
+__device__ unsigned long long oi_prof_bwd[16];
+#endif
+#define WG_T(i)                                                  \
+  do {                                                           \
+    const unsigned long long t_ = __builtin_readcyclecounter();  \
+    wacc[i] += t_ - wprev;                                       \
+    wprev = t_;                                                  \
+  } while (0)
+#else
+#define WG_T(i)
+#endif
+typedef f16x8 (*SbPtr)[4][2][64];  // [hi|lo][column tile][k-step][lane]
+// COL: the colour-head matrix (m = 7, one pair: X = uvbar, Y = a_8 = sin phi_7); otherwise a layer matrix (two pairs).  A
+// compile-time split: with `m` tested at run time hipcc turned the per-element selects of the hot loop into branches.
+template <bool COL>
+__device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, const int m, const char* __restrict__ scratch,
+                                               const float* __restrict__ op_max, const char* __restrict__ packed,
+                                               size_t plain_offset, const float* __restrict__ gamma,
+                                               float* __restrict__ d_wmat, float* __restrict__ d_gamma,
+                                               float* __restrict__ d_beta, float* __restrict__ d_small,
+                                               long long wt_per_elem, int tiles_per_chunk) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, i = lane & 31;
-  const long long t_begin = (long long)blockIdx.x * tiles_per_chunk;
-  const long long t_end = min(n_wave_tiles, t_begin + tiles_per_chunk);
-  const int npair = (m == 7) ? 1 : 2;
+  const int e = blockIdx.z;  // chunks never straddle batch elements: the FiLM gradients are per element
+  const long long t_begin = e * wt_per_elem + (long long)blockIdx.x * tiles_per_chunk;
+  const long long t_end = min((e + 1) * wt_per_elem, t_begin + tiles_per_chunk);
+  constexpr int npair = COL ? 1 : 2;
   // ONE power-of-two scale per operand for the whole launch (maxima published by the sweep): the products of all tiles
   // then share a scale and accumulate straight in the MFMA accumulators -- no per-tile maximum, no per-tile merge.
   // pair 0: X = v_l (uvbar for the colour head), Y = gbar_l (a_8 = sin, |.| <= 1);  pair 1: X = ubar_l, Y = a_l = sin
-  float scx[2], scy[2], inv[2];
+  // ONE accumulator for both pairs (round 3: 64 instead of 128 accumulator registers -- the registers that hold the SECOND
+  // tile in flight): the pair whose products are larger gets the optimal operand scales
+  // (max |X|, max |Y| -> [2^13, 2^14)), the other pair's Y scale is lowered so that both products carry the same factor.
+  // Nothing can overflow, and the smaller pair is resolved to 2^-22 of the larger one's terms -- the sum they form.
+  float scx[2], scy[2], inv[2], inv_scx[2];
   {
     // maximum over the replicas: lane r of every wave reads replica r (the table is 8 KiB and L2-resident)
     const float* rep = op_max + lane * OM_STRIDE;
-    const float mx0 = oi::wave_max(rep[m == 7 ? OM_UV : OM_V + m]);
-    const float my0 = m == 7 ? 1.0f : oi::wave_max(rep[OM_G + m]);
-    const float mx1 = oi::wave_max(rep[OM_U + (m < 7 ? m : 0)]);
+    const float mx0 = oi::wave_max(rep[COL ? OM_UV : OM_V + m]);
+    const float my0 = COL ? 1.0f : oi::wave_max(rep[OM_G + m]);
+    const float mx1 = oi::wave_max(rep[OM_U + (COL ? 0 : m)]);
     float ivx, ivy;
     pow2_scale_of(mx0, scx[0], ivx);
+    inv_scx[0] = ivx;
     pow2_scale_of(my0, scy[0], ivy);
     inv[0] = ivx * ivy;
     pow2_scale_of(mx1, scx[1], ivx);
+    inv_scx[1] = ivx;
     pow2_scale_of(1.0f, scy[1], ivy);
     inv[1] = ivx * ivy;
+    if constexpr (!COL) {  // common factor: the smaller of the two product scales (inv = 1 / (scx scy) is the larger)
+      if (inv[1] > inv[0]) {
+        scy[0] = scy[0] * (inv[0] / inv[1]);  // powers of two: exact
+        inv[0] = inv[1];
+      } else {
+        scy[1] = scy[1] * (inv[1] / inv[0]);
+        inv[1] = inv[0];
+      }
+    }
   }
-  f32x16 acc[2][4];
-  acc_zero(acc[0]);
-  acc_zero(acc[1]);
+  f32x16 acc[4];
+  acc_zero(acc);
+  float sub = 0.f;  // sum over this lane's points of (scaled) ubar_l[fo] (uvbar for the colour head): d b_l
   const int fo = 32 * wave + i;
-  for (long long wt = t_begin; wt < t_end; ++wt) {
-    const char* base = scratch + wt * (long long)(NSLOT_BWD * 16384);
-    // both Y operands of a layer matrix come from the SAME parked phi_{l-1}: one read, one sin / cos per element
-    //   pair 0: Y = gbar_l = vbar_{l-1} gamma_{l-1} cos(phi_{l-1})      pair 1: Y = a_l = sin(phi_{l-1})
-    const f32x4* gp4 = reinterpret_cast<const f32x4*>(base + (size_t)(S_PHI + m) * 16384);
-    const f32x4* gv4 = reinterpret_cast<const f32x4*>(base + (size_t)(S_VB + (m < 7 ? m : 0)) * 16384);
-    const float* grow = gamma + ((wt / wt_per_elem) * 9 + (m < 7 ? m : 0)) * C;
-    // every load of the tile is issued before any of it is used: ONE memory round trip per tile
-    const f32x4* gx0 = reinterpret_cast<const f32x4*>(base + (size_t)(m == 7 ? S_UV : S_V + m) * 16384);
-    const f32x4* gx1 = reinterpret_cast<const f32x4*>(base + (size_t)(S_U + (m < 7 ? m : 0)) * 16384);
-    f32x4 ysin[4], ygb[4], xall[2][4], ph4[4], vb4[4], gm4[4];
+  // Software pipeline over the wave tiles: the five slots of tile wt + 1 are requested as soon as tile wt's values have
+  // left the staging registers for LDS, and travel under both pairs' fragment extraction and MFMAs (round 2 issued them at
+  // the top of the tile and waited: a full memory round trip exposed per tile and workgroup, 4.4 TB/s).
+  //   both Y operands of a layer matrix come from the SAME parked phase (reduced, in revolutions): one read, one sin / cos
+  //   pair 0: Y = gbar_l = (gamma vbar)_{l-1} cos(phi_{l-1})      pair 1: Y = a_l = sin(phi_{l-1})
+  struct Stage {  // the five slots of one wave tile as they arrive: 80 registers (48 for the colour head)
+    f32x4 xall[2][4], ph4[4], vb4[4];
+  };
+  Stage stA, stB;
+  // through a buffer descriptor over the wave tile (512 KiB): the tile base and the slot offsets travel in SGPRs, the lane
+  // offset in ONE VGPR -- with flat pointers hipcc kept 20 address pairs live across the loop and spilled
+  const int t16 = tid * 16;
+  auto request = [&](long long wt, Stage& st) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(scratch) + wt * (long long)(NSLOT_BWD * 16384), 0, NSLOT_BWD * 16384, 0x00020000);
+    auto ld = [&](int slot, int it) {
+      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, t16, slot * 16384 + it * 4096,
+                                                                             OI_WGRAD_NT ? 2 : 0));
+    };
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      st.ph4[it] = ld(S_PHI + m, it);
+      st.xall[0][it] = ld(COL ? S_UV : S_V + m, it);
+      if constexpr (!COL) {
+        st.vb4[it] = ld(S_VB + m, it);  // gamma_{l-1} vbar_{l-1}
+        st.xall[1][it] = ld(S_U + m, it);
+      }
+    }
+  };
+  // fragments of one pair out of the fp32 LDS copies: this wave's column tile of Y -> shared fp16 fragments sb[pr], its
+  // own row strip of X -> registers
+  auto extract = [&](int pr, f16x8 (&ah)[2], f16x8 (&al)[2], bool last_pair) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 bh, bl;
+      frag16(sy, fo, 16 * ks + 8 * h, bh, bl);
+      sb[0][wave][ks][lane] = bh;
+      sb[1][wave][ks][lane] = bl;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float xs = frag16(sx, fo, 16 * ks + 8 * h, ah[ks], al[ks]);
+      if (last_pair) sub += xs;  // the last pair's X is ubar_l / uvbar
+    }
+  };
+  auto products = [&](const f16x8 (&ah)[2], const f16x8 (&al)[2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f16x8 bh = sb[0][t][ks][lane], bl = sb[1][t][ks][lane];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, acc[t], 0, 0, 0);
+      }
+    }
+  };
+#ifdef OI_WG_PROF
+  unsigned long long wacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long wprev = __builtin_readcyclecounter();
+  const unsigned long long wstart = wprev;
+#endif
+  // one wave tile out of staging set `st`; the set is dead once pair 1 is staged, and the tile TWO ahead is requested into it
+  auto tile = [&](long long wt, Stage& st) {
+#if OI_WG_ABL & 1  // timing ablation: the loads alone (streaming rate of this access pattern)
+    {
+      float z = 0.f;
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          z += st.ph4[it][k] + st.xall[0][it][k] + (COL ? 0.f : st.vb4[it][k] + st.xall[1][it][k]);
+      sub += z;
+      __builtin_amdgcn_sched_barrier(0);
+      if (wt + 2 < t_end) request(wt + 2, st);
+      return;
+    }
+#endif
+    // pair 0 needs only the cosine (layer matrices) and pair 1 only the sine: the phase stays in its registers until pair 1
+    // is staged, nothing else of the tile does
+    f32x4 y0[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)  // colour head (one pair): Y = a_8 = sin
+        y0[it][k] = COL ? __builtin_amdgcn_sinf(st.ph4[it][k]) * scy[0]
+                        : st.vb4[it][k] * scy[0] * __builtin_amdgcn_cosf(st.ph4[it][k]);
+    }
+    WG_T(0);
+    __syncthreads();  // (1) the previous tile's readers of sx / sy / sb are done
+    WG_T(1);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int q = it * 256 + tid;
-      ph4[it] = ld_once(gp4 + q);
-      xall[0][it] = ld_once(gx0 + q);
-      vb4[it] = gm4[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-      xall[1][it] = xall[0][it];
-      if (m < 7) {
-        vb4[it] = ld_once(gv4 + q);
-        gm4[it] = *reinterpret_cast<const f32x4*>(grow + grp_f0(q >> 6) + 4 * ((q >> 5) & 1));
-        xall[1][it] = ld_once(gx1 + q);
-      }
+      const int dq = q + (q >> 5);  // + 4 floats per 32-point block
+      reinterpret_cast<f32x4*>(sx)[dq] = st.xall[0][it] * scx[0];
+      reinterpret_cast<f32x4*>(sy)[dq] = y0[it];
     }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float sn, cs;
-        sincos_<FAST>(ph4[it][k], sn, cs);
-        ysin[it][k] = sn;
-        ygb[it][k] = vb4[it][k] * (gm4[it][k] * scy[0]) * cs;
-      }
-    }
-    for (int pr = 0; pr < npair; ++pr) {
-      const bool y_is_gbar = (m < 7) && pr == 0;
-      __syncthreads();  // previous pair's readers of sx / sy / sb are done
+    WG_T(2);
+    __syncthreads();  // (2)
+    f16x8 ah[2], al[2];
+    extract(0, ah, al, npair == 1);
+    WG_T(3);
+    __syncthreads();  // (3) sx / sy are free again, sb is complete
+    if constexpr (npair == 2) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int q = it * 256 + tid;
-        const int dq = q + (q >> 5);  // + 4 floats per 32-point block
-        reinterpret_cast<f32x4*>(sx)[dq] = xall[pr][it] * scx[pr];
-        reinterpret_cast<f32x4*>(sy)[dq] = y_is_gbar ? ygb[it] : ysin[it] * scy[pr];
-      }
-      __syncthreads();
-      // this wave's column tile of Y -> shared fp16 fragments
+        const int dq = q + (q >> 5);
+        reinterpret_cast<f32x4*>(sx)[dq] = st.xall[1][it] * scx[1];
+        f32x4 y1;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        f16x8 bh, bl;
-        frag16(sy, fo, 16 * ks + 8 * h, bh, bl);
-        sb[0][wave][ks][lane] = bh;
-        sb[1][wave][ks][lane] = bl;
-      }
-      f16x8 ah[2], al[2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) frag16(sx, fo, 16 * ks + 8 * h, ah[ks], al[ks]);
-      __syncthreads();
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const f16x8 bh = sb[0][t][ks][lane], bl = sb[1][t][ks][lane];
-          acc[pr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, acc[pr][t], 0, 0, 0);
-          acc[pr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, acc[pr][t], 0, 0, 0);
-          acc[pr][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, acc[pr][t], 0, 0, 0);
-        }
+        for (int k = 0; k < 4; ++k) y1[k] = __builtin_amdgcn_sinf(st.ph4[it][k]) * scy[1];
+        reinterpret_cast<f32x4*>(sy)[dq] = y1;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (wt + 2 < t_end) request(wt + 2, st);  // every register of the set is dead: two tiles are in flight from here on
+    __builtin_amdgcn_sched_barrier(0);
+    WG_T(4);
+    products(ah, al);
+    WG_T(5);
+    if constexpr (npair == 2) {
+      __syncthreads();  // (4)
+      extract(1, ah, al, true);
+      WG_T(6);
+      __syncthreads();  // (5)
+      products(ah, al);
+      WG_T(7);
+    }
+  };
+  if (t_begin < t_end) request(t_begin, stA);
+  if (t_begin + 1 < t_end) request(t_begin + 1, stB);
+  for (long long wt = t_begin; wt < t_end; wt += 2) {
+    tile(wt, stA);
+    if (wt + 1 < t_end) tile(wt + 1, stB);
   }
-  float* dst = d_wmat + (size_t)m * C * C;
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int rg = 0; rg < 16; ++rg) {
-      const int oo = 32 * wave + (rg & 3) + 8 * (rg >> 2) + 4 * h;
-      const float v = npair == 2 ? fmaf(acc[1][t][rg], inv[1], acc[0][t][rg] * inv[0]) : acc[0][t][rg] * inv[0];
-      atomicAdd(dst + (size_t)oo * C + 32 * t + i, v);
-    }
+#ifdef OI_WG_PROF
+  if (lane == 0 && !COL) {
+    for (int q = 0; q < 8; ++q) atomicAdd(&oi_prof_bwd[q], wacc[q]);
+    atomicAdd(&oi_prof_bwd[12], __builtin_readcyclecounter() - wstart);
+    atomicAdd(&oi_prof_bwd[13], (unsigned long long)(t_end - t_begin));
+  }
+#endif
+  const int lrow = m + 1;
+  film_identity_epilogue(
+      [&](int t, int rg) { return acc[t][rg] * inv[0]; },
+      d_wmat + (size_t)m * C * C, sub * (npair == 2 ? inv_scx[1] : inv_scx[0]), reinterpret_cast<const float*>(packed + plain_offset) + (size_t)m * C * C,
+                         reinterpret_cast<const float*>(packed) + H_BIAS + lrow * C, gamma + ((size_t)e * 9 + lrow) * C,
+                         d_gamma + ((size_t)e * 9 + lrow) * C, d_beta + ((size_t)e * 9 + lrow) * C,
+                         d_small + DS_B + lrow * C, tid);
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))  // VGPRs + AGPRs <= 256: two workgroups per CU
+mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__ op_max, const char* __restrict__ packed,
+                     size_t plain_offset, const float* __restrict__ gamma, float* __restrict__ d_wmat,
+                     float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_small,
+                     long long wt_per_elem, int tiles_per_chunk, int has_col) {
+  __shared__ __attribute__((aligned(16))) float sx[WG16_SLOT_FLOATS], sy[WG16_SLOT_FLOATS];
+  // ONE copy for both pairs (barrier 4 separates pair 0's readers from pair 1's writers)
+  __shared__ __attribute__((aligned(16))) f16x8 sb[2][4][2][64];
+  const int m = blockIdx.y;
+  if (m == 7) {
+    if (has_col)
+      wgrad_f16_body<true>(sx, sy, sb, 7, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta, d_small,
+                           wt_per_elem, tiles_per_chunk);
+  } else {
+    wgrad_f16_body<false>(sx, sy, sb, m, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta, d_small,
+                          wt_per_elem, tiles_per_chunk);
+  }
 }
 
 template <int PREC, bool FAST>
@@ -920,15 +1145,17 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
                        rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, d_gamma, d_beta, tiles, op_max, cn, n, off);
     int rc = oi::check_launch("oi_sdf_mlp_bwd(sweep)");
     if (rc != OI_OK) return rc;
-    const long long n_wt = (long long)B * grid.x * 4;
-    int chunk = (int)std::max<long long>(1, (n_wt * 8 + 2047) / 2048);  // ~2048 workgroups in total
-    dim3 g2(oi::cdiv(n_wt, chunk), 8);
+    const long long wt_per_elem = (long long)grid.x * 4, n_wt = (long long)B * wt_per_elem;
+    // ~2048 workgroups in total; a chunk never straddles two batch elements (per-element FiLM gradients)
+    const int chunk = (int)std::min<long long>(wt_per_elem, std::max<long long>(1, (n_wt * 8 + 2047) / 2048));
+    dim3 g2(oi::cdiv(wt_per_elem, chunk), 8, B);
+    const char* pk = reinterpret_cast<const char*>(packed);
     if constexpr (PREC == OI_PREC_F16X3) {
-      hipLaunchKernelGGL(mlp_wgrad_f16_kernel<FAST>, g2, block, 0, st, tiles, op_max, gamma, d_wmat, n_wt,
-                         (long long)grid.x * 4, chunk, has_col);
+      hipLaunchKernelGGL(mlp_wgrad_f16_kernel<FAST>, g2, block, 0, st, tiles, op_max, pk, plain_off(PREC), gamma, d_wmat,
+                         d_gamma, d_beta, d_small, wt_per_elem, chunk, has_col);
     } else {
-      hipLaunchKernelGGL(mlp_wgrad_kernel<FAST>, g2, block, 0, st, tiles, gamma, d_wmat, n_wt, (long long)grid.x * 4, chunk,
-                         has_col);
+      hipLaunchKernelGGL(mlp_wgrad_kernel<FAST>, g2, block, 0, st, tiles, pk, plain_off(PREC), gamma, d_wmat, d_gamma, d_beta,
+                         d_small, wt_per_elem, chunk, has_col);
     }
     rc = oi::check_launch("oi_sdf_mlp_bwd(wgrad)");
     if (rc != OI_OK) return rc;
@@ -938,7 +1165,15 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
 
 }  // namespace
 
-#ifdef OI_BWD_PROF
+#ifdef OI_WG_PROF
+extern "C" int oi_dbg_occupancy(int which) {
+  int n = -1;
+  if (which == 0) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_wgrad_f16_kernel<false>, 256, 0);
+  if (which == 1) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mlp_wgrad_kernel<false>, 256, 0);
+  return n;
+}
+#endif
+#if defined(OI_BWD_PROF) || defined(OI_WG_PROF)
 extern "C" int oi_prof_bwd_read(unsigned long long* out, int reset) {
   (void)hipDeviceSynchronize();
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(oi_prof_bwd), sizeof(unsigned long long) * 16);
@@ -978,6 +1213,7 @@ int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, con
   OI_REQUIRE(g_rgb == nullptr || (grad_fwd != nullptr && feat_fwd != nullptr),
              "oi_sdf_mlp_bwd: colour backward needs the forward gradient and the forward features");
   OI_REQUIRE(prec != OI_PREC_BF16X6, "oi_sdf_mlp_bwd: pass the OI_PREC_F32 image for the backward of the BF16X6 mode");
+  OI_REQUIRE(prec != OI_PREC_BF16X3, "oi_sdf_mlp_bwd: pass the OI_PREC_F16X3 image for the backward of the BF16X3 mode");
   hipStream_t st = oi::as_stream(stream);
 #define OI_BWD_CASE(P)                                                                                              \
   case P:                                                                                                           \
@@ -987,7 +1223,6 @@ int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, con
                                             d_wmat, d_gamma, d_beta, scratch, scratch_bytes, B, n_per_elem, st);
   switch (prec) {
     OI_BWD_CASE(OI_PREC_F32)
-    OI_BWD_CASE(OI_PREC_BF16X3)
     OI_BWD_CASE(OI_PREC_BF16)
     OI_BWD_CASE(OI_PREC_F16X3)
     default:

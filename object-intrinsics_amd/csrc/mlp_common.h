@@ -32,6 +32,13 @@ constexpr size_t H_BYTES = H_FLOATS * 4;
 __host__ __device__ constexpr int layer_bytes(int prec) {
   return prec == OI_PREC_BF16 ? 32768 : (prec == OI_PREC_BF16X6 ? 98304 : 65536);
 }
+// Behind the 16 MFMA images: the 8 forward matrices once more as plain row-major fp32 [m][out][in] (W_1..W_7, Wv[:, :128]).
+// The weight-gradient GEMM of the backward reads them for the FiLM-scale identity
+//   gamma_l[f] * d gamma_l[f] = sum_i W_l[f][i] dW_l[f][i] + b_l[f] db_l[f]
+// (phi_l = gamma_l (W_l a + b_l) + beta_l depends on gamma_l, W_l, b_l only through the products gamma_l W_l, gamma_l b_l).
+constexpr int NPLAIN = 8;
+__host__ __device__ constexpr size_t plain_off(int prec) { return H_BYTES + (size_t)NMAT * layer_bytes(prec); }
+__host__ __device__ constexpr size_t packed_total_bytes(int prec) { return plain_off(prec) + (size_t)NPLAIN * C * C * 4; }
 
 // LDS carve (bytes)
 // (small tables first so that every table access is <lane-constant VGPR> + 16-bit immediate)

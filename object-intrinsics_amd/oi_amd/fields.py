@@ -236,8 +236,11 @@ class FieldPack:
 
     @property
     def prec_bwd(self):
-        """The backward kernels have no BF16X6 variant: that mode differentiates through the exact-fp32 image."""
-        return _l.OI_PREC_F32 if self.prec == _l.OI_PREC_BF16X6 else self.prec
+        """The backward kernels exist for f32, f16x3 and bf16: BF16X6 differentiates through the exact-fp32 image, BF16X3
+        through the F16X3 one (its own backward spilled 240 registers and was dropped in round 3)."""
+        if self.prec == _l.OI_PREC_BF16X6:
+            return _l.OI_PREC_F32
+        return _l.OI_PREC_F16X3 if self.prec == _l.OI_PREC_BF16X3 else self.prec
 
     def packed(self, for_backward=False):
         sd, csd = self._refresh_key()

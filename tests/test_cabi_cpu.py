@@ -26,9 +26,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/oi_hip.h but not exported"
     assert set(names) == set(lib.declared_symbols()), set(names) ^ set(lib.declared_symbols())
     assert L.oi_arch() == b"gfx950"
-    assert L.oi_mlp_packed_bytes(0) == 2816 * 4 + 16 * 65536
-    assert L.oi_mlp_packed_bytes(2) == 2816 * 4 + 16 * 32768
-    assert L.oi_mlp_packed_bytes(3) == 2816 * 4 + 16 * 98304
+    assert L.oi_mlp_packed_bytes(0) == 2816 * 4 + 16 * 65536 + 8 * 65536  # header, 16 MFMA images, 8 plain fp32 matrices
+    assert L.oi_mlp_packed_bytes(2) == 2816 * 4 + 16 * 32768 + 8 * 65536
+    assert L.oi_mlp_packed_bytes(3) == 2816 * 4 + 16 * 98304 + 8 * 65536
 
 
 def test_ops_fail_loudly_without_gpu_tensors():
