@@ -145,16 +145,36 @@ __device__ __forceinline__ void racc_flush_row_scaled(char* lds, int row, const 
 //   phi_l / 2pi = G * acc + B2,   G = gamma / 2pi * 2^-k_img (acc = scaled-image product without bias),
 //   B2 = gamma / 2pi * b_l + beta / 2pi
 constexpr float INV_2PI = 0.15915494309189533577f;
-__device__ __forceinline__ void stage_film_bwd(char* lds, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                               const float* __restrict__ hdr, int e, int l, float inv_img, int tid) {
+// In two halves: the global loads are issued BEFORE the layer image's LDS-DMA and the LDS writes happen after the epilogue.
+// (vmcnt retires in order: with the loads issued behind the 16 DMA instructions, storing the rows drained the DMA right
+// after it was requested -- one exposed round trip per layer.)
+struct FilmRegs {
+  float g, b, bias, inv_img;
+};
+__device__ __forceinline__ FilmRegs film_load(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              const float* __restrict__ hdr, int e, int l, float inv_img, int tid) {
+  // unconditional (the upper half of the workgroup re-reads the same rows): a branch here made hipcc finish the arithmetic
+  // on the loaded values inside it, i.e. wait for the loads on the spot
+  const int f = tid & (C - 1);
+  FilmRegs r;
+  r.g = gamma[((size_t)e * 9 + l) * C + f];
+  r.b = beta[((size_t)e * 9 + l) * C + f];
+  r.bias = hdr[H_BIAS + l * C + f];
+  r.inv_img = inv_img;
+  return r;
+}
+__device__ __forceinline__ void film_store(char* lds, const FilmRegs& r, int tid) {
   float* film = reinterpret_cast<float*>(lds + L_FILM);
   if (tid < C) {
-    const float g = gamma[((size_t)e * 9 + l) * C + tid];
-    const float gr = g * INV_2PI;
-    film[tid] = g;
-    film[C + tid] = gr * inv_img;
-    film[2 * C + tid] = fmaf(gr, hdr[H_BIAS + l * C + tid], beta[((size_t)e * 9 + l) * C + tid] * INV_2PI);
+    const float gr = r.g * INV_2PI;
+    film[tid] = r.g;
+    film[C + tid] = gr * r.inv_img;
+    film[2 * C + tid] = fmaf(gr, r.bias, r.b * INV_2PI);
   }
+}
+__device__ __forceinline__ void stage_film_bwd(char* lds, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                               const float* __restrict__ hdr, int e, int l, float inv_img, int tid) {
+  film_store(lds, film_load(gamma, beta, hdr, e, l, inv_img, tid), tid);
 }
 // sin / cos of a phase in revolutions.  REDUCED: the value is already in [0, 1) (parked by the up sweep)
 template <bool FAST, bool REDUCED>
@@ -242,6 +262,12 @@ __device__ __forceinline__ void publish_max(float* op_max, int slot, float lane_
 #ifndef OI_BWD_EARLY_RELOAD
 #define OI_BWD_EARLY_RELOAD 1
 #endif
+#ifndef OI_BWD_COL_FENCE
+#define OI_BWD_COL_FENCE 1
+#endif
+#ifndef OI_BWD_STORES_LAST
+#define OI_BWD_STORES_LAST 1
+#endif
 // -DOI_BWD_PROF: per-phase shader-clock accounting of the sweep (tools/dbg/phase_prof_bwd.py)
 #ifdef OI_BWD_PROF
 __device__ unsigned long long oi_prof_bwd[16];
@@ -307,10 +333,22 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   };
   auto stage_img = [&](int image, int ws_) { stage_layer_rs<PREC>(lds + ws_ * 65536, img_rs, image, wave, o.l16); };
   // FiLM rows of layer l_; the scale of the forward image that produces u_l (layer 0 runs on the VALU, colour head = image 14)
-  auto stage_flm = [&](int l_, int fs_) {
-    const float inv_img = (PREC == OI_PREC_F16X3 && l_ >= 1) ? hdr[H_WSCALE + (l_ == 8 ? 14 : l_ - 1)] : 1.f;
-    stage_film_bwd(lds + fs_ * (L_FILM2 - L_FILM), gamma, beta, hdr, e, l_, inv_img, tid);
+  auto film_scale = [&](int l_) {
+    return (PREC == OI_PREC_F16X3 && l_ >= 1) ? hdr[H_WSCALE + (l_ == 8 ? 14 : l_ - 1)] : 1.f;
   };
+  auto stage_flm = [&](int l_, int fs_) {
+    stage_film_bwd(lds + fs_ * (L_FILM2 - L_FILM), gamma, beta, hdr, e, l_, film_scale(l_), tid);
+  };
+  auto load_flm = [&](int l_) { return film_load(gamma, beta, hdr, e, l_, film_scale(l_), tid); };
+  auto store_flm = [&](const FilmRegs& r, int fs_) { film_store(lds + fs_ * (L_FILM2 - L_FILM), r, tid); };
+  // Everything the tile needs from memory before its first product is requested up front (round 2 paid four exposed
+  // round trips in the colour head: tables, image 14, the per-point forward values, image 15): both colour images go to
+  // the two image slots, the colour head's FiLM rows to FiLM slot 1 and layer 0's to slot 0.
+  if (has_col) {
+    stage_img(14, 0);
+    stage_img(15, 1);
+    stage_flm(8, 1);
+  }
   {
     float* tabs = reinterpret_cast<float*>(lds + L_TABS);
     for (int i = tid; i < H_TABS_END; i += 256) tabs[i] = hdr[i];
@@ -337,17 +375,16 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 
   // ================= colour head backward (first: its dL/dgrad term is part of gbar_0) =================
   OI_MARK("colour x1");
+  float ac[64];  // abar_8 contribution of the colour head: stays in registers (AGPR half) until the down sweep starts
+#pragma unroll
+  for (int k = 0; k < 64; ++k) ac[k] = 0.f;
   if (has_col) {
-    __syncthreads();
-    stage_img(14, 0);
-    stage_flm(8, 0);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {  // a_8, as the forward wrote it (feat output): features grp_f0(g) + 4 h .. + 3
       const f32x4 v = *reinterpret_cast<const f32x4*>(feat_fwd + pt * C + grp_f0(g) + 4 * h);
 #pragma unroll
       for (int k = 0; k < 4; ++k) act[4 * g + k] = v[k];
     }
-    dma_sync();
     const float fx = grad_fwd[pt * 3 + 0], fy = grad_fwd[pt * 3 + 1], fz = grad_fwd[pt * 3 + 2];
     float rho[3];
 #pragma unroll
@@ -355,8 +392,12 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       const float rv = rgb_fwd[pt * 3 + k];
       rho[k] = g_rgb[pt * 3 + k] * rv * (1.0f - rv) * vmask;  // through the sigmoid
     }
+    dma_sync();
+    const LaneOff oc = layer_off(0, 1);  // image slot 0, FiLM slot 1
     acc_zero(acc);
-    (void)gemm2<PREC, false>(lds, o, act, acc, 1.f);
+    (void)gemm2<PREC, false>(lds, oc, act, acc, 1.f);
+    __syncthreads();   // every wave is done with image slot 0:
+    stage_img(0, 0);   // the up sweep's first image travels under the epilogue
     // uv -> phiv -> hv; then uvbar.  Point sums kept here: rows 3..5 dWrgb, rows 2 / 6 / 7 dWv[:, 130 / 128 / 129]; the FiLM and
     // bias gradients of the head come out of the weight-gradient GEMM (FiLM-scale identity), the part of it that belongs to
     // the three extra input columns is added at the flush below
@@ -367,9 +408,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int g = 4 * t + rr;
-        const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, o.h16);
-        const f32x4 gr = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, o.h16);
-        const f32x4 b2 = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, o.h16);
+        const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, oc.h16);
+        const f32x4 gr = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, oc.h16);
+        const f32x4 b2 = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, oc.h16);
         const f32x4 w0 = lds_f4(lds, L_TABS + (H_RGB + 0 * C + grp_f0(g)) * 4, o.h16);
         const f32x4 w1 = lds_f4(lds, L_TABS + (H_RGB + 1 * C + grp_f0(g)) * 4, o.h16);
         const f32x4 w2 = lds_f4(lds, L_TABS + (H_RGB + 2 * C + grp_f0(g)) * 4, o.h16);
@@ -397,7 +438,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         ws.store(S_UV, g, o.l16, uvb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) act[4 * g + k] = uvb[k];
+#if OI_BWD_COL_FENCE
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
 #pragma unroll
       for (int r = 2; r < 8; ++r) rs.add(r, t, R[r]);
@@ -421,7 +464,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     if (tid < C) {  // gamma_v d gamma_v += sum_{j < 3} Wv[f][128 + j] dWv[f][128 + j]  (the GEMM adds the other 128 columns and bv)
       const float* racc = reinterpret_cast<const float*>(lds + L_RACC);
       const f32x4 wx = *reinterpret_cast<const f32x4*>(lds + L_TABS + H_TABV * 4 + tid * 16);
-      const float gv = reinterpret_cast<const float*>(lds + L_FILM)[tid];
+      const float gv = reinterpret_cast<const float*>(lds + L_FILM2)[tid];  // the head's rows sit in FiLM slot 1
       atomicAdd(d_gamma + ((size_t)e * 9 + 8) * C + tid,
                 fmaf(wx[0], racc[6 * C + tid], fmaf(wx[1], racc[7 * C + tid], wx[2] * racc[2 * C + tid])) / gv);
     }
@@ -433,23 +476,16 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     racc_flush_row(lds, 7, d_small + DS_WVX + 1, 3, tid);
     __syncthreads();
     racc_zero(lds, tid);
-    // abar_8 from the colour head: Wv[:, :128]^T uvbar   (transposed colour image, matrix 15)
-    stage_img(15, 0);
-    dma_sync();
+    // abar_8 from the colour head: Wv[:, :128]^T uvbar   (transposed colour image, matrix 15: resident in slot 1 since the
+    // prologue)
     acc_zero(acc);
     float mx_uv = 0.f;
-    const float fT = gemm2<PREC, true>(lds, o, act, acc, SC ? hdr[H_WSCALE + 15] : 1.f, &mx_uv);
+    const float fT = gemm2<PREC, true>(lds, layer_off(1, 1), act, acc, SC ? hdr[H_WSCALE + 15] : 1.f, &mx_uv);
     if constexpr (SC) publish_max(op_max, OM_UV, mx_uv);
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      f32x4 v;
+    for (int g = 0; g < 16; ++g)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = SC ? acc[g >> 2][4 * (g & 3) + k] * fT : acc[g >> 2][4 * (g & 3) + k];
-      ws.store(S_AC, g, o.l16, v);
-    }
-    __syncthreads();
-    stage_flm(0, 0);
-    __syncthreads();
+      for (int k = 0; k < 4; ++k) ac[4 * g + k] = SC ? acc[g >> 2][4 * (g & 3) + k] * fT : acc[g >> 2][4 * (g & 3) + k];
   }
 
   BW_T(0);
@@ -457,7 +493,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   // ================= up sweep: recompute phi_l, carry gbar_l =================
   // FiLM rows of layer l live in FiLM slot l & 1, layer l's forward image in image slot (l - 1) & 1: both are requested one
   // layer ahead
-  stage_img(0, 0);
+  if (!has_col) stage_img(0, 0);  // (with a colour head: requested right after its first product)
+  __syncthreads();                // the colour head is done with FiLM slot 1
   stage_flm(1, 1);
   // layer 0 on the VALU: phi_0; vbar_0 = W0 gbar_0 (gbar_0 = dL/dgrad, a 3-vector); gbar_1 = vbar_0 c_0
 #pragma unroll
@@ -486,12 +523,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     OI_MARK("up_body x7");
     dma_sync();  // layer l's image and FiLM rows have landed; every wave is done with layer l - 1
     BW_T(2);
-    if (l < NL_SDF - 1) {
-      stage_img(l, l & 1);
-      stage_flm(l + 1, (l + 1) & 1);
-    } else {
-      stage_img(13, 1);  // the down sweep starts with the transposed image of layer 7 (FiLM rows 7 are resident)
-    }
+    const FilmRegs fr = load_flm(l < NL_SDF - 1 ? l + 1 : l);  // next layer's FiLM rows: requested ahead of the image DMA
+    stage_img(l < NL_SDF - 1 ? l : 13, l & 1);  // (the down sweep starts with the transposed image of layer 7)
     const LaneOff ol = layer_off((l - 1) & 1, l & 1);
     const float inv_img = SC ? hdr[H_WSCALE + l - 1] : 1.f;
     // vbar_l = W_l gbar_l
@@ -512,6 +545,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       }
       if (!(OI_BWD_ABL & 4)) ws.store(S_VB + l, g, o.l16, v);
     }
+    if (l < NL_SDF - 1) store_flm(fr, (l + 1) & 1);  // FiLM slot of layer l - 1: free since this layer's barrier
     // phi_l / 2pi = G (W_img a_l) + B2 (image scale and bias folded into the staged rows) -> a_{l+1};
     // gbar_{l+1} = vbar_l gamma_l cos phi_l
     acc_zero(acc);
@@ -558,12 +592,10 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const f32x4 w = lds_f4(lds, L_TABS + (H_SIG + grp_f0(g)) * 4, o.h16);
-    f32x4 ac = {0.f, 0.f, 0.f, 0.f};
-    if (has_col) ac = ws.load(S_AC, g, o.l16);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       gb[4 * g + k] = w[k];
-      act[4 * g + k] = fmaf(gs, w[k], ac[k]);
+      act[4 * g + k] = fmaf(gs, w[k], ac[4 * g + k]);
     }
   }
   // the transposed image of layer l sits in image slot l & 1, its FiLM rows in FiLM slot l & 1; phi_l / vbar_l of the WHOLE
@@ -585,8 +617,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       racc_zero(lds, tid);
       __syncthreads();
     }
+    const FilmRegs fr = load_flm(l >= 1 ? l - 1 : 0);  // ahead of the image DMA (see film_load)
     if (l >= 2) stage_img(7 + l - 2, (l - 1) & 1);
-    if (l >= 1) stage_flm(l - 1, (l - 1) & 1);
     const LaneOff ol = layer_off(l & 1, l & 1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -617,10 +649,12 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
             R0[3][4 * rr + k] = fmaf(ub[k], pz, vv[k] * Gz);
           }
         }
+#if !OI_BWD_STORES_LAST
         if constexpr (!L0 && !(OI_BWD_ABL & 1)) {
           ws.store<OI_BWD_ST_WGRAD>(S_V + l - 1, g, o.l16, vv);
           ws.store<OI_BWD_ST_WGRAD>(S_U + l - 1, g, o.l16, ub);
         }
+#endif
 #if OI_BWD_EARLY_RELOAD
         // this group's fragments are consumed: request the same group of the NEXT layer into the same registers -- the loads
         // travel under the rest of the epilogue and both products, and there is no separate issue phase
@@ -638,6 +672,19 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         rs.add(5, t, R0[3]);
       }
     }
+    if (l >= 1) store_flm(fr, (l - 1) & 1);  // FiLM slot of layer l + 1: free since this layer's barrier
+#if OI_BWD_STORES_LAST
+    // v_l / ubar_l leave AFTER the next layer's phi / vbar have been requested: the vector memory pipe is one in-order
+    // queue per wave, and a load issued behind two 1 KiB stores waited for their data to drain first (phase profile: the
+    // reloads cost 100k of 470k ticks per tile, 67k of them gone when the stores are removed)
+    if constexpr (!L0 && !(OI_BWD_ABL & 1)) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        ws.store<OI_BWD_ST_WGRAD>(S_V + l - 1, g, o.l16, f32x4{gb[4 * g], gb[4 * g + 1], gb[4 * g + 2], gb[4 * g + 3]});
+        ws.store<OI_BWD_ST_WGRAD>(S_U + l - 1, g, o.l16, f32x4{act[4 * g], act[4 * g + 1], act[4 * g + 2], act[4 * g + 3]});
+      }
+    }
+#endif
     BW_T(8);
     if constexpr (!OI_BWD_EARLY_RELOAD && !L0 && !(OI_BWD_ABL & 2)) {  // the next layer's fragments travel while this layer's two products run
 #pragma unroll

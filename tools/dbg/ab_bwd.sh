@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 {
-for rep in 1 2; do
+for rep in ${REPS:-1 2}; do
 for v in "$@"; do
   lib=$PWD/object-intrinsics_amd/build/ab/liboi_$v.so
   [ "$v" = tree ] && lib=$PWD/object-intrinsics_amd/oi_amd/liboi_hip.so
