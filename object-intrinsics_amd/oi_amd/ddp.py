@@ -19,6 +19,10 @@ Replaces torch.nn.parallel.DistributedDataParallel as used by the reference (scr
   * parameters are broadcast once from rank 0 at construction; the reference's per-forward buffer
     broadcast (generator `it` + camera matrices, 3x per step) is dropped: those buffers are
     deterministic functions of the step counter / config and identical on every rank.
+Whenever a process group exists the broadcast and the collectives are ISSUED, also in a group of one rank (a 1-GPU box
+then launches the same RCCL kernels on the communication stream that N ranks do); without a process group the wrapper
+only keeps the flat gradient views.  `exchange_enabled = False` (tests) makes `_exchange()` a no-op that leaves this
+rank's own gradients in the buffer.
 `.module` gives the wrapped network, as with DistributedDataParallel (the trainer uses it)."""
 import torch
 import torch.distributed as dist
@@ -30,7 +34,9 @@ class FlatGradDDP(nn.Module):
         super().__init__()
         self.module = module
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._dist = dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if self._dist else 1
+        self.exchange_enabled = True
         params = [p for p in module.parameters()]
         self._params = params
         n = sum(p.numel() for p in params)
@@ -48,7 +54,7 @@ class FlatGradDDP(nn.Module):
         self._event = None         # completion of the collective on the communication stream
         self._stream = torch.cuda.Stream(device=dev) if (comm_stream and dev.type == "cuda") else None
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
-        if broadcast_parameters and self.world > 1:
+        if broadcast_parameters and self._dist:
             flat = torch.cat([p.detach().reshape(-1) for p in params])
             dist.broadcast(flat, src=0, group=self.pg)
             off = 0
@@ -62,8 +68,8 @@ class FlatGradDDP(nn.Module):
 
     # -- gradient exchange -------------------------------------------------------------------
     def _on_grad(self, p):
-        if getattr(self, "_in_graph", False):   # captured steps (oi_amd.graphed.GraphedDStep) exchange explicitly via sync()
-            return
+        if getattr(self, "_in_graph", False):   # inside GraphedDStep._step: the hook would run at capture time only;
+            return                               # the captured step exchanges explicitly right after its replay
         # autograd may have replaced p.grad with a fresh tensor (first accumulation into a None grad): fold it back
         v = self._views[id(p)]
         if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
@@ -80,17 +86,19 @@ class FlatGradDDP(nn.Module):
 
     def _exchange(self):
         self._needs_exchange = False
-        if self.world <= 1:
+        if not self._dist or not self.exchange_enabled:
             return
         if self._stream is None:
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-            self.flat_grad.mul_(1.0 / self.world)
+            if self.world > 1:
+                self.flat_grad.mul_(1.0 / self.world)
             return
         cur = torch.cuda.current_stream(self.flat_grad.device)
         self._stream.wait_stream(cur)                       # the backward's kernels first
         with torch.cuda.stream(self._stream):
             dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-            self.flat_grad.mul_(1.0 / self.world)
+            if self.world > 1:
+                self.flat_grad.mul_(1.0 / self.world)
             self._event = torch.cuda.Event()
             self._event.record(self._stream)
 

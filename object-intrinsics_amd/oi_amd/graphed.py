@@ -61,6 +61,11 @@ class GraphedForward:
         return self.out
 
 
+def _has_geometric(aug):
+    """True when AugmentPipe.sample_G_inv can return a transform at all (augment.py:191-268: one branch per strength)."""
+    return any(float(getattr(aug, k, 0)) > 0 for k in ("xflip", "rotate90", "xint", "scale", "rotate", "aniso", "xfrac"))
+
+
 class GraphedDStep:
     """hipGraph of one discriminator training step WITHOUT the optimiser step: zero the gradients, real forward + R1
     double backward, fake forward (+ auxiliary pose regression), backward (gan_pose_trainer.py:154-200).
@@ -75,7 +80,10 @@ class GraphedDStep:
       * scalars that change per iteration (the pose-loss weight) are device scalars;
       * the optimiser step stays outside (its chunk table is re-uploaded when pointers change): the gradients come
         out of the graph at fixed addresses, `opt.step()` follows eagerly (one launch), and under FlatGradDDP the
-        gradient exchange sits between the two as in the eager trainer.
+        gradient exchange is issued right after the replay (before the caller enqueues anything else, so that on the
+        communication stream it overlaps whatever follows), `sync()` before the optimiser step waits for it.
+    A different input shape (or pose-regression presence) recaptures.  The returned loss scalars are views of ONE
+    clone taken after the replay: they stay valid when the next replay overwrites the graph's own buffers.
     Recapture after anything that replaces parameter / gradient tensors (load_state_dict keeps them)."""
 
     def __init__(self, disc, gan, aux_pose=None, reg_weight=10.0, prior=None):
@@ -94,6 +102,9 @@ class GraphedDStep:
         self.th_fake = torch.empty(B, 2, 3, device=dev)
         self.c2b = None if c2b is None else torch.empty_like(c2b)
         self.aux_w = torch.zeros((), device=dev)
+        # no geometric augmentation configured: the eager path returns the images untouched (AugmentPipe.forward), so the
+        # captured step must not run the pad / resample chain on an identity transform either
+        self._geom = _has_geometric(self._net().aug)
         # ring of pinned staging buffers: the host runs several steps ahead of the stream, and a pinned buffer may only be
         # rewritten once the copy that reads it has executed
         self._pins = [torch.empty(2, B, 2, 3, pin_memory=True) for _ in range(8)]
@@ -101,20 +112,30 @@ class GraphedDStep:
         self._pin_i = 0
 
     def _step(self):
-        from .losses import compute_grad2
         disc = self.disc
-        if hasattr(disc, "flat_grad"):
+        wrapped = hasattr(disc, "flat_grad")
+        if wrapped:
             disc._in_graph = True  # the wrapper's gradient hooks are Python: they would run at capture time only
+        try:
+            return self._step_body(disc, wrapped)
+        finally:
+            if wrapped:
+                disc._in_graph = False  # an eager `loss.backward(); opt.step()` on the same wrapper exchanges as usual
+
+    def _step_body(self, disc, wrapped):
+        from .losses import compute_grad2
+        if wrapped:
             disc.zero_grad()
         else:
             for p in disc.parameters():
                 p.grad = None
+        th_real, th_fake = (self.th_real, self.th_fake) if self._geom else (None, None)
         x_real = self.x_real.detach().clone().requires_grad_()
-        d_real = disc(x_real, aug_theta=self.th_real)[:, :1]
+        d_real = disc(x_real, aug_theta=th_real)[:, :1]
         loss_real = self.gan(d_real, 1)
         loss_reg = compute_grad2(d_real, x_real)
         x_fake = self.x_fake.detach().clone().requires_grad_()
-        d_fake = disc(x_fake, aug_theta=self.th_fake)
+        d_fake = disc(x_fake, aug_theta=th_fake)
         loss_aux = torch.zeros((), device=x_real.device)
         if d_fake.size(1) > 1:
             d_fake, d_aux = torch.split(d_fake, (1, self.prior.repr_dim), dim=1)
@@ -122,7 +143,11 @@ class GraphedDStep:
         loss_fake = self.gan(d_fake, 0)
         loss = loss_real + loss_fake + loss_reg * self.reg_weight + loss_aux * self.aux_w
         loss.backward()
-        return {"loss": loss_fake + loss_real, "reg": loss_reg, "fake": loss_fake, "real": loss_real, "aux_pose": loss_aux}
+        return torch.stack([loss_fake + loss_real, loss_reg, loss_fake, loss_real, loss_aux])
+
+    @staticmethod
+    def _named(vec):
+        return {"loss": vec[0], "reg": vec[1], "fake": vec[2], "real": vec[3], "aux_pose": vec[4]}
 
     def _thetas(self, shape):
         """Host-side augmentation parameters in the eager draw order: real batch, then fake batch."""
@@ -140,17 +165,18 @@ class GraphedDStep:
         return out
 
     def _upload(self, x_real, x_fake, c2b, aux_w):
-        th = self._thetas(tuple(x_real.shape))
-        i = self._pin_i = (self._pin_i + 1) % len(self._pins)
-        if self._pin_ev[i] is not None:
-            self._pin_ev[i].synchronize()
-        pin = self._pins[i]
-        pin[0].numpy()[:] = th[0]
-        pin[1].numpy()[:] = th[1]
-        self.th_real.copy_(pin[0], non_blocking=True)
-        self.th_fake.copy_(pin[1], non_blocking=True)
-        self._pin_ev[i] = torch.cuda.Event()
-        self._pin_ev[i].record()
+        if self._geom:
+            th = self._thetas(tuple(x_real.shape))
+            i = self._pin_i = (self._pin_i + 1) % len(self._pins)
+            if self._pin_ev[i] is not None:
+                self._pin_ev[i].synchronize()
+            pin = self._pins[i]
+            pin[0].numpy()[:] = th[0]
+            pin[1].numpy()[:] = th[1]
+            self.th_real.copy_(pin[0], non_blocking=True)
+            self.th_fake.copy_(pin[1], non_blocking=True)
+            self._pin_ev[i] = torch.cuda.Event()
+            self._pin_ev[i].record()
         self.x_real.copy_(x_real, non_blocking=True)
         self.x_fake.copy_(x_fake, non_blocking=True)
         if self.c2b is not None:
@@ -162,6 +188,8 @@ class GraphedDStep:
         self._alloc(x_real, x_fake, c2b)
         state = np.random.get_state()       # warm-up / capture must not consume the trainer's random stream
         self._upload(x_real, x_fake, c2b, aux_w)
+        # warm-up and capture on ONE stream: autograd pins every AccumulateGrad node to the stream its parameter was first
+        # used on, and a capture that meets nodes of another stream warns ("may break CUDA graph capture")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -170,22 +198,25 @@ class GraphedDStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=side):
             self.out = self._step()
         np.random.set_state(state)
+        self._sig = (tuple(x_real.shape), tuple(x_fake.shape), None if c2b is None else tuple(c2b.shape))
         return self
 
     def __call__(self, x_real, x_fake, c2b=None, aux_w=0.0):
-        if self.graph is None:
+        sig = (tuple(x_real.shape), tuple(x_fake.shape), None if c2b is None else tuple(c2b.shape))
+        if self.graph is None or sig != self._sig:
             self.capture(x_real, x_fake, c2b, aux_w)
         self._upload(x_real, x_fake, c2b, aux_w)
         if os.environ.get("OI_GRAPH_D_EAGER") == "1":   # debugging aid: the same shape-static step, launch by launch
-            self.out = self._step()
-            return self.out
-        self.graph.replay()
+            vec = self._step()
+        else:
+            self.graph.replay()
+            vec = self.out.clone()
         if hasattr(self.disc, "flat_grad"):
-            self.disc._needs_exchange = True  # the replayed backward filled the flat buffer: exchange it in sync()
-        return self.out
+            self.disc._exchange()  # the replayed backward filled the flat buffer: the collective starts now
+        return self._named(vec)
 
 
 class GraphedDForward:
@@ -207,14 +238,15 @@ class GraphedDForward:
         return aug.theta_for(G, aug.static_margins(H, W), H, W)
 
     def _upload(self, x):
-        th = self._thetas(tuple(x.shape))
-        i = self._pin_i = (self._pin_i + 1) % len(self._pins)
-        if self._pin_ev[i] is not None:
-            self._pin_ev[i].synchronize()
-        self._pins[i].numpy()[:] = th
-        self.theta.copy_(self._pins[i], non_blocking=True)
-        self._pin_ev[i] = torch.cuda.Event()
-        self._pin_ev[i].record()
+        if self._geom:
+            th = self._thetas(tuple(x.shape))
+            i = self._pin_i = (self._pin_i + 1) % len(self._pins)
+            if self._pin_ev[i] is not None:
+                self._pin_ev[i].synchronize()
+            self._pins[i].numpy()[:] = th
+            self.theta.copy_(self._pins[i], non_blocking=True)
+            self._pin_ev[i] = torch.cuda.Event()
+            self._pin_ev[i].record()
         self.x.copy_(x, non_blocking=True)
 
     def capture(self, x):
@@ -225,18 +257,20 @@ class GraphedDForward:
         self._pins = [torch.empty(B, 2, 3, pin_memory=True) for _ in range(8)]
         self._pin_ev = [None] * 8
         self._pin_i = 0
+        self._geom = _has_geometric(self.disc.aug)  # nothing to do -> nothing captured (the eager path returns x)
+        theta = self.theta if self._geom else None
         state = np.random.get_state()   # warm-up / capture must not consume the caller's random stream
         self._upload(x)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(2):
-                self.disc(self.x, aug_theta=self.theta)
+                self.disc(self.x, aug_theta=theta)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
-            self.out = self.disc(self.x, aug_theta=self.theta)
+        with torch.cuda.graph(self.graph, stream=side), torch.no_grad():
+            self.out = self.disc(self.x, aug_theta=theta)
         np.random.set_state(state)
         return self
 

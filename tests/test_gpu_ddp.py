@@ -94,9 +94,11 @@ def _close(a, b):
 
 
 def test_flat_grad_ddp_single_rank_rccl_matches_unwrapped():
-    """One RCCL rank: process group, parameter broadcast, flat views, communication-stream exchange + sync(), the
-    deferred discriminator step of the trainer -- three training iterations give the losses / weights of the
-    unwrapped run."""
+    """One RCCL rank: process group, parameter broadcast and the all-reduce of every network's flat buffer ARE issued on the
+    communication stream (FlatGradDDP runs its collectives whenever a process group exists, also in a group of one),
+    sync(), the deferred discriminator step of the trainer -- three training iterations give the losses / weights of the
+    unwrapped run.  What a group of one cannot show -- that ranks with different data end up with the mean gradient -- is
+    tested by test_two_ranks_one_gpu_* below."""
     _close(_run(1, True), _run(1, False))
 
 
@@ -104,3 +106,139 @@ def test_flat_grad_ddp_single_rank_rccl_matches_unwrapped():
 def test_flat_grad_ddp_two_ranks_rccl_matches_single_process():
     """Two RCCL ranks over xGMI fed identical data: the averaged gradients equal the single-process ones."""
     _close(_run(2, True), _run(1, False))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Two ranks on ONE GPU: backend "gloo" reduces CUDA tensors (through the host), so the multi-rank logic -- different data
+# per rank, FlatGradDDP(comm_stream=True), Trainer(graph_d_steps=True) with its captured discriminator steps, the rank
+# without a gradient -- runs on the 1-GPU box the driver tests on.  RCCL itself is covered by the tests above.
+# ------------------------------------------------------------------------------------------------------------------
+WORKER2 = r"""
+import json, os, sys
+sys.path.insert(0, os.path.join(%(root)r, "object-intrinsics_amd"))
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import bench
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("gloo", init_method="env://")
+from oi_amd.config import build_from_config
+from oi_amd.ddp import FlatGradDDP
+from oi_amd.optim import FusedAdam, FusedRMSprop
+from oi_amd.trainer import Trainer, MODULE_KEYS
+R = 16
+torch.manual_seed(5 + rank); np.random.seed(5 + rank)     # DIFFERENT initial weights per rank: the broadcast must fix that
+gen, disc = bench.build_models(R, 8, 8, 1, "f16x3", dev)
+net = lambda t, **kw: {"__target__": t, "kwargs": kw}
+mdisc = build_from_config(net("src.models.discriminator.ADADiscriminator",
+                              aug=net("src.third_party.ada.augment.AugmentPipe", scale=1, xint=1), aug_p=1,
+                              img_size=R, in_dim=1, last_bias=False, n_feat=512, out_dim=1)).to(dev)
+nets = {"generator": gen, "discriminator": disc, "mask_discriminator": mdisc}
+nets = {k: FlatGradDDP(v, comm_stream=True) for k, v in nets.items()}
+mods = dict(nets)
+mods["opt_generator"] = FusedAdam(nets["generator"].parameters(), lr=2e-5, betas=(0.0, 0.9))
+mods["opt_discriminator"] = FusedRMSprop(nets["discriminator"].parameters(), lr=1e-4)
+mods["opt_mask_discriminator"] = FusedRMSprop(nets["mask_discriminator"].parameters(), lr=1e-4)
+tr = Trainer(mods, graph_d_steps=True)
+g = torch.Generator(device=dev).manual_seed(9 + rank)      # different real data per rank
+data = {"image": torch.rand(1, 3, R, R, device=dev, generator=g), "mask": torch.rand(1, 1, R, R, device=dev, generator=g)}
+res = {}
+
+def gather(t):
+    lst = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(lst, t.contiguous())
+    return lst
+
+def flat_w(k):
+    return torch.cat([p.detach().reshape(-1) for p in nets[k].module.parameters()])
+
+# ---- A: three iterations, per-rank seeds (scripts/train.py:136 seeds rank r with seed + r) ----
+for step in range(3):
+    torch.manual_seed(100 + step + 1000 * rank); np.random.seed(100 + step + 1000 * rank)
+    out = tr.train_step(data)
+torch.cuda.synchronize()
+res["finite"] = all(bool(torch.isfinite(torch.as_tensor(v)).all()) for v in out.values())
+for k in MODULE_KEYS:
+    ws = gather(flat_w(k))
+    res["same_w_" + k] = all(bool(torch.equal(ws[0], w)) for w in ws[1:])
+
+# ---- B: the exchanged gradient is the mean of the ranks' own gradients (every network; discriminators on the captured path)
+for k in MODULE_KEYS:
+    mods["opt_" + k].step = lambda: None                  # gradients only from here on
+def rng_save():
+    return np.random.get_state(), torch.get_rng_state(), torch.cuda.get_rng_state(dev)
+def rng_load(s):
+    np.random.set_state(s[0]); torch.set_rng_state(s[1]); torch.cuda.set_rng_state(s[2], dev)
+s0 = rng_save()
+def run_step(k):
+    if k == "generator":
+        tr.train_step_generator(1)
+    else:
+        with torch.no_grad():
+            blob = tr.generator(bs=1, it=tr.it, data={}, return_raw=False)["box"]
+        tr.train_step_discriminator(k, data, {**blob["render_out"], "c2b": blob["prior_info"]["c2b"]})
+    torch.cuda.synchronize()
+    return nets[k].flat_grad.clone()
+own0 = {}
+for k in MODULE_KEYS:
+    rng_load(s0); nets[k].exchange_enabled = False
+    own = run_step(k)
+    rng_load(s0); nets[k].exchange_enabled = True
+    got = run_step(k)
+    owns = gather(own)
+    own0[k] = owns[0]
+    want = sum(owns) / world
+    scale = float(want.abs().max())
+    res["mean_err_" + k] = float((got - want).abs().max()) / max(scale, 1e-30)
+    res["ranks_differ_" + k] = float((owns[0] - owns[1]).abs().max()) / max(scale, 1e-30)
+
+# ---- C: a rank whose step produced no gradient still takes part (with zeros) -- captured path on rank 0 ----
+k = "mask_discriminator"
+rng_load(s0)
+if rank == 0:
+    got = run_step(k)
+else:
+    nets[k].zero_grad(); nets[k].sync(); torch.cuda.synchronize()
+    got = nets[k].flat_grad.clone()
+want = own0[k] / world
+res["nograd_err"] = float((got - want).abs().max()) / max(float(want.abs().max()), 1e-30)
+# ---- D: after a captured step the wrapper exchanges in an ordinary eager backward again (advisor, round 2) ----
+res["in_graph_reset"] = not getattr(nets["discriminator"], "_in_graph", False)
+allres = [None] * world
+dist.all_gather_object(allres, res)
+if rank == 0:
+    print("RESULT " + json.dumps(allres), flush=True)
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_one_gpu_gloo_graphed_trainer_mean_gradient():
+    """Two processes share cuda:0 (backend gloo): real generator + both discriminators in FlatGradDDP(comm_stream=True),
+    Trainer(graph_d_steps=True), different initial weights, data and seeds per rank.
+      A  three training iterations leave bit-identical weights on both ranks (parameter broadcast + every exchange worked);
+      B  for each network the buffer after the exchange equals the mean of the two ranks' OWN gradients of the same step
+         (own = the step re-run from the same RNG state with `exchange_enabled = False`), and those differ between ranks;
+      C  a rank that only calls zero_grad(); sync() while the other replays a captured step gets half of that gradient;
+      D  the wrapper's hook is live again after a captured step.
+    (A single process fed both shards cannot serve as the oracle: the generator draws poses / latents from per-rank RNG
+    streams inside the step.)  Tolerance 1e-4 of the largest entry: the small convolutions sum with atomics."""
+    import json
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", GLOO_SOCKET_IFNAME="lo")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER2 % {"root": ROOT}], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT ")][-1]
+    for r in json.loads(line[len("RESULT "):]):
+        assert r["finite"] and r["in_graph_reset"], r
+        for k in ("generator", "discriminator", "mask_discriminator"):
+            assert r["same_w_" + k], (k, r)
+            assert r["mean_err_" + k] < 1e-4, (k, r)
+            assert r["ranks_differ_" + k] > 1e-3, (k, r)
+        assert r["nograd_err"] < 1e-4, r
