@@ -25,6 +25,7 @@ Extra objects in that line:
                 workload (N=1, rank 0 only) -- a reported baseline, not the target
 """
 import argparse
+import contextlib
 import json
 import math
 import os
@@ -208,7 +209,16 @@ def bench_training(args, gen, disc, device, world, barrier, distributed, sub_leg
     t_dstep = timed(lambda: tr.train_step_discriminator("discriminator", data, fake_d), n_sub)
     tr_eager = Trainer(mods)
     tr_eager.it = tr.it
-    t_dstep_eager = timed(lambda: tr_eager.train_step_discriminator("discriminator", data, fake_d), n_sub)
+    # the eager comparison runs on the stream the captured step was recorded on: autograd pinned the discriminator's
+    # AccumulateGrad nodes to it, and a backward from another stream warns about the mismatch
+    gd = (tr._graphed or {}).get("discriminator")
+    cap = getattr(gd, "stream", None)
+    if cap is not None:
+        cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap) if cap is not None else contextlib.nullcontext():
+        t_dstep_eager = timed(lambda: tr_eager.train_step_discriminator("discriminator", data, fake_d), n_sub)
+    if cap is not None:
+        torch.cuda.current_stream().wait_stream(cap)
     return {"it_per_s": it_s, "ms_per_it": 1e3 / it_s, "steps": args.train_steps,
             "rays_per_s": 3 * world * B * R * R * it_s, "d_train_images_per_s": 4 * world * B * it_s,
             "render_fwd_bwd": {"ms": 1e3 * t_render, "rays_per_s_per_gpu": B * R * R / t_render,
@@ -369,8 +379,19 @@ def main():
             torch.cuda.synchronize()
             dtb = time.perf_counter() - t1
             timer_on[0] = False
+            kms = timer.mean_ms()
+            fl = B * R * R * (args.samples + args.importance) * (F_SDF + F_GRAD + F_COL)
+            ach = fl / (kms * 1e-3) / 1e12 if kms else None
+            tr_b, tr_src = measured_traffic(args, "bf16")
             bf16_mode = {"value": B * R * R * args.steps / dtb, "unit": "rays/s", "ms_per_step": dtb / args.steps * 1e3,
-                         "kernel_ms": timer.mean_ms(), "note": "same workload with --precision bf16 (tolerance 3e-2 on "
+                         "kernel_ms": kms,
+                         "roofline": {"bound": "mfma", "kernel": "sdf_mlp_kernel<bf16, full> (one bf16 MFMA per product, fp16 "
+                                      "gamma*cos(phi) scratch stream)", "achieved": ach, "peak": PEAK_TFLOPS["bf16"],
+                                      "unit": "TFLOP/s", "frac": (ach / PEAK_TFLOPS["bf16"]) if ach else None,
+                                      "traffic": tr_b, "traffic_source": tr_src,
+                                      "hbm": ({"achieved": tr_b / (kms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                               "frac": tr_b / (kms * 1e-3) / 8e12} if (kms and tr_b) else None)},
+                         "note": "same workload with --precision bf16 (tolerance 3e-2 on "
                          "sdf, 1.5e-1 relative on d sdf/dx: tests/test_gpu_kernels.py); not the 1e-4 parity path"}
         except Exception as ex:
             bf16_mode = {"error": f"{type(ex).__name__}: {ex}"}
@@ -488,6 +509,16 @@ def extras(args, gen, device):
                      "full": {"ms": ms_full, "points_per_s": n / ms_full * 1e3,
                               "algorithmic_TFLOP_per_s": n * (F_SDF + F_GRAD + F_COL) / ms_full / 1e9,
                               "frac_of_mfma_peak": n * (F_SDF + F_GRAD + F_COL) / ms_full / 1e9 / peak}}
+    # C5 at the size BASELINE.json states: 2^20 rays x 512 samples = 2^29 points, sdf-only (123.7 TFLOP), as
+    # 256 back-to-back launches over the resident 2^21-point buffer (the full point set would be 6 GB of inputs for nothing
+    # the kernel could tell apart); one pass, HIP events around all of it
+    with torch.no_grad():
+        ms_c5 = _ev_time(lambda: [ops.sdf_mlp_fwd(pts, pack.packed(), gamma, beta, 1, pack.prec, pack.fast_trig)
+                                  for _ in range(256)], 1, warm=0)
+    n5 = n * 256
+    out["c5_mlp"]["full_size_sdf_only"] = {"points": n5, "launches": 256, "ms": ms_c5, "points_per_s": n5 / ms_c5 * 1e3,
+                                           "algorithmic_TFLOP_per_s": n5 * F_SDF / ms_c5 / 1e9,
+                                           "frac_of_mfma_peak": n5 * F_SDF / ms_c5 / 1e9 / peak}
     del pts, full, scratch
     # ---- discriminator batch sweep (forward, eval, no grad)
     disc = build_from_config(net("src.models.discriminator.ADADiscriminatorView",
@@ -502,12 +533,17 @@ def extras(args, gen, device):
         sweep[f"B{bsz}"] = {"ms": ms, "images_per_s": bsz / ms * 1e3,
                             "roofline": {"mfma_fp32": {"achieved_TFLOP_per_s": bsz * d_flops / ms / 1e9, "peak": 157.3,
                                                        "frac": bsz * d_flops / ms / 1e9 / 157.3},
+                                         # the large-batch convolutions run on the fp16 matrix cores (3 MFMAs per MAC)
+                                         "mfma_f16": {"achieved_TFLOP_per_s": bsz * d_flops / ms / 1e9, "peak": 2500.0,
+                                                      "frac": bsz * d_flops / ms / 1e9 / 2500.0,
+                                                      "executed_mfma_frac_of_peak": 3 * bsz * d_flops / ms / 1e9 / 2500.0},
                                          "weight_read_hbm": {"achieved_GB_per_s": d_wbytes / ms / 1e6, "peak": 8000.0,
                                                              "frac": d_wbytes / ms / 1e6 / 8000.0}}}
     out["discriminator"] = {"what": "ADADiscriminatorView forward (ADA xint + scale, 5 conv4x4 s2 + head), 64^2; convolutions: fp32 MFMA "
                                     "per-wave gather below 512 output pixels per layer, LDS-tiled f16x3 (22-bit operands, fp32 "
                                     "accumulate, fixed summation order) above; wall time per forward incl. host launches; bound: "
-                                    "weight read at B = 1, fp32-MFMA peak as the yardstick at B = 64", **sweep}
+                                    "weight read at B = 1; at B = 64 both yardsticks: the fp32-MFMA peak (what an fp32 convolution could reach) and the fp16-MFMA "
+                                    "peak of the unit the tiled kernel actually runs on", **sweep}
     del disc
     # ---- shipped training configuration
     import copy
@@ -553,21 +589,24 @@ def csrc_digest():
     return mod._digest()
 
 
-def measured_traffic(args):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r2_traffic.json,
+TRAFFIC_FILE = "r3_traffic.json"
+
+
+def measured_traffic(args, precision=None):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r3_traffic.json,
     written by tools/traffic_json.py: FETCH_SIZE x2 -- the gfx950 correction of MI355X_MICROARCH.md -- + WRITE_SIZE).
     Counters cannot be collected from inside the timed process, so the figure is tied to the kernel sources by digest:
     a build whose csrc/ differs from the profiled one reports traffic = null instead of a stale number."""
-    path = os.path.join(ROOT, "profiles", "r2_traffic.json")
+    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if not os.path.exists(path):
-        return None, "profiles/r2_traffic.json missing"
+        return None, f"profiles/{TRAFFIC_FILE} missing"
     rec = json.load(open(path))
-    key = f"{args.precision}:{args.batch}x{args.res}x{args.res}:{args.samples}+{args.importance}"
+    key = f"{precision or args.precision}:{args.batch}x{args.res}x{args.res}:{args.samples}+{args.importance}"
     ent = rec.get("entries", {}).get(key)
     if ent is None:
         return None, f"no PMC record for {key}"
     if rec.get("csrc_digest") != csrc_digest():
-        return None, "csrc/ changed since the PMC passes of profiles/r2_traffic.json were taken (re-run tools/refresh_profiles.sh)"
+        return None, f"csrc/ changed since the PMC passes of profiles/{TRAFFIC_FILE} were taken (re-run tools/refresh_profiles.sh)"
     return float(ent["bytes_per_launch"]), ent["source"]
 
 

@@ -314,11 +314,16 @@ int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, 
 /* Chain form for forward-only passes:  y = lrelu_slope( conv( lrelu_x_slope(x) ) + bias ).
  *   x_slope != 1: the LeakyReLU of the PRODUCING layer is applied while x is loaded, so a split-K producer can hand
  *     over its pre-activation sums (slope = 1, no bias) and needs no activation pass of its own;
- *   y_is_zero != 0: the caller promises that y already holds zeros; the split-K path then skips its zero-fill, so a
- *     chain of layers shares ONE fill of an arena holding all their outputs. */
+ *   flags & OI_CONV_Y_IS_ZERO: the caller promises that y already holds zeros; the split-K path then skips its zero-fill,
+ *     so a chain of layers shares ONE fill of an arena holding all their outputs;
+ *   flags & OI_CONV_ANY_SCALE: an operand may be of gradient scale (the R1 double backward runs d loss / d image through
+ *     this entry): keeps the call on the fp32 matrix cores -- the large-batch kernel splits operands into UNSCALED fp16
+ *     limbs, exact to 2^-22 only for |v| >~ 3e-4. */
+#define OI_CONV_Y_IS_ZERO 1
+#define OI_CONV_ANY_SCALE 2
 int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float* y, int B, int Cin,
                         int H, int W, int Cout, int stride, int pad, float slope, float x_slope,
-                        int y_is_zero, oi_stream_t stream);
+                        int flags, oi_stream_t stream);
 
 /* Backward of the convolution (cuDNN bwd-data / bwd-filter in the reference, issued by autograd for
  * discriminator.py:80-83).  g = dL/d(conv output, pre-activation) [B][Cout][Ho][Wo].

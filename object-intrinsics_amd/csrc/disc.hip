@@ -305,25 +305,19 @@ __global__ void bias_lrelu_kernel(float* __restrict__ y, const float* __restrict
 //   reference's autograd wrapper calls                             ada/torch_utils/ops/grid_sample_gradfix.py:33-66
 // Both are HBM-bound elementwise / gather kernels: coalesced along the innermost dimension, nothing staged.
 // ------------------------------------------------------------------------------------------
-__global__ void fused_bias_act_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ b,
-                                      const float* __restrict__ ref, int act, int grad, float alpha, float scale,
-                                      long long size_x, long long step_b, int size_b) {
+// y = (x + bias) * g * scale with a per-element gain g in {1, alpha, 0} selected without branches from the (act, grad) code:
+//   value            (grad 0): gate = the biased input itself;        g = gate > 0 ? 1 : slope
+//   first derivative (grad 1): gate = `refer` (the forward's output); g = gate > 0 ? 1 : slope
+//   second derivative (grad 2) of either activation is zero;          g = 0
+// slope = alpha for the leaky relu (act 3) and 1 for the linear activation (act 1, any other code).
+__global__ void fused_bias_act_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ bias,
+                                      const float* __restrict__ refer, float slope, float zero_or_one, bool gate_on_refer,
+                                      float scale, long long n, long long inner, int channels) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= size_x) return;
-  float v = x[i];
-  if (b != nullptr) v += b[(i / step_b) % size_b];
-  const float r = ref != nullptr ? ref[i] : 0.f;
-  float y;
-  switch (act * 10 + grad) {
-    default:
-    case 10:
-    case 11: y = v; break;
-    case 12:
-    case 32: y = 0.f; break;
-    case 30: y = v > 0.f ? v : v * alpha; break;
-    case 31: y = r > 0.f ? v : v * alpha; break;
-  }
-  out[i] = y * scale;
+  if (i >= n) return;
+  const float v = in[i] + (bias != nullptr ? bias[(i / inner) % channels] : 0.f);
+  const float gate = gate_on_refer ? (refer != nullptr ? refer[i] : 0.f) : v;
+  out[i] = v * (gate > 0.f ? 1.f : slope) * zero_or_one * scale;
 }
 
 // unnormalise (align_corners = False): [-1, 1] -> [-0.5, size - 0.5]
@@ -557,7 +551,7 @@ int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, 
 }
 
 int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
-                        int Cout, int stride, int pad, float slope, float x_slope, int y_is_zero,
+                        int Cout, int stride, int pad, float slope, float x_slope, int flags,
                         oi_stream_t stream) {
   OI_REQUIRE(x && w && y, "oi_conv4x4_fwd: null pointer");
   OI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && stride > 0 && pad >= 0, "oi_conv4x4_fwd: bad shape");
@@ -565,6 +559,11 @@ int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float
   OI_REQUIRE(Ho > 0 && Wo > 0, "oi_conv4x4_fwd: input %dx%d too small", H, W);
   const long long M = (long long)B * Ho * Wo;
   hipStream_t st = oi::as_stream(stream);
+  const bool y_is_zero = (flags & OI_CONV_Y_IS_ZERO) != 0;
+  // OI_CONV_ANY_SCALE: an operand may be a gradient (the R1 double backward feeds d loss / d image and d loss / d w through
+  // this entry): the tiled kernel's UNSCALED fp16 limbs lose precision below |v| ~ 3e-4 and flush below ~3e-8, so such
+  // calls stay on the fp32 matrix cores
+  const bool any_scale = (flags & OI_CONV_ANY_SCALE) != 0;
   // large batches: LDS-tiled F16X3 implicit GEMM, K never split (OI_CONV_TILED=0 keeps the per-wave fp32-MFMA path)
   static const bool tiled_on = [] { const char* e = getenv("OI_CONV_TILED"); return e == nullptr || e[0] != '0'; }();
   const int K = Cin * 16;
@@ -574,7 +573,7 @@ int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float
   const int splits = (small && (long long)oi::cdiv(M, 64) * (Cout / 64) < 192 && K >= 1024) ? 2 : 1;
   // worth it from ~half a chip of workgroups; below that the per-wave split-K kernel spreads the K loop over more CUs
   const bool enough = (long long)oi::cdiv(M, small ? 64 : 128) * (Cout / 64) * splits >= 128;
-  if (tiled_on && M >= 512 && enough && Cout % 64 == 0 && K % 64 == 0) {
+  if (tiled_on && !any_scale && M >= 512 && enough && Cout % 64 == 0 && K % 64 == 0) {
     const int k_per_split = splits == 2 ? ((K / 2 + 63) / 64) * 64 : K;
     const long long total = (long long)B * Cout * Ho * Wo;
     if (splits == 2 && !y_is_zero) {
@@ -632,13 +631,17 @@ int oi_upfirdn2d(const float* x, const float* f, float* y, int BC, int H, int W,
   const int Wo = (W * upx + padx0 + padx1 - fw + downx) / downx;
   const int Ho = (H * upy + pady0 + pady1 - fh + downy) / downy;
   OI_REQUIRE(Wo >= 1 && Ho >= 1, "oi_upfirdn2d: output size %dx%d", Ho, Wo);
-  OI_REQUIRE(Ho <= 65535 && BC <= 65535, "oi_upfirdn2d: %d rows x %d planes exceed the launch grid", Ho, BC);
+  OI_REQUIRE(Ho <= 65535, "oi_upfirdn2d: %d output rows exceed the launch grid", Ho);
   int bx = 64;  // row segment width with the least padding (ties: the wider one)
   for (int c = 128; c <= 256; c *= 2)
     if (oi::cdiv(Wo, c) * c <= oi::cdiv(Wo, bx) * bx) bx = c;
-  hipLaunchKernelGGL(upfirdn2d_kernel, dim3(oi::cdiv(Wo, bx), Ho, BC), dim3(bx), fh * fw * sizeof(float),
-                     oi::as_stream(stream), x, f, y, BC, H, W, Ho, Wo, fh, fw, upx, upy, downx, downy, padx0, pady0,
-                     flip, gain);
+  // grid.z holds at most 65535 planes: more (e.g. 128 x 512 feature planes of a StyleGAN2 layer) go in several launches
+  for (int p0 = 0; p0 < BC; p0 += 65535) {
+    const int np = BC - p0 < 65535 ? BC - p0 : 65535;
+    hipLaunchKernelGGL(upfirdn2d_kernel, dim3(oi::cdiv(Wo, bx), Ho, np), dim3(bx), fh * fw * sizeof(float),
+                       oi::as_stream(stream), x + (size_t)p0 * H * W, f, y + (size_t)p0 * Ho * Wo, np, H, W, Ho, Wo, fh, fw,
+                       upx, upy, downx, downy, padx0, pady0, flip, gain);
+  }
   return oi::check_launch("oi_upfirdn2d");
 }
 
@@ -672,7 +675,7 @@ int oi_fused_bias_act(float* out, const float* x, const float* bias, const float
   OI_REQUIRE((act == 1 || act == 3) && grad >= 0 && grad <= 2, "oi_fused_bias_act: act %d grad %d (linear = 1, lrelu = 3)", act,
              grad);
   hipLaunchKernelGGL(fused_bias_act_kernel, dim3(oi::cdiv(size_x, 256)), dim3(256), 0, oi::as_stream(stream), out, x, bias,
-                     refer, act, grad, alpha, scale, size_x, step_b, size_b);
+                     refer, act == 3 ? alpha : 1.0f, grad == 2 ? 0.0f : 1.0f, grad == 1, scale, size_x, step_b, size_b);
   return oi::check_launch("oi_fused_bias_act");
 }
 

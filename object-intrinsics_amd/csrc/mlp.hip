@@ -810,14 +810,19 @@ int oi_film_params_bwd(const float* d_gamma, const float* d_beta, const float* w
                        float* d_gw, float* d_gb, float* d_bw, float* d_bb, float* d_w, const float* style_w,
                        const float* style_b, const float* z, float* d_style_w, float* d_style_b, float* d_z, int B,
                        int NL, oi_stream_t stream) {
-  OI_REQUIRE(B > 0 && NL > 0, "oi_film_params_bwd: B=%d NL=%d", B, NL);
-  OI_REQUIRE(d_gamma && d_beta && w && gw && bw && d_gw && d_gb && d_bw && d_bb && d_w, "oi_film_params_bwd: null pointer");
+  // NL == 0: the style MLP alone (ShapeNetwork.style(z) under autograd, fields.py:15-21) -- d_w is then the upstream gradient
+  OI_REQUIRE(B > 0 && NL >= 0 && (NL > 0 || z != nullptr), "oi_film_params_bwd: B=%d NL=%d", B, NL);
+  OI_REQUIRE(d_w && (NL == 0 || (d_gamma && d_beta && w && gw && bw && d_gw && d_gb && d_bw && d_bb)),
+             "oi_film_params_bwd: null pointer");
   OI_REQUIRE(z == nullptr || (style_w && style_b && d_style_w && d_style_b),
              "oi_film_params_bwd: style backward needs style_w, style_b, d_style_w, d_style_b");
   hipStream_t st = oi::as_stream(stream);
-  hipLaunchKernelGGL(film_heads_bwd_kernel, dim3(NL), dim3(256), 0, st, d_gamma, d_beta, w, gw, bw, d_gw, d_gb, d_bw, d_bb,
-                     d_w, B, NL);
-  int rc = oi::check_launch("oi_film_params_bwd(heads)");
+  int rc = OI_OK;
+  if (NL > 0) {
+    hipLaunchKernelGGL(film_heads_bwd_kernel, dim3(NL), dim3(256), 0, st, d_gamma, d_beta, w, gw, bw, d_gw, d_gb, d_bw,
+                       d_bb, d_w, B, NL);
+    rc = oi::check_launch("oi_film_params_bwd(heads)");
+  }
   if (rc != OI_OK || z == nullptr) return rc;
   hipLaunchKernelGGL(style_bwd_kernel, dim3(B), dim3(64), 0, st, style_w, style_b, z, d_w, d_style_w, d_style_b, d_z);
   return oi::check_launch("oi_film_params_bwd(style)");

@@ -57,14 +57,30 @@ class FilmParamsFunction(torch.autograd.Function):
         return None, r["d_w"], None, None, r["d_gw"], r["d_gb"], r["d_bw"], r["d_bb"]
 
 
+class StyleFunction(torch.autograd.Function):
+    """The style MLP alone (`ShapeNetwork.style(z)`, fields.py:15-21; generator.py:237 calls it under autograd): the
+    forward is oi_film_params without FiLM layers, the backward oi_film_params_bwd with NL = 0 (style_bwd_kernel)."""
+
+    @staticmethod
+    def forward(ctx, z, ws, bs):
+        w = ops.film_params(ws, bs, None, None, None, None, z=z)[0]
+        ctx.save_for_backward(z, ws, bs)
+        ctx.need_dz = bool(z.requires_grad)
+        return w
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_w):
+        z, ws, bs = ctx.saved_tensors
+        r = ops.style_bwd(d_w, ws, bs, z, want_dz=ctx.need_dz)
+        return r.get("d_z"), r["d_style_w"], r["d_style_b"]
+
+
 def style_mlp(style_module, z):
     ws = torch.stack([m.weight for m in style_module])
     bs = torch.stack([m.bias for m in style_module])
     if _needs_grad(z, ws, bs):
-        h = z
-        for i in range(3):
-            h = torch.nn.functional.leaky_relu(h @ ws[i].t() + bs[i], 0.2)
-        return h
+        return StyleFunction.apply(z, ws, bs)
     with torch.no_grad():
         return ops.film_params(ws, bs, None, None, None, None, z=z)[0]
 

@@ -8,13 +8,14 @@ from . import ops
 
 
 class _Conv(torch.autograd.Function):
-    """y = conv(x, w) (linear, no bias)."""
+    """y = conv(x, w) (linear, no bias).  Also the double-backward node of _Dgrad / _Wgrad, where `x` or `w` is a gradient
+    of arbitrary magnitude: always the exact fp32-MFMA path (any_scale), never the unscaled-fp16-limb large-batch kernel."""
 
     @staticmethod
     def forward(ctx, x, w, stride, pad):
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad)
-        return ops.conv4x4_fwd(x, w, None, stride, pad, 1.0)
+        return ops.conv4x4_fwd(x, w, None, stride, pad, 1.0, any_scale=True)
 
     @staticmethod
     def backward(ctx, gy):

@@ -200,6 +200,7 @@ class GraphedDStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side):
             self.out = self._step()
+        self.stream = side  # an EAGER step on the same parameters should run under it too (their AccumulateGrad nodes live here)
         np.random.set_state(state)
         self._sig = (tuple(x_real.shape), tuple(x_fake.shape), None if c2b is None else tuple(c2b.shape))
         return self

@@ -86,6 +86,20 @@ def film_params_bwd(d_gamma, d_beta, w, gw, bw, style_w=None, style_b=None, z=No
     return out
 
 
+def style_bwd(d_w, style_w, style_b, z, want_dz=False):
+    """Backward of the style MLP alone (oi_film_params_bwd with no FiLM layer) -> dict(d_style_w, d_style_b [, d_z])."""
+    L = _l.load()
+    B = z.shape[0]
+    out = {"d_style_w": torch.zeros_like(style_w), "d_style_b": torch.zeros_like(style_b)}
+    if want_dz:
+        out["d_z"] = torch.empty_like(z)
+    d_w = d_w.contiguous().clone()
+    _l.check(L.oi_film_params_bwd(None, None, None, None, None, None, None, None, None, _p(d_w), _p(_c(style_w)),
+                                  _p(_c(style_b)), _p(_c(z)), _p(out["d_style_w"]), _p(out["d_style_b"]), _p(out.get("d_z")),
+                                  B, 0, _stream()), "oi_film_params_bwd")
+    return out
+
+
 def mlp_pack_weights(w0, b0, wh, bh, wsig, bsig, wv, bv, wrgb, brgb, prec):
     L = _l.load()
     packed = torch.empty(L.oi_mlp_packed_bytes(prec), dtype=torch.uint8, device=w0.device)
@@ -297,10 +311,11 @@ def conv4x4_out_shape(x_shape, Cout, stride, pad):
     return B, Cout, (H + 2 * pad - 4) // stride + 1, (W + 2 * pad - 4) // stride + 1
 
 
-def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2, out=None, x_slope=1.0):
+def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2, out=None, x_slope=1.0, any_scale=False):
     """y = lrelu_slope(conv(lrelu_x_slope(x)) + bias).  `out`: optional ZERO-FILLED contiguous output (e.g. a view of an
     arena shared by a chain of layers): the split-K path then needs no fill launch of its own.  `x_slope`: LeakyReLU
-    applied to x while it is loaded (the producing layer handed over pre-activations)."""
+    applied to x while it is loaded (the producing layer handed over pre-activations).  `any_scale`: an operand may be a
+    gradient (OI_CONV_ANY_SCALE: fp32 matrix cores only)."""
     L = _l.load()
     x, w = _c(x), _c(w)
     B, Cin, H, W = x.shape
@@ -313,7 +328,7 @@ def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2, out=None, x_slope=1
         assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.float32, (out.shape, shape)
         y = out
     _l.check(L.oi_conv4x4_fwd_into(_p(x), _p(w), _p(_c(bias)), _p(y), B, Cin, H, W, Cout, stride, pad, float(slope),
-                                   float(x_slope), int(out is not None), _stream()), "oi_conv4x4_fwd")
+                                   float(x_slope), int(out is not None) | (2 if any_scale else 0), _stream()), "oi_conv4x4_fwd")
     return y
 
 

@@ -450,6 +450,29 @@ def test_film_params_backward_vs_oracle(sdf_sd, col_sd, from_z):
             chk(p.grad, csd[name].grad, "col." + name)
 
 
+def test_style_mlp_under_autograd_runs_on_hip_kernels(sdf_sd):
+    """`ShapeNetwork.style(z)` with gradients (the reference's own call site, generator.py:237) goes through
+    oi_film_params / oi_film_params_bwd(NL = 0), not through ATen matmuls: values and gradients vs fp64 autograd through
+    the oracle, and no `mm` / `addmm` / `leaky_relu` kernel in the autograd graph."""
+    from oi_amd.fields import ShapeNetwork
+    g = torch.Generator().manual_seed(13)
+    z, cw = torch.randn(4, 64, generator=g), torch.randn(4, 64, generator=g)
+    sd = {k: v.double().requires_grad_() for k, v in sdf_sd.items()}
+    zs = z.double().requires_grad_()
+    (O.style_mlp(sd, zs) * cw.double()).sum().backward()
+    net = ShapeNetwork(SDF_NPZ, **NET_KW).cuda()
+    zh = z.cuda().requires_grad_()
+    w = net.style(zh)
+    assert type(w.grad_fn).__name__ == "StyleFunctionBackward", type(w.grad_fn).__name__
+    (w * cw.cuda()).sum().backward()
+    assert maxdiff(w.detach().cpu(), O.style_mlp(sdf_sd, z)) < 1e-5
+    assert maxdiff(zh.grad.cpu(), zs.grad.float()) < 2e-5 * max(1.0, float(zs.grad.abs().max()))
+    for name, p in net.named_parameters():
+        if name.startswith("style."):
+            ref = sd[name].grad.float()
+            assert maxdiff(p.grad.cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max())), name
+
+
 def test_training_trajectory_f16x3_tracks_native_fp32():
     """Six full training iterations (G / D / mask-D steps, fused optimisers) from identical seeds in the default
     f16x3 operand mode and in native fp32 MFMA: every logged loss agrees to 1e-4 while the dynamics are still

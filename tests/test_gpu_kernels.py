@@ -504,3 +504,37 @@ def test_upfirdn2d_general_factors_vs_dense_restatement(ops, up, down, taps, pad
     y = ops.upfirdn2d(x.cuda(), f.cuda(), upx, upy, dx, dy, px0, px1, py0, py1)
     assert tuple(y.shape) == tuple(ref.shape), (y.shape, ref.shape)
     assert maxdiff(y.cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv_double_backward_operands_of_gradient_scale_stay_exact(ops):
+    """The R1 double backward runs gradients (1e-5-scale here) through the forward convolution entry (_Dgrad.backward ->
+    _Conv.apply(ggx, w)) at a batch that would select the large-batch kernel with its UNSCALED fp16 limbs; the autograd node
+    asks for OI_CONV_ANY_SCALE and must match an fp64 convolution to fp32 accuracy at any operand scale (advisor, round 2)."""
+    from oi_amd.autograd_conv import _Conv
+    g = torch.Generator().manual_seed(3)
+    B, Cin, H, Cout = 64, 64, 16, 128
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) / math.sqrt(Cin * 16)
+    for scale in (1.0, 1e-5, 1e-8):
+        x = torch.randn(B, Cin, H, H, generator=g) * scale
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), stride=2, padding=1)
+        y = _Conv.apply(x.cuda(), w.cuda(), 2, 1)
+        assert maxdiff(y.cpu(), ref) < 5e-6 * float(ref.abs().max()), (scale, maxdiff(y.cpu(), ref), float(ref.abs().max()))
+    # the same call WITHOUT the flag takes the tiled kernel and is only good for O(1) operands -- which is all it is used for
+    y = ops.conv4x4_fwd((x / scale).cuda(), w.cuda(), None, 2, 1, 1.0)
+    ref = torch.nn.functional.conv2d((x / scale).double(), w.double(), stride=2, padding=1)
+    assert maxdiff(y.cpu(), ref) < 5e-6 * float(ref.abs().max())
+
+
+def test_upfirdn2d_more_planes_than_one_launch_grid(ops):
+    """B * C = 65,539 planes (a 128 x 512-channel StyleGAN2 layer is 65,536): grid.z holds 65,535, the rest goes in a second
+    launch (advisor, round 2)."""
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 65539, 4, 4, generator=g)
+    f = torch.tensor([1.0, 3.0, 3.0, 1.0]) / 8
+    y = ops.upfirdn2d(x.cuda(), f[None].cuda(), 2, 1, 1, 1, 2, 1, 0, 0)
+    import torch.nn.functional as F
+    u = torch.zeros(1, 65539, 4, 8, dtype=torch.float64)
+    u[..., ::2] = x.double()
+    ref = F.conv2d(F.pad(u, [2, 1, 0, 0]).view(65539, 1, 4, 11), f.double().flip(0).view(1, 1, 1, 4)).view(1, 65539, 4, 8)
+    assert tuple(y.shape) == (1, 65539, 4, 8)
+    assert maxdiff(y.cpu(), ref) < 1e-6
