@@ -5,10 +5,12 @@ weights of the reference trainer (src/trainers/gan_pose_trainer.py:77-202; confi
     D step:   render (no grad) -> BCE(D(real),1) + BCE(D(fake)[:, :1],0) + 10*R1(real) + w(it)*MSE(D(fake)[:,1:7], pose)
     maskD:    render (no grad) -> same without the pose term
 i.e. 3 renders, 3+3 discriminator forwards, 3 backward passes (each followed by the flat-gradient
-all-reduce when wrapped in oi_amd.ddp.FlatGradDDP) per iteration.  The modules keep the interfaces the
-reference's own Trainer class uses, but that class cannot be imported in this image (tu.*, tensorboard,
-torchvision are absent), so running it on top is untested; this compact restatement is what bench.py and
-the tests drive (pinned by the F9 fixture)."""
+all-reduce when wrapped in oi_amd.ddp.FlatGradDDP) per iteration.  Pinned by F13 (tests/test_gpu_trainer_f13.py): two
+iterations of the reference's OWN `Trainer.train_step` (imported in the build container with torchvision / imageio
+stubbed, oracle/gen_golden_r3.py; ADA on, pinned percentile) -- every render, every returned loss, the generator's
+gradient norms and the three networks' weights after each iteration -- eager and with captured discriminator steps;
+F9 pins the per-parameter gradients of one iteration assembled from the reference's pieces.  Running the reference's
+class itself on top of the oi_amd modules stays untested (its module imports tu.loggers / visualisation helpers)."""
 import torch
 
 from .losses import GANLoss, PositionLoss, compute_grad2, linear_increase
