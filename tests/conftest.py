@@ -38,3 +38,24 @@ def col_sd():
 
 def maxdiff(a, b):
     return float((a.detach().double() - b.detach().double()).abs().max())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Measured margins.  The gradient tests report the worst relative error of every tensor they check; with
+# OI_MARGIN_OUT=<file.json> the collection is written at the end of the session (tools/grad_margin.py turns it into the
+# table of DESIGN.md section 5).  The test tolerances are set from these measurements (<= 3x the native-fp32 error).
+# ------------------------------------------------------------------------------------------------------------------
+MARGINS = {}
+
+
+def record_margin(case, name, err):
+    d = MARGINS.setdefault(case, {})
+    d[name] = max(float(err), d.get(name, 0.0))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    out = os.environ.get("OI_MARGIN_OUT")
+    if out and MARGINS:
+        import json
+        with open(out, "w") as fh:
+            json.dump(MARGINS, fh, indent=1, sort_keys=True)

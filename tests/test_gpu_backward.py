@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import oi_oracle as O
-from conftest import GOLDEN, load_golden, maxdiff, sub_sd
+from conftest import GOLDEN, load_golden, maxdiff, sub_sd, record_margin
 
 pytestmark = pytest.mark.gpu
 NET_KW = dict(D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64)
@@ -39,6 +39,9 @@ def test_conv_dgrad_wgrad_vs_torch(B, Cin, H, Cout, stride, pad):
     assert rel_err(dx, gx) < 2e-5 and rel_err(dw, gw) < 2e-5
 
 
+F7_TOL = 3e-6   # measured 7.0e-7 worst over 13 tensors (tools/grad_margin.py); round 2 accepted 2e-4
+
+
 @pytest.mark.parametrize("tag,res,nf,cin,cout", [("r16c3_", 16, 32, 3, 7), ("r64c3_", 64, 64, 3, 7), ("r64c1_", 64, 32, 1, 1)])
 def test_discriminator_r1_grads_golden_f7(tag, res, nf, cin, cout):
     """loss = BCE(D(x)[:, :1], 1) + 10 * R1: weight gradients need the conv double-backward."""
@@ -60,7 +63,8 @@ def test_discriminator_r1_grads_golden_f7(tag, res, nf, cin, cout):
     gw = torch.autograd.grad(loss, list(D.parameters()))
     for (k, _), gr in zip(D.named_parameters(), gw):
         ref = g[tag + "g." + k]
-        assert rel_err(gr, ref) < 2e-4, (k, rel_err(gr, ref))
+        record_margin("f7_discriminator_r1_weight_grads_vs_reference", tag + k, rel_err(gr, ref))
+        assert rel_err(gr, ref) < F7_TOL, (k, rel_err(gr, ref))
 
 
 def test_ada_discriminator_backward_vs_oracle():
@@ -99,6 +103,9 @@ def test_ada_discriminator_backward_vs_oracle():
 # ---------------------------------------------------------------------------------------------
 # compositing
 # ---------------------------------------------------------------------------------------------
+COMPOSITE_BWD_TOL = 1.2e-3  # the shininess exponent (d/dn x^n = x^n ln x in fp32): measured 3.8e-4; every other input <= 1e-5
+
+
 def test_composite_backward_vs_oracle(sdf_sd, col_sd):
     from oi_amd import ops
     from oi_amd.autograd_render import CompositeFunction
@@ -171,7 +178,8 @@ def test_composite_backward_vs_oracle(sdf_sd, col_sd):
     g_h = torch.autograd.grad(loss_h, [sdf_h, grad_h, rgb_h, var_h, lp["param_ambient"], lp["param_specular"],
                                        lp["param_shininess"], lp["param_direction"]])
     for name, a, b in zip(("sdf", "grad", "rgb", "variance", "ambient", "specular", "shininess", "direction"), g_h, g_o):
-        assert rel_err(a, b) < 2e-3, (name, rel_err(a, b), a.flatten()[:4], b.flatten()[:4])
+        record_margin("composite_backward_vs_fp64_oracle", name, rel_err(a, b))
+        assert rel_err(a, b) < COMPOSITE_BWD_TOL, (name, rel_err(a, b), a.flatten()[:4], b.flatten()[:4])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -189,8 +197,10 @@ def _oracle_mlp_grads(sdf_sd, col_sd, pts, w, cs, cg, cr):
     return float(loss), {n: g_ for (n, _), g_ in zip(names, gr)}
 
 
-@pytest.mark.parametrize("n,B,precision,tol", [(96, 2, "f32", 2e-3), (300, 1, "f32", 2e-3), (64, 2, "bf16x3", 1e-2),
-                                               (160, 1, "bf16x6", 2e-3), (160, 1, "f16x3", 2e-3)])
+# tolerances: 3x the error measured in the native-fp32 mode (6.7e-6 worst over 59 tensors, tools/grad_margin.py; DESIGN.md
+# section 5); bf16x3 (bf16x3 forward, f16x3 backward) 3x its own 1.2e-5
+@pytest.mark.parametrize("n,B,precision,tol", [(96, 2, "f32", 2e-5), (300, 1, "f32", 2e-5), (64, 2, "bf16x3", 4e-5),
+                                               (160, 1, "bf16x6", 2e-5), (160, 1, "f16x3", 2e-5)])
 def test_mlp_backward_vs_oracle(sdf_sd, col_sd, n, B, precision, tol):
     """dL/d(every parameter, w) for L = <cs, sdf> + <cg, d sdf/dx> + <cr, rgb> (random cotangents)."""
     from oi_amd.fields import ShapeNetwork, ColorNetwork, FieldPack
@@ -217,11 +227,19 @@ def test_mlp_backward_vs_oracle(sdf_sd, col_sd, n, B, precision, tol):
     worst = {}
     for (name, _), a in zip(named, gr):
         worst[name] = rel_err(a, g_o[name])
+        record_margin(f"mlp_backward_vs_fp64_oracle[{precision}]", name, worst[name])
     bad = {k: v for k, v in worst.items() if v > tol}
     assert not bad, bad
 
 
-def _f6_render():
+# 3x the error measured in the native-fp32 mode against the reference's own (fp32) gradients: 2.3e-5 (F6), 3.5e-5 (F9)
+# worst over 69 tensors (tools/grad_margin.py); round 2 accepted 3e-3
+F9_D_TOL = 3e-6  # discriminator weight gradients of the D / mask-D steps: measured 9.2e-7; round 2 accepted 2e-3
+F6_TOL = 7e-5
+F9_TOL = 1e-4
+
+
+def _f6_render(precision="f16x3"):
     """The F6 forward (reference weights, rays, latent, background, jitter draw) through the HIP path:
     returns the golden dict, image / shading / mask maps, the eikonal term and the named generator parameters."""
     from oi_amd.fields import ShapeNetwork, ColorNetwork, SingleVarianceNetwork
@@ -238,7 +256,8 @@ def _f6_render():
     light = DirectionalLightWithSpecularFixInit(direction=[0, 0, -1.0])
     light.load_state_dict(sub_sd(p, "light."))
     sdf, col, dev, light = sdf.cuda(), col.cuda(), dev.cuda(), light.cuda()
-    r = NeuSRenderer(None, sdf, dev, col, n_samples=8, n_importance=8, n_outside=0, up_sample_steps=1, perturb=1)
+    r = NeuSRenderer(None, sdf, dev, col, n_samples=8, n_importance=8, n_outside=0, up_sample_steps=1, perturb=1,
+                     precision=precision)
     ro, rd = g["rays_o"].cuda(), g["rays_d"].cuda()
     near, far = O.near_far_from_sphere(g["rays_o"], g["rays_d"])
     real_rand = torch.rand
@@ -256,13 +275,14 @@ def _f6_render():
     return g, to_map(c["image"]), to_map(c["shading"]).expand(1, 3, 8, 8), to_map(c["mask"]), c["reduce4"][0] / (c["reduce4"][1] + 1e-5), named
 
 
-def test_scripted_train_step_golden_f9():
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_scripted_train_step_golden_f9(precision):
     """F9: one training iteration assembled from the reference's own pieces (gan_pose_trainer.py:103-200 call pattern,
     configs/train.yaml loss weights): G-step loss + generator gradients through both discriminators, D / mask-D step
     losses (real, fake, R1, auxiliary pose regression) + their weight gradients."""
     from oi_amd.config import build_from_config
     from oi_amd.losses import GANLoss, PositionLoss, compute_grad2, linear_increase
-    g6, image, _, mask, eik, named = _f6_render()
+    g6, image, _, mask, eik, named = _f6_render(precision)
     g = load_golden("f9_train_step")
     it = int(g["it"])
     aug = {"__target__": "src.third_party.ada.augment.AugmentPipe", "kwargs": {"scale": 1, "xint": 1}}
@@ -288,7 +308,8 @@ def test_scripted_train_step_golden_f9():
             assert gr is None or float(gr.abs().max()) == 0.0, name
             continue
         err = maxdiff(gr.cpu(), g[key]) / max(1e-3, float(g[key].abs().max()))
-        if err > 3e-3:
+        record_margin(f"f9_g_step_grads_vs_reference[{precision}]", name, err)
+        if err > F9_TOL:
             bad[name] = err
         checked += 1
     assert checked > 60 and not bad, bad
@@ -312,10 +333,13 @@ def test_scripted_train_step_golden_f9():
         gw = torch.autograd.grad(loss, list(net.parameters()))
         for (k, _), gr in zip(net.named_parameters(), gw):
             ref = g[f"{tag}_g." + k]
-            assert maxdiff(gr.cpu(), ref) < 2e-3 * max(1e-3, float(ref.abs().max())), (tag, k, maxdiff(gr.cpu(), ref), float(ref.abs().max()))
+            record_margin(f"f9_d_step_weight_grads_vs_reference[{precision}]", f"{tag}.{k}",
+                          maxdiff(gr.cpu(), ref) / max(1e-3, float(ref.abs().max())))
+            assert maxdiff(gr.cpu(), ref) < F9_D_TOL * max(1e-3, float(ref.abs().max())), (tag, k, maxdiff(gr.cpu(), ref), float(ref.abs().max()))
 
 
-def test_generator_grads_golden_f6():
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_generator_grads_golden_f6(precision):
     """The reference's own parameter gradients for loss = sum(image) + 10*eikonal + sum(shading) + 0.5*sum(mask)
     (training mode: jitter on, cos_anneal 0.4) -- exercises MLP double-backward + compositing backward + light."""
     from oi_amd.fields import ShapeNetwork, ColorNetwork, SingleVarianceNetwork
@@ -332,7 +356,8 @@ def test_generator_grads_golden_f6():
     light = DirectionalLightWithSpecularFixInit(direction=[0, 0, -1.0])
     light.load_state_dict(sub_sd(p, "light."))
     sdf, col, dev, light = sdf.cuda(), col.cuda(), dev.cuda(), light.cuda()
-    r = NeuSRenderer(None, sdf, dev, col, n_samples=8, n_importance=8, n_outside=0, up_sample_steps=1, perturb=1)
+    r = NeuSRenderer(None, sdf, dev, col, n_samples=8, n_importance=8, n_outside=0, up_sample_steps=1, perturb=1,
+                     precision=precision)
     ro, rd = g["rays_o"].cuda(), g["rays_d"].cuda()
     near, far = O.near_far_from_sphere(g["rays_o"], g["rays_d"])
     # inject the reference's jitter draw (first RNG call of render, renderer.py:372)
@@ -364,7 +389,8 @@ def test_generator_grads_golden_f6():
             continue
         ref = g[key]
         err = maxdiff(gr.cpu(), ref) / max(1.0, float(ref.abs().max()))
-        if err > 3e-3:
+        record_margin(f"f6_generator_grads_vs_reference[{precision}]", name, err)
+        if err > F6_TOL:
             bad[name] = err
         checked += 1
     assert checked > 60 and not bad, bad
@@ -615,6 +641,9 @@ def test_pack_status_reports_non_finite_weights(col_sd):
         pack.check()
 
 
+WIDE_RANGE_TOL = 2e-5  # measured 5.0e-6 worst over 59 tensors; round 2 accepted 2e-3
+
+
 def test_mlp_backward_wide_dynamic_range_cotangents(sdf_sd, col_sd):
     """The weight-gradient GEMM scales every operand by ONE power of two per launch (the launch-wide maximum published by
     the sweep).  Cotangents spread over 8 decades between points -- a few surface samples carrying almost all of the loss,
@@ -642,5 +671,8 @@ def test_mlp_backward_wide_dynamic_range_cotangents(sdf_sd, col_sd):
     named = [("sdf." + k, v) for k, v in sdf_net.named_parameters() if not k.startswith("style.")] + \
             [("col." + k, v) for k, v in col_net.named_parameters()] + [("w", wh)]
     gr = torch.autograd.grad(loss, [v for _, v in named])
-    bad = {name: rel_err(a, g_o[name]) for (name, _), a in zip(named, gr) if rel_err(a, g_o[name]) > 2e-3}
+    errs = {name: rel_err(a, g_o[name]) for (name, _), a in zip(named, gr)}
+    for name, e in errs.items():
+        record_margin("mlp_backward_cotangents_over_8_decades_vs_fp64_oracle[f16x3]", name, e)
+    bad = {k: v for k, v in errs.items() if v > WIDE_RANGE_TOL}
     assert not bad, bad

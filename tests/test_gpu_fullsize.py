@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import oi_oracle as O
-from conftest import GOLDEN, load_golden, maxdiff
+from conftest import GOLDEN, load_golden, maxdiff, record_margin
 
 pytestmark = pytest.mark.gpu
 NET_KW = dict(D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64)
@@ -62,7 +62,7 @@ def test_full_size_render_properties(sdf_sd, col_sd, name, B, R, S, I, K, precis
                        cos_anneal_ratio=0.5, w=w.cuda())
         assert maxdiff(sub["color_fine"], out["color_fine"][sl]) < 1e-6
     # oracle agreement on a subset of rays (K>1: see test_render_vs_oracle_hierarchical for the ray-wise criterion)
-    idx = torch.randperm(N, generator=torch.Generator().manual_seed(1))[:48]
+    idx = torch.randperm(N, generator=torch.Generator().manual_seed(1))[:256]
     ref = O.render(sdf_sd, col_sd, torch.tensor(0.3), ro[idx], rd[idx], near[idx], far[idx], w, S, I, K, 0.5)
     dz = (out["mid_z_vals"].cpu()[idx] - ref["mid_z_vals"]).abs().max(-1).values
     ok = dz < 1e-4
@@ -100,7 +100,15 @@ def test_c5_mlp_only_microbench_size(sdf_sd, col_sd):
     assert maxdiff(s, ref) < 2e-5
 
 
-def test_c2_size_mlp_backward_vs_oracle(sdf_sd, col_sd):
+# 3x the error measured in the native-fp32 mode against fp64 autograd through the oracle: 8.8e-6 (MLP op, 59 tensors),
+# 6.4e-6 (training render, 58 tensors) -- tools/grad_margin.py; round 2 accepted 2e-3 / 3e-3
+C2_MLP_BWD_TOL = 2.5e-5
+C2_RENDER_BWD_TOL = 2e-5
+
+
+@pytest.mark.parametrize("n,precision", [(4096 * 128, "f16x3"), (4096 * 128, "f32"), (128 * 128 * 256, "f16x3")],
+                         ids=["C2-f16x3", "C2-f32", "C4-eight-chunks-f16x3"])
+def test_c2_size_mlp_backward_vs_oracle(sdf_sd, col_sd, n, precision):
     """Backward of the MLP op at the full C2 launch size (524,288 points = 4,096 rays x 128 samples; the real grid of the
     sweep kernel, its scratch indexing, the split weight-gradient GEMM and every atomics-accumulated output): the
     cotangents are non-zero on 2,048 points scattered over the launch, so the parameter gradients equal those of the
@@ -108,7 +116,9 @@ def test_c2_size_mlp_backward_vs_oracle(sdf_sd, col_sd):
     from oi_amd.fields import ShapeNetwork, ColorNetwork, FieldPack
     from oi_amd.autograd import sdf_mlp
     from test_gpu_backward import _oracle_mlp_grads, rel_err
-    n, B, n_sub = 4096 * 128, 1, 2048
+    # (C4 per rank: 128 x 128 rays x 256 samples = 4,194,304 points -- the backward then walks the points in eight chunks
+    #  of the default 9 GiB working-memory bound, every chunk accumulating into the same outputs)
+    B, n_sub = 1, 2048
     g = torch.Generator().manual_seed(42)
     pts = torch.rand(n, 3, generator=g) * 2.0 - 1.0
     w = O.style_mlp(sdf_sd, torch.randn(B, 64, generator=g))
@@ -122,7 +132,7 @@ def test_c2_size_mlp_backward_vs_oracle(sdf_sd, col_sd):
     col_net = ColorNetwork(**NET_KW)
     col_net.load_state_dict(col_sd)
     col_net = col_net.cuda()
-    pack = FieldPack(sdf_net, col_net, "f16x3")
+    pack = FieldPack(sdf_net, col_net, precision)
     wh = w.cuda().requires_grad_(True)
     _, gamma, beta = pack.film(w=wh)
     sdf, grad, rgb, _ = sdf_mlp(pack, pts.cuda(), gamma, beta, B, True, True, False)
@@ -131,11 +141,15 @@ def test_c2_size_mlp_backward_vs_oracle(sdf_sd, col_sd):
     named = [("sdf." + k, v) for k, v in sdf_net.named_parameters() if not k.startswith("style.")] + \
             [("col." + k, v) for k, v in col_net.named_parameters()] + [("w", wh)]
     gr = torch.autograd.grad(loss, [v for _, v in named])
-    bad = {name: rel_err(a, g_o[name]) for (name, _), a in zip(named, gr) if rel_err(a, g_o[name]) > 2e-3}
+    errs = {name: rel_err(a, g_o[name]) for (name, _), a in zip(named, gr)}
+    for name, e in errs.items():
+        record_margin(f"{'c2' if n < 1 << 20 else 'c4'}_size_mlp_backward_vs_fp64_oracle[{precision}]", name, e)
+    bad = {k: v for k, v in errs.items() if v > C2_MLP_BWD_TOL}
     assert not bad, bad
 
 
-def test_c2_size_render_backward_ray_subset_vs_oracle(sdf_sd, col_sd):
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_c2_size_render_backward_ray_subset_vs_oracle(sdf_sd, col_sd, precision):
     """Training render at C2 size (4,096 rays x 64+64 samples, gradient enabled): loss = <c, color_fine> + <c', weight_sum>
     with cotangents on a 128-ray subset.  Rays are independent, so the parameter gradients equal those of the subset
     alone, which the fp64 oracle differentiates with autograd (render_core on the HIP path's own samples of those rays:
@@ -145,7 +159,7 @@ def test_c2_size_render_backward_ray_subset_vs_oracle(sdf_sd, col_sd):
     N, S, I = 4096, 64, 64
     ro, rd, near, far = _rays(N, 23)
     w = O.style_mlp(sdf_sd, torch.randn(1, 64, generator=torch.Generator().manual_seed(6)))
-    r = _renderer(col_sd, S, I, 1, "f16x3")
+    r = _renderer(col_sd, S, I, 1, precision)
     g = torch.Generator().manual_seed(7)
     idx = torch.sort(torch.randperm(N, generator=g)[:128]).values
     c_col, c_ws = torch.zeros(N, 3), torch.zeros(N, 1)
@@ -172,6 +186,7 @@ def test_c2_size_render_backward_ray_subset_vs_oracle(sdf_sd, col_sd):
         if a is None or b is None or name.startswith("sdf.style."):
             continue
         checked += 1
-        if rel_err(a, b) > 3e-3:
+        record_margin(f"c2_size_render_backward_vs_fp64_oracle[{precision}]", name, rel_err(a, b))
+        if rel_err(a, b) > C2_RENDER_BWD_TOL:
             bad[name] = rel_err(a, b)
     assert checked > 50 and not bad, bad
