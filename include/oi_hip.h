@@ -324,6 +324,12 @@ int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, 
 int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float* y, int B, int Cin,
                         int H, int W, int Cout, int stride, int pad, float slope, float x_slope,
                         int flags, oi_stream_t stream);
+/* The same for the first layer of a chain whose outputs share one arena: `y` is this layer's output at the start of the
+ * arena region, and the `zero_tail_floats` floats behind it (from y + round_up(B * Cout * Ho * Wo, 4)) are cleared by the
+ * same launch -- the later layers then run with OI_CONV_Y_IS_ZERO and the chain needs no fill launch at all. */
+int oi_conv4x4_fwd_arena(const float* x, const float* w, const float* bias, float* y, int B, int Cin,
+                         int H, int W, int Cout, int stride, int pad, float slope, float x_slope,
+                         int flags, long long zero_tail_floats, oi_stream_t stream);
 
 /* Backward of the convolution (cuDNN bwd-data / bwd-filter in the reference, issued by autograd for
  * discriminator.py:80-83).  g = dL/d(conv output, pre-activation) [B][Cout][Ho][Wo].
@@ -361,6 +367,15 @@ int oi_affine_grid_sample_fwd(const float* x, const float* theta, float* y, int 
                               int Wi, int Ho, int Wo, oi_stream_t stream);
 int oi_affine_grid_sample_bwd(const float* gy, const float* theta, float* gx, int B, int C, int Hi,
                               int Wi, int Ho, int Wo, oi_stream_t stream);
+
+/* The whole geometric augmentation of AugmentPipe.forward (src/third_party/ada/augment.py:284-301) for a given sampling
+ * grid, in two launches: reflect pad (margins mx0, mx1, my0, my1) + x2 up-FIR | affine bilinear resample + /2 down-FIR.
+ *   x [B][C][H][W], theta [B][2][3] (the matrix F.affine_grid receives, augment.py:297), f: the 12 taps of Hz_geom
+ *   -> y [B][C][H][W];  canvas: working memory of B * C * 2 (H + my0 + my1) * 2 (W + mx0 + mx1) floats.
+ * Equal to oi_reflect_pad_fwd -> oi_upfirdn2d (up 2, x then y) -> oi_affine_grid_sample_fwd -> oi_upfirdn2d (down 2, x then
+ * y) up to fp32 summation order; linear in x (the adjoint is the chain of the four adjoint entries). */
+int oi_ada_geom_fwd(const float* x, const float* theta, const float* f, float* y, float* canvas, int B, int C, int H,
+                    int W, int mx0, int mx1, int my0, int my1, oi_stream_t stream);
 
 /* Stand-alone plugin ops, for a caller that keeps the reference's own Python layers and only swaps the compiled ops
  * (INTEGRATION.md 3).

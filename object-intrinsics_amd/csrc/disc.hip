@@ -31,7 +31,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ void __launch_bounds__(256)
 conv4x4_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                    float* __restrict__ y, int B, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride,
-                   int pad, float slope, int m_tiles, int n_tiles, int k_splits, int rows_per_split, float x_slope) {
+                   int pad, float slope, int m_tiles, int n_tiles, int k_splits, int rows_per_split, float x_slope,
+                   float* __restrict__ zero_ptr, long long zero_n) {
+  // side job of the FIRST layer of a forward-only chain (OI_CONV_ZERO_TAIL): clear the part of the arena that the later
+  // layers' split-K sums accumulate into -- one launch less than a separate fill
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += (long long)gridDim.x * blockDim.x)
+    zero_ptr[i] = 0.f;
   const int lane = threadIdx.x & 63;
   const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long n_items = (long long)m_tiles * n_tiles * k_splits;
@@ -541,9 +546,131 @@ __global__ void reflect_pad_kernel(const float* __restrict__ src, float* __restr
   else dst[idx] = src[(bc * H + iy) * W + ix];
 }
 
+// ------------------------------------------------------------------------------------------
+// The ADA geometric augmentation in TWO launches instead of six (augment.py:284-301):
+//   K1  reflect pad + x2 up-FIR (12 taps, zero insertion, gain 4)       x [BC][H][W] -> canvas [BC][2 Hp][2 Wp]
+//   K2  affine bilinear resample onto 2 (H + 6) x 2 (W + 6) + /2 down-FIR   canvas, theta [B][2][3] -> y [BC][H][W]
+// Same arithmetic as the separate passes (upfirdn2d(up = 2, pad 6 / 5, gain 2 per axis), grid_sample(zeros, align_corners =
+// False), upfirdn2d(down = 2, pad -1 / -1, flipped filter)); only the order of the fp32 sums inside a 6 x 6 / 12 x 12
+// window differs.  The padded image, the row-upsampled image, the resampled grid and the row-filtered grid never reach
+// memory.  Linear in x: the adjoint is the existing chain of adjoint kernels (oi_amd.autograd_disc).
+// ------------------------------------------------------------------------------------------
+constexpr int ADA_TAPS = 12, ADA_PAD = ADA_TAPS / 4 * 2;  // Hz_pad * 2 = 6: the grid is 2 (H + 6) x 2 (W + 6)
+
+__global__ void __launch_bounds__(256)
+ada_pad_up2_kernel(const float* __restrict__ x, const float* __restrict__ f, float* __restrict__ canvas, int BC, int H,
+                   int W, int mx0, int my0, int Hp, int Wp) {
+  __shared__ float fr[ADA_TAPS];  // correlation taps of the convolution: reversed, sqrt(gain) = 2 per axis
+  if (threadIdx.x < ADA_TAPS) fr[threadIdx.x] = 2.0f * f[ADA_TAPS - 1 - threadIdx.x];
+  __syncthreads();
+  const int Wc = 2 * Wp, Hc = 2 * Hp;
+  const int u = blockIdx.y, v = blockIdx.x * blockDim.x + threadIdx.x;  // canvas row / column
+  if (v >= Wc) return;
+  const float* xp = x + (size_t)blockIdx.z * H * W;
+  // out[n] = sum_k fr[k] xup[n + k - 6], xup[2 m] = P[m]: the six taps k = k0, k0 + 2, .. with (n + k) even
+  const int ku = u & 1, kv = v & 1;           // first tap of this output's phase (n + k - 6 even <=> k = n mod 2)
+  const int pu = (u + ku - 6) / 2, pv = (v + kv - 6) / 2;  // P index of that tap (arithmetic on a possibly negative even number)
+  int ri[6], ci[6];
+  float wr[6], wc[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    const int r = pu + t, c = pv + t;
+    wr[t] = (r >= 0 && r < Hp) ? fr[ku + 2 * t] : 0.f;  // zero outside the padded image (the FIR's own padding)
+    wc[t] = (c >= 0 && c < Wp) ? fr[kv + 2 * t] : 0.f;
+    ri[t] = reflect_idx(min(max(r, 0), Hp - 1) - my0, H);
+    ci[t] = reflect_idx(min(max(c, 0), Wp - 1) - mx0, W);
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const float* row = xp + (size_t)ri[a] * W;
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) s = fmaf(wc[b], row[ci[b]], s);
+    acc = fmaf(wr[a], s, acc);
+  }
+  canvas[((size_t)blockIdx.z * Hc + u) * Wc + v] = acc;
+}
+
+constexpr int ADA_T = 16;                          // output tile edge
+constexpr int ADA_G = 2 * ADA_T + ADA_TAPS - 2;    // 42: grid points a tile's down-FIR windows cover per axis
+
+__global__ void __launch_bounds__(256)
+ada_resample_down2_kernel(const float* __restrict__ canvas, const float* __restrict__ theta, const float* __restrict__ f,
+                          float* __restrict__ y, int C, int H, int W, int Hc, int Wc) {
+  __shared__ float g[ADA_G][ADA_G + 1];     // resampled grid tile
+  __shared__ float gy[ADA_T][ADA_G + 1];    // after the vertical pass
+  __shared__ float fs[ADA_TAPS];
+  const int tid = threadIdx.x;
+  if (tid < ADA_TAPS) fs[tid] = f[tid];     // flip_filter = True: the correlation taps are the filter itself
+  const int bc = blockIdx.z, b = bc / C;
+  const int ox0 = blockIdx.x * ADA_T, oy0 = blockIdx.y * ADA_T;
+  const int Ho = 2 * (H + ADA_PAD), Wo = 2 * (W + ADA_PAD);
+  const float* cp = canvas + (size_t)bc * Hc * Wc;
+  // y[oy][ox] = sum_{k, l} f[k] f[l] G[2 oy + k + 1][2 ox + l + 1]
+  for (int i = tid; i < ADA_G * ADA_G; i += 256) {
+    const int r = i / ADA_G, c = i % ADA_G;
+    const int gyi = 2 * oy0 + 1 + r, gxi = 2 * ox0 + 1 + c;
+    float v = 0.f;
+    if (gyi < Ho && gxi < Wo) {
+      float ix, iy;
+      affine_src(theta + b * 6, gxi, gyi, Wo, Ho, Wc, Hc, ix, iy);
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fx, y0 = (int)fy;
+      const float tx = ix - fx, ty = iy - fy;
+      if (y0 >= 0 && y0 < Hc) {
+        if (x0 >= 0 && x0 < Wc) v += cp[(size_t)y0 * Wc + x0] * (1.f - tx) * (1.f - ty);
+        if (x0 + 1 >= 0 && x0 + 1 < Wc) v += cp[(size_t)y0 * Wc + x0 + 1] * tx * (1.f - ty);
+      }
+      if (y0 + 1 >= 0 && y0 + 1 < Hc) {
+        if (x0 >= 0 && x0 < Wc) v += cp[(size_t)(y0 + 1) * Wc + x0] * (1.f - tx) * ty;
+        if (x0 + 1 >= 0 && x0 + 1 < Wc) v += cp[(size_t)(y0 + 1) * Wc + x0 + 1] * tx * ty;
+      }
+    }
+    g[r][c] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < ADA_T * ADA_G; i += 256) {  // vertical pass: row 2 t + k of the tile
+    const int t = i / ADA_G, c = i % ADA_G;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < ADA_TAPS; ++k) s = fmaf(fs[k], g[2 * t + k][c], s);
+    gy[t][c] = s;
+  }
+  __syncthreads();
+  {
+    const int t = tid / ADA_T, c = tid % ADA_T;
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < ADA_TAPS; ++l) s = fmaf(fs[l], gy[t][2 * c + l], s);
+    const int oy = oy0 + t, ox = ox0 + c;
+    if (oy < H && ox < W) y[((size_t)bc * H + oy) * W + ox] = s;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int oi_ada_geom_fwd(const float* x, const float* theta, const float* f, float* y, float* canvas, int B, int C, int H, int W,
+                    int mx0, int mx1, int my0, int my1, oi_stream_t stream) {
+  OI_REQUIRE(x && theta && f && y && canvas, "oi_ada_geom_fwd: null pointer");
+  OI_REQUIRE(B > 0 && C > 0 && H > 1 && W > 1, "oi_ada_geom_fwd: bad shape");
+  OI_REQUIRE(mx0 >= 0 && mx1 >= 0 && my0 >= 0 && my1 >= 0 && mx0 < W && mx1 < W && my0 < H && my1 < H,
+             "oi_ada_geom_fwd: reflect margins must be in [0, size)");
+  const long long BC = (long long)B * C;
+  OI_REQUIRE(BC <= 65535, "oi_ada_geom_fwd: %lld planes exceed the launch grid", BC);
+  const int Hp = H + my0 + my1, Wp = W + mx0 + mx1;
+  OI_REQUIRE(2 * Hp <= 65535, "oi_ada_geom_fwd: canvas of %d rows", 2 * Hp);
+  hipStream_t st = oi::as_stream(stream);
+  hipLaunchKernelGGL(ada_pad_up2_kernel, dim3(oi::cdiv(2 * Wp, 256), 2 * Hp, (unsigned)BC), dim3(256), 0, st, x, f, canvas,
+                     (int)BC, H, W, mx0, my0, Hp, Wp);
+  int rc = oi::check_launch("oi_ada_geom_fwd(pad + upsample)");
+  if (rc != OI_OK) return rc;
+  hipLaunchKernelGGL(ada_resample_down2_kernel, dim3(oi::cdiv(W, ADA_T), oi::cdiv(H, ADA_T), (unsigned)BC), dim3(256), 0, st,
+                     canvas, theta, f, y, C, H, W, 2 * Hp, 2 * Wp);
+  return oi::check_launch("oi_ada_geom_fwd(resample + downsample)");
+}
 
 int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,
                    int stride, int pad, float slope, oi_stream_t stream) {
@@ -553,7 +680,14 @@ int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, 
 int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
                         int Cout, int stride, int pad, float slope, float x_slope, int flags,
                         oi_stream_t stream) {
+  return oi_conv4x4_fwd_arena(x, w, bias, y, B, Cin, H, W, Cout, stride, pad, slope, x_slope, flags, 0, stream);
+}
+
+int oi_conv4x4_fwd_arena(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W,
+                         int Cout, int stride, int pad, float slope, float x_slope, int flags, long long zero_tail_floats,
+                         oi_stream_t stream) {
   OI_REQUIRE(x && w && y, "oi_conv4x4_fwd: null pointer");
+  OI_REQUIRE(zero_tail_floats >= 0, "oi_conv4x4_fwd_arena: zero_tail_floats %lld", zero_tail_floats);
   OI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && stride > 0 && pad >= 0, "oi_conv4x4_fwd: bad shape");
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
   OI_REQUIRE(Ho > 0 && Wo > 0, "oi_conv4x4_fwd: input %dx%d too small", H, W);
@@ -578,6 +712,10 @@ int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float
     const long long total = (long long)B * Cout * Ho * Wo;
     if (splits == 2 && !y_is_zero) {
       hipError_t e = oi::zero_async(y, total, st);
+      if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_fwd: zero fill: %s", hipGetErrorString(e));
+    }
+    if (zero_tail_floats > 0) {
+      hipError_t e = oi::zero_async(y + (total + 3) / 4 * 4, zero_tail_floats, st);
       if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_fwd: zero fill: %s", hipGetErrorString(e));
     }
     dim3 grid(oi::cdiv(M, small ? 64 : 128), Cout / 64, splits), block(256);
@@ -609,8 +747,17 @@ int oi_conv4x4_fwd_into(const float* x, const float* w, const float* bias, float
     if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_fwd: memset: %s", hipGetErrorString(e));
   }
   const long long items = tiles * k_splits;
+  // the tail of the arena (behind this layer's own output, rounded up to 4 floats as the caller lays it out) is cleared by
+  // this launch when the layer itself does not accumulate (no split-K); otherwise by a fill of its own
+  float* tail = y + (total + 3) / 4 * 4;
+  if (zero_tail_floats > 0 && k_splits > 1) {
+    hipError_t e = oi::zero_async(tail, zero_tail_floats, st);
+    if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_fwd: memset: %s", hipGetErrorString(e));
+    zero_tail_floats = 0;
+  }
   hipLaunchKernelGGL(conv4x4_fwd_kernel, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, x, w, bias, y, B, Cin, H, W,
-                     Cout, Ho, Wo, stride, pad, slope, m_tiles, n_tiles, k_splits, rows_per_split, x_slope);
+                     Cout, Ho, Wo, stride, pad, slope, m_tiles, n_tiles, k_splits, rows_per_split, x_slope, tail,
+                     zero_tail_floats);
   int rc = oi::check_launch("oi_conv4x4_fwd");
   if (rc != OI_OK) return rc;
   if (k_splits > 1 && (slope != 1.0f || bias != nullptr)) {

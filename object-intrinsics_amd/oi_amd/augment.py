@@ -9,7 +9,13 @@ built from the same kernels (arbitrary order, as the reference's upfirdn2d / gri
 import numpy as np
 import torch
 
-from .autograd_disc import affine_grid_sample, reflect_pad, upfirdn2d_separable
+import os
+
+from .autograd_disc import ada_geom, affine_grid_sample, reflect_pad, upfirdn2d_separable
+
+# OI_ADA_FUSED=0: the four stages as separate kernels (the round-1 / round-2 path; kept for A/B and as the second opinion of
+# tests/test_gpu_kernels.py::test_ada_geom_fused_matches_the_staged_chain)
+FUSED = os.environ.get("OI_ADA_FUSED", "1") != "0"
 
 SYM6 = [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633,
         0.4910559419267466, 0.787641141030194, 0.3379294217276218, -0.07263752278646252,
@@ -56,6 +62,9 @@ class AugmentPipe(torch.nn.Module):
         self.scale, self.rotate, self.aniso, self.xfrac = float(scale), float(rotate), float(aniso), float(xfrac)
         self.scale_std, self.rotate_max = float(scale_std), float(rotate_max)
         self.aniso_std, self.xfrac_std = float(aniso_std), float(xfrac_std)
+        self._only_xint_scale = (self.xint > 0 and self.scale > 0 and
+                                 not any(v > 0 for v in (self.xflip, self.rotate90, self.rotate, self.aniso, self.xfrac)))
+        self._theta_ab = {}
         f = torch.tensor(SYM6, dtype=torch.float32)
         self.register_buffer("Hz_geom", f / f.sum())
         # kept for state_dict compatibility with the reference (augment.py:171-179); unused here
@@ -87,6 +96,39 @@ class AugmentPipe(torch.nn.Module):
 
         rand = lambda *s: np.random.rand(*s).astype(f32)
         randn = lambda *s: np.random.randn(*s).astype(f32)
+        if self._only_xint_scale:
+            # the shipped configuration (train.yaml:80-85) in closed form -- same draws in the same order, same fp32 values as
+            # the generic branches below (translate2d(-round(t W), -round(t H)) @ scale2d(1/s, 1/s)), a tenth of the host time:
+            # at batch 1 the augmentation parameters cost more than the whole discriminator forward on the GPU
+            if B <= 4 and pct is None:
+                # tiny batches: the same fp32 operations on numpy SCALARS (an array op costs ~1 us whatever its size)
+                r_t, r_tg = np.random.rand(B, 2), np.random.rand(B, 1)
+                r_s, r_sg = np.random.randn(B), np.random.rand(B)
+                G = np.zeros((B, 3, 3), f32)
+                xm, ss, two, one = f32(self.xint_max), f32(self.scale_std), f32(2), f32(1)
+                for i in range(B):
+                    on = f32(r_tg[i, 0]) < self.xint * p
+                    tx = (f32(r_t[i, 0]) * two - one) * xm if on else f32(0)
+                    ty = (f32(r_t[i, 1]) * two - one) * xm if on else f32(0)
+                    sc = np.exp2(f32(r_s[i]) * ss) if f32(r_sg[i]) < self.scale * p else one
+                    G[i, 0, 0] = G[i, 1, 1] = one / sc
+                    G[i, 0, 2] = -np.round(tx * f32(W))
+                    G[i, 1, 2] = -np.round(ty * f32(H))
+                    G[i, 2, 2] = 1
+                return G
+            t = (rand(B, 2) * 2 - 1) * f32(self.xint_max)
+            t = np.where(rand(B, 1) < self.xint * p, t, 0).astype(f32)
+            s = np.exp2(randn(B) * f32(self.scale_std))
+            s = np.where(rand(B) < self.scale * p, s, 1).astype(f32)
+            if pct is not None:
+                t = np.full((B, 2), (f32(pct) * 2 - 1) * f32(self.xint_max), f32)
+                s = np.full(B, np.exp2(f32(_erfinv(pct * 2 - 1)) * f32(self.scale_std)), f32)
+            G = np.zeros((B, 3, 3), f32)
+            G[:, 0, 0] = G[:, 1, 1] = f32(1) / s
+            G[:, 0, 2] = -np.round(t[:, 0] * f32(W))
+            G[:, 1, 2] = -np.round(t[:, 1] * f32(H))
+            G[:, 2, 2] = 1
+            return G
         if self.xflip > 0:
             i = np.floor(rand(B) * 2)
             i = np.where(rand(B) < self.xflip * p, i, 0).astype(f32)
@@ -165,6 +207,21 @@ class AugmentPipe(torch.nn.Module):
         B = G_inv.shape[0]
         mx0, my0, mx1, my1 = margins
         Hz_pad = self.Hz_geom.shape[0] // 4
+        if mx0 == mx1 and my0 == my1:
+            # symmetric (e.g. static) margins: the first factor is the identity; the constant pre / post factors are composed
+            # once per shape in fp64 (they are powers of two, +-0.5 shifts and one 2 / size scale), so theta = L @ G_inv @ R:
+            # two products instead of seven (the fp32 chain below agrees to 1 ulp; at batch 1 this code, not the GPU, set the
+            # discriminator's image rate)
+            key = (mx0, my0, H, W)
+            ab = self._theta_ab.get(key)
+            if ab is None:
+                d = lambda m_: m_[0].astype(np.float64)
+                Ho, Wo = (H + Hz_pad * 2) * 2, (W + Hz_pad * 2) * 2
+                Wp, Hp = (W + mx0 + mx1) * 2, (H + my0 + my1) * 2
+                L = d(scale2d(2 / Wp, 2 / Hp, 1)) @ d(translate2d(-0.5, -0.5, 1)) @ d(scale2d(2, 2, 1))
+                R = d(scale2d(0.5, 0.5, 1)) @ d(translate2d(0.5, 0.5, 1)) @ d(scale2d(Wo / 2, Ho / 2, 1))
+                ab = self._theta_ab[key] = (L[:2], R)
+            return np.ascontiguousarray((ab[0] @ G_inv.astype(np.float64) @ ab[1]).astype(f32))
         mm = lambda a, b: (a @ b).astype(f32)
         G_inv = mm(translate2d((mx0 - mx1) / 2, (my0 - my1) / 2, B), G_inv)
         G_inv = mm(mm(scale2d(2, 2, B), G_inv), scale2d(0.5, 0.5, B))
@@ -180,6 +237,8 @@ class AugmentPipe(torch.nn.Module):
         B, C, H, W = images.shape
         mx0, my0, mx1, my1 = margins
         Hz_pad = self.Hz_geom.shape[0] // 4
+        if FUSED and self.Hz_geom.shape[0] == 12 and B * C <= 65535:
+            return ada_geom(images, theta, self.Hz_geom, margins)   # the same four stages in two launches
         x = reflect_pad(images, mx0, mx1, my0, my1)
         x = upfirdn2d_separable(x, self.Hz_geom, up=2, pad=(6, 5, 6, 5), flip=False, gain=4.0)  # upsample2d
         Ho, Wo = (H + Hz_pad * 2) * 2, (W + Hz_pad * 2) * 2

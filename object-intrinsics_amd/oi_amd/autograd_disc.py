@@ -108,6 +108,53 @@ def reflect_pad(x, px0, px1, py0, py1):
 
 
 # ------------------------------------------------------------------------------------------
+# the whole geometric augmentation (reflect pad -> x2 up-FIR -> affine resample -> /2 down-FIR) as ONE node: two launches
+# forward (oi_ada_geom_fwd).  The map is linear in the images, so nothing is saved but theta; the backward is the chain of
+# the four adjoint Functions above (themselves differentiable: the R1 double backward comes back through the forward ops).
+# ------------------------------------------------------------------------------------------
+def _ada_geom_adjoint(gy, theta, f1, H, W, margins):
+    mx0, my0, mx1, my1 = margins
+    Hp, Wp = H + my0 + my1, W + mx0 + mx1
+    Hz_pad = f1.shape[0] // 4
+    Ho, Wo = (H + Hz_pad * 2) * 2, (W + Hz_pad * 2) * 2
+    n = f1.shape[0]
+    # adjoint of upfirdn2d(x, f, up, down, pads, flip, g) on an input of `size`: upfirdn2d with up <-> down, the other flip
+    # and the pads of upfirdn2d.py:243-262 -- one axis at a time, in reverse order of the forward's x-then-y passes
+    def adj_y(g, up, down, p0, size_in, flip, gain):
+        oh = g.shape[2]
+        return upfirdn2d(g, f1[:, None], 1, down, 1, up, 0, 0, n - p0 - 1, size_in * up - oh * down + p0 - up + 1, not flip, gain)
+
+    def adj_x(g, up, down, p0, size_in, flip, gain):
+        ow = g.shape[3]
+        return upfirdn2d(g, f1[None, :], down, 1, up, 1, n - p0 - 1, size_in * up - ow * down + p0 - up + 1, 0, 0, not flip, gain)
+
+    g = adj_y(gy, 1, 2, -1, Ho, True, 1.0)          # downsample2d(padding = -2 Hz_pad, flip_filter): pads (-1, -1)
+    g = adj_x(g, 1, 2, -1, Wo, True, 1.0)
+    g = _AffineGridSampleBwd.apply(g, theta, 2 * Hp, 2 * Wp)
+    g = adj_y(g, 2, 1, 6, Hp, False, 2.0)           # upsample2d: pads (6, 5), gain 4 = 2 per axis
+    g = adj_x(g, 2, 1, 6, Wp, False, 2.0)
+    return _ReflectPadBwd.apply(g, H, W, mx0, mx1, my0, my1)
+
+
+class _AdaGeom(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, theta, f1, margins):
+        ctx.save_for_backward(theta, f1)
+        ctx.cfg = (x.shape[2], x.shape[3], tuple(margins))
+        return ops.ada_geom_fwd(x, theta, f1, margins)
+
+    @staticmethod
+    def backward(ctx, gy):
+        theta, f1 = ctx.saved_tensors
+        H, W, margins = ctx.cfg
+        return _ada_geom_adjoint(gy, theta, f1, H, W, margins), None, None, None
+
+
+def ada_geom(x, theta, f1, margins):
+    return _AdaGeom.apply(x, theta.detach(), f1, tuple(int(m) for m in margins))
+
+
+# ------------------------------------------------------------------------------------------
 # conv 4x4 (+ fused LeakyReLU)
 # ------------------------------------------------------------------------------------------
 def conv4x4_lrelu(x, w, bias, stride, pad, slope):

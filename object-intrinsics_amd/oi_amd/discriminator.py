@@ -45,13 +45,15 @@ class DCDiscriminator(nn.Module):
             shp = ops.conv4x4_out_shape(shp, w.shape[0], stride, pad)
             shapes.append(shp)
         sizes = [(s[0] * s[1] * s[2] * s[3] + 3) // 4 * 4 for s in shapes]
-        arena = torch.zeros(sum(sizes), dtype=torch.float32, device=x.device)
+        # no fill launch: the first layer (K = 16 in_dim taps: never split) clears the rest of the arena while it runs
+        arena = torch.empty(sum(sizes), dtype=torch.float32, device=x.device)
         off = 0
         x_slope = 1.0
         for i, ((w, b, stride, pad, slope), s, n) in enumerate(zip(layers, shapes, sizes)):
             last = i == len(layers) - 1
             x = ops.conv4x4_fwd(x, w, b, stride, pad, slope if last else 1.0, x_slope=x_slope,
-                                out=arena[off:off + s[0] * s[1] * s[2] * s[3]].view(s))
+                                out=arena[off:off + s[0] * s[1] * s[2] * s[3]].view(s),
+                                zero_tail=sum(sizes) - sizes[0] if i == 0 else 0, out_is_zero=i > 0)
             x_slope = slope  # this block's activation, deferred to the next layer's loads
             off += n
         return x

@@ -67,11 +67,13 @@ _SIGS = {
     "oi_composite_fwd": (_i, [ctypes.POINTER(CompositeParams), _vp]),
     "oi_conv4x4_fwd": (_i, [_vp] * 4 + [_i] * 7 + [_f, _vp]),
     "oi_conv4x4_fwd_into": (_i, [_vp] * 4 + [_i] * 7 + [_f, _f, _i, _vp]),
+    "oi_conv4x4_fwd_arena": (_i, [_vp] * 4 + [_i] * 7 + [_f, _f, _i, ctypes.c_longlong, _vp]),
     "oi_conv4x4_dgrad": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
     "oi_conv4x4_wgrad": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
     "oi_lrelu_mask_mul": (_i, [_vp] * 3 + [_ll, _f, _vp]),
     "oi_channel_sum": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "oi_upfirdn2d": (_i, [_vp] * 3 + [_i] * 14 + [_f, _vp]),
+    "oi_ada_geom_fwd": (_i, [_vp] * 5 + [_i] * 8 + [_vp]),
     "oi_affine_grid_sample_fwd": (_i, [_vp] * 3 + [_i] * 6 + [_vp]),
     "oi_affine_grid_sample_bwd": (_i, [_vp] * 3 + [_i] * 6 + [_vp]),
     "oi_fused_bias_act": (_i, [_vp] * 4 + [_i, _i, _f, _f, _ll, _ll, _i, _vp]),

@@ -311,7 +311,8 @@ def conv4x4_out_shape(x_shape, Cout, stride, pad):
     return B, Cout, (H + 2 * pad - 4) // stride + 1, (W + 2 * pad - 4) // stride + 1
 
 
-def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2, out=None, x_slope=1.0, any_scale=False):
+def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2, out=None, x_slope=1.0, any_scale=False, zero_tail=0,
+                out_is_zero=None):
     """y = lrelu_slope(conv(lrelu_x_slope(x)) + bias).  `out`: optional ZERO-FILLED contiguous output (e.g. a view of an
     arena shared by a chain of layers): the split-K path then needs no fill launch of its own.  `x_slope`: LeakyReLU
     applied to x while it is loaded (the producing layer handed over pre-activations).  `any_scale`: an operand may be a
@@ -327,8 +328,12 @@ def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2, out=None, x_slope=1
     else:
         assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.float32, (out.shape, shape)
         y = out
-    _l.check(L.oi_conv4x4_fwd_into(_p(x), _p(w), _p(_c(bias)), _p(y), B, Cin, H, W, Cout, stride, pad, float(slope),
-                                   float(x_slope), int(out is not None) | (2 if any_scale else 0), _stream()), "oi_conv4x4_fwd")
+    # `zero_tail`: floats of the arena behind `out` that this launch also clears (oi_conv4x4_fwd_arena);
+    # `out_is_zero`: whether `out` already holds zeros (default: it does when given)
+    zero = (out is not None) if out_is_zero is None else bool(out_is_zero)
+    _l.check(L.oi_conv4x4_fwd_arena(_p(x), _p(w), _p(_c(bias)), _p(y), B, Cin, H, W, Cout, stride, pad, float(slope),
+                                    float(x_slope), int(zero) | (2 if any_scale else 0), int(zero_tail), _stream()),
+             "oi_conv4x4_fwd")
     return y
 
 
@@ -380,6 +385,20 @@ def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, p
     y = _new(x, B, C, Ho, Wo)
     _l.check(L.oi_upfirdn2d(_p(x), _p(f), _p(y), B * C, H, W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0,
                             pady1, int(bool(flip)), float(gain), _stream()), "oi_upfirdn2d")
+    return y
+
+
+def ada_geom_fwd(x, theta, f12, margins):
+    """reflect pad + x2 up-FIR + affine resample + /2 down-FIR (AugmentPipe geometry) in two launches; see oi_ada_geom_fwd."""
+    L = _l.load()
+    x, theta, f12 = _c(x), _c(theta), _c(f12)
+    B, C, H, W = x.shape
+    mx0, my0, mx1, my1 = margins
+    assert f12.numel() == 12 and theta.shape == (B, 2, 3)
+    y = torch.empty_like(x)
+    canvas = _new(x, B * C * 2 * (H + my0 + my1) * 2 * (W + mx0 + mx1))
+    _l.check(L.oi_ada_geom_fwd(_p(x), _p(theta), _p(f12), _p(y), _p(canvas), B, C, H, W, mx0, mx1, my0, my1, _stream()),
+             "oi_ada_geom_fwd")
     return y
 
 

@@ -538,3 +538,32 @@ def test_upfirdn2d_more_planes_than_one_launch_grid(ops):
     ref = F.conv2d(F.pad(u, [2, 1, 0, 0]).view(65539, 1, 4, 11), f.double().flip(0).view(1, 1, 1, 4)).view(1, 65539, 4, 8)
     assert tuple(y.shape) == (1, 65539, 4, 8)
     assert maxdiff(y.cpu(), ref) < 1e-6
+
+
+@pytest.mark.parametrize("B,C,R,static", [(2, 3, 64, True), (3, 1, 32, False), (1, 3, 128, True)])
+def test_ada_geom_fused_matches_the_staged_chain(ops, B, C, R, static, monkeypatch):
+    """oi_ada_geom_fwd (pad + up-FIR | resample + down-FIR: two launches) against the four separate stages it replaces, for
+    translations, scales and a rotation, with fitted and with static margins: values, the gradient to the images (the fused
+    node's backward is the adjoint chain) and the double backward an R1 penalty takes."""
+    import oi_amd.augment as A
+    aug = A.AugmentPipe(xint=1, scale=1, rotate=1).cuda()
+    np.random.seed(B * 7 + R)
+    x = torch.rand(B, C, R, R, generator=torch.Generator().manual_seed(R)).cuda()
+    G = aug.sample_G_inv(x)
+    margins = aug.static_margins(R, R) if static else aug.margins_for(G, R, R)
+    theta = torch.from_numpy(aug.theta_for(G, margins, R, R)).cuda()
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(A, "FUSED", fused)
+        xi = x.clone().requires_grad_()
+        y = aug.apply_theta(xi, theta, margins)
+        cot = torch.rand(y.shape, generator=torch.Generator().manual_seed(1)).cuda()
+        (gx,) = torch.autograd.grad((y * cot).sum(), xi, create_graph=True)
+        # R1-style second order: d/dx of |gx|^2 contracted with another direction goes back through the forward ops
+        xi2 = x.clone().requires_grad_()
+        y2 = aug.apply_theta(xi2, theta, margins)
+        (g1,) = torch.autograd.grad(y2.square().sum(), xi2, create_graph=True)
+        (g2,) = torch.autograd.grad(g1.square().sum(), xi2)
+        outs.append((y.detach(), gx.detach(), g2.detach()))
+    for name, a, b in zip(("value", "gradient", "double backward"), outs[0], outs[1]):
+        assert maxdiff(a, b) < 2e-6 * max(1.0, float(b.abs().max())), (name, maxdiff(a, b), float(b.abs().max()))
