@@ -601,6 +601,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   // the transposed image of layer l sits in image slot l & 1, its FiLM rows in FiLM slot l & 1; phi_l / vbar_l of the WHOLE
   // layer are requested one layer ahead (128 registers: the reason this kernel runs one wave per SIMD)
   f32x4 phn[16], vbn[16];
+  f32x4 abl_sink;  // (OI_BWD_ABL & 8)
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     phn[g] = ws.load(S_PHI + 7, g, o.l16);
@@ -661,6 +662,10 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         if constexpr (!L0 && !(OI_BWD_ABL & 2)) {
           phn[g] = ws.load(S_PHI + l - 1, g, o.l16);
           vbn[g] = ws.load(S_VB + l - 1, g, o.l16);
+        }
+        if constexpr (!L0 && (OI_BWD_ABL & 8)) {  // timing ablation: the loads are ISSUED but nothing ever waits for them
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen offset:1024 nt"
+                       : "=&v"(abl_sink) : "v"(o.l16), "s"(ws.rs));
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);

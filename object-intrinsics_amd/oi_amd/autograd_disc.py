@@ -113,41 +113,58 @@ def reflect_pad(x, px0, px1, py0, py1):
 # the four adjoint Functions above (themselves differentiable: the R1 double backward comes back through the forward ops).
 # ------------------------------------------------------------------------------------------
 def _ada_geom_adjoint(gy, theta, f1, H, W, margins):
+    """A^T gy with the raw kernels (no autograd nodes: the caller is a Function whose own backward is the forward map)."""
     mx0, my0, mx1, my1 = margins
     Hp, Wp = H + my0 + my1, W + mx0 + mx1
     Hz_pad = f1.shape[0] // 4
     Ho, Wo = (H + Hz_pad * 2) * 2, (W + Hz_pad * 2) * 2
     n = f1.shape[0]
+    fx, fy = f1[None, :], f1[:, None]
     # adjoint of upfirdn2d(x, f, up, down, pads, flip, g) on an input of `size`: upfirdn2d with up <-> down, the other flip
     # and the pads of upfirdn2d.py:243-262 -- one axis at a time, in reverse order of the forward's x-then-y passes
     def adj_y(g, up, down, p0, size_in, flip, gain):
-        oh = g.shape[2]
-        return upfirdn2d(g, f1[:, None], 1, down, 1, up, 0, 0, n - p0 - 1, size_in * up - oh * down + p0 - up + 1, not flip, gain)
+        return ops.upfirdn2d(g, fy, 1, down, 1, up, 0, 0, n - p0 - 1, size_in * up - g.shape[2] * down + p0 - up + 1,
+                             not flip, gain)
 
     def adj_x(g, up, down, p0, size_in, flip, gain):
-        ow = g.shape[3]
-        return upfirdn2d(g, f1[None, :], down, 1, up, 1, n - p0 - 1, size_in * up - ow * down + p0 - up + 1, 0, 0, not flip, gain)
+        return ops.upfirdn2d(g, fx, down, 1, up, 1, n - p0 - 1, size_in * up - g.shape[3] * down + p0 - up + 1, 0, 0,
+                             not flip, gain)
 
     g = adj_y(gy, 1, 2, -1, Ho, True, 1.0)          # downsample2d(padding = -2 Hz_pad, flip_filter): pads (-1, -1)
     g = adj_x(g, 1, 2, -1, Wo, True, 1.0)
-    g = _AffineGridSampleBwd.apply(g, theta, 2 * Hp, 2 * Wp)
+    g = ops.affine_grid_sample_bwd(g, theta, 2 * Hp, 2 * Wp)
     g = adj_y(g, 2, 1, 6, Hp, False, 2.0)           # upsample2d: pads (6, 5), gain 4 = 2 per axis
     g = adj_x(g, 2, 1, 6, Wp, False, 2.0)
-    return _ReflectPadBwd.apply(g, H, W, mx0, mx1, my0, my1)
+    return ops.reflect_pad_bwd(g, H, W, mx0, mx1, my0, my1)
 
 
 class _AdaGeom(torch.autograd.Function):
+    """y = A(theta) x.  backward: A^T (as _AdaGeomAdjoint); the backward of THAT is this forward again -- so the double
+    backward an R1 penalty takes runs the two fused launches too, not six separate stages."""
+
     @staticmethod
     def forward(ctx, x, theta, f1, margins):
         ctx.save_for_backward(theta, f1)
-        ctx.cfg = (x.shape[2], x.shape[3], tuple(margins))
+        ctx.margins = tuple(margins)
         return ops.ada_geom_fwd(x, theta, f1, margins)
 
     @staticmethod
     def backward(ctx, gy):
         theta, f1 = ctx.saved_tensors
-        H, W, margins = ctx.cfg
-        return _ada_geom_adjoint(gy, theta, f1, H, W, margins), None, None, None
+        return _AdaGeomAdjoint.apply(gy, theta, f1, ctx.margins), None, None, None
+
+
+class _AdaGeomAdjoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy, theta, f1, margins):
+        ctx.save_for_backward(theta, f1)
+        ctx.margins = tuple(margins)
+        return _ada_geom_adjoint(gy, theta, f1, gy.shape[2], gy.shape[3], margins)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        theta, f1 = ctx.saved_tensors
+        return _AdaGeom.apply(ggx, theta, f1, ctx.margins), None, None, None
 
 
 def ada_geom(x, theta, f1, margins):

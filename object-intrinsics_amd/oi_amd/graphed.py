@@ -134,7 +134,7 @@ class GraphedDStep:
         d_real = disc(x_real, aug_theta=th_real)[:, :1]
         loss_real = self.gan(d_real, 1)
         loss_reg = compute_grad2(d_real, x_real)
-        x_fake = self.x_fake.detach().clone().requires_grad_()
+        x_fake = self.x_fake   # (the reference marks it requires_grad too: a gradient nothing reads)
         d_fake = disc(x_fake, aug_theta=th_fake)
         loss_aux = torch.zeros((), device=x_real.device)
         if d_fake.size(1) > 1:
@@ -142,7 +142,8 @@ class GraphedDStep:
             loss_aux = self.aux_pose(d_aux, self.prior.pose_to_vec_repr(self.c2b))
         loss_fake = self.gan(d_fake, 0)
         loss = loss_real + loss_fake + loss_reg * self.reg_weight + loss_aux * self.aux_w
-        loss.backward()
+        # only the parameters' gradients: not the images' (see oi_amd.trainer._backward_to)
+        torch.autograd.backward(loss, inputs=[p for p in self._net().parameters() if p.requires_grad])
         return torch.stack([loss_fake + loss_real, loss_reg, loss_fake, loss_real, loss_aux])
 
     @staticmethod

@@ -47,6 +47,19 @@ class _GradToggle:
         self.state[key] = requires_grad
 
 
+def _cat(tensors):
+    """torch.cat along the channel axis; a single tensor is returned as is (both discriminators take ONE map:
+    MODULE_KEYS_TO_DATA_KEYS of gan_pose_trainer.py:27-31 -- the reference's cat of one tensor is a copy launch)."""
+    return tensors[0] if len(tensors) == 1 else torch.cat(tensors, dim=-3)
+
+
+def _backward_to(loss, net):
+    """loss.backward() restricted to the network's parameters: the reference marks the discriminator INPUTS as requiring
+    grad (gan_pose_trainer.py:160, 168) and so also back-propagates both losses through the augmentation into the images,
+    a gradient nothing reads; the R1 term's own second-order path is unaffected."""
+    torch.autograd.backward(loss, inputs=[p for p in net.parameters() if p.requires_grad])
+
+
 def _unwrap(m):
     return m.module if hasattr(m, "module") and isinstance(m.module, torch.nn.Module) else m
 
@@ -111,9 +124,9 @@ class Trainer:
             self._toggle(k, self.modules[k], k == "generator")
         _zero_grad(self.generator, self.opt_generator)
         blob = self.generator(bs=bs, it=self.it, data={}, return_raw=False)["box"]
-        x_fake = torch.cat([blob["render_out"][k] for k in DATA_KEYS["discriminator"]], dim=-3)
+        x_fake = _cat([blob["render_out"][k] for k in DATA_KEYS["discriminator"]])
         loss_disc = self.gan(self.discriminator(x_fake, it=self.it)[:, :1], 1)
-        m_fake = torch.cat([blob["render_out"][k] for k in DATA_KEYS["mask_discriminator"]], dim=-3)
+        m_fake = _cat([blob["render_out"][k] for k in DATA_KEYS["mask_discriminator"]])
         loss_mask = self.gan(self.mask_discriminator(m_fake, it=self.it), 1)
         loss = loss_disc * self.loss_weight["disc_in_gen"] + loss_mask * self.loss_weight["mask_disc_in_gen"]
         ret = {"generator/loss": loss_disc, "generator/loss_mask": loss_mask}
@@ -132,11 +145,11 @@ class Trainer:
         if self._graphed is not None:
             return self._graphed_d_step(key, disc, opt, real, fake, defer_step)
         _zero_grad(disc, opt)
-        x_real = torch.cat([real[k] for k in DATA_KEYS[key]], dim=-3).detach().clone().requires_grad_()
+        x_real = _cat([real[k] for k in DATA_KEYS[key]]).detach().clone().requires_grad_()
         d_real = disc(x_real, it=self.it)[:, :1]
         loss_real = self.gan(d_real, 1)
         loss_reg = compute_grad2(d_real, x_real)
-        x_fake = torch.cat([fake[k] for k in DATA_KEYS[key]], dim=-3).detach().clone().requires_grad_()
+        x_fake = _cat([fake[k] for k in DATA_KEYS[key]]).detach()   # (the reference also marks it requires_grad: unused)
         d_fake = disc(x_fake, it=self.it)
         loss_aux = 0
         if d_fake.size(1) > 1:
@@ -145,7 +158,7 @@ class Trainer:
             loss_aux = self.aux_pose(d_aux, prior.pose_to_vec_repr(fake["c2b"]))
         loss_fake = self.gan(d_fake, 0)
         loss = loss_real + loss_fake + loss_reg * self.loss_weight["reg"] + loss_aux * self.loss_weight["aux_pose"](self.it)
-        loss.backward()
+        _backward_to(loss, disc)
         ret = {f"{key}/loss": loss_fake + loss_real, f"{key}/reg": loss_reg, f"{key}/fake": loss_fake,
                f"{key}/real": loss_real, f"{key}/aux_pose": loss_aux}
 
@@ -164,8 +177,8 @@ class Trainer:
         if gd is None:
             gd = self._graphed[key] = GraphedDStep(disc, self.gan, self.aux_pose, self.loss_weight["reg"],
                                                    _unwrap(self.generator).pose_prior)
-        x_real = torch.cat([real[k] for k in DATA_KEYS[key]], dim=-3).detach()
-        x_fake = torch.cat([fake[k] for k in DATA_KEYS[key]], dim=-3).detach()
+        x_real = _cat([real[k] for k in DATA_KEYS[key]]).detach()
+        x_fake = _cat([fake[k] for k in DATA_KEYS[key]]).detach()
         has_aux = _unwrap(disc).out_dim > 1
         out = gd(x_real, x_fake, fake["c2b"].detach() if has_aux else None,
                  self.loss_weight["aux_pose"](self.it) if has_aux else 0.0)
