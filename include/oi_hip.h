@@ -368,6 +368,14 @@ int oi_affine_grid_sample_fwd(const float* x, const float* theta, float* y, int 
 int oi_affine_grid_sample_bwd(const float* gy, const float* theta, float* gx, int B, int C, int Hi,
                               int Wi, int Ho, int Wo, oi_stream_t stream);
 
+/* Outputs that are ACCUMULATED into (the split-K sums of oi_conv4x4_fwd* / oi_conv4x4_wgrad, the scatter-adds of
+ * oi_conv4x4_dgrad, oi_affine_grid_sample_bwd, oi_grid_sample_bwd, oi_reflect_pad_bwd) are cleared by their launcher with a
+ * fill of their own.  A caller that takes every such output from memory it has already zeroed -- one fill per training step
+ * instead of ~90 -- declares so: oi_outputs_prezeroed(1) ... oi_outputs_prezeroed(0).  The setting is process-wide (a
+ * backward pass issues its launches from the framework's autograd thread); it returns the previous setting.
+ * (oi_amd.ops.ZeroPool does this around a captured discriminator step.) */
+int oi_outputs_prezeroed(int on);
+
 /* The whole geometric augmentation of AugmentPipe.forward (src/third_party/ada/augment.py:284-301) for a given sampling
  * grid, in two launches: reflect pad (margins mx0, mx1, my0, my1) + x2 up-FIR | affine bilinear resample + /2 down-FIR.
  *   x [B][C][H][W], theta [B][2][3] (the matrix F.affine_grid receives, augment.py:297), f: the 12 taps of Hz_geom

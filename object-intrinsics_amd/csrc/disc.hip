@@ -711,7 +711,7 @@ int oi_conv4x4_fwd_arena(const float* x, const float* w, const float* bias, floa
     const int k_per_split = splits == 2 ? ((K / 2 + 63) / 64) * 64 : K;
     const long long total = (long long)B * Cout * Ho * Wo;
     if (splits == 2 && !y_is_zero) {
-      hipError_t e = oi::zero_async(y, total, st);
+      hipError_t e = oi::zero_output_async(y, total, st);
       if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_fwd: zero fill: %s", hipGetErrorString(e));
     }
     if (zero_tail_floats > 0) {
@@ -743,7 +743,7 @@ int oi_conv4x4_fwd_arena(const float* x, const float* w, const float* bias, floa
   k_splits = oi::cdiv(krows, rows_per_split);
   const long long total = (long long)B * Cout * Ho * Wo;
   if (k_splits > 1 && !y_is_zero) {
-    hipError_t e = oi::zero_async(y, total, st);
+    hipError_t e = oi::zero_output_async(y, total, st);
     if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_fwd: memset: %s", hipGetErrorString(e));
   }
   const long long items = tiles * k_splits;
@@ -807,7 +807,7 @@ int oi_affine_grid_sample_bwd(const float* gy, const float* theta, float* gx, in
   OI_REQUIRE(gy && theta && gx, "oi_affine_grid_sample_bwd: null pointer");
   OI_REQUIRE(B > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "oi_affine_grid_sample_bwd: bad shape");
   hipStream_t st = oi::as_stream(stream);
-  hipError_t e = oi::zero_async(gx, (size_t)B * C * Hi * Wi, st);
+  hipError_t e = oi::zero_output_async(gx, (size_t)B * C * Hi * Wi, st);
   if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_affine_grid_sample_bwd: memset: %s", hipGetErrorString(e));
   const long long n = (long long)B * C * Ho * Wo;
   hipLaunchKernelGGL(affine_grid_sample_bwd_kernel, dim3(oi::cdiv(n, 256)), dim3(256), 0, st, gy, theta, gx, B, C, Hi,
@@ -843,7 +843,7 @@ int oi_grid_sample_bwd(const float* gy, const float* x, const float* grid, float
   OI_REQUIRE(N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "oi_grid_sample_bwd: bad shape");
   hipStream_t st = oi::as_stream(stream);
   if (gx != nullptr) {
-    hipError_t e = oi::zero_async(gx, (size_t)N * C * Hi * Wi, st);
+    hipError_t e = oi::zero_output_async(gx, (size_t)N * C * Hi * Wi, st);
     if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_grid_sample_bwd: zero fill: %s", hipGetErrorString(e));
   }
   const long long n = (long long)N * Ho * Wo;
@@ -870,13 +870,17 @@ int oi_reflect_pad_bwd(const float* gy, float* gx, int BC, int H, int W, int px0
   OI_REQUIRE(px0 >= 0 && px1 >= 0 && py0 >= 0 && py1 >= 0 && px0 < W && px1 < W && py0 < H && py1 < H,
              "oi_reflect_pad_bwd: padding must be in [0, size)");
   hipStream_t st = oi::as_stream(stream);
-  hipError_t e = oi::zero_async(gx, (size_t)BC * H * W, st);
+  hipError_t e = oi::zero_output_async(gx, (size_t)BC * H * W, st);
   if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_reflect_pad_bwd: memset: %s", hipGetErrorString(e));
   const int Ho = H + py0 + py1, Wo = W + px0 + px1;
   const long long n = (long long)BC * Ho * Wo;
   hipLaunchKernelGGL(reflect_pad_kernel<true>, dim3(oi::cdiv(n, 256)), dim3(256), 0, st, gy, gx, BC, H, W, px0, py0,
                      Ho, Wo);
   return oi::check_launch("oi_reflect_pad_bwd");
+}
+
+int oi_outputs_prezeroed(int on) {
+  return oi::outputs_prezeroed().exchange(on != 0);
 }
 
 int oi_version(void) { return 1; }

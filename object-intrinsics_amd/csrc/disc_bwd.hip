@@ -176,7 +176,7 @@ int oi_conv4x4_dgrad(const float* g, const float* w, float* gx, int B, int Cin, 
   k_splits = oi::cdiv(Cout, cps);
   hipStream_t st = oi::as_stream(stream);
   // rows/cols no tap reaches (e.g. the last row when (H + 2 pad - 4) % stride != 0) keep the zero fill
-  hipError_t e = oi::zero_async(gx, (size_t)B * Cin * H * W, st);
+  hipError_t e = oi::zero_output_async(gx, (size_t)B * Cin * H * W, st);
   if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_dgrad: memset: %s", hipGetErrorString(e));
   const long long items = tiles * k_splits;
   if (stride == 2)
@@ -203,7 +203,7 @@ int oi_conv4x4_wgrad(const float* g, const float* x, float* gw, int B, int Cin, 
   k_splits = oi::cdiv(P, pps);
   hipStream_t st = oi::as_stream(stream);
   if (k_splits > 1) {
-    hipError_t e = oi::zero_async(gw, (size_t)Cout * Cin * 16, st);
+    hipError_t e = oi::zero_output_async(gw, (size_t)Cout * Cin * 16, st);
     if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_wgrad: memset: %s", hipGetErrorString(e));
   }
   const long long items = tiles * k_splits;

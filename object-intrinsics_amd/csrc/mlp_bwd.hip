@@ -985,6 +985,9 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
         inv[1] = inv[0];
       }
     }
+    // wave-uniform by construction (wave_max): keep them in SGPRs, the VGPR file holds two tiles of staging
+    auto uni = [](float& v) { v = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    uni(scx[0]); uni(scx[1]); uni(scy[0]); uni(scy[1]); uni(inv[0]); uni(inv[1]); uni(inv_scx[0]); uni(inv_scx[1]);
   }
   f32x16 acc[4];
   acc_zero(acc);

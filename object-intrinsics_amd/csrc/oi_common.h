@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
@@ -137,6 +138,18 @@ inline hipError_t zero_async(float* p, size_t n_floats, hipStream_t st) {
   const long long blocks = (long long)((n_floats + 255) / 256);
   hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, p, (long long)n_floats);
   return hipGetLastError();
+}
+
+// Accumulate-outputs (split-K sums, scatter-adds) are cleared by their launcher -- unless the caller has declared that it
+// hands every such output out of memory it has already zeroed (oi_outputs_prezeroed: one fill per captured step instead
+// of one per op).  Process-wide, not thread-local: PyTorch runs a backward pass on its autograd worker thread, and the
+// declaration has to cover the launches issued from there.
+inline std::atomic<int>& outputs_prezeroed() {
+  static std::atomic<int> v{0};
+  return v;
+}
+inline hipError_t zero_output_async(float* p, size_t n_floats, hipStream_t st) {
+  return outputs_prezeroed().load(std::memory_order_relaxed) ? hipSuccess : zero_async(p, n_floats, st);
 }
 
 }  // namespace oi

@@ -123,7 +123,15 @@ class GraphedDStep:
                 disc._in_graph = False  # an eager `loss.backward(); opt.step()` on the same wrapper exchanges as usual
 
     def _step_body(self, disc, wrapped):
+        from . import ops
         from .losses import compute_grad2
+        if getattr(self, "_pool", None) is None:
+            self._pool = ops.ZeroPool()
+        self._pool.begin(self.x_real.device)   # ONE fill for every split-K / scatter output of the step
+        with self._pool:
+            return self._step_ops(disc, wrapped, compute_grad2)
+
+    def _step_ops(self, disc, wrapped, compute_grad2):
         if wrapped:
             disc.zero_grad()
         else:

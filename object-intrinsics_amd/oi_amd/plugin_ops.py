@@ -51,7 +51,7 @@ def _gs_fwd(x, grid):
 def _gs_bwd(gy, x, grid, need_x, need_grid):
     N, C, Hi, Wi = x.shape
     Ho, Wo = grid.shape[1], grid.shape[2]
-    gx = torch.empty_like(x) if need_x else None
+    gx = _ops._new_acc(x, *x.shape) if need_x else None   # a scatter-add target: pre-zeroed when a ZeroPool is active
     gg = torch.empty_like(grid) if need_grid else None
     _l.check(_l.load().oi_grid_sample_bwd(_p(_c(gy)), _p(_c(x)), _p(_c(grid)), _p(gx), _p(gg), N, C, Hi, Wi, Ho, Wo,
                                           _ops._stream()), "oi_grid_sample_bwd")
