@@ -64,6 +64,29 @@ constexpr int DS_TOTAL = 2440;
 // while the current layer computes, so a layer boundary costs a barrier and not an LDS-DMA round trip + the drain of
 // every scratch store in flight.
 constexpr int L_RACC = L_WBUF + 2 * 65536;  // per-workgroup reduction scratch: [8][128] floats
+// Waves per workgroup of the sweep (one workgroup per CU either way: the two image slots fill the LDS).  4 = one wave per
+// SIMD with 512 registers; 8 = two waves per SIMD with 256 registers each (the co-resident wave fills the other's LDS /
+// MFMA-result / memory stalls and the VALU issues 1.45 x faster with two waves to pick from: tools/dbg/valu_issue.hip).
+#ifndef OI_BWD_NW
+#define OI_BWD_NW 8
+#endif
+constexpr int BW_NW = OI_BWD_NW, BW_THREADS = 64 * BW_NW, BW_TILE = WAVE_PTS * BW_NW;
+// groups (of 16) of parked phi / vbar fragments the down sweep requests ahead of their use
+// ... and how many of those stay in flight ACROSS the two products (the accumulators are dead during the epilogue: the
+// ring can be deep there even with 256 registers, but only CARRY groups fit next to three point vectors)
+#ifndef OI_BWD_PF
+#define OI_BWD_PF (OI_BWD_NW == 4 ? 16 : 8)
+#endif
+#ifndef OI_BWD_CARRY
+#define OI_BWD_CARRY (OI_BWD_NW == 4 ? 16 : 1)
+#endif
+#ifndef OI_BWD_PF_F32  // the fp32-MFMA product keeps more fragments live
+#define OI_BWD_PF_F32 (OI_BWD_NW == 4 ? 16 : 4)
+#endif
+// the colour head's contribution to abar_8 waits for the down sweep in registers (1) or in scratch slot S_AC (0)
+#ifndef OI_BWD_AC_REGS
+#define OI_BWD_AC_REGS (OI_BWD_NW == 4)
+#endif
 constexpr int L_FILM2 = L_RACC + 8 * C * 4;
 constexpr int L_TOTAL_BWD = L_FILM2 + 1536;
 
@@ -128,7 +151,7 @@ struct RowSum {
 
 __device__ __forceinline__ void racc_zero(char* lds, int tid) {
   float* racc = reinterpret_cast<float*>(lds + L_RACC);
-  for (int i = tid; i < 8 * C; i += 256) racc[i] = 0.f;
+  for (int i = tid; i < 8 * C; i += BW_THREADS) racc[i] = 0.f;
 }
 // flush `rows` accumulator rows: row r goes to dst[r] (a global base pointer per row)
 __device__ __forceinline__ void racc_flush_row(char* lds, int row, float* dst, int stride, int tid) {
@@ -191,6 +214,16 @@ __device__ __forceinline__ void dma_sync() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
+// the same, but the KEEP most recently issued vector-memory operations (scratch stores nobody waits for) stay in flight:
+// the counter retires in issue order, so everything older -- the LDS-DMA -- has landed
+template <int KEEP>
+__device__ __forceinline__ void dma_sync_keep() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+  __syncthreads();
+}
+#ifndef OI_BWD_UP_KEEP
+#define OI_BWD_UP_KEEP 32
+#endif
 
 // One layer product of the backward sweeps: acc = W_img . v with only ONE k-step of A fragments (4 output blocks x hi / lo
 // limb = 32 VGPRs) live at a time -- two 64-register point vectors and the accumulators are live around every product of
@@ -209,6 +242,9 @@ __device__ __forceinline__ void gemm_lean(const char* lds, const LaneOff& o, con
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, bh, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bl, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, bh, acc[t], 0, 0, 0);
+#if OI_BWD_NW == 8
+        if (t & 1) __builtin_amdgcn_sched_barrier(0);  // (256 registers: at most two output blocks' fragments in flight)
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -249,18 +285,9 @@ __device__ __forceinline__ void publish_max(float* op_max, int slot, float lane_
     atomicMax(reinterpret_cast<unsigned*>(op_max) + rep * OM_STRIDE + slot, __builtin_bit_cast(unsigned, m));
 }
 
-// OI_BWD_WAVES_PER_SIMD = 1: one workgroup per CU with the whole 512-entry register file per wave (two 64-register point
-// vectors, the accumulators and a full layer of prefetched phi / vbar fragments are live at once; with 256 registers hipcc
-// spilled ~370 of them: same-box A/B 4.86 -> 4.29 ms before the double-buffered staging below)
-#ifndef OI_BWD_WAVES_PER_SIMD
-#define OI_BWD_WAVES_PER_SIMD 1
-#endif
 // timing ablations (results are garbage): -DOI_BWD_ABL=1 no v / ubar stores, 2 no phi / vbar reloads, 4 no up-sweep stores
 #ifndef OI_BWD_ABL
 #define OI_BWD_ABL 0
-#endif
-#ifndef OI_BWD_EARLY_RELOAD
-#define OI_BWD_EARLY_RELOAD 1
 #endif
 #ifndef OI_BWD_COL_FENCE
 #define OI_BWD_COL_FENCE 1
@@ -284,7 +311,7 @@ __device__ unsigned long long oi_prof_bwd[16];
 // the up / down layer bodies are run-time loops and execute 7 times per tile
 #define OI_MARK(name) asm volatile("; OI_MARK " name)
 template <int PREC, bool FAST>
-__global__ void __launch_bounds__(256, OI_BWD_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(BW_THREADS)
 mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ packed, const float* __restrict__ gamma,
                      const float* __restrict__ beta, const float* __restrict__ grad_fwd,
                      const float* __restrict__ rgb_fwd, const float* __restrict__ feat_fwd,
@@ -310,7 +337,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   asm volatile("" : "+v"(o.h16), "+v"(o.h64), "+v"(o.l16), "+v"(o.l16hi));
 
   const RowSum rs{reinterpret_cast<float*>(lds + L_RACC) + 8 * ((lane & 15) >> 2) + 4 * h + (lane & 3), lane};
-  const long long local = (long long)blockIdx.x * TILE_PTS + wave * WAVE_PTS + j;
+  const long long local = (long long)blockIdx.x * BW_TILE + wave * WAVE_PTS + j;
   const bool valid = local < n_per_elem;
   const long long pt = (long long)e * n_stride + pt_off + (valid ? local : n_per_elem - 1);
   const float vmask = valid ? 1.f : 0.f;  // tail points contribute nothing
@@ -319,7 +346,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 
   WaveScratchB ws;
   {
-    const long long wt = ((long long)e * gridDim.x + blockIdx.x) * 4 + wave;
+    const long long wt = ((long long)e * gridDim.x + blockIdx.x) * BW_NW + wave;
     ws.rs = __builtin_amdgcn_make_buffer_rsrc(scratch + wt * (long long)(NSLOT_BWD * 16384), 0, NSLOT_BWD * 16384,
                                               0x00020000);
   }
@@ -331,7 +358,15 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     r.h16 += fs_ * (L_FILM2 - L_FILM);
     return r;
   };
-  auto stage_img = [&](int image, int ws_) { stage_layer_rs<PREC>(lds + ws_ * 65536, img_rs, image, wave, o.l16); };
+  auto stage_img = [&](int image, int ws_) {  // 1 KiB per instruction, the chunks dealt round-robin to the waves
+    constexpr int NCHUNK = layer_bytes(PREC) / 1024;
+#pragma unroll
+    for (int c0 = 0; c0 < NCHUNK / BW_NW; ++c0) {
+      const int c = c0 * BW_NW + wave;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, (__attribute__((address_space(3))) void*)(lds + ws_ * 65536 + L_WBUF + c * 1024),
+                                               16, o.l16, image * layer_bytes(PREC) + c * 1024, 0, 0);
+    }
+  };
   // FiLM rows of layer l_; the scale of the forward image that produces u_l (layer 0 runs on the VALU, colour head = image 14)
   auto film_scale = [&](int l_) {
     return (PREC == OI_PREC_F16X3 && l_ >= 1) ? hdr[H_WSCALE + (l_ == 8 ? 14 : l_ - 1)] : 1.f;
@@ -351,7 +386,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   }
   {
     float* tabs = reinterpret_cast<float*>(lds + L_TABS);
-    for (int i = tid; i < H_TABS_END; i += 256) tabs[i] = hdr[i];
+    for (int i = tid; i < H_TABS_END; i += BW_THREADS) tabs[i] = hdr[i];
     stage_flm(0, 0);
     racc_zero(lds, tid);
   }
@@ -375,9 +410,13 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 
   // ================= colour head backward (first: its dL/dgrad term is part of gbar_0) =================
   OI_MARK("colour x1");
-  float ac[64];  // abar_8 contribution of the colour head: stays in registers (AGPR half) until the down sweep starts
+  // abar_8 contribution of the colour head: waits for the down sweep in registers (one wave per SIMD: the AGPR half has
+  // room) or in scratch slot S_AC
+#if OI_BWD_AC_REGS
+  float ac[64];
 #pragma unroll
   for (int k = 0; k < 64; ++k) ac[k] = 0.f;
+#endif
   if (has_col) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) {  // a_8, as the forward wrote it (feat output): features grp_f0(g) + 4 h .. + 3
@@ -404,7 +443,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     float dGx = 0.f, dGy = 0.f, dGz = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      float R[8][16];
+      float uv16[16], hv16[16];  // the six summed rows are products of these with per-point scalars: formed one at a time
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int g = 4 * t + rr;
@@ -425,12 +464,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           sincos_rev(rev_reduce<FAST, false>(ph), hv, cv);
           const float hvb = w0[k] * rho[0] + w1[k] * rho[1] + w2[k] * rho[2];
           uvb[k] = hvb * cv * gm[k];
-          R[2][4 * rr + k] = uvb[k] * fz;
-          R[3][4 * rr + k] = rho[0] * hv;
-          R[4][4 * rr + k] = rho[1] * hv;
-          R[5][4 * rr + k] = rho[2] * hv;
-          R[6][4 * rr + k] = uvb[k] * fx;
-          R[7][4 * rr + k] = uvb[k] * fy;
+          uv16[4 * rr + k] = uvb[k];
+          hv16[4 * rr + k] = hv;
           dGx = fmaf(uvb[k], wx[0], dGx);
           dGy = fmaf(uvb[k], wx[1], dGy);
           dGz = fmaf(uvb[k], wx[2], dGz);
@@ -443,7 +478,13 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #endif
       }
 #pragma unroll
-      for (int r = 2; r < 8; ++r) rs.add(r, t, R[r]);
+      for (int r = 2; r < 8; ++r) {
+        const float sc = r == 2 ? fz : r == 6 ? fx : r == 7 ? fy : rho[r - 3];
+        float row[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) row[i] = (r >= 3 && r <= 5) ? sc * hv16[i] : uv16[i] * sc;
+        rs.add(r, t, row);
+      }
     }
     // contribution to dL/dgrad through the colour-head input
     dGx += __shfl_xor(dGx, 32, 64);
@@ -483,9 +524,17 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     const float fT = gemm2<PREC, true>(lds, layer_off(1, 1), act, acc, SC ? hdr[H_WSCALE + 15] : 1.f, &mx_uv);
     if constexpr (SC) publish_max(op_max, OM_UV, mx_uv);
 #pragma unroll
-    for (int g = 0; g < 16; ++g)
+    for (int g = 0; g < 16; ++g) {
+      f32x4 v;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) ac[4 * g + k] = SC ? acc[g >> 2][4 * (g & 3) + k] * fT : acc[g >> 2][4 * (g & 3) + k];
+      for (int k = 0; k < 4; ++k) v[k] = SC ? acc[g >> 2][4 * (g & 3) + k] * fT : acc[g >> 2][4 * (g & 3) + k];
+#if OI_BWD_AC_REGS
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ac[4 * g + k] = v[k];
+#else
+      ws.store(S_AC, g, o.l16, v);
+#endif
+    }
   }
 
   BW_T(0);
@@ -521,7 +570,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   BW_T(1);
   for (int l = 1; l < NL_SDF; ++l) {
     OI_MARK("up_body x7");
-    dma_sync();  // layer l's image and FiLM rows have landed; every wave is done with layer l - 1
+    // layer l's image and FiLM rows have landed; every wave is done with layer l - 1.  The 32 phi / vbar stores of the
+    // previous layer were issued after that DMA and need not have drained.
+    if constexpr (OI_BWD_ABL & 4) dma_sync(); else dma_sync_keep<OI_BWD_UP_KEEP>();
     BW_T(2);
     const FilmRegs fr = load_flm(l < NL_SDF - 1 ? l + 1 : l);  // next layer's FiLM rows: requested ahead of the image DMA
     stage_img(l < NL_SDF - 1 ? l : 13, l & 1);  // (the down sweep starts with the transposed image of layer 7)
@@ -592,18 +643,26 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
     const f32x4 w = lds_f4(lds, L_TABS + (H_SIG + grp_f0(g)) * 4, o.h16);
+#if OI_BWD_AC_REGS
+    const f32x4 a8 = {ac[4 * g], ac[4 * g + 1], ac[4 * g + 2], ac[4 * g + 3]};
+#else
+    const f32x4 a8 = has_col ? ws.load(S_AC, g, o.l16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       gb[4 * g + k] = w[k];
-      act[4 * g + k] = fmaf(gs, w[k], ac[4 * g + k]);
+      act[4 * g + k] = fmaf(gs, w[k], a8[k]);
     }
   }
   // the transposed image of layer l sits in image slot l & 1, its FiLM rows in FiLM slot l & 1; phi_l / vbar_l of the WHOLE
   // layer are requested one layer ahead (128 registers: the reason this kernel runs one wave per SIMD)
-  f32x4 phn[16], vbn[16];
+  // (a ring of PF groups: with 512 registers a whole layer, PF = 16, is in flight across the two products)
+  constexpr int PF = PREC == OI_PREC_F32 ? OI_BWD_PF_F32 : OI_BWD_PF, CARRY = OI_BWD_CARRY;
+  static_assert(PF >= 1 && PF <= 16 && (PF & (PF - 1)) == 0 && CARRY >= 1 && CARRY <= PF, "OI_BWD_PF / OI_BWD_CARRY");
+  f32x4 phn[PF], vbn[PF];
   f32x4 abl_sink;  // (OI_BWD_ABL & 8)
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
+  for (int g = 0; g < CARRY; ++g) {
     phn[g] = ws.load(S_PHI + 7, g, o.l16);
     vbn[g] = ws.load(S_VB + 7, g, o.l16);
   }
@@ -619,17 +678,21 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       __syncthreads();
     }
     const FilmRegs fr = load_flm(l >= 1 ? l - 1 : 0);  // ahead of the image DMA (see film_load)
+    if constexpr (CARRY < PF && !(OI_BWD_ABL & 2)) {  // groups 0 .. CARRY-1 travelled under the products; fill the ring
+#pragma unroll
+      for (int g = CARRY; g < PF; ++g) {
+        phn[g] = ws.load(S_PHI + l, g, o.l16);
+        vbn[g] = ws.load(S_VB + l, g, o.l16);
+      }
+    }
     if (l >= 2) stage_img(7 + l - 2, (l - 1) & 1);
     const LaneOff ol = layer_off(l & 1, l & 1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      // layer 0 only (its "weight gradient" is three columns, summed here): rows 1 d b_0 = sum ubar_0, 3..5 d W0[:, 0..2].
-      // Layers 1..7 need NO point sum in this kernel (FiLM-scale identity, see the header comment).
-      float R0[4][16];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int g = 4 * t + rr;
-        const f32x4 ph = phn[g], vb = vbn[g];
+        const f32x4 ph = phn[g & (PF - 1)], vb = vbn[g & (PF - 1)];
         const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, ol.h16);
         f32x4 ub, vv;
 #pragma unroll
@@ -643,12 +706,11 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           ub[k] = phb * gm[k];                                         // ubar_l
           gb[4 * g + k] = vv[k];
           act[4 * g + k] = ub[k];
-          if constexpr (L0) {  // d W0 = sum_p (ubar_0 x^T + v_0 gbar_0^T)
-            R0[0][4 * rr + k] = ub[k];
-            R0[1][4 * rr + k] = fmaf(ub[k], px, vv[k] * Gx);
-            R0[2][4 * rr + k] = fmaf(ub[k], py, vv[k] * Gy);
-            R0[3][4 * rr + k] = fmaf(ub[k], pz, vv[k] * Gz);
-          }
+#if OI_BWD_NW == 8
+          // (pure arithmetic is not ordered against sched_barrier: without this pin LLVM sinks the whole epilogue below
+          // the 16 groups' loads and spills the point vectors to make room for 32 in-flight fragments)
+          asm volatile("" : "+v"(gb[4 * g + k]), "+v"(act[4 * g + k]));
+#endif
         }
 #if !OI_BWD_STORES_LAST
         if constexpr (!L0 && !(OI_BWD_ABL & 1)) {
@@ -656,25 +718,38 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           ws.store<OI_BWD_ST_WGRAD>(S_U + l - 1, g, o.l16, ub);
         }
 #endif
-#if OI_BWD_EARLY_RELOAD
         // this group's fragments are consumed: request the same group of the NEXT layer into the same registers -- the loads
         // travel under the rest of the epilogue and both products, and there is no separate issue phase
-        if constexpr (!L0 && !(OI_BWD_ABL & 2)) {
-          phn[g] = ws.load(S_PHI + l - 1, g, o.l16);
-          vbn[g] = ws.load(S_VB + l - 1, g, o.l16);
+        if constexpr (!(OI_BWD_ABL & 2)) {
+          // ring slot g & (PF - 1) next holds group g + PF of this layer, or group g + PF - 16 of the layer below
+          if (g + PF < 16) {
+            phn[g & (PF - 1)] = ws.load(S_PHI + l, g + PF, o.l16);
+            vbn[g & (PF - 1)] = ws.load(S_VB + l, g + PF, o.l16);
+          } else if constexpr (!L0) {
+            if (g + PF - 16 < CARRY) {
+              phn[g & (PF - 1)] = ws.load(S_PHI + l - 1, g + PF - 16, o.l16);
+              vbn[g & (PF - 1)] = ws.load(S_VB + l - 1, g + PF - 16, o.l16);
+            }
+          }
         }
         if constexpr (!L0 && (OI_BWD_ABL & 8)) {  // timing ablation: the loads are ISSUED but nothing ever waits for them
           asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen offset:1024 nt"
                        : "=&v"(abl_sink) : "v"(o.l16), "s"(ws.rs));
         }
-#endif
         __builtin_amdgcn_sched_barrier(0);
       }
+      // layer 0 only (its "weight gradient" is three columns, summed here): rows 1 d b_0 = sum ubar_0, 3..5
+      // d W0[:, 0..2] = sum_p (ubar_0 x^T + v_0 gbar_0^T).  Layers 1..7 need NO point sum in this kernel (FiLM-scale identity,
+      // see the header comment).
       if constexpr (L0) {
-        rs.add(1, t, R0[0]);
-        rs.add(3, t, R0[1]);
-        rs.add(4, t, R0[2]);
-        rs.add(5, t, R0[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float xs = r == 1 ? px : r == 2 ? py : pz, gs_ = r == 1 ? Gx : r == 2 ? Gy : Gz;
+          float row[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) row[i] = r == 0 ? act[16 * t + i] : fmaf(act[16 * t + i], xs, gb[16 * t + i] * gs_);
+          rs.add(r == 0 ? 1 : r + 2, t, row);
+        }
       }
     }
     if (l >= 1) store_flm(fr, (l - 1) & 1);  // FiLM slot of layer l + 1: free since this layer's barrier
@@ -691,13 +766,6 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     }
 #endif
     BW_T(8);
-    if constexpr (!OI_BWD_EARLY_RELOAD && !L0 && !(OI_BWD_ABL & 2)) {  // the next layer's fragments travel while this layer's two products run
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        phn[g] = ws.load(S_PHI + l - 1, g, o.l16);
-        vbn[g] = ws.load(S_VB + l - 1, g, o.l16);
-      }
-    }
     if constexpr (!L0) {
       const float inv_t = SC ? hdr[H_WSCALE + 7 + l - 1] : 1.f;
       acc_zero(acc);
@@ -1173,8 +1241,8 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
                hipStream_t st) {
   // The scratch is a bound, not a function of the problem: the points of every batch element are processed in chunks of
   // as many 128-point tiles as `scratch_bytes` holds; all outputs are accumulated, so chunks simply add up.
-  const long long tile_bytes = 4LL * NSLOT_BWD * 16384;
-  const long long tiles_all = oi::cdiv(n, TILE_PTS);
+  const long long tile_bytes = (long long)BW_NW * NSLOT_BWD * 16384;
+  const long long tiles_all = oi::cdiv(n, BW_TILE);
   OI_REQUIRE(scratch_bytes > OM_FLOATS * sizeof(float), "oi_sdf_mlp_bwd: scratch of %zu bytes", scratch_bytes);
   float* op_max = reinterpret_cast<float*>(scratch);             // header: launch-wide operand maxima
   char* tiles = reinterpret_cast<char*>(scratch) + OM_FLOATS * sizeof(float);
@@ -1190,17 +1258,17 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL_BWD);
   for (long long t0 = 0; t0 < tiles_all; t0 += tiles_fit) {
     const long long nt = std::min(tiles_fit, tiles_all - t0);
-    const long long off = t0 * TILE_PTS, cn = std::min<long long>(nt * TILE_PTS, n - off);
+    const long long off = t0 * BW_TILE, cn = std::min<long long>(nt * BW_TILE, n - off);
     dim3 grid((unsigned)nt, B), block(256);
     if constexpr (PREC == OI_PREC_F16X3) {
       hipError_t e = oi::zero_async(op_max, OM_FLOATS, st);
       if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_sdf_mlp_bwd: zero fill: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(k, grid, block, L_TOTAL_BWD, st, pts, reinterpret_cast<const char*>(packed), gamma, beta, grad_fwd,
+    hipLaunchKernelGGL(k, grid, dim3(BW_THREADS), L_TOTAL_BWD, st, pts, reinterpret_cast<const char*>(packed), gamma, beta, grad_fwd,
                        rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, d_gamma, d_beta, tiles, op_max, cn, n, off);
     int rc = oi::check_launch("oi_sdf_mlp_bwd(sweep)");
     if (rc != OI_OK) return rc;
-    const long long wt_per_elem = (long long)grid.x * 4, n_wt = (long long)B * wt_per_elem;
+    const long long wt_per_elem = (long long)grid.x * BW_NW, n_wt = (long long)B * wt_per_elem;
     // ~2048 workgroups in total; a chunk never straddles two batch elements (per-element FiLM gradients)
     const int chunk = (int)std::min<long long>(wt_per_elem, std::max<long long>(1, (n_wt * 8 + 2047) / 2048));
     dim3 g2(oi::cdiv(wt_per_elem, chunk), 8, B);
@@ -1243,12 +1311,12 @@ extern "C" int oi_prof_bwd_read(unsigned long long* out, int reset) {
 extern "C" {
 
 size_t oi_mlp_bwd_scratch_bytes(int B, long long n_per_elem) {
-  const long long tiles = (n_per_elem + TILE_PTS - 1) / TILE_PTS;
-  return (size_t)B * tiles * 4 * NSLOT_BWD * 16384 + OM_FLOATS * sizeof(float);
+  const long long tiles = (n_per_elem + BW_TILE - 1) / BW_TILE;
+  return (size_t)B * tiles * BW_NW * NSLOT_BWD * 16384 + OM_FLOATS * sizeof(float);
 }
 
 size_t oi_mlp_bwd_scratch_bytes_capped(int B, long long n_per_elem, size_t cap_bytes) {
-  const size_t per_tile = (size_t)B * 4 * NSLOT_BWD * 16384, head = OM_FLOATS * sizeof(float);
+  const size_t per_tile = (size_t)B * BW_NW * NSLOT_BWD * 16384, head = OM_FLOATS * sizeof(float);
   const size_t full = oi_mlp_bwd_scratch_bytes(B, n_per_elem);
   if (full <= cap_bytes) return full;
   const size_t tiles = cap_bytes > head ? (cap_bytes - head) / per_tile : 0;
