@@ -41,8 +41,10 @@ namespace {
 using namespace oimlp;
 
 // scratch slots of one wave tile (16 KiB each)
-constexpr int S_PHI = 0;    // 8: phi_l
-constexpr int S_VB = 8;     // 8: gamma_l vbar_l, vbar_l = W_l gbar_l   (down sweep: gamma_l cbar_l = . g_{l+1}; wgrad: gbar_{l+1} = . cos phi_l)
+constexpr int S_PHI = 0;    // 8: phi_l, l = 1..7.  Layer 0 (three input columns, formed on the VALU) is NOT parked: the down
+                            //    sweep and the weight-gradient GEMM form phi_0 / vbar_0 again from the point and dL/dgrad,
+                            //    which sit in the first KiB of this slot: [32 points][x y z 0 | Gx Gy Gz 0]
+constexpr int S_VB = 8;     // 8: gamma_l vbar_l, vbar_l = W_l gbar_l, l = 1..7   (down sweep: gamma_l cbar_l = . g_{l+1}; wgrad: gbar_{l+1} = . cos phi_l)
 constexpr int S_V = 16;     // 7: v_l,    l = 1..7   (wgrad operand)
 constexpr int S_U = 23;     // 7: ubar_l, l = 1..7   (wgrad operand)
 constexpr int S_UV = 30;    // 1: uvbar (colour head pre-activation gradient)
@@ -560,22 +562,31 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       float s, c;
       sincos_rev(ph[k], s, c);
       act[4 * g + k] = s;
-      vb[k] = fmaf(Gz, w[2], fmaf(Gy, w[1], Gx * w[0])) * gm[k];  // parked with gamma folded in
+      vb[k] = fmaf(Gz, w[2], fmaf(Gy, w[1], Gx * w[0])) * gm[k];  // gamma folded in
       gb[4 * g + k] = vb[k] * c;
+      // (nothing with a side effect is left in this loop: without the pin hipcc reads all 64 table rows first and spills)
+      asm volatile("" : "+v"(act[4 * g + k]), "+v"(gb[4 * g + k]));
     }
-    ws.store(S_PHI + 0, g, o.l16, ph);
-    ws.store(S_VB + 0, g, o.l16, vb);
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (h == 0) {  // what the weight-gradient GEMM needs to form phi_0 / vbar_0 itself (lane j = point j)
+    oi::buffer_store_b128<OI_BWD_ST_WGRAD>(__builtin_bit_cast(u32x4, f32x4{px, py, pz, 0.f}), ws.rs, 32 * j, S_PHI * 16384);
+    oi::buffer_store_b128<OI_BWD_ST_WGRAD>(__builtin_bit_cast(u32x4, f32x4{Gx, Gy, Gz, 0.f}), ws.rs, 32 * j + 16, S_PHI * 16384);
+  }
   BW_T(1);
-  for (int l = 1; l < NL_SDF; ++l) {
-    OI_MARK("up_body x7");
+  // The last layer is peeled: its phase and vbar are what the down sweep consumes FIRST, so they stay in the two point
+  // vectors across the turn instead of making a round trip through the scratch (0.8 GB per launch at C2: vbar_7 is never
+  // written, phi_7 is written for the colour head's weight gradient only); the w_sigma sums, which need a_8 and gbar_8, are
+  // formed inside its epilogue.
+  auto up_layer = [&](int l, auto is_last) {
+    constexpr bool LAST = decltype(is_last)::value;
+    if constexpr (LAST) OI_MARK("up_last x1"); else OI_MARK("up_body x6");
     // layer l's image and FiLM rows have landed; every wave is done with layer l - 1.  The 32 phi / vbar stores of the
     // previous layer were issued after that DMA and need not have drained.
     if constexpr (OI_BWD_ABL & 4) dma_sync(); else dma_sync_keep<OI_BWD_UP_KEEP>();
     BW_T(2);
-    const FilmRegs fr = load_flm(l < NL_SDF - 1 ? l + 1 : l);  // next layer's FiLM rows: requested ahead of the image DMA
-    stage_img(l < NL_SDF - 1 ? l : 13, l & 1);  // (the down sweep starts with the transposed image of layer 7)
+    const FilmRegs fr = load_flm(LAST ? l : l + 1);  // next layer's FiLM rows: requested ahead of the image DMA
+    stage_img(LAST ? 13 : l, l & 1);  // (the down sweep starts with the transposed image of layer 7)
     const LaneOff ol = layer_off((l - 1) & 1, l & 1);
     const float inv_img = SC ? hdr[H_WSCALE + l - 1] : 1.f;
     // vbar_l = W_l gbar_l
@@ -594,15 +605,16 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         v[k] = SC ? acc[g >> 2][4 * (g & 3) + k] * (fA * gm[k]) : acc[g >> 2][4 * (g & 3) + k] * gm[k];
         gb[4 * g + k] = v[k];
       }
-      if (!(OI_BWD_ABL & 4)) ws.store(S_VB + l, g, o.l16, v);
+      if (!LAST && !(OI_BWD_ABL & 4)) ws.store(S_VB + l, g, o.l16, v);
     }
-    if (l < NL_SDF - 1) store_flm(fr, (l + 1) & 1);  // FiLM slot of layer l - 1: free since this layer's barrier
+    if constexpr (!LAST) store_flm(fr, (l + 1) & 1);  // FiLM slot of layer l - 1: free since this layer's barrier
     // phi_l / 2pi = G (W_img a_l) + B2 (image scale and bias folded into the staged rows) -> a_{l+1};
     // gbar_{l+1} = vbar_l gamma_l cos phi_l
     acc_zero(acc);
     BW_T(5);
     (void)gemm2<PREC, false>(lds, ol, act, acc, 1.f);
     BW_T(4);
+    float wsig_row[16];
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const f32x4 gr = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, ol.h16);
@@ -613,23 +625,25 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         ph[k] = rev_reduce<FAST, false>(fmaf(gr[k], acc[g >> 2][4 * (g & 3) + k], b2[k]));
         float s, c;
         sincos_rev(ph[k], s, c);
-        act[4 * g + k] = s;
-        gb[4 * g + k] *= c;
+        if constexpr (LAST) {  // act keeps phi_7, gb keeps gamma_7 vbar_7;  d w_sigma = sum_p (gbar_8 + gs a_8)  (row 3)
+          wsig_row[4 * (g & 3) + k] = fmaf(gs, s, gb[4 * g + k] * c);
+          act[4 * g + k] = ph[k];
+        } else {
+          act[4 * g + k] = s;
+          gb[4 * g + k] *= c;
+        }
       }
       if (!(OI_BWD_ABL & 4)) ws.store(S_PHI + l, g, o.l16, ph);
+      if constexpr (LAST)
+        if ((g & 3) == 3) rs.add(3, g >> 2, wsig_row);
       __builtin_amdgcn_sched_barrier(0);
     }
     BW_T(5);
-  }
+  };
+  for (int l = 1; l < NL_SDF - 1; ++l) up_layer(l, std::false_type{});
+  up_layer(NL_SDF - 1, std::true_type{});
   OI_MARK("mid x1");
-  // d w_sigma = sum_p (gbar_8 + gs a_8)  (row 3);  d b_sigma = sum_p gs
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = fmaf(gs, act[16 * t + i], gb[16 * t + i]);
-    rs.add(3, t, v);
-  }
+  // d b_sigma = sum_p gs
   {
     float b = (h == 0) ? gs : 0.f;
     b = oi::wave_sum(b);
@@ -639,21 +653,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   racc_flush_row(lds, 3, d_small + DS_WSIG, 1, tid);
 
   // ================= down sweep: g_l and abar_l together =================
-  // g_8 = w_sigma;  abar_8 = gs * w_sigma (+ the colour head's contribution)
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const f32x4 w = lds_f4(lds, L_TABS + (H_SIG + grp_f0(g)) * 4, o.h16);
-#if OI_BWD_AC_REGS
-    const f32x4 a8 = {ac[4 * g], ac[4 * g + 1], ac[4 * g + 2], ac[4 * g + 3]};
-#else
-    const f32x4 a8 = has_col ? ws.load(S_AC, g, o.l16) : f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      gb[4 * g + k] = w[k];
-      act[4 * g + k] = fmaf(gs, w[k], a8[k]);
-    }
-  }
+  // The top layer (7) takes phi_7 / vbar_7 from the point vectors, g_8 = w_sigma from the tables and abar_8 = gs * w_sigma
+  // (+ the colour head's contribution: registers or slot S_AC, which then travels through the phi half of the ring).
   // the transposed image of layer l sits in image slot l & 1, its FiLM rows in FiLM slot l & 1; phi_l / vbar_l of the WHOLE
   // layer are requested one layer ahead (128 registers: the reason this kernel runs one wave per SIMD)
   // (a ring of PF groups: with 512 registers a whole layer, PF = 16, is in flight across the two products)
@@ -661,16 +662,17 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   static_assert(PF >= 1 && PF <= 16 && (PF & (PF - 1)) == 0 && CARRY >= 1 && CARRY <= PF, "OI_BWD_PF / OI_BWD_CARRY");
   f32x4 phn[PF], vbn[PF];
   f32x4 abl_sink;  // (OI_BWD_ABL & 8)
+  constexpr int PFT = PF < 4 ? PF : 4;  // ring depth of the top layer (its point vectors carry phi_7 / vbar_7 as well)
+#if !OI_BWD_AC_REGS
 #pragma unroll
-  for (int g = 0; g < CARRY; ++g) {
-    phn[g] = ws.load(S_PHI + 7, g, o.l16);
-    vbn[g] = ws.load(S_VB + 7, g, o.l16);
-  }
+  for (int g = 0; g < PFT; ++g) phn[g] = ws.load(S_AC, g, o.l16);  // (no colour head: never written, never used)
+#endif
   BW_T(6);
   // layer 0 is peeled (its extra d W0 rows and missing products are compile-time): no branch inside the unrolled epilogue
-  auto down_layer = [&](int l, auto is_layer0) {
-    constexpr bool L0 = decltype(is_layer0)::value;
-    if constexpr (L0) OI_MARK("down0 x1"); else OI_MARK("down_body x7");
+  // KIND 0: layers 6..1 (a run-time loop), 1: layer 0, 2: the top layer 7
+  auto down_layer = [&](int l, auto kind) {
+    constexpr bool L0 = decltype(kind)::value == 1, TOP = decltype(kind)::value == 2;
+    if constexpr (L0) OI_MARK("down0 x1"); else if constexpr (TOP) OI_MARK("down_top x1"); else OI_MARK("down_body x6");
     dma_sync();  // layer l's transposed image and FiLM rows have landed
     BW_T(7);
     if constexpr (L0) {  // the reduction rows still hold the w_sigma sums of the up sweep (flushed many barriers ago)
@@ -678,7 +680,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       __syncthreads();
     }
     const FilmRegs fr = load_flm(l >= 1 ? l - 1 : 0);  // ahead of the image DMA (see film_load)
-    if constexpr (CARRY < PF && !(OI_BWD_ABL & 2)) {  // groups 0 .. CARRY-1 travelled under the products; fill the ring
+    if constexpr (!L0 && !TOP && CARRY < PF && !(OI_BWD_ABL & 2)) {  // groups 0 .. CARRY-1 travelled under the products; fill the ring
 #pragma unroll
       for (int g = CARRY; g < PF; ++g) {
         phn[g] = ws.load(S_PHI + l, g, o.l16);
@@ -687,22 +689,60 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     }
     if (l >= 2) stage_img(7 + l - 2, (l - 1) & 1);
     const LaneOff ol = layer_off(l & 1, l & 1);
+    // layer 0 only: the point and dL/dgrad come back from the slot the up sweep left them in for the weight-gradient GEMM
+    // (six registers that would otherwise stay live through both sweeps)
+    f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, G0 = x0;
+    if constexpr (L0) {
+      x0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rs, 32 * j, S_PHI * 16384, 0));
+      G0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws.rs, 32 * j, S_PHI * 16384 + 16, 0));
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int g = 4 * t + rr;
-        const f32x4 ph = phn[g & (PF - 1)], vb = vbn[g & (PF - 1)];
         const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, ol.h16);
+        f32x4 ph, vb;
+        if constexpr (L0) {  // formed again exactly as the up sweep did (same operations in the same order: same bits)
+          const f32x4 gr = lds_f4(lds, L_FILM + (C + grp_f0(g)) * 4, ol.h16);
+          const f32x4 b2 = lds_f4(lds, L_FILM + (2 * C + grp_f0(g)) * 4, ol.h16);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const f32x4 w = lds_f4(lds, L_TABS + H_TAB0 * 4 + (grp_f0(g) + k) * 16, o.h64);
+            const float u = fmaf(x0[2], w[2], fmaf(x0[1], w[1], x0[0] * w[0]));
+            ph[k] = rev_reduce<FAST, false>(fmaf(gr[k], u, b2[k]));
+            vb[k] = fmaf(G0[2], w[2], fmaf(G0[1], w[1], G0[0] * w[0])) * gm[k];
+          }
+        } else if constexpr (TOP) {  // left in the point vectors by the up sweep's last layer
+          ph = f32x4{act[4 * g], act[4 * g + 1], act[4 * g + 2], act[4 * g + 3]};
+          vb = f32x4{gb[4 * g], gb[4 * g + 1], gb[4 * g + 2], gb[4 * g + 3]};
+        } else {
+          ph = phn[g & (PF - 1)];
+          vb = vbn[g & (PF - 1)];
+        }
+        f32x4 gnx, abx;  // g_{l+1}, abar_{l+1}
+        if constexpr (TOP) {
+          gnx = lds_f4(lds, L_TABS + (H_SIG + grp_f0(g)) * 4, o.h16);  // g_8 = w_sigma
+#if OI_BWD_AC_REGS
+          const f32x4 a8 = {ac[4 * g], ac[4 * g + 1], ac[4 * g + 2], ac[4 * g + 3]};
+#else
+          const f32x4 a8 = phn[g & (PFT - 1)];
+#endif
+#pragma unroll
+          for (int k = 0; k < 4; ++k) abx[k] = has_col ? fmaf(gs, gnx[k], a8[k]) : gs * gnx[k];  // abar_8
+        } else {
+          gnx = f32x4{gb[4 * g], gb[4 * g + 1], gb[4 * g + 2], gb[4 * g + 3]};
+          abx = f32x4{act[4 * g], act[4 * g + 1], act[4 * g + 2], act[4 * g + 3]};
+        }
         f32x4 ub, vv;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float s, c;
           sincos_rev(ph[k], s, c);                                     // parked reduced phase (revolutions)
-          const float gn = gb[4 * g + k];                              // g_{l+1}
+          const float gn = gnx[k];                                     // g_{l+1}
           const float cb = vb[k] * gn;                                 // gamma_l cbar_l (gamma folded into the parked vbar)
           vv[k] = gn * c * gm[k];                                      // v_l
-          const float phb = fmaf(act[4 * g + k], c, -cb * s);          // phibar_l
+          const float phb = fmaf(abx[k], c, -cb * s);                  // phibar_l
           ub[k] = phb * gm[k];                                         // ubar_l
           gb[4 * g + k] = vv[k];
           act[4 * g + k] = ub[k];
@@ -722,10 +762,16 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         // travel under the rest of the epilogue and both products, and there is no separate issue phase
         if constexpr (!(OI_BWD_ABL & 2)) {
           // ring slot g & (PF - 1) next holds group g + PF of this layer, or group g + PF - 16 of the layer below
-          if (g + PF < 16) {
+          if constexpr (TOP) {
+#if !OI_BWD_AC_REGS
+            if (g + PFT < 16) phn[g & (PFT - 1)] = ws.load(S_AC, g + PFT, o.l16);
+#endif
+          } else if (!L0 && g + PF < 16) {
             phn[g & (PF - 1)] = ws.load(S_PHI + l, g + PF, o.l16);
             vbn[g & (PF - 1)] = ws.load(S_VB + l, g + PF, o.l16);
           } else if constexpr (!L0) {
+            // (layer 1 requests CARRY groups of the un-parked layer 0 as well: nobody reads them, and a run-time test of `l`
+            // here splits the unrolled epilogue into blocks the register allocator handles badly -- 220 spilled registers)
             if (g + PF - 16 < CARRY) {
               phn[g & (PF - 1)] = ws.load(S_PHI + l - 1, g + PF - 16, o.l16);
               vbn[g & (PF - 1)] = ws.load(S_VB + l - 1, g + PF - 16, o.l16);
@@ -744,7 +790,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       if constexpr (L0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float xs = r == 1 ? px : r == 2 ? py : pz, gs_ = r == 1 ? Gx : r == 2 ? Gy : Gz;
+          const float xs = r == 0 ? 0.f : x0[r - 1], gs_ = r == 0 ? 0.f : G0[r - 1];
           float row[16];
 #pragma unroll
           for (int i = 0; i < 16; ++i) row[i] = r == 0 ? act[16 * t + i] : fmaf(act[16 * t + i], xs, gb[16 * t + i] * gs_);
@@ -787,6 +833,13 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #pragma unroll
         for (int r = 0; r < 16; ++r) act[16 * t + r] = SC ? acc[t][r] * f2 : acc[t][r];
     }
+    if constexpr (TOP && !(OI_BWD_ABL & 2)) {  // (the top layer's products run at the register limit: its successor's first
+#pragma unroll                                 // groups are requested after them, not under them)
+      for (int q = 0; q < CARRY; ++q) {
+        phn[q] = ws.load(S_PHI + l - 1, q, o.l16);
+        vbn[q] = ws.load(S_VB + l - 1, q, o.l16);
+      }
+    }
     BW_T(10);
     if constexpr (L0) {
       __syncthreads();
@@ -806,8 +859,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     }
     BW_T(11);
   };
-  for (int l = NL_SDF - 1; l >= 1; --l) down_layer(l, std::false_type{});
-  down_layer(0, std::true_type{});
+  down_layer(NL_SDF - 1, std::integral_constant<int, 2>{});
+  for (int l = NL_SDF - 2; l >= 1; --l) down_layer(l, std::integral_constant<int, 0>{});
+  down_layer(0, std::integral_constant<int, 1>{});
 #ifdef OI_BWD_PROF
   if (lane == 0) {
     for (int i = 0; i < 12; ++i) atomicAdd(&oi_prof_bwd[i], pacc[i]);
@@ -815,6 +869,31 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     atomicAdd(&oi_prof_bwd[13], 1ull);
   }
 #endif
+}
+
+// Layer 0 is not parked by the sweep (see S_PHI): the weight-gradient kernels form phi_0 / (gamma vbar)_0 of matrix m = 0 from
+// the point and dL/dgrad, with the operations of the sweep in the sweep's order -- the same bits the sweep consumed.
+//   tab (LDS): [128 features][8] = (w0x, w0y, w0z, G = gamma_0 / 2pi | B2 = G b_0 + beta_0 / 2pi, gamma_0, -, -)
+constexpr int L0TAB_FLOATS = C * 8;
+__device__ __forceinline__ void l0tab_fill(float* tab, const float* __restrict__ hdr, const float* __restrict__ gamma,
+                                           const float* __restrict__ beta, int e, int tid) {
+  if (tid < C) {
+    const float g = gamma[(size_t)e * 9 * C + tid], b = beta[(size_t)e * 9 * C + tid], bias = hdr[H_BIAS + tid];
+    const float gr = g * INV_2PI;  // (film_store: gr * inv_img with inv_img = 1 for layer 0)
+    reinterpret_cast<f32x4*>(tab)[2 * tid] = f32x4{hdr[H_TAB0 + 4 * tid], hdr[H_TAB0 + 4 * tid + 1], hdr[H_TAB0 + 4 * tid + 2], gr};
+    reinterpret_cast<f32x4*>(tab)[2 * tid + 1] = f32x4{fmaf(gr, bias, b * INV_2PI), g, 0.f, 0.f};
+  }
+}
+// features f0 .. f0+3 of one point: x = (x y z .), G = dL/dgrad (incl. the colour head's term)
+template <bool FAST>
+__device__ __forceinline__ void l0_phase_vb(const float* tab, f32x4 x, f32x4 G, int f0, f32x4& ph, f32x4& vb) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(tab)[2 * (f0 + k)], c = reinterpret_cast<const f32x4*>(tab)[2 * (f0 + k) + 1];
+    const float u = fmaf(x[2], a[2], fmaf(x[1], a[1], x[0] * a[0]));
+    ph[k] = rev_reduce<FAST, false>(fmaf(a[3], u, c[0]));
+    vb[k] = fmaf(G[2], a[2], fmaf(G[1], a[1], G[0] * a[0])) * c[1];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -882,15 +961,17 @@ __device__ __forceinline__ void film_identity_epilogue(DW dw, float* __restrict_
 template <bool FAST>
 __global__ void __launch_bounds__(256)
 mlp_wgrad_kernel(const char* __restrict__ scratch, const char* __restrict__ packed, size_t plain_offset,
-                 const float* __restrict__ gamma, float* __restrict__ d_wmat, float* __restrict__ d_gamma,
-                 float* __restrict__ d_beta, float* __restrict__ d_small, long long wt_per_elem, int tiles_per_chunk,
-                 int has_col) {
+                 const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ d_wmat,
+                 float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_small, long long wt_per_elem,
+                 int tiles_per_chunk, int has_col) {
   __shared__ __attribute__((aligned(16))) float sx[WG_SLOT_FLOATS], sy[WG_SLOT_FLOATS];
+  __shared__ __attribute__((aligned(16))) float l0tab[L0TAB_FLOATS];
   const int m = blockIdx.y;
   if (m == 7 && !has_col) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, i = lane & 31;
   const int e = blockIdx.z;  // chunks never straddle batch elements: the FiLM gradients are per element
+  if (m == 0) l0tab_fill(l0tab, reinterpret_cast<const float*>(packed), gamma, beta, e, tid);  // (first barrier below)
   const long long t_begin = e * wt_per_elem + (long long)blockIdx.x * tiles_per_chunk;
   const long long t_end = min((e + 1) * wt_per_elem, t_begin + tiles_per_chunk);
   f32x16 acc[4];
@@ -919,9 +1000,14 @@ mlp_wgrad_kernel(const char* __restrict__ scratch, const char* __restrict__ pack
         const int q = it * 256 + tid;
         const int dq = q + 2 * (q >> 5);  // + 8 floats per 32-point block
         reinterpret_cast<f32x4*>(sx)[dq] = gx4[q];
-        f32x4 y = gy4[q];
-        f32x4 vb = {0.f, 0.f, 0.f, 0.f};
-        if (y_is_gbar) vb = gv4[q];
+        f32x4 y, vb = {0.f, 0.f, 0.f, 0.f};
+        if (m == 0) {  // slot S_PHI holds the points and dL/dgrad instead (lane j = point j)
+          const f32x4* pd = reinterpret_cast<const f32x4*>(base + (size_t)S_PHI * 16384) + 2 * (tid & 31);
+          l0_phase_vb<FAST>(l0tab, pd[0], pd[1], grp_f0(4 * it + wave) + 4 * h, y, vb);
+        } else {
+          y = gy4[q];
+          if (y_is_gbar) vb = gv4[q];
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float s, c;
@@ -1008,8 +1094,10 @@ __device__ unsigned long long oi_prof_bwd[16];
 typedef f16x8 (*SbPtr)[4][2][64];  // [hi|lo][column tile][k-step][lane]
 // COL: the colour-head matrix (m = 7, one pair: X = uvbar, Y = a_8 = sin phi_7); otherwise a layer matrix (two pairs).  A
 // compile-time split: with `m` tested at run time hipcc turned the per-element selects of the hot loop into branches.
-template <bool COL>
-__device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, const int m, const char* __restrict__ scratch,
+// MODE 0: a layer matrix m = 1..6;  1 (COL): the colour head;  2 (FIRST): m = 0, whose Y operands come from layer 0 -- not
+// parked, formed here from the point and dL/dgrad (l0tab)
+template <int MODE, bool FAST>
+__device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, const float* l0tab, const int m, const char* __restrict__ scratch,
                                                const float* __restrict__ op_max, const char* __restrict__ packed,
                                                size_t plain_offset, const float* __restrict__ gamma,
                                                float* __restrict__ d_wmat, float* __restrict__ d_gamma,
@@ -1020,6 +1108,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
   const int e = blockIdx.z;  // chunks never straddle batch elements: the FiLM gradients are per element
   const long long t_begin = e * wt_per_elem + (long long)blockIdx.x * tiles_per_chunk;
   const long long t_end = min((e + 1) * wt_per_elem, t_begin + tiles_per_chunk);
+  constexpr bool COL = MODE == 1, FIRST = MODE == 2;
   constexpr int npair = COL ? 1 : 2;
   // ONE power-of-two scale per operand for the whole launch (maxima published by the sweep): the products of all tiles
   // then share a scale and accumulate straight in the MFMA accumulators -- no per-tile maximum, no per-tile merge.
@@ -1082,12 +1171,18 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
     };
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      st.ph4[it] = ld(S_PHI + m, it);
+      if constexpr (!FIRST) st.ph4[it] = ld(S_PHI + m, it);
       st.xall[0][it] = ld(COL ? S_UV : S_V + m, it);
       if constexpr (!COL) {
-        st.vb4[it] = ld(S_VB + m, it);  // gamma_{l-1} vbar_{l-1}
+        if constexpr (!FIRST) st.vb4[it] = ld(S_VB + m, it);  // gamma_{l-1} vbar_{l-1}
         st.xall[1][it] = ld(S_U + m, it);
       }
+    }
+    if constexpr (FIRST) {  // this thread's point (lane j = point j): (x y z .), (Gx Gy Gz .)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        st.ph4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * (tid & 31), S_PHI * 16384 + 16 * q,
+                                                                                   OI_WGRAD_NT ? 2 : 0));
     }
   };
   // fragments of one pair out of the fp32 LDS copies: this wave's column tile of Y -> shared fp16 fragments sb[pr], its
@@ -1132,7 +1227,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
       for (int it = 0; it < 4; ++it)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          z += st.ph4[it][k] + st.xall[0][it][k] + (COL ? 0.f : st.vb4[it][k] + st.xall[1][it][k]);
+          z += st.ph4[it & (FIRST ? 1 : 3)][k] + st.xall[0][it][k] + (COL ? 0.f : (FIRST ? 0.f : st.vb4[it][k]) + st.xall[1][it][k]);
       sub += z;
       __builtin_amdgcn_sched_barrier(0);
       if (wt + 2 < t_end) request(wt + 2, st);
@@ -1141,13 +1236,19 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
 #endif
     // pair 0 needs only the cosine (layer matrices) and pair 1 only the sine: the phase stays in its registers until pair 1
     // is staged, nothing else of the tile does
-    f32x4 y0[4];
+    f32x4 y0[4], ph4[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
+      f32x4 vb4;
+      if constexpr (FIRST) {
+        l0_phase_vb<FAST>(l0tab, st.ph4[0], st.ph4[1], grp_f0(4 * it + wave) + 4 * h, ph4[it], vb4);
+      } else {
+        ph4[it] = st.ph4[it];
+        vb4 = st.vb4[it];
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k)  // colour head (one pair): Y = a_8 = sin
-        y0[it][k] = COL ? __builtin_amdgcn_sinf(st.ph4[it][k]) * scy[0]
-                        : st.vb4[it][k] * scy[0] * __builtin_amdgcn_cosf(st.ph4[it][k]);
+        y0[it][k] = COL ? __builtin_amdgcn_sinf(ph4[it][k]) * scy[0] : vb4[k] * scy[0] * __builtin_amdgcn_cosf(ph4[it][k]);
     }
     WG_T(0);
     __syncthreads();  // (1) the previous tile's readers of sx / sy / sb are done
@@ -1173,7 +1274,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
         reinterpret_cast<f32x4*>(sx)[dq] = st.xall[1][it] * scx[1];
         f32x4 y1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) y1[k] = __builtin_amdgcn_sinf(st.ph4[it][k]) * scy[1];
+        for (int k = 0; k < 4; ++k) y1[k] = __builtin_amdgcn_sinf(ph4[it][k]) * scy[1];
         reinterpret_cast<f32x4*>(sy)[dq] = y1;
       }
     }
@@ -1217,20 +1318,27 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
 template <bool FAST>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))  // VGPRs + AGPRs <= 256: two workgroups per CU
 mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__ op_max, const char* __restrict__ packed,
-                     size_t plain_offset, const float* __restrict__ gamma, float* __restrict__ d_wmat,
-                     float* __restrict__ d_gamma, float* __restrict__ d_beta, float* __restrict__ d_small,
-                     long long wt_per_elem, int tiles_per_chunk, int has_col) {
+                     size_t plain_offset, const float* __restrict__ gamma, const float* __restrict__ beta,
+                     float* __restrict__ d_wmat, float* __restrict__ d_gamma, float* __restrict__ d_beta,
+                     float* __restrict__ d_small, long long wt_per_elem, int tiles_per_chunk, int has_col) {
   __shared__ __attribute__((aligned(16))) float sx[WG16_SLOT_FLOATS], sy[WG16_SLOT_FLOATS];
+  __shared__ __attribute__((aligned(16))) float l0tab[L0TAB_FLOATS];
   // ONE copy for both pairs (barrier 4 separates pair 0's readers from pair 1's writers)
   __shared__ __attribute__((aligned(16))) f16x8 sb[2][4][2][64];
   const int m = blockIdx.y;
+  // a compile-time split per kind of matrix: with `m` tested at run time hipcc turned per-element selects into branches
   if (m == 7) {
     if (has_col)
-      wgrad_f16_body<true>(sx, sy, sb, 7, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta, d_small,
-                           wt_per_elem, tiles_per_chunk);
+      wgrad_f16_body<1, FAST>(sx, sy, sb, l0tab, 7, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
+                              d_small, wt_per_elem, tiles_per_chunk);
+  } else if (m == 0) {
+    l0tab_fill(l0tab, reinterpret_cast<const float*>(packed), gamma, beta, blockIdx.z, threadIdx.x);
+    __syncthreads();
+    wgrad_f16_body<2, FAST>(sx, sy, sb, l0tab, 0, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
+                            d_small, wt_per_elem, tiles_per_chunk);
   } else {
-    wgrad_f16_body<false>(sx, sy, sb, m, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta, d_small,
-                          wt_per_elem, tiles_per_chunk);
+    wgrad_f16_body<0, FAST>(sx, sy, sb, l0tab, m, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
+                            d_small, wt_per_elem, tiles_per_chunk);
   }
 }
 
@@ -1274,11 +1382,11 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
     dim3 g2(oi::cdiv(wt_per_elem, chunk), 8, B);
     const char* pk = reinterpret_cast<const char*>(packed);
     if constexpr (PREC == OI_PREC_F16X3) {
-      hipLaunchKernelGGL(mlp_wgrad_f16_kernel<FAST>, g2, block, 0, st, tiles, op_max, pk, plain_off(PREC), gamma, d_wmat,
-                         d_gamma, d_beta, d_small, wt_per_elem, chunk, has_col);
+      hipLaunchKernelGGL(mlp_wgrad_f16_kernel<FAST>, g2, block, 0, st, tiles, op_max, pk, plain_off(PREC), gamma, beta,
+                         d_wmat, d_gamma, d_beta, d_small, wt_per_elem, chunk, has_col);
     } else {
-      hipLaunchKernelGGL(mlp_wgrad_kernel<FAST>, g2, block, 0, st, tiles, pk, plain_off(PREC), gamma, d_wmat, d_gamma, d_beta,
-                         d_small, wt_per_elem, chunk, has_col);
+      hipLaunchKernelGGL(mlp_wgrad_kernel<FAST>, g2, block, 0, st, tiles, pk, plain_off(PREC), gamma, beta, d_wmat, d_gamma,
+                         d_beta, d_small, wt_per_elem, chunk, has_col);
     }
     rc = oi::check_launch("oi_sdf_mlp_bwd(wgrad)");
     if (rc != OI_OK) return rc;
