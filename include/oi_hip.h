@@ -368,6 +368,22 @@ int oi_affine_grid_sample_fwd(const float* x, const float* theta, float* y, int 
 int oi_affine_grid_sample_bwd(const float* gy, const float* theta, float* gx, int B, int C, int Hi,
                               int Wi, int Ho, int Wo, oi_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The scalar losses of a GAN training step, one launch each way (csrc/loss.hip).  Replaces GANLoss("bce") =
+ * F.binary_cross_entropy_with_logits against a constant target (src/loss/gan.py:39-49), compute_grad2's
+ * grad.pow(2).reshape(B, -1).sum(1).mean() (src/loss/gan.py:5-14), PositionLoss("mse") (src/loss/position.py:4-18) and their
+ * weighted sum (src/trainers/gan_pose_trainer.py:122-137 generator step, 163-190 discriminator steps).
+ *   d_real, d_fake [B][K] discriminator outputs (column 0 = the GAN logit; null = term absent): real = BCE(d_real[:, 0], 1),
+ *   fake = BCE(d_fake[:, 0], 0);  pose [B][K-1] (null = absent): aux = mean (d_fake[:, 1:] - pose)^2;  gx [B][N] (null or
+ *   N = 0 = absent): reg = mean_b sum_i gx^2;  aux_w: DEVICE scalar (changes per iteration inside a captured step).
+ *   out6 = { real + fake + reg_w reg + aux_w aux,  real + fake,  reg,  fake,  real,  aux }
+ * _bwd: g_total (device scalar) -> g_real, g_fake [B][K] (unused columns zero), g_gx [B][N]; any of them null = not wanted. */
+int oi_gan_losses_fwd(const float* d_real, const float* d_fake, const float* pose, const float* gx, const float* aux_w,
+                      float reg_w, float* out6, int B, int K, long long N, oi_stream_t stream);
+int oi_gan_losses_bwd(const float* g_total, const float* d_real, const float* d_fake, const float* pose, const float* gx,
+                      const float* aux_w, float reg_w, float* g_real, float* g_fake, float* g_gx, int B, int K, long long N,
+                      oi_stream_t stream);
+
 /* Outputs that are ACCUMULATED into (the split-K sums of oi_conv4x4_fwd* / oi_conv4x4_wgrad, the scatter-adds of
  * oi_conv4x4_dgrad, oi_affine_grid_sample_bwd, oi_grid_sample_bwd, oi_reflect_pad_bwd) are cleared by their launcher with a
  * fill of their own.  A caller that takes every such output from memory it has already zeroed -- one fill per training step

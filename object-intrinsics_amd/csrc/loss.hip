@@ -1,0 +1,117 @@
+// The scalar losses of one GAN training step for gfx950, one launch forward and one backward.
+//
+// Replaces what the reference composes from a dozen tiny tensor ops per term (src/loss/gan.py:5-22 compute_grad2 /
+// GANLoss "bce" = F.binary_cross_entropy_with_logits, src/loss/position.py:4-18 PositionLoss "mse", summed with the weights
+// of gan_pose_trainer.py:122-137, 163-190): at batch 1 the operands are 1..7 logits and one image-sized gradient, and
+// every one of those ops is a launch of ~4 us -- 45 of the ~200 launches of a discriminator step.
+//   real  = mean_b softplus(-d_real[b][0])                       BCE with logits against 1
+//   fake  = mean_b softplus(+d_fake[b][0])                       ... against 0
+//   reg   = mean_b sum_i gx[b][i]^2                              R1 (gx = d sum_b d_real[b][0] / d x_real)
+//   aux   = mean_{b, k >= 1} (d_fake[b][k] - pose[b][k - 1])^2   pose regression on the remaining logits
+//   total = real + fake + reg_w * reg + aux_w * aux              (every term optional: null pointer = 0)
+#include <algorithm>
+
+#include "oi_common.h"
+
+namespace {
+
+// F.binary_cross_entropy_with_logits against a constant target t (0 or 1), torch's stable form:
+// (1 - t) x + m + log(exp(-m) + exp(-x - m)),  m = max(-x, 0)
+__device__ __forceinline__ float bce_logits(float x, float t) {
+  const float m = fmaxf(-x, 0.f);
+  return (1.f - t) * x + m + logf(expf(-m) + expf(-x - m));
+}
+
+__global__ void __launch_bounds__(1024)
+gan_losses_fwd_kernel(const float* __restrict__ d_real, const float* __restrict__ d_fake, const float* __restrict__ pose,
+                      const float* __restrict__ gx, const float* __restrict__ aux_w, float reg_w, float* __restrict__ out,
+                      int B, int K, long long N) {
+  __shared__ float part[16];
+  const int tid = threadIdx.x;
+  float s = 0.f;
+  if (gx != nullptr)
+    for (long long i = tid; i < (long long)B * N; i += 1024) s = fmaf(gx[i], gx[i], s);
+  s = oi::wave_sum(s);
+  if ((tid & 63) == 0) part[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    float reg = 0.f;
+    for (int w = 0; w < 16; ++w) reg += part[w];
+    reg /= (float)B;
+    float real = 0.f, fake = 0.f, aux = 0.f;
+    for (int b = 0; b < B; ++b) {
+      if (d_real != nullptr) real += bce_logits(d_real[(size_t)b * K], 1.f);
+      if (d_fake != nullptr) {
+        fake += bce_logits(d_fake[(size_t)b * K], 0.f);
+        if (pose != nullptr)
+          for (int k = 1; k < K; ++k) {
+            const float d = d_fake[(size_t)b * K + k] - pose[(size_t)b * (K - 1) + k - 1];
+            aux = fmaf(d, d, aux);
+          }
+      }
+    }
+    real /= (float)B;
+    fake /= (float)B;
+    if (pose != nullptr && K > 1) aux /= (float)(B * (K - 1));
+    const float aw = (pose != nullptr && aux_w != nullptr) ? aux_w[0] : 0.f;
+    out[0] = real + fake + reg_w * reg + aw * aux;
+    out[1] = real + fake;
+    out[2] = reg;
+    out[3] = fake;
+    out[4] = real;
+    out[5] = aux;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gan_losses_bwd_kernel(const float* __restrict__ g_total, const float* __restrict__ d_real, const float* __restrict__ d_fake,
+                      const float* __restrict__ pose, const float* __restrict__ gx, const float* __restrict__ aux_w,
+                      float reg_w, float* __restrict__ g_real, float* __restrict__ g_fake, float* __restrict__ g_gx, int B,
+                      int K, long long N) {
+  const float go = g_total[0];
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gx != nullptr) {
+    const float c = 2.f * reg_w * go / (float)B;
+    for (long long i = gid; i < (long long)B * N; i += (long long)gridDim.x * 256) g_gx[i] = c * gx[i];
+  }
+  if (gid < (long long)B * K) {  // d/dx BCE = (sigmoid(x) - t) / B;  d/dx MSE = 2 (x - p) / count
+    const int b = (int)(gid / K), k = (int)(gid % K);
+    if (g_real != nullptr) g_real[gid] = k == 0 ? go * (oi::sigmoidf_(d_real[gid]) - 1.f) / (float)B : 0.f;
+    if (g_fake != nullptr) {
+      float g = 0.f;
+      if (k == 0) g = go * oi::sigmoidf_(d_fake[gid]) / (float)B;
+      else if (pose != nullptr) g = go * aux_w[0] * 2.f * (d_fake[gid] - pose[(size_t)b * (K - 1) + k - 1]) / (float)(B * (K - 1));
+      g_fake[gid] = g;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int oi_gan_losses_fwd(const float* d_real, const float* d_fake, const float* pose, const float* gx, const float* aux_w,
+                      float reg_w, float* out6, int B, int K, long long N, oi_stream_t stream) {
+  OI_REQUIRE(out6 != nullptr && B > 0 && K > 0 && N >= 0, "oi_gan_losses_fwd: B=%d K=%d N=%lld", B, K, N);
+  OI_REQUIRE(pose == nullptr || (d_fake != nullptr && aux_w != nullptr), "oi_gan_losses_fwd: the pose term needs d_fake and aux_w");
+  hipLaunchKernelGGL(gan_losses_fwd_kernel, dim3(1), dim3(1024), 0, oi::as_stream(stream), d_real, d_fake, pose,
+                     N > 0 ? gx : nullptr, aux_w, reg_w, out6, B, K, N);
+  return oi::check_launch("oi_gan_losses_fwd");
+}
+
+int oi_gan_losses_bwd(const float* g_total, const float* d_real, const float* d_fake, const float* pose, const float* gx,
+                      const float* aux_w, float reg_w, float* g_real, float* g_fake, float* g_gx, int B, int K, long long N,
+                      oi_stream_t stream) {
+  OI_REQUIRE(g_total != nullptr && B > 0 && K > 0 && N >= 0, "oi_gan_losses_bwd: B=%d K=%d N=%lld", B, K, N);
+  OI_REQUIRE((g_real == nullptr || d_real != nullptr) && (g_fake == nullptr || d_fake != nullptr) &&
+                 (g_gx == nullptr || gx != nullptr),
+             "oi_gan_losses_bwd: a gradient output without its operand");
+  if (g_gx == nullptr || N == 0) gx = nullptr;  // (the R1 term's gradient is not wanted)
+  const long long work = std::max<long long>((long long)B * K, gx != nullptr ? (long long)B * N : 0);
+  const int blocks = (int)std::min<long long>(1024, std::max<long long>(1, (work + 255) / 256));
+  hipLaunchKernelGGL(gan_losses_bwd_kernel, dim3(blocks), dim3(256), 0, oi::as_stream(stream), g_total, d_real, d_fake, pose,
+                     gx, aux_w, reg_w, g_real, g_fake, g_gx, B, K, N);
+  return oi::check_launch("oi_gan_losses_bwd");
+}
+
+}  // extern "C"

@@ -102,6 +102,7 @@ class GraphedDStep:
         self.th_fake = torch.empty(B, 2, 3, device=dev)
         self.c2b = None if c2b is None else torch.empty_like(c2b)
         self.aux_w = torch.zeros((), device=dev)
+        self._one = torch.ones((), device=dev)
         # no geometric augmentation configured: the eager path returns the images untouched (AugmentPipe.forward), so the
         # captured step must not run the pad / resample chain on an identity transform either
         self._geom = _has_geometric(self._net().aug)
@@ -124,35 +125,30 @@ class GraphedDStep:
 
     def _step_body(self, disc, wrapped):
         from . import ops
-        from .losses import compute_grad2
         if getattr(self, "_pool", None) is None:
             self._pool = ops.ZeroPool()
         self._pool.begin(self.x_real.device)   # ONE fill for every split-K / scatter output of the step
         with self._pool:
-            return self._step_ops(disc, wrapped, compute_grad2)
+            return self._step_ops(disc, wrapped)
 
-    def _step_ops(self, disc, wrapped, compute_grad2):
+    def _step_ops(self, disc, wrapped):
+        from .losses import gan_losses, grad_wrt_input
         if wrapped:
             disc.zero_grad()
         else:
             for p in disc.parameters():
                 p.grad = None
         th_real, th_fake = (self.th_real, self.th_fake) if self._geom else (None, None)
-        x_real = self.x_real.detach().clone().requires_grad_()
-        d_real = disc(x_real, aug_theta=th_real)[:, :1]
-        loss_real = self.gan(d_real, 1)
-        loss_reg = compute_grad2(d_real, x_real)
-        x_fake = self.x_fake   # (the reference marks it requires_grad too: a gradient nothing reads)
-        d_fake = disc(x_fake, aug_theta=th_fake)
-        loss_aux = torch.zeros((), device=x_real.device)
-        if d_fake.size(1) > 1:
-            d_fake, d_aux = torch.split(d_fake, (1, self.prior.repr_dim), dim=1)
-            loss_aux = self.aux_pose(d_aux, self.prior.pose_to_vec_repr(self.c2b))
-        loss_fake = self.gan(d_fake, 0)
-        loss = loss_real + loss_fake + loss_reg * self.reg_weight + loss_aux * self.aux_w
+        x_real = self.x_real.detach().requires_grad_()   # (a fresh leaf over the static buffer: nothing writes it in the step)
+        d_real = disc(x_real, aug_theta=th_real)
+        gx = grad_wrt_input(d_real[:, :1], x_real)        # R1: d sum(d_real[:, 0]) / d x_real, graph kept
+        d_fake = disc(self.x_fake, aug_theta=th_fake)    # (the reference marks x_fake requires_grad too: a gradient nothing reads)
+        pose = self.prior.pose_to_vec_repr(self.c2b) if d_fake.size(1) > 1 else None
+        # BCE(real, 1) + BCE(fake, 0) + reg_weight R1 + aux_w MSE(pose): one launch forward, one backward (losses.gan_losses)
+        loss, parts = gan_losses(d_real, d_fake, pose, gx, self.aux_w if pose is not None else None, self.reg_weight)
         # only the parameters' gradients: not the images' (see oi_amd.trainer._backward_to)
-        torch.autograd.backward(loss, inputs=[p for p in self._net().parameters() if p.requires_grad])
-        return torch.stack([loss_fake + loss_real, loss_reg, loss_fake, loss_real, loss_aux])
+        torch.autograd.backward(loss, grad_tensors=self._one, inputs=[p for p in self._net().parameters() if p.requires_grad])
+        return parts   # [fake + real, reg, fake, real, aux]
 
     @staticmethod
     def _named(vec):

@@ -1,6 +1,7 @@
 """GAN losses of the path (host-side glue over D outputs): src/loss/gan.py:5-22, 39-49 and
 src/loss/position.py:4-18.  The R1 term differentiates through oi_amd's discriminator, whose
 autograd Functions supply the double-backward from HIP kernels."""
+import torch
 import torch.nn.functional as F
 from torch import autograd
 
@@ -28,6 +29,51 @@ class PositionLoss:
 
     def __call__(self, pred, target, reduction="mean"):
         return self.loss(pred, target, reduction=reduction)
+
+
+class _GanLosses(autograd.Function):
+    """The scalar losses of one step in ONE launch each way (csrc/loss.hip).  At batch 1 every ATen op of the composition
+    above is a ~4 us launch on 1..7 elements: 45 of the ~200 launches of a discriminator step."""
+
+    @staticmethod
+    def forward(ctx, d_real, d_fake, pose, gx, aux_w, reg_w):
+        from . import ops
+        ts = [None if t is None else t.detach().contiguous() for t in (d_real, d_fake, pose, gx, aux_w)]
+        out = ops.gan_losses_fwd(*ts, reg_w)
+        ctx.ts, ctx.reg_w = ts, reg_w
+        total, parts = out[0], out[1:]
+        ctx.mark_non_differentiable(parts)
+        return total, parts
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        from . import ops
+        d_real, d_fake, pose, gx, aux_w = ctx.ts
+        need = ctx.needs_input_grad
+        g = ops.gan_losses_bwd(g_total.contiguous(), d_real, d_fake, pose, gx, aux_w, ctx.reg_w,
+                               d_real is not None and need[0], d_fake is not None and need[1], gx is not None and need[3])
+        return g[0], g[1], None, g[2], None, None
+
+
+def gan_losses(d_real=None, d_fake=None, pose=None, gx=None, aux_w=None, reg_w=0.0):
+    """-> (total, parts) with total = BCE(d_real[:, :1], 1) + BCE(d_fake[:, :1], 0) + reg_w * R1(gx) + aux_w * MSE(d_fake[:, 1:],
+    pose) (absent terms: None) and parts = [real + fake, reg, fake, real, aux] (no gradient).  `aux_w`: device scalar tensor.
+    Same arithmetic as GANLoss / compute_grad2 / PositionLoss above, which stay the reference-facing interface."""
+    return _GanLosses.apply(d_real, d_fake, pose, gx, aux_w, float(reg_w))
+
+
+_ONES = {}
+
+
+def grad_wrt_input(d_out, x_in):
+    """d sum(d_out) / d x_in with the graph kept (the R1 penalty's inner gradient, compute_grad2 above) -- `grad_outputs`
+    from a cached tensor of ones instead of a `sum()` whose backward expands one."""
+    key = (tuple(d_out.shape), d_out.device)
+    ones = _ONES.get(key)
+    if ones is None:
+        ones = _ONES[key] = torch.ones(d_out.shape, device=d_out.device)
+    (g,) = autograd.grad(outputs=d_out, inputs=x_in, grad_outputs=ones, create_graph=True, retain_graph=True, only_inputs=True)
+    return g
 
 
 def linear_increase(max_it, max_weight):

@@ -13,7 +13,7 @@ F9 pins the per-parameter gradients of one iteration assembled from the referenc
 class itself on top of the oi_amd modules stays untested (its module imports tu.loggers / visualisation helpers)."""
 import torch
 
-from .losses import GANLoss, PositionLoss, compute_grad2, linear_increase
+from .losses import GANLoss, PositionLoss, gan_losses, grad_wrt_input, linear_increase
 
 MODULE_KEYS = ("generator", "discriminator", "mask_discriminator")
 DATA_KEYS = {"generator": ["image"], "discriminator": ["image"], "mask_discriminator": ["mask"]}
@@ -51,6 +51,10 @@ def _cat(tensors):
     """torch.cat along the channel axis; a single tensor is returned as is (both discriminators take ONE map:
     MODULE_KEYS_TO_DATA_KEYS of gan_pose_trainer.py:27-31 -- the reference's cat of one tensor is a copy launch)."""
     return tensors[0] if len(tensors) == 1 else torch.cat(tensors, dim=-3)
+
+
+def _scaled(v, w):
+    return v if w == 1 else v * w
 
 
 def _backward_to(loss, net):
@@ -124,14 +128,15 @@ class Trainer:
             self._toggle(k, self.modules[k], k == "generator")
         _zero_grad(self.generator, self.opt_generator)
         blob = self.generator(bs=bs, it=self.it, data={}, return_raw=False)["box"]
+        # BCE(D(fake)[:, :1], 1) per discriminator: one launch each way (losses.gan_losses = GANLoss("bce") fused)
         x_fake = _cat([blob["render_out"][k] for k in DATA_KEYS["discriminator"]])
-        loss_disc = self.gan(self.discriminator(x_fake, it=self.it)[:, :1], 1)
+        loss_disc, _ = gan_losses(d_real=self.discriminator(x_fake, it=self.it))
         m_fake = _cat([blob["render_out"][k] for k in DATA_KEYS["mask_discriminator"]])
-        loss_mask = self.gan(self.mask_discriminator(m_fake, it=self.it), 1)
-        loss = loss_disc * self.loss_weight["disc_in_gen"] + loss_mask * self.loss_weight["mask_disc_in_gen"]
+        loss_mask, _ = gan_losses(d_real=self.mask_discriminator(m_fake, it=self.it))
+        loss = _scaled(loss_disc, self.loss_weight["disc_in_gen"]) + _scaled(loss_mask, self.loss_weight["mask_disc_in_gen"])
         ret = {"generator/loss": loss_disc, "generator/loss_mask": loss_mask}
         for k, v in blob["loss"].items():
-            loss = loss + self.loss_weight[k] * v
+            loss = loss + _scaled(v, self.loss_weight[k])
             ret[f"generator/{k}"] = v
         loss.backward()
         _sync(self.generator)
@@ -146,21 +151,19 @@ class Trainer:
             return self._graphed_d_step(key, disc, opt, real, fake, defer_step)
         _zero_grad(disc, opt)
         x_real = _cat([real[k] for k in DATA_KEYS[key]]).detach().clone().requires_grad_()
-        d_real = disc(x_real, it=self.it)[:, :1]
-        loss_real = self.gan(d_real, 1)
-        loss_reg = compute_grad2(d_real, x_real)
+        d_real = disc(x_real, it=self.it)
+        gx = grad_wrt_input(d_real[:, :1], x_real)                  # the R1 penalty's inner gradient (compute_grad2)
         x_fake = _cat([fake[k] for k in DATA_KEYS[key]]).detach()   # (the reference also marks it requires_grad: unused)
         d_fake = disc(x_fake, it=self.it)
-        loss_aux = 0
+        pose, aux_w = None, None
         if d_fake.size(1) > 1:
-            prior = _unwrap(self.generator).pose_prior
-            d_fake, d_aux = torch.split(d_fake, (1, prior.repr_dim), dim=1)
-            loss_aux = self.aux_pose(d_aux, prior.pose_to_vec_repr(fake["c2b"]))
-        loss_fake = self.gan(d_fake, 0)
-        loss = loss_real + loss_fake + loss_reg * self.loss_weight["reg"] + loss_aux * self.loss_weight["aux_pose"](self.it)
+            pose = _unwrap(self.generator).pose_prior.pose_to_vec_repr(fake["c2b"])
+            aux_w = torch.full((), float(self.loss_weight["aux_pose"](self.it)), device=d_fake.device)
+        # BCE(real, 1) + BCE(fake, 0) + reg R1 + aux_w MSE(pose) in one launch each way (losses.gan_losses)
+        loss, parts = gan_losses(d_real, d_fake, pose, gx, aux_w, self.loss_weight["reg"])
         _backward_to(loss, disc)
-        ret = {f"{key}/loss": loss_fake + loss_real, f"{key}/reg": loss_reg, f"{key}/fake": loss_fake,
-               f"{key}/real": loss_real, f"{key}/aux_pose": loss_aux}
+        ret = {f"{key}/loss": parts[0], f"{key}/reg": parts[1], f"{key}/fake": parts[2], f"{key}/real": parts[3],
+               f"{key}/aux_pose": parts[4] if pose is not None else 0}
 
         def finish():
             _sync(disc)

@@ -567,3 +567,42 @@ def test_ada_geom_fused_matches_the_staged_chain(ops, B, C, R, static, monkeypat
         outs.append((y.detach(), gx.detach(), g2.detach()))
     for name, a, b in zip(("value", "gradient", "double backward"), outs[0], outs[1]):
         assert maxdiff(a, b) < 2e-6 * max(1.0, float(b.abs().max())), (name, maxdiff(a, b), float(b.abs().max()))
+
+
+def test_gan_losses_fused_match_the_reference_composition():
+    """oi_gan_losses_fwd / _bwd (one launch each way) against GANLoss + compute_grad2 + PositionLoss summed as the trainer
+    sums them (src/loss/gan.py:5-22, 39-49; src/loss/position.py:4-18; gan_pose_trainer.py:163-190), through a toy
+    discriminator whose R1 double backward reaches its weights."""
+    from oi_amd.losses import GANLoss, PositionLoss, compute_grad2, gan_losses, grad_wrt_input
+    torch.manual_seed(3)
+    B, K, n = 3, 7, 3 * 8 * 8
+    w = (torch.randn(K, n, device="cuda") * 0.2).requires_grad_()
+    net = lambda x: torch.tanh(x.reshape(B, -1) @ w.t()) * 3.0
+    xr = torch.randn(B, 3, 8, 8, device="cuda")
+    xf = torch.randn(B, 3, 8, 8, device="cuda")
+    pose = torch.randn(B, K - 1, device="cuda")
+    aux_w, reg_w = 0.37, 10.0
+    gan, mse = GANLoss("bce"), PositionLoss("mse")
+
+    x1 = xr.clone().requires_grad_()
+    d_real, d_fake = net(x1), net(xf)
+    real, fake = gan(d_real[:, :1], 1), gan(d_fake[:, :1], 0)
+    reg, aux = compute_grad2(d_real[:, :1], x1), mse(d_fake[:, 1:], pose)
+    ref = real + fake + reg_w * reg + aux_w * aux
+    (gw_ref,) = torch.autograd.grad(ref, w)
+
+    x2 = xr.clone().requires_grad_()
+    d_real, d_fake = net(x2), net(xf)
+    gx = grad_wrt_input(d_real[:, :1], x2)
+    total, parts = gan_losses(d_real, d_fake, pose, gx, torch.full((), aux_w, device="cuda"), reg_w)
+    (gw,) = torch.autograd.grad(total, w)
+    for got, want in ((total, ref), (parts[0], real + fake), (parts[1], reg), (parts[2], fake), (parts[3], real), (parts[4], aux)):
+        assert abs(float(got.detach()) - float(want.detach())) < 2e-6 * max(1.0, abs(float(want.detach()))), (float(got.detach()), float(want.detach()))
+    assert float((gw - gw_ref).abs().max()) < 2e-6 * float(gw_ref.abs().max())
+    # generator-step use: BCE against 1 alone, gradient w.r.t. the logits only in column 0
+    d = net(xf).detach().requires_grad_()
+    t2, _ = gan_losses(d_real=d)
+    (gd,) = torch.autograd.grad(t2, d)
+    d3 = d.detach().clone().requires_grad_()
+    (gd_ref,) = torch.autograd.grad(gan(d3[:, :1], 1), d3)
+    assert abs(float(t2) - float(gan(d3[:, :1], 1))) < 1e-6 and float((gd - gd_ref).abs().max()) < 1e-7

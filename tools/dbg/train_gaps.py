@@ -36,6 +36,20 @@ def main(d, i0=6, n=8):
     print("largest idle gaps (sum over the window, ms / count / after kernel -> before kernel):")
     for (p, q), (g, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
         print(f"  {g / 1e6:8.3f} {c:5d}  {p} -> {q}")
+    # one iteration, launch by launch (runs of the same kernel folded): start offset us, count, kernel us, idle-before us
+    a1 = sw[i0 + 1]
+    one = rows[a:a1]
+    print(f"\none iteration: {len(one)} dispatches")
+    k = 0
+    while k < len(one):
+        j, busy_us, idle_us = k, 0.0, 0.0
+        while j < len(one) and one[j][2] == one[k][2]:
+            busy_us += (one[j][1] - one[j][0]) / 1e3
+            if j:
+                idle_us += max(0, one[j][0] - max(r[1] for r in one[max(0, j - 4):j])) / 1e3
+            j += 1
+        print(f"  {(one[k][0] - one[0][0]) / 1e3:9.1f}  x{j - k:<3d} {busy_us:8.1f}  idle {idle_us:7.1f}  {one[k][2]}")
+        k = j
 
 
 if __name__ == "__main__":

@@ -17,7 +17,7 @@ mods = {"generator": gen, "discriminator": disc, "mask_discriminator": mdisc,
         "opt_generator": FusedAdam(gen.parameters(), lr=2e-5, betas=(0.0, 0.9)),
         "opt_discriminator": FusedRMSprop(disc.parameters(), lr=1e-4),
         "opt_mask_discriminator": FusedRMSprop(mdisc.parameters(), lr=1e-4)}
-tr = Trainer(mods)
+tr = Trainer(mods, graph_d_steps=os.environ.get("OI_GRAPH", "1") == "1")  # what bench.py times
 data = {"image": torch.rand(1, 3, 64, 64, device=dev), "mask": torch.rand(1, 1, 64, 64, device=dev)}
 for _ in range(3):
     tr.train_step(data)
