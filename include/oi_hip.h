@@ -341,6 +341,14 @@ int oi_conv4x4_dgrad(const float* g, const float* w, float* gx, int B, int Cin, 
                      int stride, int pad, oi_stream_t stream);
 int oi_conv4x4_wgrad(const float* g, const float* x, float* gw, int B, int Cin, int H, int W, int Cout,
                      int stride, int pad, oi_stream_t stream);
+/* The same with the producing layer's LeakyReLU applied to the incoming gradient on load (ref = that layer's forward output,
+ * same shape as g: g_eff = ref > 0 ? g : slope g; ref null = plain), and, for the weight gradient, accumulation into a buffer
+ * that already holds a gradient or zeros (accumulate != 0: atomic adds, no clearing) -- what autograd otherwise does with one
+ * oi_lrelu_mask_mul launch per layer and one `+=` launch per weight and contribution. */
+int oi_conv4x4_dgrad_masked(const float* g, const float* ref, float slope, const float* w, float* gx, int B, int Cin, int H,
+                            int W, int Cout, int stride, int pad, oi_stream_t stream);
+int oi_conv4x4_wgrad_masked(const float* g, const float* ref, float slope, const float* x, float* gw, int accumulate, int B,
+                            int Cin, int H, int W, int Cout, int stride, int pad, oi_stream_t stream);
 int oi_lrelu_mask_mul(const float* v, const float* ref, float* out, long long n, float slope,
                       oi_stream_t stream);
 int oi_channel_sum(const float* g, float* gb, int B, int C, int HW, oi_stream_t stream);

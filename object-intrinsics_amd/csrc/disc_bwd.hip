@@ -24,9 +24,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------
 template <int S>
 __global__ void __launch_bounds__(256)
-conv4x4_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ gx, int B, int Cin,
-                     int H, int W, int Cout, int Ho, int Wo, int pad, int m_tiles, int n_tiles, int k_splits,
-                     int couts_per_split, int Hc, int Wc) {
+conv4x4_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ ref, float slope, const float* __restrict__ w,
+                     float* __restrict__ gx, int B, int Cin, int H, int W, int Cout, int Ho, int Wo, int pad, int m_tiles,
+                     int n_tiles, int k_splits, int couts_per_split, int Hc, int Wc) {
+  // ref != null: the incoming gradient is taken through the LeakyReLU of the layer's forward output on load,
+  // g_eff = ref > 0 ? g : slope * g (what lrelu_mask_mul_kernel would have written out first)
   constexpr int TJ = 4 / S;      // taps per axis
   const int lane = threadIdx.x & 63;
   const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -60,7 +62,8 @@ conv4x4_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ w, f
     const int n = n0 + h;
     const bool n_ok = n < n_end;
     const float* wn = w + ((size_t)(n_ok ? n : 0) * Cin + (c_ok ? c : 0)) * 16;
-    const float* gn = g + ((size_t)b * Cout + (n_ok ? n : 0)) * Ho * Wo;
+    const size_t gn_off = ((size_t)b * Cout + (n_ok ? n : 0)) * Ho * Wo;
+    const float* gn = g + gn_off;
 #pragma unroll
     for (int jy = 0; jy < TJ; ++jy) {
       const int ky = ca + S * jy, oy = oy_base - jy;
@@ -69,7 +72,9 @@ conv4x4_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ w, f
       for (int jx = 0; jx < TJ; ++jx) {
         const int kx = cb + S * jx, ox = ox_base - jx;
         a[jx] = (n_ok && c_ok) ? wn[ky * 4 + kx] : 0.f;
-        bv[jx] = (n_ok && pix_ok && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) ? gn[oy * Wo + ox] : 0.f;
+        const bool ok = n_ok && pix_ok && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+        bv[jx] = ok ? gn[oy * Wo + ox] : 0.f;
+        if (ref != nullptr && ok && !(ref[gn_off + oy * Wo + ox] > 0.f)) bv[jx] *= slope;
       }
 #pragma unroll
       for (int jx = 0; jx < TJ; ++jx) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jx], bv[jx], acc, 0, 0, 0);
@@ -90,9 +95,10 @@ conv4x4_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ w, f
 // taps spread over ... columns j = (c_local * 16 + ky*4 + kx): 32 columns = 2 input channels x 16 taps.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-conv4x4_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ gw, int B, int Cin,
-                     int H, int W, int Cout, int Ho, int Wo, int stride, int pad, int m_tiles, int n_tiles,
-                     int k_splits, int pix_per_split) {
+conv4x4_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ ref, float slope, const float* __restrict__ x,
+                     float* __restrict__ gw, int accumulate, int B, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride,
+                     int pad, int m_tiles, int n_tiles, int k_splits, int pix_per_split) {
+  // ref / slope: as in the dgrad kernel;  accumulate: gw already holds a gradient (or zeros) that this one adds to
   const int lane = threadIdx.x & 63;
   const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long n_items = (long long)m_tiles * n_tiles * k_splits;
@@ -118,7 +124,8 @@ conv4x4_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x, f
       const int pp = p_ok ? p : 0;
       const int b = pp / HW, pl = pp % HW, oy = pl / Wo, ox = pl % Wo;
       const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
-      const float a = (p_ok && n_ok) ? g[((size_t)b * Cout + n) * HW + pl] : 0.f;
+      float a = (p_ok && n_ok) ? g[((size_t)b * Cout + n) * HW + pl] : 0.f;
+      if (ref != nullptr && p_ok && n_ok && !(ref[((size_t)b * Cout + n) * HW + pl] > 0.f)) a *= slope;
       const float bv = (p_ok && c_ok && iy >= 0 && iy < H && ix >= 0 && ix < W)
                            ? x[(((size_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
@@ -131,7 +138,7 @@ conv4x4_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x, f
     const int nn = mt * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * h;
     if (nn >= Cout) continue;
     float* dst = gw + ((size_t)nn * Cin + c) * 16 + tap;
-    if (k_splits == 1) *dst = acc[rg]; else atomicAdd(dst, acc[rg]);
+    if (k_splits == 1 && !accumulate) *dst = acc[rg]; else atomicAdd(dst, acc[rg]);
   }
 }
 
@@ -162,6 +169,11 @@ extern "C" {
 
 int oi_conv4x4_dgrad(const float* g, const float* w, float* gx, int B, int Cin, int H, int W, int Cout, int stride,
                      int pad, oi_stream_t stream) {
+  return oi_conv4x4_dgrad_masked(g, nullptr, 1.f, w, gx, B, Cin, H, W, Cout, stride, pad, stream);
+}
+
+int oi_conv4x4_dgrad_masked(const float* g, const float* ref, float slope, const float* w, float* gx, int B, int Cin, int H,
+                            int W, int Cout, int stride, int pad, oi_stream_t stream) {
   OI_REQUIRE(g && w && gx, "oi_conv4x4_dgrad: null pointer");
   OI_REQUIRE(stride == 1 || stride == 2, "oi_conv4x4_dgrad: stride %d (1 or 2 supported)", stride);
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
@@ -180,16 +192,21 @@ int oi_conv4x4_dgrad(const float* g, const float* w, float* gx, int B, int Cin, 
   if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_dgrad: memset: %s", hipGetErrorString(e));
   const long long items = tiles * k_splits;
   if (stride == 2)
-    hipLaunchKernelGGL(conv4x4_dgrad_kernel<2>, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, g, w, gx, B, Cin, H, W,
-                       Cout, Ho, Wo, pad, m_tiles, n_tiles, k_splits, cps, Hc, Wc);
+    hipLaunchKernelGGL(conv4x4_dgrad_kernel<2>, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, g, ref, slope, w, gx, B, Cin, H,
+                       W, Cout, Ho, Wo, pad, m_tiles, n_tiles, k_splits, cps, Hc, Wc);
   else
-    hipLaunchKernelGGL(conv4x4_dgrad_kernel<1>, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, g, w, gx, B, Cin, H, W,
-                       Cout, Ho, Wo, pad, m_tiles, n_tiles, k_splits, cps, Hc, Wc);
+    hipLaunchKernelGGL(conv4x4_dgrad_kernel<1>, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, g, ref, slope, w, gx, B, Cin, H,
+                       W, Cout, Ho, Wo, pad, m_tiles, n_tiles, k_splits, cps, Hc, Wc);
   return oi::check_launch("oi_conv4x4_dgrad");
 }
 
 int oi_conv4x4_wgrad(const float* g, const float* x, float* gw, int B, int Cin, int H, int W, int Cout, int stride,
                      int pad, oi_stream_t stream) {
+  return oi_conv4x4_wgrad_masked(g, nullptr, 1.f, x, gw, 0, B, Cin, H, W, Cout, stride, pad, stream);
+}
+
+int oi_conv4x4_wgrad_masked(const float* g, const float* ref, float slope, const float* x, float* gw, int accumulate, int B,
+                            int Cin, int H, int W, int Cout, int stride, int pad, oi_stream_t stream) {
   OI_REQUIRE(g && x && gw, "oi_conv4x4_wgrad: null pointer");
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
   OI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0 && stride > 0, "oi_conv4x4_wgrad: bad shape");
@@ -202,13 +219,13 @@ int oi_conv4x4_wgrad(const float* g, const float* x, float* gw, int B, int Cin, 
   pps = (pps + 7) & ~7;
   k_splits = oi::cdiv(P, pps);
   hipStream_t st = oi::as_stream(stream);
-  if (k_splits > 1) {
+  if (k_splits > 1 && !accumulate) {
     hipError_t e = oi::zero_output_async(gw, (size_t)Cout * Cin * 16, st);
     if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_wgrad: memset: %s", hipGetErrorString(e));
   }
   const long long items = tiles * k_splits;
-  hipLaunchKernelGGL(conv4x4_wgrad_kernel, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, g, x, gw, B, Cin, H, W, Cout, Ho,
-                     Wo, stride, pad, m_tiles, n_tiles, k_splits, pps);
+  hipLaunchKernelGGL(conv4x4_wgrad_kernel, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, g, ref, slope, x, gw, accumulate, B, Cin,
+                     H, W, Cout, Ho, Wo, stride, pad, m_tiles, n_tiles, k_splits, pps);
   return oi::check_launch("oi_conv4x4_wgrad");
 }
 

@@ -2,9 +2,29 @@
 whose backward passes are expressed with each other, so derivatives of any order run on the HIP
 implicit-GEMM kernels (csrc/disc.hip, csrc/disc_bwd.hip).  The fused LeakyReLU is differentiated
 through the saved *output* (sign(y) == sign(pre-activation))."""
+import os
+
 import torch
 
 from . import ops
+
+# plain (not create_graph) backward passes: LeakyReLU mask applied on load by the gradient kernels, weight gradients added
+# straight into a registered accumulator.  OI_CONV_FUSED_BWD=0: the staged ops (A/B switch)
+FUSED_BWD = os.environ.get("OI_CONV_FUSED_BWD", "1") == "1"
+
+
+def _wgrad(w, g, x, stride, pad, mask_ref=None, slope=1.0):
+    """Weight gradient of `w` inside a backward pass.  A plain backward (grad mode off: nothing will differentiate the
+    result) with a registered accumulator (ops.GradSink) adds into it and returns None; otherwise the differentiable node."""
+    if FUSED_BWD and not torch.is_grad_enabled():
+        acc = ops.GradSink.lookup(w)
+        if acc is not None:
+            ops.conv4x4_wgrad(g, x, stride, pad, mask_ref, slope, acc=acc)
+            return None
+        return ops.conv4x4_wgrad(g, x, stride, pad, mask_ref, slope)
+    if mask_ref is not None:
+        g = _MaskMul.apply(g, mask_ref, slope)
+    return _Wgrad.apply(g, x, stride, pad)
 
 
 class _Conv(torch.autograd.Function):
@@ -22,7 +42,7 @@ class _Conv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, pad = ctx.cfg
         gx = _Dgrad.apply(gy, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
-        gw = _Wgrad.apply(gy, x, stride, pad) if ctx.needs_input_grad[1] else None
+        gw = _wgrad(w, gy, x, stride, pad) if ctx.needs_input_grad[1] else None
         return gx, gw, None, None
 
 
@@ -40,7 +60,7 @@ class _Dgrad(torch.autograd.Function):
         g, w = ctx.saved_tensors
         stride, pad = ctx.cfg
         d_g = _Conv.apply(ggx, w, stride, pad) if ctx.needs_input_grad[0] else None
-        d_w = _Wgrad.apply(g, ggx, stride, pad) if ctx.needs_input_grad[1] else None
+        d_w = _wgrad(w, g, ggx, stride, pad) if ctx.needs_input_grad[1] else None
         return d_g, d_w, None, None, None, None
 
 
@@ -91,6 +111,11 @@ class _ConvLrelu(torch.autograd.Function):
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         stride, pad, slope = ctx.cfg
+        if FUSED_BWD and not torch.is_grad_enabled():
+            # plain backward: the LeakyReLU mask is applied to gy on load by both gradient kernels (no g_pre round trip)
+            gx = ops.conv4x4_dgrad(gy, w, x.shape[2], x.shape[3], stride, pad, y, slope) if ctx.needs_input_grad[0] else None
+            gw = _wgrad(w, gy, x, stride, pad, y, slope) if ctx.needs_input_grad[1] else None
+            return gx, gw, None, None, None
         g_pre = _MaskMul.apply(gy, y, slope)
         gx = _Dgrad.apply(g_pre, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
         gw = _Wgrad.apply(g_pre, x, stride, pad) if ctx.needs_input_grad[1] else None

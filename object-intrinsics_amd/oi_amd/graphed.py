@@ -146,8 +146,20 @@ class GraphedDStep:
         pose = self.prior.pose_to_vec_repr(self.c2b) if d_fake.size(1) > 1 else None
         # BCE(real, 1) + BCE(fake, 0) + reg_weight R1 + aux_w MSE(pose): one launch forward, one backward (losses.gan_losses)
         loss, parts = gan_losses(d_real, d_fake, pose, gx, self.aux_w if pose is not None else None, self.reg_weight)
-        # only the parameters' gradients: not the images' (see oi_amd.trainer._backward_to)
-        torch.autograd.backward(loss, grad_tensors=self._one, inputs=[p for p in self._net().parameters() if p.requires_grad])
+        # only the parameters' gradients: not the images' (see oi_amd.trainer._backward_to).  The convolution weights collect
+        # their four contributions (real, R1 x2, fake) in place: the flat gradient buffer under FlatGradDDP (just zeroed),
+        # pre-zeroed pool memory otherwise
+        from . import ops
+        params = [p for p in self._net().parameters() if p.requires_grad]
+        from .autograd_conv import FUSED_BWD
+        convw = [p for p in params if p.dim() == 4 and tuple(p.shape[2:]) == (4, 4)] if FUSED_BWD else []
+        sink = {p.data_ptr(): (p.grad if wrapped else ops._new_acc(p, *p.shape)) for p in convw}
+        with ops.GradSink(sink):
+            torch.autograd.backward(loss, grad_tensors=self._one, inputs=params)
+        if not wrapped:
+            for p in convw:
+                assert p.grad is None, "a convolution weight received a gradient outside the sink"
+                p.grad = sink[p.data_ptr()]
         return parts   # [fake + real, reg, fake, real, aux]
 
     @staticmethod

@@ -389,24 +389,56 @@ def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2, out=None, x_slope=1
     return y
 
 
-def conv4x4_dgrad(g, w, H, W, stride=2, pad=1):
+def conv4x4_dgrad(g, w, H, W, stride=2, pad=1, mask_ref=None, slope=1.0):
+    """mask_ref: the producing layer's forward output -- its LeakyReLU is applied to `g` on load (oi_conv4x4_dgrad_masked)."""
     L = _l.load()
     g, w = _c(g), _c(w)
     B, Cout = g.shape[:2]
     Cin = w.shape[1]
     gx = _new_acc(g, B, Cin, H, W)
-    _l.check(L.oi_conv4x4_dgrad(_p(g), _p(w), _p(gx), B, Cin, H, W, Cout, stride, pad, _stream()), "oi_conv4x4_dgrad")
+    _l.check(L.oi_conv4x4_dgrad_masked(_p(g), _p(_c(mask_ref)), float(slope), _p(w), _p(gx), B, Cin, H, W, Cout, stride, pad,
+                                       _stream()), "oi_conv4x4_dgrad")
     return gx
 
 
-def conv4x4_wgrad(g, x, stride=2, pad=1):
+def conv4x4_wgrad(g, x, stride=2, pad=1, mask_ref=None, slope=1.0, acc=None):
+    """acc: a [Cout, Cin, 4, 4] buffer that already holds a gradient (or zeros) -- this one is added to it and `acc` returned."""
     L = _l.load()
     g, x = _c(g), _c(x)
     B, Cin, H, W = x.shape
     Cout = g.shape[1]
-    gw = _new_acc(g, Cout, Cin, 4, 4)
-    _l.check(L.oi_conv4x4_wgrad(_p(g), _p(x), _p(gw), B, Cin, H, W, Cout, stride, pad, _stream()), "oi_conv4x4_wgrad")
+    if acc is not None and (tuple(acc.shape) != (Cout, Cin, 4, 4) or not acc.is_contiguous()):
+        raise _l.OiHipError(f"conv4x4_wgrad: accumulator of shape {tuple(acc.shape)} for a {(Cout, Cin, 4, 4)} gradient")
+    gw = _new_acc(g, Cout, Cin, 4, 4) if acc is None else acc
+    _l.check(L.oi_conv4x4_wgrad_masked(_p(g), _p(_c(mask_ref)), float(slope), _p(x), _p(gw), int(acc is not None), B, Cin, H, W,
+                                       Cout, stride, pad, _stream()), "oi_conv4x4_wgrad")
     return gw
+
+
+class GradSink:
+    """Weight-gradient accumulators for ONE plain backward pass (not create_graph): while active, the convolution Functions
+    of oi_amd.autograd_conv add every weight-gradient contribution of a registered weight straight into its buffer
+    (oi_conv4x4_wgrad_masked, accumulate) and hand autograd nothing for it -- instead of one fresh tensor per contribution
+    that autograd then sums with one `+=` launch each (a discriminator step has four contributions per weight).  The owner
+    zeroes the buffers beforehand and installs them as `.grad` afterwards (oi_amd.graphed.GraphedDStep)."""
+
+    _active = None
+
+    def __init__(self, buffers):
+        self.buffers = {int(k): v for k, v in buffers.items()}   # weight.data_ptr() -> accumulator
+
+    def __enter__(self):
+        assert GradSink._active is None, "nested GradSink"
+        GradSink._active = self
+        return self
+
+    def __exit__(self, *exc):
+        GradSink._active = None
+
+    @staticmethod
+    def lookup(w):
+        s = GradSink._active
+        return None if s is None else s.buffers.get(w.data_ptr())
 
 
 def lrelu_mask_mul(v, ref, slope):

@@ -605,4 +605,26 @@ def test_gan_losses_fused_match_the_reference_composition():
     (gd,) = torch.autograd.grad(t2, d)
     d3 = d.detach().clone().requires_grad_()
     (gd_ref,) = torch.autograd.grad(gan(d3[:, :1], 1), d3)
-    assert abs(float(t2) - float(gan(d3[:, :1], 1))) < 1e-6 and float((gd - gd_ref).abs().max()) < 1e-7
+    assert abs(float(t2.detach()) - float(gan(d3[:, :1], 1).detach())) < 1e-6 and float((gd - gd_ref).abs().max()) < 1e-7
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,stride,pad", [(1, 32, 64, 32, 2, 1), (3, 5, 7, 9, 2, 1), (2, 256, 7, 4, 1, 0)])
+def test_conv_gradients_masked_on_load_and_accumulated_match_the_staged_ops(B, Cin, Cout, H, stride, pad):
+    """oi_conv4x4_dgrad_masked / oi_conv4x4_wgrad_masked: LeakyReLU mask of the forward output applied to the incoming
+    gradient on load == oi_lrelu_mask_mul followed by the plain kernels; accumulate adds to what the buffer holds."""
+    from oi_amd import ops
+    torch.manual_seed(B + Cin)
+    x = torch.randn(B, Cin, H, H, device="cuda")
+    w = torch.randn(Cout, Cin, 4, 4, device="cuda") * 0.1
+    Ho = (H + 2 * pad - 4) // stride + 1
+    g = torch.randn(B, Cout, Ho, Ho, device="cuda")
+    y = torch.randn(B, Cout, Ho, Ho, device="cuda")
+    gm = ops.lrelu_mask_mul(g, y, 0.2)
+    for got, want in ((ops.conv4x4_dgrad(g, w, H, H, stride, pad, y, 0.2), ops.conv4x4_dgrad(gm, w, H, H, stride, pad)),
+                      (ops.conv4x4_wgrad(g, x, stride, pad, y, 0.2), ops.conv4x4_wgrad(gm, x, stride, pad))):
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())   # (split-K atomics: order of summation)
+    base = torch.randn(Cout, Cin, 4, 4, device="cuda")
+    acc = base.clone()
+    assert ops.conv4x4_wgrad(g, x, stride, pad, y, 0.2, acc=acc) is acc
+    want = base + ops.conv4x4_wgrad(gm, x, stride, pad)
+    assert float((acc - want).abs().max()) <= 1e-5 * float(want.abs().max())
