@@ -11,9 +11,15 @@ Restrictions: eval mode only (no per-ray jitter: its RNG offset would be frozen)
 iteration counter (`cos_anneal_ratio` is a launch argument and therefore baked in), and parameters must not be
 re-packed between capture and replay (call `recapture()` after an optimiser step or `load_state_dict`).
 """
+import contextlib
 import os
 
 import torch
+
+# captured discriminator step: real and fake branch on two streams (parallel branches of the graph).  Off by default: the
+# step alone replays in 0.66 instead of 0.75 ms, but a training iteration got 0.05-0.1 ms SLOWER on the same box (four
+# runs) -- a graph with branches costs more to launch than the shorter chain saves between the neighbouring renders
+FORK = os.environ.get("OI_GRAPH_D_FORK", "0") == "1"
 
 
 class GraphedForward:
@@ -103,6 +109,7 @@ class GraphedDStep:
         self.c2b = None if c2b is None else torch.empty_like(c2b)
         self.aux_w = torch.zeros((), device=dev)
         self._one = torch.ones((), device=dev)
+        self._fork = torch.cuda.Stream(device=dev)
         # no geometric augmentation configured: the eager path returns the images untouched (AugmentPipe.forward), so the
         # captured step must not run the pad / resample chain on an identity transform either
         self._geom = _has_geometric(self._net().aug)
@@ -140,10 +147,20 @@ class GraphedDStep:
                 p.grad = None
         th_real, th_fake = (self.th_real, self.th_fake) if self._geom else (None, None)
         x_real = self.x_real.detach().requires_grad_()   # (a fresh leaf over the static buffer: nothing writes it in the step)
+        # The fake branch (forward, and -- autograd runs a node's backward on its forward's stream -- its backward) goes to a
+        # second stream: the step is a chain of ~110 launches of a few microseconds, each waiting for its predecessor; the
+        # real branch (forward + R1 double backward) is two thirds of them, and the captured graph runs the two side by side.
+        main = torch.cuda.current_stream()
+        fork = self._fork if FORK else None
+        if fork is not None:
+            fork.wait_stream(main)
+        with torch.cuda.stream(fork) if fork is not None else contextlib.nullcontext():
+            d_fake = disc(self.x_fake, aug_theta=th_fake)    # (the reference marks x_fake requires_grad too: a gradient nothing reads)
+            pose = self.prior.pose_to_vec_repr(self.c2b) if d_fake.size(1) > 1 else None
         d_real = disc(x_real, aug_theta=th_real)
         gx = grad_wrt_input(d_real[:, :1], x_real)        # R1: d sum(d_real[:, 0]) / d x_real, graph kept
-        d_fake = disc(self.x_fake, aug_theta=th_fake)    # (the reference marks x_fake requires_grad too: a gradient nothing reads)
-        pose = self.prior.pose_to_vec_repr(self.c2b) if d_fake.size(1) > 1 else None
+        if fork is not None:
+            main.wait_stream(fork)
         # BCE(real, 1) + BCE(fake, 0) + reg_weight R1 + aux_w MSE(pose): one launch forward, one backward (losses.gan_losses)
         loss, parts = gan_losses(d_real, d_fake, pose, gx, self.aux_w if pose is not None else None, self.reg_weight)
         # only the parameters' gradients: not the images' (see oi_amd.trainer._backward_to).  The convolution weights collect
