@@ -818,16 +818,14 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       BW_T(9);
       float mx_v = 0.f, mx_u = 0.f;
       const float f1 = gemm2<PREC, true>(lds, ol, gb, acc, inv_t, &mx_v);   // g_l = W_l^T v_l
+      if constexpr (SC) publish_max(op_max, OM_V + l - 1, mx_v);  // (at once: nothing scalar stays live across the next product)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gb[16 * t + r] = SC ? acc[t][r] * f1 : acc[t][r];
       acc_zero(acc);
       const float f2 = gemm2<PREC, true>(lds, ol, act, acc, inv_t, &mx_u);  // abar_l = W_l^T ubar_l
-      if constexpr (SC) {
-        publish_max(op_max, OM_V + l - 1, mx_v);
-        publish_max(op_max, OM_U + l - 1, mx_u);
-      }
+      if constexpr (SC) publish_max(op_max, OM_U + l - 1, mx_u);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
