@@ -38,6 +38,7 @@ class FilmParamsFunction(torch.autograd.Function):
         w_out, gamma, beta = ops.film_params(style_w, style_b, gw, gb, bw, bb, z=z, w=w)
         ctx.save_for_backward(z, w_out, style_w, style_b, gw, bw)
         ctx.from_z = z is not None
+        ctx.set_materialize_grads(False)   # (backward handles the absent ones)
         ctx.need_dz = bool(z is not None and z.requires_grad)
         return w_out, gamma, beta
 

@@ -26,6 +26,7 @@ class SdfMlpFunction(torch.autograd.Function):
         sdf, grad, rgb, feat, _ = ops.sdf_mlp_fwd(pts, packed, gamma, beta, B, pack.prec, pack.fast_trig, want_grad,
                                                   want_rgb, want_feat or want_rgb)
         ctx.pack, ctx.B = pack, B
+        ctx.set_materialize_grads(False)   # an output no loss touches: None -> null pointer, not a zero-filled tensor
         # the image of the weights the forward used (parameters may be stepped before backward is called)
         ctx.packed = packed if pack.prec_bwd == pack.prec else pack.packed(for_backward=True)
         ctx.save_for_backward(pts, gamma, beta, grad, rgb, feat)

@@ -25,6 +25,9 @@ class CompositeFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg, car, B):
         out = ops.composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, ldir_n, bg, variance, light, car, B)
+        # ~20 outputs of which a loss touches a few: absent upstream gradients arrive as None (a null pointer for the kernel),
+        # not as one zero-filled tensor -- one fill launch -- each
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg)
         ctx.car, ctx.B = car, B
         ctx.mark_non_differentiable(*[out[k] for k in NON_DIFF])

@@ -41,6 +41,7 @@ class _GanLosses(autograd.Function):
         ts = [None if t is None else t.detach().contiguous() for t in (d_real, d_fake, pose, gx, aux_w)]
         out = ops.gan_losses_fwd(*ts, reg_w)
         ctx.ts, ctx.reg_w = ts, reg_w
+        ctx.set_materialize_grads(False)
         total, parts = out[0], out[1:]
         ctx.mark_non_differentiable(parts)
         return total, parts
@@ -49,6 +50,8 @@ class _GanLosses(autograd.Function):
     def backward(ctx, g_total, _g_parts):
         from . import ops
         d_real, d_fake, pose, gx, aux_w = ctx.ts
+        if g_total is None:
+            return (None,) * 6
         need = ctx.needs_input_grad
         g = ops.gan_losses_bwd(g_total.contiguous(), d_real, d_fake, pose, gx, aux_w, ctx.reg_w,
                                d_real is not None and need[0], d_fake is not None and need[1], gx is not None and need[3])

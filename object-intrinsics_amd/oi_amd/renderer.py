@@ -98,11 +98,10 @@ _INV_S_CACHE = {}
 
 
 def _inv_s(variance):
-    """-> (inv_s, 1 / inv_s), inv_s = exp(10 variance).clamp(1e-6, 1e6) (renderer.py:404): four launches, cached per parameter version when no
-    gradient is being recorded (the compositing kernel computes its own copy from `variance`)."""
-    if torch.is_grad_enabled() and variance.requires_grad:
-        inv = torch.exp(variance * 10.0).clamp(1e-6, 1e6)
-        return inv, 1.0 / inv
+    """-> (inv_s, 1 / inv_s), inv_s = exp(10 variance).clamp(1e-6, 1e6) (renderer.py:404): four launches, cached per parameter
+    version.  Reported values only: the compositing kernel computes its own copy from `variance` and owns the gradient (the
+    reference's `s_val` entry carries a graph that no loss of the path uses; ours does not -- four launches forward and four
+    backward per training render otherwise)."""
     key = (variance.data_ptr(), variance._version)
     hit = _INV_S_CACHE.get(variance.device)
     if hit is None or hit[0] != key:

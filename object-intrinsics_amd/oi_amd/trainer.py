@@ -127,6 +127,26 @@ class Trainer:
         for k in MODULE_KEYS:
             self._toggle(k, self.modules[k], k == "generator")
         _zero_grad(self.generator, self.opt_generator)
+        with self._zero_pool():
+            ret = self._generator_loss_backward(bs)
+        _sync(self.generator)
+        self.opt_generator.step()
+        return ret
+
+    def _zero_pool(self):
+        """ONE fill for the split-K / scatter outputs of the step's discriminator passes (ops.ZeroPool: ~20 fill launches of
+        the generator step otherwise; sized by the first step, valid until the next one begins)."""
+        from . import ops
+        dev = next(_unwrap(self.generator).parameters()).device
+        if dev.type != "cuda":
+            import contextlib
+            return contextlib.nullcontext()
+        if getattr(self, "_gpool", None) is None:
+            self._gpool = ops.ZeroPool()
+        self._gpool.begin(dev)
+        return self._gpool
+
+    def _generator_loss_backward(self, bs):
         blob = self.generator(bs=bs, it=self.it, data={}, return_raw=False)["box"]
         # BCE(D(fake)[:, :1], 1) per discriminator: one launch each way (losses.gan_losses = GANLoss("bce") fused)
         x_fake = _cat([blob["render_out"][k] for k in DATA_KEYS["discriminator"]])
@@ -139,8 +159,6 @@ class Trainer:
             loss = loss + _scaled(v, self.loss_weight[k])
             ret[f"generator/{k}"] = v
         loss.backward()
-        _sync(self.generator)
-        self.opt_generator.step()
         return ret
 
     def train_step_discriminator(self, key, real, fake, defer_step=False):
