@@ -458,6 +458,10 @@ int oi_multi_adam(const oi_mt_chunk* table, int n_chunks, float lr, float beta1,
                   float bias_correction1, float bias_correction2_sqrt, oi_stream_t stream);
 int oi_multi_rmsprop(const oi_mt_chunk* table, int n_chunks, float lr, float alpha, float eps, oi_stream_t stream);
 int oi_multi_lerp(const oi_mt_chunk* table, int n_chunks, float beta, oi_stream_t stream);
+/* p <- g for every chunk: many small tensors gathered into (slices of) one buffer in ONE launch -- the stacked parameter
+ * layouts of oi_film_params / oi_mlp_pack_weights after an optimiser step (oi_amd.params.StackCache; the reference's modules
+ * hold one nn.Parameter per layer, fields.py:49-77, and torch.stack would be one launch per stacked array). */
+int oi_multi_copy(const oi_mt_chunk* table, int n_chunks, oi_stream_t stream);
 
 #ifdef __cplusplus
 }

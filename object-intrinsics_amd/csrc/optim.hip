@@ -48,6 +48,12 @@ multi_lerp_kernel(const oi_mt_chunk* __restrict__ table, float beta) {
   for (int i = threadIdx.x; i < c.n; i += 256) c.p[i] = lerp_(c.g[i], c.p[i], beta);  // p_ema <- p.lerp(p_ema, beta)
 }
 
+__global__ void __launch_bounds__(256)
+multi_copy_kernel(const oi_mt_chunk* __restrict__ table) {
+  const oi_mt_chunk c = table[blockIdx.x];
+  for (int i = threadIdx.x; i < c.n; i += 256) c.p[i] = c.g[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -78,6 +84,14 @@ int oi_multi_lerp(const oi_mt_chunk* table, int n_chunks, float beta, oi_stream_
   if (n_chunks == 0) return OI_OK;
   hipLaunchKernelGGL(multi_lerp_kernel, dim3(n_chunks), dim3(256), 0, oi::as_stream(stream), table, beta);
   return oi::check_launch("oi_multi_lerp");
+}
+
+int oi_multi_copy(const oi_mt_chunk* table, int n_chunks, oi_stream_t stream) {
+  OI_REQUIRE(table != nullptr || n_chunks == 0, "oi_multi_copy: null table");
+  OI_REQUIRE(n_chunks >= 0, "oi_multi_copy: n_chunks=%d", n_chunks);
+  if (n_chunks == 0) return OI_OK;
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(n_chunks), dim3(256), 0, oi::as_stream(stream), table);
+  return oi::check_launch("oi_multi_copy");
 }
 
 }  // extern "C"

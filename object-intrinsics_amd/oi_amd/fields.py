@@ -170,6 +170,7 @@ class FieldPack:
         self.set_precision(precision, fast_trig)
         self._key = None
         self._packs = {}
+        self._stacks = None
 
     def set_precision(self, precision, fast_trig=None):
         self.prec = _l.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
@@ -187,7 +188,7 @@ class FieldPack:
         return self._sd_cache
 
     def invalidate(self):
-        self._sd_cache, self._key, self._packs, self._plists = None, None, {}, None
+        self._sd_cache, self._key, self._packs, self._plists, self._stacks = None, None, {}, None, None
 
     def param_lists(self):
         """(all parameters, style + FiLM-head parameters): cached flat lists for the requires-grad checks."""
@@ -211,8 +212,27 @@ class FieldPack:
                    "views_linears.beta.weight": z(128, 64), "views_linears.beta.bias": z(128)}
         return sd, csd
 
+    def _stack_cache(self):
+        """params.StackCache, current: one gather launch per parameter version (CUDA); None on other devices."""
+        sd, csd = self._refresh_key()
+        if not sd["pts_linears.1.weight"].is_cuda:
+            return None
+        sc = getattr(self, "_stacks", None)
+        if sc is None or sc.flat.device != sd["pts_linears.1.weight"].device:
+            from .params import StackCache
+            sc = self._stacks = StackCache(sd, csd)
+            self._stacks_key = None
+        if self._stacks_key != self._key:
+            with torch.no_grad():
+                sc.refresh()
+            self._stacks_key = self._key
+        return sc
+
     def stacked(self):
-        return stack_field_params(*self._sds())
+        sc = self._stack_cache()
+        if sc is None:
+            return stack_field_params(*self._sds())
+        return sc.get(torch.is_grad_enabled())
 
     def _refresh_key(self):
         sd, csd = self._sds()
@@ -223,10 +243,13 @@ class FieldPack:
         return sd, csd
 
     def film_stacked(self, differentiable):
-        """Stacked style / FiLM-head parameters for `oi_film_params`.  The non-differentiable copy is cached per
-        parameter version (six torch.stack launches per forward otherwise)."""
+        """Stacked style / FiLM-head parameters for `oi_film_params`: views of the stack cache (no launch; the
+        differentiable ones carry the graph back to the per-layer parameters)."""
         from .params import FILM_KEYS
-        sd, csd = self._refresh_key()
+        sc = self._stack_cache()
+        if sc is not None:
+            return sc.get(differentiable, FILM_KEYS)
+        sd, csd = self._sds()
         if differentiable:
             return stack_field_params(sd, csd, keys=FILM_KEYS)
         if "film" not in self._packs:
@@ -247,7 +270,8 @@ class FieldPack:
         prec = self.prec_bwd if for_backward else self.prec
         if prec not in self._packs:
             with torch.no_grad():
-                P = stack_field_params(sd, csd)
+                sc = self._stack_cache()
+                P = stack_field_params(sd, csd) if sc is None else sc.get(False)
                 self._packs[prec] = ops.mlp_pack_weights(P["w0"], P["b0"], P["wh"], P["bh"], P["wsig"], P["bsig"],
                                                          P["wv"], P["bv"], P["wrgb"], P["brgb"], prec)
         return self._packs[prec]

@@ -90,6 +90,7 @@ _SIGS = {
     "oi_multi_adam": (_i, [_vp, _i, _f, _f, _f, _f, _f, _f, _vp]),
     "oi_multi_rmsprop": (_i, [_vp, _i, _f, _f, _f, _vp]),
     "oi_multi_lerp": (_i, [_vp, _i, _f, _vp]),
+    "oi_multi_copy": (_i, [_vp, _i, _vp]),
 }
 
 # entry points added by later source files (backward kernels); bound when present in the .so
