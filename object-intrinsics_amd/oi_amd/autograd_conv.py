@@ -12,6 +12,16 @@ from . import ops
 # straight into a registered accumulator.  OI_CONV_FUSED_BWD=0: the staged ops (A/B switch)
 FUSED_BWD = os.environ.get("OI_CONV_FUSED_BWD", "1") == "1"
 
+# > 0 while a caller differentiates with respect to the network INPUT only (the R1 penalty's inner gradient,
+# losses.grad_wrt_input): `ctx.needs_input_grad` is fixed at forward time and says "the weight requires grad", so every
+# layer would compute a weight gradient that `autograd.grad(..., inputs=x)` throws away -- five launches per discriminator
+# step, and five dead nodes in the double-backward graph
+INPUT_GRAD_ONLY = 0
+
+
+def _want_w(ctx):
+    return ctx.needs_input_grad[1] and not INPUT_GRAD_ONLY
+
 
 def _wgrad(w, g, x, stride, pad, mask_ref=None, slope=1.0):
     """Weight gradient of `w` inside a backward pass.  A plain backward (grad mode off: nothing will differentiate the
@@ -42,7 +52,7 @@ class _Conv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         stride, pad = ctx.cfg
         gx = _Dgrad.apply(gy, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
-        gw = _wgrad(w, gy, x, stride, pad) if ctx.needs_input_grad[1] else None
+        gw = _wgrad(w, gy, x, stride, pad) if _want_w(ctx) else None
         return gx, gw, None, None
 
 
@@ -114,11 +124,11 @@ class _ConvLrelu(torch.autograd.Function):
         if FUSED_BWD and not torch.is_grad_enabled():
             # plain backward: the LeakyReLU mask is applied to gy on load by both gradient kernels (no g_pre round trip)
             gx = ops.conv4x4_dgrad(gy, w, x.shape[2], x.shape[3], stride, pad, y, slope) if ctx.needs_input_grad[0] else None
-            gw = _wgrad(w, gy, x, stride, pad, y, slope) if ctx.needs_input_grad[1] else None
+            gw = _wgrad(w, gy, x, stride, pad, y, slope) if _want_w(ctx) else None
             return gx, gw, None, None, None
         g_pre = _MaskMul.apply(gy, y, slope)
         gx = _Dgrad.apply(g_pre, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
-        gw = _Wgrad.apply(g_pre, x, stride, pad) if ctx.needs_input_grad[1] else None
+        gw = _Wgrad.apply(g_pre, x, stride, pad) if _want_w(ctx) else None
         return gx, gw, None, None, None
 
 
@@ -140,7 +150,7 @@ class _AddBias(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g, _ChannelSum.apply(g)
+        return g, (_ChannelSum.apply(g) if _want_w(ctx) else None)
 
 
 def conv4x4_lrelu_autograd(x, w, bias, stride, pad, slope):

@@ -75,7 +75,13 @@ def grad_wrt_input(d_out, x_in):
     ones = _ONES.get(key)
     if ones is None:
         ones = _ONES[key] = torch.ones(d_out.shape, device=d_out.device)
-    (g,) = autograd.grad(outputs=d_out, inputs=x_in, grad_outputs=ones, create_graph=True, retain_graph=True, only_inputs=True)
+    from . import autograd_conv
+    autograd_conv.INPUT_GRAD_ONLY += 1   # (the convolutions skip their weight gradients: nothing here asks for them)
+    try:
+        (g,) = autograd.grad(outputs=d_out, inputs=x_in, grad_outputs=ones, create_graph=True, retain_graph=True,
+                             only_inputs=True)
+    finally:
+        autograd_conv.INPUT_GRAD_ONLY -= 1
     return g
 
 
