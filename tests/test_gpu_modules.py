@@ -536,3 +536,43 @@ def test_graphed_discriminator_forward_matches_eager():
         np.random.seed(100 + i)
         got = gd(x).clone()
         assert maxdiff(got, want) < 2e-4 * max(1.0, float(want.abs().max())), (i, maxdiff(got, want))
+
+
+def test_stack_cache_equals_torch_stack_forward_and_backward():
+    """params.StackCache (one gather launch per parameter version, no launch for the differentiable stack) against
+    params.stack_field_params (torch.stack): same values, same per-parameter gradients, refreshed after an optimiser step,
+    and a graph that saved the OLD contents refuses to run backward."""
+    from oi_amd.optim import FusedAdam
+    from oi_amd.params import stack_field_params
+    gen = build_generator(8, 8, 8, 1, "f16x3")
+    pack = gen.renderer.pack
+    sd, csd = pack._sds()
+    ref = stack_field_params(sd, csd)
+    got = pack.stacked()
+    assert set(got) == set(ref)
+    for k in ref:
+        assert got[k].shape == ref[k].shape and maxdiff(got[k].detach(), ref[k].detach()) == 0.0, k
+    # gradients: a random linear functional of every stacked entry
+    torch.manual_seed(0)
+    cot = {k: torch.randn_like(v) for k, v in ref.items()}
+    params = list(sd.values()) + list(csd.values())
+    g_ref = torch.autograd.grad(sum((ref[k] * cot[k]).sum() for k in ref), params, allow_unused=True)
+    g_got = torch.autograd.grad(sum((got[k] * cot[k]).sum() for k in got), params, allow_unused=True)
+    for p, a, b in zip(params, g_got, g_ref):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert maxdiff(a, b) == 0.0
+    # an optimiser step changes the parameters: the next request sees the new values (one gather launch) ...
+    stale = pack.stacked()
+    opt = FusedAdam(params, lr=1e-2, betas=(0.0, 0.9))
+    for p in params:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    with torch.no_grad():
+        new = pack.stacked()
+        ref2 = stack_field_params(sd, csd)
+    for k in ref2:
+        assert maxdiff(new[k], ref2[k]) == 0.0 and (k not in ("gw", "wh") or maxdiff(new[k], ref[k].detach()) > 1e-3), k
+    # ... and a graph built on the old contents fails loudly instead of differentiating with the new ones
+    with pytest.raises(RuntimeError, match="modified (by an )?inplace"):
+        (stale["gw"] * stale["gw"]).sum().backward()
