@@ -376,6 +376,13 @@ int oi_affine_grid_sample_fwd(const float* x, const float* theta, float* y, int 
 int oi_affine_grid_sample_bwd(const float* gy, const float* theta, float* gx, int B, int C, int Hi,
                               int Wi, int Ho, int Wo, oi_stream_t stream);
 
+/* Unit light direction in every box frame, and the gradient with respect to the raw direction parameter, one launch each:
+ *   n[b] = normalize(w2b[b][:3][:3] normalize(d)),  d [3], w2b [B][4][4], n / g_n [B][3], g_d [3] (summed over the batch)
+ * = DirectionalLightWithSpecularFixInit.direction -> batch_direction (src/utils/lighting.py:35-39, 115-119) -> the
+ * normalisation in front of the Phong terms (src/models/generator.py:84-100). */
+int oi_light_dir_fwd(const float* d, const float* w2b, float* n, int B, oi_stream_t stream);
+int oi_light_dir_bwd(const float* d, const float* w2b, const float* g_n, float* g_d, int B, oi_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * The scalar losses of a GAN training step, one launch each way (csrc/loss.hip).  Replaces GANLoss("bce") =
  * F.binary_cross_entropy_with_logits against a constant target (src/loss/gan.py:39-49), compute_grad2's

@@ -302,7 +302,76 @@ composite_bwd_reduce_kernel(const oi_composite_params p, const oi_composite_grad
   if (q.d_variance && inv_s_raw > 1e-6f && inv_s_raw < 1e6f) atomicAdd(q.d_variance, s[7] * inv_s_raw * 10.0f);
 }
 
+// ------------------------------------------------------------------------------------------
+// Unit light direction in every box frame and its gradient, one launch each way:
+//   u = d / |d|,  v_b = R_b u  (R_b = w2b[b][:3][:3]),  n_b = v_b / max(|v_b|, 1e-6)
+// = DirectionalLight.direction (lighting.py:35-39) -> batch_direction (lighting.py:115-119) -> the F.normalize in front of the
+// Phong terms.  As tensor ops with autograd that is 8 launches forward and ~18 backward of 3..9 elements each.
+// ------------------------------------------------------------------------------------------
+__global__ void light_dir_fwd_kernel(const float* __restrict__ d, const float* __restrict__ w2b, float* __restrict__ n, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const float u[3] = {d[0] * inv, d[1] * inv, d[2] * inv};
+  const float* R = w2b + (size_t)b * 16;
+  float v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = R[4 * i] * u[0] + R[4 * i + 1] * u[1] + R[4 * i + 2] * u[2];
+  const float nv = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-6f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) n[b * 3 + i] = v[i] / nv;
+}
+
+__global__ void __launch_bounds__(64)
+light_dir_bwd_kernel(const float* __restrict__ d, const float* __restrict__ w2b, const float* __restrict__ g_n,
+                     float* __restrict__ g_d, int B) {
+  const float nd = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const float u[3] = {d[0] / nd, d[1] / nd, d[2] / nd};
+  float gu[3] = {0.f, 0.f, 0.f};  // sum_b R_b^T (I - n n^T) g_n / |v|
+  for (int b = threadIdx.x; b < B; b += 64) {
+    const float* R = w2b + (size_t)b * 16;
+    float v[3], g[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      v[i] = R[4 * i] * u[0] + R[4 * i + 1] * u[1] + R[4 * i + 2] * u[2];
+      g[i] = g_n[b * 3 + i];
+    }
+    const float raw = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    float gv[3];
+    if (raw > 1e-6f) {
+      const float nn[3] = {v[0] / raw, v[1] / raw, v[2] / raw};
+      const float dot = nn[0] * g[0] + nn[1] * g[1] + nn[2] * g[2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) gv[i] = (g[i] - nn[i] * dot) / raw;
+    } else {  // the clamp is active: n = v / eps
+#pragma unroll
+      for (int i = 0; i < 3; ++i) gv[i] = g[i] * 1e6f;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gu[j] += R[j] * gv[0] + R[4 + j] * gv[1] + R[8 + j] * gv[2];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) gu[j] = oi::wave_sum(gu[j]);
+  if (threadIdx.x == 0) {
+    const float dot = u[0] * gu[0] + u[1] * gu[1] + u[2] * gu[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g_d[j] = (gu[j] - u[j] * dot) / nd;
+  }
+}
+
 }  // namespace
+
+extern "C" int oi_light_dir_fwd(const float* d, const float* w2b, float* n, int B, oi_stream_t stream) {
+  OI_REQUIRE(d && w2b && n && B > 0, "oi_light_dir_fwd: bad argument");
+  hipLaunchKernelGGL(light_dir_fwd_kernel, dim3(oi::cdiv(B, 64)), dim3(64), 0, oi::as_stream(stream), d, w2b, n, B);
+  return oi::check_launch("oi_light_dir_fwd");
+}
+
+extern "C" int oi_light_dir_bwd(const float* d, const float* w2b, const float* g_n, float* g_d, int B, oi_stream_t stream) {
+  OI_REQUIRE(d && w2b && g_n && g_d && B > 0, "oi_light_dir_bwd: bad argument");
+  hipLaunchKernelGGL(light_dir_bwd_kernel, dim3(1), dim3(64), 0, oi::as_stream(stream), d, w2b, g_n, g_d, B);
+  return oi::check_launch("oi_light_dir_bwd");
+}
 
 extern "C" int oi_composite_bwd(const oi_composite_params* p, const oi_composite_grads* g, oi_stream_t stream) {
   OI_REQUIRE(p && g, "oi_composite_bwd: null params");

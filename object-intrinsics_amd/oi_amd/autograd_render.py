@@ -14,7 +14,8 @@ class CompositeFunction(torch.autograd.Function):
             outputs=None):
         # the kernel normalises the light direction; doing it here too (idempotent) lets autograd own the
         # Jacobian of the normalisation, the kernel returns d/d(unit vector)
-        ldir_n = torch.nn.functional.normalize(light_dir, dim=-1, eps=1e-6)
+        # (a direction from DirectionalLight.batch_direction_unit is already that, with its own backward)
+        ldir_n = light_dir if getattr(light_dir, "_oi_unit", False) else torch.nn.functional.normalize(light_dir, dim=-1, eps=1e-6)
         outs = CompositeFunction.apply(sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg,
                                        float(cos_anneal_ratio), B)
         res = dict(zip(OUT_KEYS, outs))

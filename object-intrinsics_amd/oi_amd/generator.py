@@ -215,7 +215,12 @@ class Generator(nn.Module):
             bg = getattr(self, "_bg_dev", None)
             if bg is None:
                 bg = self._h2d(self.bg_color(bs))
-        ldir = prior["light"].direction() if grad_light else rays["light_dir"]
+        if grad_light and prior["w2b"].is_cuda:
+            # unit direction per box frame with its own backward: one launch each way (tensor ops: 8 + ~18 launches)
+            ldir = self.light.batch_direction_unit(prior["w2b"])
+            ldir._oi_unit = True   # (CompositeFunction.run: already normalised, Jacobian owned by the producer)
+        else:
+            ldir = prior["light"].direction() if grad_light else rays["light_dir"]
         lpk = self.light.packed()
 
         ro_all, rd_all = rays["rays_o"].view(bs, h * w, 3), rays["rays_d"].view(bs, h * w, 3)

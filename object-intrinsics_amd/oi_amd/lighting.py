@@ -67,8 +67,29 @@ class DirectionalLightWithSpecularFixInit(nn.Module):
         """(B,3) light direction in each box frame (lighting.py:115-119)."""
         return torch.einsum("bij,j->bi", w2b[:, :3, :3], self.direction)
 
+    def batch_direction_unit(self, w2b):
+        """normalize(batch_direction(w2b)) with the gradient back to `param_direction`, one launch each way
+        (oi_light_dir_fwd / _bwd) -- what the compositing kernel consumes.  CUDA tensors; w2b carries no gradient (poses
+        are sampled)."""
+        return _LightDir.apply(self.param_direction, w2b.detach())
+
     def batch_transform(self, *, w2b):
         return BatchLight(self, w2b)
+
+
+class _LightDir(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d, w2b):
+        from . import ops
+        ctx.save_for_backward(d, w2b)
+        return ops.light_dir_fwd(d, w2b)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_n):
+        from . import ops
+        d, w2b = ctx.saved_tensors
+        return ops.light_dir_bwd(d, w2b, g_n).view_as(d), None
 
 
 class BatchLight:

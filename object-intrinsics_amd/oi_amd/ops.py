@@ -449,6 +449,22 @@ def lrelu_mask_mul(v, ref, slope):
     return out
 
 
+def light_dir_fwd(d, w2b):
+    L = _l.load()
+    d, w2b = _c(d), _c(w2b)
+    n = _new(w2b, w2b.shape[0], 3)
+    _l.check(L.oi_light_dir_fwd(_p(d), _p(w2b), _p(n), w2b.shape[0], _stream()), "oi_light_dir_fwd")
+    return n
+
+
+def light_dir_bwd(d, w2b, g_n):
+    L = _l.load()
+    d, w2b, g_n = _c(d), _c(w2b), _c(g_n)
+    g_d = _new(d, 3)
+    _l.check(L.oi_light_dir_bwd(_p(d), _p(w2b), _p(g_n), _p(g_d), w2b.shape[0], _stream()), "oi_light_dir_bwd")
+    return g_d
+
+
 def gan_losses_fwd(d_real, d_fake, pose, gx, aux_w, reg_w):
     """-> out6 = (total, real + fake, reg, fake, real, aux): see oi_gan_losses_fwd.  d_real / d_fake [B, K] (or None),
     pose [B, K-1] (or None), gx [B, ...] (or None), aux_w a device scalar tensor (or None)."""

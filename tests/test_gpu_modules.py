@@ -576,3 +576,20 @@ def test_stack_cache_equals_torch_stack_forward_and_backward():
     # ... and a graph built on the old contents fails loudly instead of differentiating with the new ones
     with pytest.raises(RuntimeError, match="modified (by an )?inplace"):
         (stale["gw"] * stale["gw"]).sum().backward()
+
+
+def test_light_direction_fused_matches_tensor_path():
+    """oi_light_dir_fwd / _bwd against direction -> batch_direction -> F.normalize with autograd (lighting.py:35-39, 115-119)."""
+    from oi_amd.lighting import DirectionalLightWithSpecularFixInit
+    torch.manual_seed(5)
+    light = DirectionalLightWithSpecularFixInit(direction=[0.3, -0.5, 0.8]).cuda()
+    B = 5
+    w2b = torch.eye(4, device="cuda").repeat(B, 1, 1)
+    w2b[:, :3, :3] = torch.linalg.qr(torch.randn(B, 3, 3, device="cuda"))[0] * torch.tensor([1.0, 0.7, 1.3, 1.0, 0.2], device="cuda")[:, None, None]
+    cot = torch.randn(B, 3, device="cuda")
+    ref = torch.nn.functional.normalize(light.batch_direction(w2b), dim=-1, eps=1e-6)
+    (g_ref,) = torch.autograd.grad((ref * cot).sum(), light.param_direction)
+    got = light.batch_direction_unit(w2b)
+    (g_got,) = torch.autograd.grad((got * cot).sum(), light.param_direction)
+    assert maxdiff(got.detach(), ref.detach()) < 3e-7
+    assert maxdiff(g_got, g_ref) < 1e-6 * max(1.0, float(g_ref.abs().max()))
