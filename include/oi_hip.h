@@ -349,6 +349,9 @@ int oi_conv4x4_dgrad_masked(const float* g, const float* ref, float slope, const
                             int W, int Cout, int stride, int pad, oi_stream_t stream);
 int oi_conv4x4_wgrad_masked(const float* g, const float* ref, float slope, const float* x, float* gw, int accumulate, int B,
                             int Cin, int H, int W, int Cout, int stride, int pad, oi_stream_t stream);
+/* Both of the above in ONE launch (the two gradients of a layer share the incoming gradient and nothing else). */
+int oi_conv4x4_bwd_masked(const float* g, const float* ref, float slope, const float* w, const float* x, float* gx, float* gw,
+                          int accumulate, int B, int Cin, int H, int W, int Cout, int stride, int pad, oi_stream_t stream);
 int oi_lrelu_mask_mul(const float* v, const float* ref, float* out, long long n, float slope,
                       oi_stream_t stream);
 int oi_channel_sum(const float* g, float* gb, int B, int C, int HW, oi_stream_t stream);

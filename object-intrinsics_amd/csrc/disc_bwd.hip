@@ -22,16 +22,35 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // pixels are processed per parity class (a, b) = ((iy+pad)%S, (ix+pad)%S) so that a tile of 32 pixels
 // shares its tap set: 4/S x 4/S taps per output channel.
 // ------------------------------------------------------------------------------------------
+struct DgradArgs {
+  const float *g, *ref, *w;
+  float* gx;
+  float slope;
+  int B, Cin, H, W, Cout, Ho, Wo, pad, m_tiles, n_tiles, k_splits, couts_per_split, Hc, Wc;
+  long long items;
+};
+struct WgradArgs {
+  const float *g, *ref, *x;
+  float* gw;
+  float slope;
+  int accumulate, B, Cin, H, W, Cout, Ho, Wo, stride, pad, m_tiles, n_tiles, k_splits, pix_per_split;
+  long long items;
+};
+
 template <int S>
-__global__ void __launch_bounds__(256)
-conv4x4_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ ref, float slope, const float* __restrict__ w,
-                     float* __restrict__ gx, int B, int Cin, int H, int W, int Cout, int Ho, int Wo, int pad, int m_tiles,
-                     int n_tiles, int k_splits, int couts_per_split, int Hc, int Wc) {
+__device__ __forceinline__ void dgrad_body(const DgradArgs& A, long long block) {
+  const float* __restrict__ g = A.g;
+  const float* __restrict__ ref = A.ref;
+  const float* __restrict__ w = A.w;
+  float* __restrict__ gx = A.gx;
+  const float slope = A.slope;
+  const int B = A.B, Cin = A.Cin, H = A.H, W = A.W, Cout = A.Cout, Ho = A.Ho, Wo = A.Wo, pad = A.pad, m_tiles = A.m_tiles,
+            n_tiles = A.n_tiles, k_splits = A.k_splits, couts_per_split = A.couts_per_split, Hc = A.Hc, Wc = A.Wc;
   // ref != null: the incoming gradient is taken through the LeakyReLU of the layer's forward output on load,
   // g_eff = ref > 0 ? g : slope * g (what lrelu_mask_mul_kernel would have written out first)
   constexpr int TJ = 4 / S;      // taps per axis
   const int lane = threadIdx.x & 63;
-  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long item = block * 4 + (threadIdx.x >> 6);
   const long long n_items = (long long)S * S * m_tiles * n_tiles * k_splits;
   if (item >= n_items) return;
   const int ks = item % k_splits;
@@ -94,13 +113,21 @@ conv4x4_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ ref,
 // wgrad.  A = G[n][pix] (rows = output channel), B = X gathered for ONE (c, ky) kernel row and the 4 kx
 // taps spread over ... columns j = (c_local * 16 + ky*4 + kx): 32 columns = 2 input channels x 16 taps.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-conv4x4_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ ref, float slope, const float* __restrict__ x,
-                     float* __restrict__ gw, int accumulate, int B, int Cin, int H, int W, int Cout, int Ho, int Wo, int stride,
-                     int pad, int m_tiles, int n_tiles, int k_splits, int pix_per_split) {
+template <int S>
+__global__ void __launch_bounds__(256) conv4x4_dgrad_kernel(const DgradArgs A) { dgrad_body<S>(A, blockIdx.x); }
+
+__device__ __forceinline__ void wgrad_body(const WgradArgs& A, long long block) {
+  const float* __restrict__ g = A.g;
+  const float* __restrict__ ref = A.ref;
+  const float* __restrict__ x = A.x;
+  float* __restrict__ gw = A.gw;
+  const float slope = A.slope;
+  const int accumulate = A.accumulate, B = A.B, Cin = A.Cin, H = A.H, W = A.W, Cout = A.Cout, Ho = A.Ho, Wo = A.Wo,
+            stride = A.stride, pad = A.pad, m_tiles = A.m_tiles, n_tiles = A.n_tiles, k_splits = A.k_splits,
+            pix_per_split = A.pix_per_split;
   // ref / slope: as in the dgrad kernel;  accumulate: gw already holds a gradient (or zeros) that this one adds to
   const int lane = threadIdx.x & 63;
-  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long item = block * 4 + (threadIdx.x >> 6);
   const long long n_items = (long long)m_tiles * n_tiles * k_splits;
   if (item >= n_items) return;
   const int ks = item % k_splits;
@@ -142,6 +169,17 @@ conv4x4_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ ref,
   }
 }
 
+__global__ void __launch_bounds__(256) conv4x4_wgrad_kernel(const WgradArgs A) { wgrad_body(A, blockIdx.x); }
+
+// Both gradients of one layer in ONE launch (they share the incoming gradient and nothing else): the first `blocks_d`
+// workgroups run data-gradient items, the rest weight-gradient items.  At batch 1 a discriminator step is a chain of ~100
+// launches of a few microseconds each; every launch less is ~6 us of a 0.7 ms step.
+template <int S>
+__global__ void __launch_bounds__(256) conv4x4_bwd_kernel(const DgradArgs D, const WgradArgs Wg, int blocks_d) {
+  if ((int)blockIdx.x < blocks_d) dgrad_body<S>(D, blockIdx.x);
+  else wgrad_body(Wg, (long long)blockIdx.x - blocks_d);
+}
+
 // out = ref > 0 ? v : slope * v     (LeakyReLU forward with ref = v, and its gradient with ref = output)
 __global__ void lrelu_mask_mul_kernel(const float* __restrict__ v, const float* __restrict__ ref,
                                       float* __restrict__ out, long long n, float slope) {
@@ -172,8 +210,8 @@ int oi_conv4x4_dgrad(const float* g, const float* w, float* gx, int B, int Cin, 
   return oi_conv4x4_dgrad_masked(g, nullptr, 1.f, w, gx, B, Cin, H, W, Cout, stride, pad, stream);
 }
 
-int oi_conv4x4_dgrad_masked(const float* g, const float* ref, float slope, const float* w, float* gx, int B, int Cin, int H,
-                            int W, int Cout, int stride, int pad, oi_stream_t stream) {
+static int make_dgrad(DgradArgs& A, const float* g, const float* ref, float slope, const float* w, float* gx, int B, int Cin,
+                      int H, int W, int Cout, int stride, int pad) {
   OI_REQUIRE(g && w && gx, "oi_conv4x4_dgrad: null pointer");
   OI_REQUIRE(stride == 1 || stride == 2, "oi_conv4x4_dgrad: stride %d (1 or 2 supported)", stride);
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
@@ -186,27 +224,12 @@ int oi_conv4x4_dgrad_masked(const float* g, const float* ref, float slope, const
   int cps = oi::cdiv(Cout, k_splits);
   cps += cps & 1;
   k_splits = oi::cdiv(Cout, cps);
-  hipStream_t st = oi::as_stream(stream);
-  // rows/cols no tap reaches (e.g. the last row when (H + 2 pad - 4) % stride != 0) keep the zero fill
-  hipError_t e = oi::zero_output_async(gx, (size_t)B * Cin * H * W, st);
-  if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_dgrad: memset: %s", hipGetErrorString(e));
-  const long long items = tiles * k_splits;
-  if (stride == 2)
-    hipLaunchKernelGGL(conv4x4_dgrad_kernel<2>, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, g, ref, slope, w, gx, B, Cin, H,
-                       W, Cout, Ho, Wo, pad, m_tiles, n_tiles, k_splits, cps, Hc, Wc);
-  else
-    hipLaunchKernelGGL(conv4x4_dgrad_kernel<1>, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, g, ref, slope, w, gx, B, Cin, H,
-                       W, Cout, Ho, Wo, pad, m_tiles, n_tiles, k_splits, cps, Hc, Wc);
-  return oi::check_launch("oi_conv4x4_dgrad");
+  A = DgradArgs{g, ref, w, gx, slope, B, Cin, H, W, Cout, Ho, Wo, pad, m_tiles, n_tiles, k_splits, cps, Hc, Wc, tiles * k_splits};
+  return OI_OK;
 }
 
-int oi_conv4x4_wgrad(const float* g, const float* x, float* gw, int B, int Cin, int H, int W, int Cout, int stride,
-                     int pad, oi_stream_t stream) {
-  return oi_conv4x4_wgrad_masked(g, nullptr, 1.f, x, gw, 0, B, Cin, H, W, Cout, stride, pad, stream);
-}
-
-int oi_conv4x4_wgrad_masked(const float* g, const float* ref, float slope, const float* x, float* gw, int accumulate, int B,
-                            int Cin, int H, int W, int Cout, int stride, int pad, oi_stream_t stream) {
+static int make_wgrad(WgradArgs& A, const float* g, const float* ref, float slope, const float* x, float* gw, int accumulate,
+                      int B, int Cin, int H, int W, int Cout, int stride, int pad) {
   OI_REQUIRE(g && x && gw, "oi_conv4x4_wgrad: null pointer");
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
   OI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0 && stride > 0, "oi_conv4x4_wgrad: bad shape");
@@ -218,15 +241,60 @@ int oi_conv4x4_wgrad_masked(const float* g, const float* ref, float slope, const
   int pps = oi::cdiv(P, k_splits);
   pps = (pps + 7) & ~7;
   k_splits = oi::cdiv(P, pps);
+  A = WgradArgs{g, ref, x, gw, slope, accumulate, B, Cin, H, W, Cout, Ho, Wo, stride, pad, m_tiles, n_tiles, k_splits, pps,
+                tiles * k_splits};
+  return OI_OK;
+}
+
+int oi_conv4x4_dgrad_masked(const float* g, const float* ref, float slope, const float* w, float* gx, int B, int Cin, int H,
+                            int W, int Cout, int stride, int pad, oi_stream_t stream) {
+  DgradArgs A;
+  int rc = make_dgrad(A, g, ref, slope, w, gx, B, Cin, H, W, Cout, stride, pad);
+  if (rc != OI_OK) return rc;
   hipStream_t st = oi::as_stream(stream);
-  if (k_splits > 1 && !accumulate) {
+  // rows/cols no tap reaches (e.g. the last row when (H + 2 pad - 4) % stride != 0) keep the zero fill
+  hipError_t e = oi::zero_output_async(gx, (size_t)B * Cin * H * W, st);
+  if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_dgrad: memset: %s", hipGetErrorString(e));
+  if (stride == 2) hipLaunchKernelGGL(conv4x4_dgrad_kernel<2>, dim3(oi::cdiv(A.items, 4)), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(conv4x4_dgrad_kernel<1>, dim3(oi::cdiv(A.items, 4)), dim3(256), 0, st, A);
+  return oi::check_launch("oi_conv4x4_dgrad");
+}
+
+int oi_conv4x4_wgrad(const float* g, const float* x, float* gw, int B, int Cin, int H, int W, int Cout, int stride,
+                     int pad, oi_stream_t stream) {
+  return oi_conv4x4_wgrad_masked(g, nullptr, 1.f, x, gw, 0, B, Cin, H, W, Cout, stride, pad, stream);
+}
+
+int oi_conv4x4_wgrad_masked(const float* g, const float* ref, float slope, const float* x, float* gw, int accumulate, int B,
+                            int Cin, int H, int W, int Cout, int stride, int pad, oi_stream_t stream) {
+  WgradArgs A;
+  int rc = make_wgrad(A, g, ref, slope, x, gw, accumulate, B, Cin, H, W, Cout, stride, pad);
+  if (rc != OI_OK) return rc;
+  hipStream_t st = oi::as_stream(stream);
+  if (A.k_splits > 1 && !accumulate) {
     hipError_t e = oi::zero_output_async(gw, (size_t)Cout * Cin * 16, st);
     if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_wgrad: memset: %s", hipGetErrorString(e));
   }
-  const long long items = tiles * k_splits;
-  hipLaunchKernelGGL(conv4x4_wgrad_kernel, dim3(oi::cdiv(items, 4)), dim3(256), 0, st, g, ref, slope, x, gw, accumulate, B, Cin,
-                     H, W, Cout, Ho, Wo, stride, pad, m_tiles, n_tiles, k_splits, pps);
+  hipLaunchKernelGGL(conv4x4_wgrad_kernel, dim3(oi::cdiv(A.items, 4)), dim3(256), 0, st, A);
   return oi::check_launch("oi_conv4x4_wgrad");
+}
+
+int oi_conv4x4_bwd_masked(const float* g, const float* ref, float slope, const float* w, const float* x, float* gx, float* gw,
+                          int accumulate, int B, int Cin, int H, int W, int Cout, int stride, int pad, oi_stream_t stream) {
+  DgradArgs D;
+  WgradArgs Wg;
+  int rc = make_dgrad(D, g, ref, slope, w, gx, B, Cin, H, W, Cout, stride, pad);
+  if (rc == OI_OK) rc = make_wgrad(Wg, g, ref, slope, x, gw, accumulate, B, Cin, H, W, Cout, stride, pad);
+  if (rc != OI_OK) return rc;
+  hipStream_t st = oi::as_stream(stream);
+  hipError_t e = oi::zero_output_async(gx, (size_t)B * Cin * H * W, st);
+  if (e == hipSuccess && !accumulate) e = oi::zero_output_async(gw, (size_t)Cout * Cin * 16, st);  // (the fused kernel always adds)
+  if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_bwd: memset: %s", hipGetErrorString(e));
+  Wg.accumulate = 1;
+  const int blocks_d = oi::cdiv(D.items, 4), blocks_w = oi::cdiv(Wg.items, 4);
+  if (stride == 2) hipLaunchKernelGGL(conv4x4_bwd_kernel<2>, dim3(blocks_d + blocks_w), dim3(256), 0, st, D, Wg, blocks_d);
+  else hipLaunchKernelGGL(conv4x4_bwd_kernel<1>, dim3(blocks_d + blocks_w), dim3(256), 0, st, D, Wg, blocks_d);
+  return oi::check_launch("oi_conv4x4_bwd");
 }
 
 int oi_lrelu_mask_mul(const float* v, const float* ref, float* out, long long n, float slope, oi_stream_t stream) {

@@ -37,6 +37,18 @@ def _wgrad(w, g, x, stride, pad, mask_ref=None, slope=1.0):
     return _Wgrad.apply(g, x, stride, pad)
 
 
+def _bwd_plain(ctx, w, gy, x, stride, pad, mask_ref=None, slope=1.0):
+    """Both gradients of a layer in a plain backward: ONE launch when both are wanted (ops.conv4x4_bwd)."""
+    want_x, want_w = ctx.needs_input_grad[0], _want_w(ctx)
+    if want_x and want_w:
+        acc = ops.GradSink.lookup(w)
+        gx, gw = ops.conv4x4_bwd(gy, w, x, stride, pad, mask_ref, slope, acc=acc)
+        return gx, (None if acc is not None else gw)
+    gx = ops.conv4x4_dgrad(gy, w, x.shape[2], x.shape[3], stride, pad, mask_ref, slope) if want_x else None
+    gw = _wgrad(w, gy, x, stride, pad, mask_ref, slope) if want_w else None
+    return gx, gw
+
+
 class _Conv(torch.autograd.Function):
     """y = conv(x, w) (linear, no bias).  Also the double-backward node of _Dgrad / _Wgrad, where `x` or `w` is a gradient
     of arbitrary magnitude: always the exact fp32-MFMA path (any_scale), never the unscaled-fp16-limb large-batch kernel."""
@@ -51,6 +63,8 @@ class _Conv(torch.autograd.Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         stride, pad = ctx.cfg
+        if FUSED_BWD and not torch.is_grad_enabled():
+            return _bwd_plain(ctx, w, gy, x, stride, pad) + (None, None)
         gx = _Dgrad.apply(gy, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
         gw = _wgrad(w, gy, x, stride, pad) if _want_w(ctx) else None
         return gx, gw, None, None
@@ -123,9 +137,7 @@ class _ConvLrelu(torch.autograd.Function):
         stride, pad, slope = ctx.cfg
         if FUSED_BWD and not torch.is_grad_enabled():
             # plain backward: the LeakyReLU mask is applied to gy on load by both gradient kernels (no g_pre round trip)
-            gx = ops.conv4x4_dgrad(gy, w, x.shape[2], x.shape[3], stride, pad, y, slope) if ctx.needs_input_grad[0] else None
-            gw = _wgrad(w, gy, x, stride, pad, y, slope) if _want_w(ctx) else None
-            return gx, gw, None, None, None
+            return _bwd_plain(ctx, w, gy, x, stride, pad, y, slope) + (None, None, None)
         g_pre = _MaskMul.apply(gy, y, slope)
         gx = _Dgrad.apply(g_pre, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
         gw = _Wgrad.apply(g_pre, x, stride, pad) if _want_w(ctx) else None

@@ -415,6 +415,21 @@ def conv4x4_wgrad(g, x, stride=2, pad=1, mask_ref=None, slope=1.0, acc=None):
     return gw
 
 
+def conv4x4_bwd(g, w, x, stride=2, pad=1, mask_ref=None, slope=1.0, acc=None):
+    """Data and weight gradient of one layer in one launch (oi_conv4x4_bwd_masked) -> gx, gw (gw is `acc` when given)."""
+    L = _l.load()
+    g, w, x = _c(g), _c(w), _c(x)
+    B, Cin, H, W = x.shape
+    Cout = g.shape[1]
+    if acc is not None and (tuple(acc.shape) != (Cout, Cin, 4, 4) or not acc.is_contiguous()):
+        raise _l.OiHipError(f"conv4x4_bwd: accumulator of shape {tuple(acc.shape)} for a {(Cout, Cin, 4, 4)} gradient")
+    gx = _new_acc(g, B, Cin, H, W)
+    gw = _new_acc(g, Cout, Cin, 4, 4) if acc is None else acc
+    _l.check(L.oi_conv4x4_bwd_masked(_p(g), _p(_c(mask_ref)), float(slope), _p(w), _p(x), _p(gx), _p(gw), int(acc is not None),
+                                     B, Cin, H, W, Cout, stride, pad, _stream()), "oi_conv4x4_bwd")
+    return gx, gw
+
+
 class GradSink:
     """Weight-gradient accumulators for ONE plain backward pass (not create_graph): while active, the convolution Functions
     of oi_amd.autograd_conv add every weight-gradient contribution of a registered weight straight into its buffer

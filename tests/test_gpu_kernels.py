@@ -628,3 +628,23 @@ def test_conv_gradients_masked_on_load_and_accumulated_match_the_staged_ops(B, C
     assert ops.conv4x4_wgrad(g, x, stride, pad, y, 0.2, acc=acc) is acc
     want = base + ops.conv4x4_wgrad(gm, x, stride, pad)
     assert float((acc - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,stride,pad", [(1, 32, 64, 32, 2, 1), (3, 5, 7, 9, 2, 1), (2, 256, 7, 4, 1, 0)])
+def test_conv_backward_in_one_launch_matches_the_two_kernels(B, Cin, Cout, H, stride, pad):
+    """oi_conv4x4_bwd_masked (data + weight gradient, one launch) == oi_conv4x4_dgrad_masked + oi_conv4x4_wgrad_masked."""
+    from oi_amd import ops
+    torch.manual_seed(B + Cout)
+    x = torch.randn(B, Cin, H, H, device="cuda")
+    w = torch.randn(Cout, Cin, 4, 4, device="cuda") * 0.1
+    Ho = (H + 2 * pad - 4) // stride + 1
+    g, y = torch.randn(B, Cout, Ho, Ho, device="cuda"), torch.randn(B, Cout, Ho, Ho, device="cuda")
+    for ref in (None, y):
+        gx, gw = ops.conv4x4_bwd(g, w, x, stride, pad, ref, 0.2)
+        gx0, gw0 = ops.conv4x4_dgrad(g, w, H, H, stride, pad, ref, 0.2), ops.conv4x4_wgrad(g, x, stride, pad, ref, 0.2)
+        assert float((gx - gx0).abs().max()) <= 1e-5 * float(gx0.abs().max())
+        assert float((gw - gw0).abs().max()) <= 1e-5 * float(gw0.abs().max())
+    base = torch.randn_like(w)
+    acc = base.clone()
+    _, out = ops.conv4x4_bwd(g, w, x, stride, pad, y, 0.2, acc=acc)
+    assert out is acc and float((acc - (base + gw0)).abs().max()) <= 1e-5 * float((base + gw0).abs().max())
