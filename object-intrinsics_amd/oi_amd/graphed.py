@@ -20,6 +20,8 @@ import torch
 # step alone replays in 0.66 instead of 0.75 ms, but a training iteration got 0.05-0.1 ms SLOWER on the same box (four
 # runs) -- a graph with branches costs more to launch than the shorter chain saves between the neighbouring renders
 FORK = os.environ.get("OI_GRAPH_D_FORK", "0") == "1"
+# captured discriminator step: real and fake batch through the discriminator in ONE pass of 2B images (OI_GRAPH_D_CAT=0: two)
+CAT = os.environ.get("OI_GRAPH_D_CAT", "1") == "1"
 
 
 class GraphedForward:
@@ -102,10 +104,15 @@ class GraphedDStep:
     def _alloc(self, x_real, x_fake, c2b):
         dev = x_real.device
         B = x_real.shape[0]
-        self.x_real = torch.empty_like(x_real)
-        self.x_fake = torch.empty_like(x_fake)
-        self.th_real = torch.empty(B, 2, 3, device=dev)
-        self.th_fake = torch.empty(B, 2, 3, device=dev)
+        # real and fake batch side by side: ONE discriminator pass over 2B images when CAT (the step is a chain of launches
+        # that wait for each other, ~6 us each whatever their size: half as many for the forward and the plain backward)
+        self._cat = CAT and x_real.shape == x_fake.shape
+        self.x_cat = torch.empty(2 * B, *x_real.shape[1:], device=dev) if self._cat else None
+        self.x_real = self.x_cat[:B] if self._cat else torch.empty_like(x_real)
+        self.x_fake = self.x_cat[B:] if self._cat else torch.empty_like(x_fake)
+        self.th_cat = torch.empty(2 * B, 2, 3, device=dev)
+        self.th_real, self.th_fake = self.th_cat[:B], self.th_cat[B:]
+        self._gsel = None
         self.c2b = None if c2b is None else torch.empty_like(c2b)
         self.aux_w = torch.zeros((), device=dev)
         self._one = torch.ones((), device=dev)
@@ -145,6 +152,9 @@ class GraphedDStep:
         else:
             for p in disc.parameters():
                 p.grad = None
+        if self._cat:
+            loss, parts = self._losses_cat(disc)
+            return self._backward(loss, parts, wrapped)
         th_real, th_fake = (self.th_real, self.th_fake) if self._geom else (None, None)
         x_real = self.x_real.detach().requires_grad_()   # (a fresh leaf over the static buffer: nothing writes it in the step)
         # The fake branch (forward, and -- autograd runs a node's backward on its forward's stream -- its backward) goes to a
@@ -163,6 +173,23 @@ class GraphedDStep:
             main.wait_stream(fork)
         # BCE(real, 1) + BCE(fake, 0) + reg_weight R1 + aux_w MSE(pose): one launch forward, one backward (losses.gan_losses)
         loss, parts = gan_losses(d_real, d_fake, pose, gx, self.aux_w if pose is not None else None, self.reg_weight)
+        return self._backward(loss, parts, wrapped)
+
+    def _losses_cat(self, disc):
+        """One pass over [real; fake]: D is per-sample (no batch statistics), so row b of the output depends on image b only.
+        R1's inner gradient is d sum(d[:B, 0]) / d x_all -- its fake half is exactly zero and contributes nothing."""
+        from .losses import gan_losses_cat, grad_wrt_input
+        B = self.x_real.shape[0]
+        x = self.x_cat.detach().requires_grad_()
+        d = disc(x, aug_theta=self.th_cat if self._geom else None)
+        if self._gsel is None or self._gsel.shape != d.shape:
+            self._gsel = torch.zeros_like(d)
+            self._gsel[:B, 0] = 1.0
+        gx = grad_wrt_input(d, x, self._gsel)
+        pose = self.prior.pose_to_vec_repr(self.c2b) if d.size(1) > 1 else None
+        return gan_losses_cat(d, B, pose, gx, self.aux_w if pose is not None else None, self.reg_weight)
+
+    def _backward(self, loss, parts, wrapped):
         # only the parameters' gradients: not the images' (see oi_amd.trainer._backward_to).  The convolution weights collect
         # their four contributions (real, R1 x2, fake) in place: the flat gradient buffer under FlatGradDDP (just zeroed),
         # pre-zeroed pool memory otherwise
@@ -207,8 +234,7 @@ class GraphedDStep:
             pin = self._pins[i]
             pin[0].numpy()[:] = th[0]
             pin[1].numpy()[:] = th[1]
-            self.th_real.copy_(pin[0], non_blocking=True)
-            self.th_fake.copy_(pin[1], non_blocking=True)
+            self.th_cat.copy_(pin.view(-1, 2, 3), non_blocking=True)   # (th_real | th_fake are its halves)
             self._pin_ev[i] = torch.cuda.Event()
             self._pin_ev[i].record()
         self.x_real.copy_(x_real, non_blocking=True)

@@ -58,6 +58,39 @@ class _GanLosses(autograd.Function):
         return g[0], g[1], None, g[2], None, None
 
 
+class _GanLossesCat(autograd.Function):
+    """The same for ONE discriminator pass over [real batch; fake batch] (oi_amd.graphed.GraphedDStep): d_all [2B, K], gx_all
+    [2B, ...] = d sum(d_all[:B, 0]) / d x_all (its fake half is exactly zero), one gradient tensor per input."""
+
+    @staticmethod
+    def forward(ctx, d_all, pose, gx_all, aux_w, reg_w, B):
+        from . import ops
+        d_all, gx_all = d_all.detach().contiguous(), gx_all.detach().contiguous()
+        pose = None if pose is None else pose.detach().contiguous()
+        out = ops.gan_losses_fwd(d_all[:B], d_all[B:], pose, gx_all.view(B, -1), aux_w, reg_w)
+        ctx.ts, ctx.reg_w, ctx.B = (d_all, pose, gx_all, aux_w), reg_w, B
+        ctx.set_materialize_grads(False)
+        total, parts = out[0], out[1:]
+        ctx.mark_non_differentiable(parts)
+        return total, parts
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        from . import ops
+        d_all, pose, gx_all, aux_w = ctx.ts
+        if g_total is None:
+            return (None,) * 6
+        B = ctx.B
+        g_all, g_gx = torch.empty_like(d_all), torch.empty_like(gx_all)
+        ops.gan_losses_bwd(g_total.contiguous(), d_all[:B], d_all[B:], pose, gx_all.view(B, -1), aux_w, ctx.reg_w, True, True,
+                           True, out=(g_all[:B], g_all[B:], g_gx.view(B, -1)))
+        return g_all, None, g_gx, None, None, None
+
+
+def gan_losses_cat(d_all, n_real, pose=None, gx_all=None, aux_w=None, reg_w=0.0):
+    return _GanLossesCat.apply(d_all, pose, gx_all, aux_w, float(reg_w), int(n_real))
+
+
 def gan_losses(d_real=None, d_fake=None, pose=None, gx=None, aux_w=None, reg_w=0.0):
     """-> (total, parts) with total = BCE(d_real[:, :1], 1) + BCE(d_fake[:, :1], 0) + reg_w * R1(gx) + aux_w * MSE(d_fake[:, 1:],
     pose) (absent terms: None) and parts = [real + fake, reg, fake, real, aux] (no gradient).  `aux_w`: device scalar tensor.
@@ -68,11 +101,11 @@ def gan_losses(d_real=None, d_fake=None, pose=None, gx=None, aux_w=None, reg_w=0
 _ONES = {}
 
 
-def grad_wrt_input(d_out, x_in):
+def grad_wrt_input(d_out, x_in, grad_outputs=None):
     """d sum(d_out) / d x_in with the graph kept (the R1 penalty's inner gradient, compute_grad2 above) -- `grad_outputs`
-    from a cached tensor of ones instead of a `sum()` whose backward expands one."""
+    from a cached tensor of ones instead of a `sum()` whose backward expands one (or the caller's selection)."""
     key = (tuple(d_out.shape), d_out.device)
-    ones = _ONES.get(key)
+    ones = grad_outputs if grad_outputs is not None else _ONES.get(key)
     if ones is None:
         ones = _ONES[key] = torch.ones(d_out.shape, device=d_out.device)
     from . import autograd_conv

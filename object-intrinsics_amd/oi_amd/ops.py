@@ -493,14 +493,18 @@ def gan_losses_fwd(d_real, d_fake, pose, gx, aux_w, reg_w):
     return out
 
 
-def gan_losses_bwd(g_total, d_real, d_fake, pose, gx, aux_w, reg_w, want_real, want_fake, want_gx):
+def gan_losses_bwd(g_total, d_real, d_fake, pose, gx, aux_w, reg_w, want_real, want_fake, want_gx, out=None):
+    """out: optional (g_real, g_fake, g_gx) destinations (contiguous; e.g. slices of one tensor)."""
     L = _l.load()
     ref = d_real if d_real is not None else d_fake
     B, K = ref.shape
     N = 0 if gx is None else gx.numel() // B
-    g_real = torch.empty_like(d_real) if want_real else None
-    g_fake = torch.empty_like(d_fake) if want_fake else None
-    g_gx = torch.empty_like(gx) if want_gx else None
+    if out is not None:
+        g_real, g_fake, g_gx = out
+    else:
+        g_real = torch.empty_like(d_real) if want_real else None
+        g_fake = torch.empty_like(d_fake) if want_fake else None
+        g_gx = torch.empty_like(gx) if want_gx else None
     _l.check(L.oi_gan_losses_bwd(_p(g_total), _p(d_real), _p(d_fake), _p(pose), _p(gx), _p(aux_w), float(reg_w), _p(g_real),
                                  _p(g_fake), _p(g_gx), B, K, N, _stream()), "oi_gan_losses_bwd")
     return g_real, g_fake, g_gx
