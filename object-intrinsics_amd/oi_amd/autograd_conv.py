@@ -11,6 +11,7 @@ from . import ops
 # plain (not create_graph) backward passes: LeakyReLU mask applied on load by the gradient kernels, weight gradients added
 # straight into a registered accumulator.  OI_CONV_FUSED_BWD=0: the staged ops (A/B switch)
 FUSED_BWD = os.environ.get("OI_CONV_FUSED_BWD", "1") == "1"
+MASK_FIRST = os.environ.get("OI_CONV_MASK_FIRST", "1") == "1"
 
 # > 0 while a caller differentiates with respect to the network INPUT only (the R1 penalty's inner gradient,
 # losses.grad_wrt_input): `ctx.needs_input_grad` is fixed at forward time and says "the weight requires grad", so every
@@ -40,6 +41,11 @@ def _wgrad(w, g, x, stride, pad, mask_ref=None, slope=1.0):
 def _bwd_plain(ctx, w, gy, x, stride, pad, mask_ref=None, slope=1.0):
     """Both gradients of a layer in a plain backward: ONE launch when both are wanted (ops.conv4x4_bwd)."""
     want_x, want_w = ctx.needs_input_grad[0], _want_w(ctx)
+    if mask_ref is not None and want_x and MASK_FIRST:
+        # the data-gradient kernel reads an incoming-gradient value once per tap: a mask applied on load costs it more (31 vs
+        # ~20 us per layer at two images) than the 5 us launch that writes the masked gradient out first.  A weight gradient
+        # alone keeps the mask on load (one read per value).
+        gy, mask_ref = ops.lrelu_mask_mul(gy, mask_ref, slope), None
     if want_x and want_w:
         acc = ops.GradSink.lookup(w)
         gx, gw = ops.conv4x4_bwd(gy, w, x, stride, pad, mask_ref, slope, acc=acc)
