@@ -77,27 +77,38 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs& A, long long block) 
 
   f32x16 acc = {0};
   const int n_begin = ks * couts_per_split, n_end = min(Cout, n_begin + couts_per_split);
-  for (int n0 = n_begin; n0 < n_end; n0 += 2) {
-    const int n = n0 + h;
-    const bool n_ok = n < n_end;
-    const float* wn = w + ((size_t)(n_ok ? n : 0) * Cin + (c_ok ? c : 0)) * 16;
-    const size_t gn_off = ((size_t)b * Cout + (n_ok ? n : 0)) * Ho * Wo;
-    const float* gn = g + gn_off;
+  // U channel pairs per trip, all of their loads issued before the first MFMA (the loop is latency-bound: one wave per tile,
+  // every load a dependent round trip -- 31 -> ~20 us for the largest layer of a 64^2 discriminator at two images)
+  constexpr int U = S == 2 ? 4 : 2;
+  for (int n0 = n_begin; n0 < n_end; n0 += 2 * U) {
+    float a[U][TJ][TJ], bv[U][TJ][TJ];
 #pragma unroll
-    for (int jy = 0; jy < TJ; ++jy) {
-      const int ky = ca + S * jy, oy = oy_base - jy;
-      float a[TJ], bv[TJ];
+    for (int u = 0; u < U; ++u) {
+      const int n = n0 + 2 * u + h;
+      const bool n_ok = n < n_end;
+      const float* wn = w + ((size_t)(n_ok ? n : 0) * Cin + (c_ok ? c : 0)) * 16;
+      const size_t gn_off = ((size_t)b * Cout + (n_ok ? n : 0)) * Ho * Wo;
+      const float* gn = g + gn_off;
 #pragma unroll
-      for (int jx = 0; jx < TJ; ++jx) {
-        const int kx = cb + S * jx, ox = ox_base - jx;
-        a[jx] = (n_ok && c_ok) ? wn[ky * 4 + kx] : 0.f;
-        const bool ok = n_ok && pix_ok && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
-        bv[jx] = ok ? gn[oy * Wo + ox] : 0.f;
-        if (ref != nullptr && ok && !(ref[gn_off + oy * Wo + ox] > 0.f)) bv[jx] *= slope;
+      for (int jy = 0; jy < TJ; ++jy) {
+        const int ky = ca + S * jy, oy = oy_base - jy;
+#pragma unroll
+        for (int jx = 0; jx < TJ; ++jx) {
+          const int kx = cb + S * jx, ox = ox_base - jx;
+          a[u][jy][jx] = (n_ok && c_ok) ? wn[ky * 4 + kx] : 0.f;
+          const bool ok = n_ok && pix_ok && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+          float v = ok ? gn[oy * Wo + ox] : 0.f;
+          if (ref != nullptr && ok && !(ref[gn_off + oy * Wo + ox] > 0.f)) v *= slope;
+          bv[u][jy][jx] = v;
+        }
       }
-#pragma unroll
-      for (int jx = 0; jx < TJ; ++jx) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jx], bv[jx], acc, 0, 0, 0);
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int jy = 0; jy < TJ; ++jy)
+#pragma unroll
+        for (int jx = 0; jx < TJ; ++jx) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][jy][jx], bv[u][jy][jx], acc, 0, 0, 0);
   }
   if (!pix_ok) return;
 #pragma unroll
@@ -143,20 +154,21 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& A, long long block) 
 
   f32x16 acc = {0};
   const int p_begin = ks * pix_per_split, p_end = min(P, p_begin + pix_per_split);
-  for (int p0 = p_begin; p0 < p_end; p0 += 8) {
+  for (int p0 = p_begin; p0 < p_end; p0 += 16) {  // two 8-pixel k-steps per trip, their 16 loads before the 8 MFMAs
+    float a[8], bv[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int p = p0 + 4 * h + u;  // (half, u) -> k: both operands use the same map
+    for (int q = 0; q < 8; ++q) {
+      const int p = p0 + 8 * (q >> 2) + 4 * h + (q & 3);  // (half, u) -> k: both operands use the same map
       const bool p_ok = p < p_end;
       const int pp = p_ok ? p : 0;
       const int b = pp / HW, pl = pp % HW, oy = pl / Wo, ox = pl % Wo;
       const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
-      float a = (p_ok && n_ok) ? g[((size_t)b * Cout + n) * HW + pl] : 0.f;
-      if (ref != nullptr && p_ok && n_ok && !(ref[((size_t)b * Cout + n) * HW + pl] > 0.f)) a *= slope;
-      const float bv = (p_ok && c_ok && iy >= 0 && iy < H && ix >= 0 && ix < W)
-                           ? x[(((size_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+      a[q] = (p_ok && n_ok) ? g[((size_t)b * Cout + n) * HW + pl] : 0.f;
+      if (ref != nullptr && p_ok && n_ok && !(ref[((size_t)b * Cout + n) * HW + pl] > 0.f)) a[q] *= slope;
+      bv[q] = (p_ok && c_ok && iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
     }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bv[q], acc, 0, 0, 0);
   }
   if (!c_ok) return;
   // D: column = lane & 31 = (c, tap), row = channel n
