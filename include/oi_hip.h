@@ -352,6 +352,15 @@ int oi_conv4x4_wgrad_masked(const float* g, const float* ref, float slope, const
 /* Both of the above in ONE launch (the two gradients of a layer share the incoming gradient and nothing else). */
 int oi_conv4x4_bwd_masked(const float* g, const float* ref, float slope, const float* w, const float* x, float* gx, float* gw,
                           int accumulate, int B, int Cin, int H, int W, int Cout, int stride, int pad, oi_stream_t stream);
+/* The same for a layer fed with the PRE-activation of its predecessor, y = conv(lrelu_{x_slope}(x), w) (the chain form of
+ * oi_conv4x4_fwd_into, where a layer's LeakyReLU is applied by its consumer on load -- no activation pass of its own): the
+ * weight gradient takes lrelu_{x_slope}(x) on load, the data gradient is returned with respect to x, i.e. multiplied by
+ * lrelu'(x) in the kernel's epilogue.  x_slope = 1: plain input.  _dgrad_pre: the data gradient alone (frozen weights). */
+int oi_conv4x4_bwd_pre(const float* g, const float* ref, float slope, const float* w, const float* x, float x_slope, float* gx,
+                       float* gw, int accumulate, int B, int Cin, int H, int W, int Cout, int stride, int pad,
+                       oi_stream_t stream);
+int oi_conv4x4_dgrad_pre(const float* g, const float* w, const float* x, float x_slope, float* gx, int B, int Cin, int H, int W,
+                         int Cout, int stride, int pad, oi_stream_t stream);
 int oi_lrelu_mask_mul(const float* v, const float* ref, float* out, long long n, float slope,
                       oi_stream_t stream);
 int oi_channel_sum(const float* g, float* gb, int B, int C, int HW, oi_stream_t stream);

@@ -26,6 +26,8 @@ struct DgradArgs {
   const float *g, *ref, *w;
   float* gx;
   float slope;
+  const float* out_ref;  // non-null: the layer's input was a PRE-activation x; gx is returned with respect to it, i.e.
+  float out_slope;       // multiplied by lrelu'(x) = (out_ref > 0 ? 1 : out_slope) (every split-K partial: the mask is linear)
   int B, Cin, H, W, Cout, Ho, Wo, pad, m_tiles, n_tiles, k_splits, couts_per_split, Hc, Wc;
   long long items;
 };
@@ -33,6 +35,7 @@ struct WgradArgs {
   const float *g, *ref, *x;
   float* gw;
   float slope;
+  float x_slope;  // != 1: x is a pre-activation, the operand is lrelu_{x_slope}(x), applied on load
   int accumulate, B, Cin, H, W, Cout, Ho, Wo, stride, pad, m_tiles, n_tiles, k_splits, pix_per_split;
   long long items;
 };
@@ -115,8 +118,10 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs& A, long long block) 
   for (int rg = 0; rg < 16; ++rg) {
     const int cc = nt * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * h;
     if (cc >= Cin) continue;
-    float* dst = gx + (((size_t)b * Cin + cc) * H + iy) * W + ix;
-    if (k_splits == 1) *dst = acc[rg]; else atomicAdd(dst, acc[rg]);
+    const size_t di = (((size_t)b * Cin + cc) * H + iy) * W + ix;
+    float v = acc[rg];
+    if (A.out_ref != nullptr && !(A.out_ref[di] > 0.f)) v *= A.out_slope;
+    if (k_splits == 1) gx[di] = v; else atomicAdd(gx + di, v);
   }
 }
 
@@ -166,6 +171,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& A, long long block) 
       a[q] = (p_ok && n_ok) ? g[((size_t)b * Cout + n) * HW + pl] : 0.f;
       if (ref != nullptr && p_ok && n_ok && !(ref[((size_t)b * Cout + n) * HW + pl] > 0.f)) a[q] *= slope;
       bv[q] = (p_ok && c_ok && iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
+      if (A.x_slope != 1.0f && !(bv[q] > 0.f)) bv[q] *= A.x_slope;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bv[q], acc, 0, 0, 0);
@@ -223,7 +229,7 @@ int oi_conv4x4_dgrad(const float* g, const float* w, float* gx, int B, int Cin, 
 }
 
 static int make_dgrad(DgradArgs& A, const float* g, const float* ref, float slope, const float* w, float* gx, int B, int Cin,
-                      int H, int W, int Cout, int stride, int pad) {
+                      int H, int W, int Cout, int stride, int pad, const float* out_ref = nullptr, float out_slope = 1.f) {
   OI_REQUIRE(g && w && gx, "oi_conv4x4_dgrad: null pointer");
   OI_REQUIRE(stride == 1 || stride == 2, "oi_conv4x4_dgrad: stride %d (1 or 2 supported)", stride);
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
@@ -236,12 +242,13 @@ static int make_dgrad(DgradArgs& A, const float* g, const float* ref, float slop
   int cps = oi::cdiv(Cout, k_splits);
   cps += cps & 1;
   k_splits = oi::cdiv(Cout, cps);
-  A = DgradArgs{g, ref, w, gx, slope, B, Cin, H, W, Cout, Ho, Wo, pad, m_tiles, n_tiles, k_splits, cps, Hc, Wc, tiles * k_splits};
+  A = DgradArgs{g, ref, w, gx, slope, out_slope != 1.f ? out_ref : nullptr, out_slope, B, Cin, H, W, Cout, Ho, Wo, pad, m_tiles,
+                n_tiles, k_splits, cps, Hc, Wc, tiles * k_splits};
   return OI_OK;
 }
 
 static int make_wgrad(WgradArgs& A, const float* g, const float* ref, float slope, const float* x, float* gw, int accumulate,
-                      int B, int Cin, int H, int W, int Cout, int stride, int pad) {
+                      int B, int Cin, int H, int W, int Cout, int stride, int pad, float x_slope = 1.f) {
   OI_REQUIRE(g && x && gw, "oi_conv4x4_wgrad: null pointer");
   const int Ho = (H + 2 * pad - 4) / stride + 1, Wo = (W + 2 * pad - 4) / stride + 1;
   OI_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0 && stride > 0, "oi_conv4x4_wgrad: bad shape");
@@ -253,7 +260,7 @@ static int make_wgrad(WgradArgs& A, const float* g, const float* ref, float slop
   int pps = oi::cdiv(P, k_splits);
   pps = (pps + 7) & ~7;
   k_splits = oi::cdiv(P, pps);
-  A = WgradArgs{g, ref, x, gw, slope, accumulate, B, Cin, H, W, Cout, Ho, Wo, stride, pad, m_tiles, n_tiles, k_splits, pps,
+  A = WgradArgs{g, ref, x, gw, slope, x_slope, accumulate, B, Cin, H, W, Cout, Ho, Wo, stride, pad, m_tiles, n_tiles, k_splits, pps,
                 tiles * k_splits};
   return OI_OK;
 }
@@ -293,10 +300,30 @@ int oi_conv4x4_wgrad_masked(const float* g, const float* ref, float slope, const
 
 int oi_conv4x4_bwd_masked(const float* g, const float* ref, float slope, const float* w, const float* x, float* gx, float* gw,
                           int accumulate, int B, int Cin, int H, int W, int Cout, int stride, int pad, oi_stream_t stream) {
+  return oi_conv4x4_bwd_pre(g, ref, slope, w, x, 1.f, gx, gw, accumulate, B, Cin, H, W, Cout, stride, pad, stream);
+}
+
+int oi_conv4x4_dgrad_pre(const float* g, const float* w, const float* x, float x_slope, float* gx, int B, int Cin, int H, int W,
+                         int Cout, int stride, int pad, oi_stream_t stream) {
+  OI_REQUIRE(x != nullptr || x_slope == 1.f, "oi_conv4x4_dgrad_pre: x_slope without x");
+  DgradArgs A;
+  int rc = make_dgrad(A, g, nullptr, 1.f, w, gx, B, Cin, H, W, Cout, stride, pad, x, x_slope);
+  if (rc != OI_OK) return rc;
+  hipStream_t st = oi::as_stream(stream);
+  hipError_t e = oi::zero_output_async(gx, (size_t)B * Cin * H * W, st);
+  if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_dgrad: memset: %s", hipGetErrorString(e));
+  if (stride == 2) hipLaunchKernelGGL(conv4x4_dgrad_kernel<2>, dim3(oi::cdiv(A.items, 4)), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(conv4x4_dgrad_kernel<1>, dim3(oi::cdiv(A.items, 4)), dim3(256), 0, st, A);
+  return oi::check_launch("oi_conv4x4_dgrad_pre");
+}
+
+int oi_conv4x4_bwd_pre(const float* g, const float* ref, float slope, const float* w, const float* x, float x_slope, float* gx,
+                       float* gw, int accumulate, int B, int Cin, int H, int W, int Cout, int stride, int pad,
+                       oi_stream_t stream) {
   DgradArgs D;
   WgradArgs Wg;
-  int rc = make_dgrad(D, g, ref, slope, w, gx, B, Cin, H, W, Cout, stride, pad);
-  if (rc == OI_OK) rc = make_wgrad(Wg, g, ref, slope, x, gw, accumulate, B, Cin, H, W, Cout, stride, pad);
+  int rc = make_dgrad(D, g, ref, slope, w, gx, B, Cin, H, W, Cout, stride, pad, x, x_slope);
+  if (rc == OI_OK) rc = make_wgrad(Wg, g, ref, slope, x, gw, accumulate, B, Cin, H, W, Cout, stride, pad, x_slope);
   if (rc != OI_OK) return rc;
   hipStream_t st = oi::as_stream(stream);
   hipError_t e = oi::zero_output_async(gx, (size_t)B * Cin * H * W, st);

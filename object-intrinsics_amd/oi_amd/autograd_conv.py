@@ -12,6 +12,8 @@ from . import ops
 # straight into a registered accumulator.  OI_CONV_FUSED_BWD=0: the staged ops (A/B switch)
 FUSED_BWD = os.environ.get("OI_CONV_FUSED_BWD", "1") == "1"
 MASK_FIRST = os.environ.get("OI_CONV_MASK_FIRST", "1") == "1"
+# discriminator forward under autograd as a chain of pre-activations (_ConvPre).  OI_CONV_PRE=0: conv + activation per layer
+PRE_CHAIN = os.environ.get("OI_CONV_PRE", "1") == "1"
 
 # > 0 while a caller differentiates with respect to the network INPUT only (the R1 penalty's inner gradient,
 # losses.grad_wrt_input): `ctx.needs_input_grad` is fixed at forward time and says "the weight requires grad", so every
@@ -148,6 +150,50 @@ class _ConvLrelu(torch.autograd.Function):
         gx = _Dgrad.apply(g_pre, w, x.shape[2], x.shape[3], stride, pad) if ctx.needs_input_grad[0] else None
         gw = _Wgrad.apply(g_pre, x, stride, pad) if _want_w(ctx) else None
         return gx, gw, None, None, None
+
+
+class _ConvPre(torch.autograd.Function):
+    """u = conv(lrelu_{slope_in}(x), w): a layer fed with the PRE-activation of its predecessor (slope_in = 1: plain input).
+    The chain form of the no-grad forward (oi_conv4x4_fwd_into) with autograd: a layer's LeakyReLU is applied by its consumer
+    on load, so the split-K layers need no activation pass forward and no mask pass backward.  Plain backward: ONE launch
+    (oi_conv4x4_bwd_pre: weight gradient with lrelu(x) formed on load, data gradient times lrelu'(x) in the epilogue).
+    create_graph backward (the R1 inner pass): the differentiable pieces, as before."""
+
+    @staticmethod
+    def forward(ctx, x, w, slope_in, stride, pad):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (slope_in, stride, pad)
+        return ops.conv4x4_fwd(x, w, None, stride, pad, 1.0, x_slope=slope_in)   # (activations, not gradients: either kernel)
+
+    @staticmethod
+    def backward(ctx, gu):
+        x, w = ctx.saved_tensors
+        slope_in, stride, pad = ctx.cfg
+        want_x, want_w = ctx.needs_input_grad[0], _want_w(ctx)
+        if not torch.is_grad_enabled():
+            if want_x and want_w:
+                acc = ops.GradSink.lookup(w)
+                gx, gw = ops.conv4x4_bwd(gu, w, x, stride, pad, acc=acc, x_slope=slope_in)
+                return gx, (None if acc is not None else gw), None, None, None
+            gx = ops.conv4x4_dgrad_pre(gu, w, x, slope_in, stride, pad) if want_x else None
+            gw = None
+            if want_w:
+                a = x if slope_in == 1.0 else ops.lrelu_mask_mul(x, x, slope_in)
+                gw = _wgrad(w, gu, a, stride, pad)
+            return gx, gw, None, None, None
+        gx = None
+        if want_x:
+            gx = _Dgrad.apply(gu, w, x.shape[2], x.shape[3], stride, pad)
+            if slope_in != 1.0:
+                gx = _MaskMul.apply(gx, x, slope_in)
+        gw = None
+        if want_w:
+            gw = _Wgrad.apply(gu, x if slope_in == 1.0 else _MaskMul.apply(x, x, slope_in), stride, pad)
+        return gx, gw, None, None, None
+
+
+def conv4x4_pre(x, w, slope_in, stride, pad):
+    return _ConvPre.apply(x, w, float(slope_in), stride, pad)
 
 
 class _ChannelSum(torch.autograd.Function):

@@ -63,6 +63,18 @@ class DCDiscriminator(nn.Module):
         assert x.shape[1] == self.in_dim, x.shape
         if not torch.is_grad_enabled():
             return self._forward_nograd(x.float()).reshape(batch_size, self.out_dim)
+        from . import autograd_conv as AC
+        if AC.PRE_CHAIN and x.is_cuda:
+            # pre-activation chain (autograd_conv._ConvPre): every block hands over its sums, the next layer applies the
+            # LeakyReLU while it loads them -- no activation pass forward, no mask pass backward
+            slope_in = 1.0
+            for layer in self.blocks:
+                x = AC.conv4x4_pre(x, layer.weight, slope_in, 2, 1)
+                slope_in = 0.2
+            out = AC.conv4x4_pre(x, self.conv_out.weight, slope_in, 1, 0)
+            if self.conv_out.bias is not None:
+                out = AC._AddBias.apply(out, self.conv_out.bias)
+            return out.reshape(batch_size, self.out_dim)
         for layer in self.blocks:
             x = conv4x4_lrelu(x, layer.weight, None, stride=2, pad=1, slope=0.2)
         out = conv4x4_lrelu(x, self.conv_out.weight, self.conv_out.bias, stride=1, pad=0, slope=1.0)

@@ -73,6 +73,8 @@ _SIGS = {
     "oi_conv4x4_dgrad_masked": (_i, [_vp, _vp, _f, _vp, _vp] + [_i] * 7 + [_vp]),
     "oi_conv4x4_wgrad_masked": (_i, [_vp, _vp, _f, _vp, _vp, _i] + [_i] * 7 + [_vp]),
     "oi_conv4x4_bwd_masked": (_i, [_vp, _vp, _f, _vp, _vp, _vp, _vp, _i] + [_i] * 7 + [_vp]),
+    "oi_conv4x4_bwd_pre": (_i, [_vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _i] + [_i] * 7 + [_vp]),
+    "oi_conv4x4_dgrad_pre": (_i, [_vp, _vp, _vp, _f, _vp] + [_i] * 7 + [_vp]),
     "oi_lrelu_mask_mul": (_i, [_vp] * 3 + [_ll, _f, _vp]),
     "oi_channel_sum": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "oi_upfirdn2d": (_i, [_vp] * 3 + [_i] * 14 + [_f, _vp]),

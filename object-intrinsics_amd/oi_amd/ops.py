@@ -415,8 +415,20 @@ def conv4x4_wgrad(g, x, stride=2, pad=1, mask_ref=None, slope=1.0, acc=None):
     return gw
 
 
-def conv4x4_bwd(g, w, x, stride=2, pad=1, mask_ref=None, slope=1.0, acc=None):
-    """Data and weight gradient of one layer in one launch (oi_conv4x4_bwd_masked) -> gx, gw (gw is `acc` when given)."""
+def conv4x4_dgrad_pre(g, w, x, x_slope, stride=2, pad=1):
+    """Data gradient of y = conv(lrelu_{x_slope}(x), w) with respect to the pre-activation x (oi_conv4x4_dgrad_pre)."""
+    L = _l.load()
+    g, w, x = _c(g), _c(w), _c(x)
+    B, Cin, H, W = x.shape
+    gx = _new_acc(g, B, Cin, H, W)
+    _l.check(L.oi_conv4x4_dgrad_pre(_p(g), _p(w), _p(x), float(x_slope), _p(gx), B, Cin, H, W, g.shape[1], stride, pad,
+                                    _stream()), "oi_conv4x4_dgrad_pre")
+    return gx
+
+
+def conv4x4_bwd(g, w, x, stride=2, pad=1, mask_ref=None, slope=1.0, acc=None, x_slope=1.0):
+    """Data and weight gradient of one layer in one launch (oi_conv4x4_bwd_pre) -> gx, gw (gw is `acc` when given).
+    x_slope != 1: x is a pre-activation (the layer computed conv(lrelu(x), w)); gx is the gradient with respect to it."""
     L = _l.load()
     g, w, x = _c(g), _c(w), _c(x)
     B, Cin, H, W = x.shape
@@ -425,8 +437,8 @@ def conv4x4_bwd(g, w, x, stride=2, pad=1, mask_ref=None, slope=1.0, acc=None):
         raise _l.OiHipError(f"conv4x4_bwd: accumulator of shape {tuple(acc.shape)} for a {(Cout, Cin, 4, 4)} gradient")
     gx = _new_acc(g, B, Cin, H, W)
     gw = _new_acc(g, Cout, Cin, 4, 4) if acc is None else acc
-    _l.check(L.oi_conv4x4_bwd_masked(_p(g), _p(_c(mask_ref)), float(slope), _p(w), _p(x), _p(gx), _p(gw), int(acc is not None),
-                                     B, Cin, H, W, Cout, stride, pad, _stream()), "oi_conv4x4_bwd")
+    _l.check(L.oi_conv4x4_bwd_pre(_p(g), _p(_c(mask_ref)), float(slope), _p(w), _p(x), float(x_slope), _p(gx), _p(gw),
+                                  int(acc is not None), B, Cin, H, W, Cout, stride, pad, _stream()), "oi_conv4x4_bwd")
     return gx, gw
 
 

@@ -676,3 +676,35 @@ def test_mlp_backward_wide_dynamic_range_cotangents(sdf_sd, col_sd):
         record_margin("mlp_backward_cotangents_over_8_decades_vs_fp64_oracle[f16x3]", name, e)
     bad = {k: v for k, v in errs.items() if v > WIDE_RANGE_TOL}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_discriminator_preactivation_chain_matches_layerwise_autograd(B):
+    """DCDiscriminator under autograd as a chain of pre-activations (autograd_conv._ConvPre: LeakyReLU applied by the consumer
+    on load, one backward launch per layer) against conv + activation per layer: logits, the R1 inner gradient, and every
+    parameter gradient of BCE + 10 R1 (first- and second-order paths)."""
+    from oi_amd import autograd_conv as AC
+    from oi_amd.discriminator import DCDiscriminator
+    from oi_amd.losses import gan_losses, grad_wrt_input
+    torch.manual_seed(11)
+    D = DCDiscriminator(in_dim=3, out_dim=7, n_feat=64, img_size=32, last_bias=True).cuda()
+    x0 = torch.randn(B, 3, 32, 32, device="cuda")
+    res = []
+    for pre in (False, True):
+        AC.PRE_CHAIN = pre
+        try:
+            for p in D.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_()
+            d = D(x)
+            gx = grad_wrt_input(d[:, :1], x)
+            loss, _ = gan_losses(d_real=d, gx=gx, reg_w=10.0)
+            loss.backward()
+            res.append((d.detach().clone(), gx.detach().clone(), [p.grad.clone() for p in D.parameters()]))
+        finally:
+            AC.PRE_CHAIN = True
+    (d0, g0, p0), (d1, g1, p1) = res
+    rel = lambda a, b: float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+    assert rel(d1, d0) < 2e-6 and rel(g1, g0) < 2e-6, (rel(d1, d0), rel(g1, g0))
+    for a, b in zip(p1, p0):
+        assert rel(a, b) < 5e-6, rel(a, b)
