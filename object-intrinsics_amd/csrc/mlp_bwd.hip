@@ -156,8 +156,15 @@ __device__ __forceinline__ void racc_zero(char* lds, int tid) {
   for (int i = tid; i < 8 * C; i += BW_THREADS) racc[i] = 0.f;
 }
 // flush `rows` accumulator rows: row r goes to dst[r] (a global base pointer per row)
+// (`tid` goes through an empty asm: the destination address is then formed HERE -- hipcc otherwise computes the 64-bit
+// per-lane addresses of every flush in the kernel's prologue and keeps, i.e. spills, them across both sweeps)
+__device__ __forceinline__ int late(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 __device__ __forceinline__ void racc_flush_row(char* lds, int row, float* dst, int stride, int tid) {
   const float* racc = reinterpret_cast<const float*>(lds + L_RACC) + row * C;
+  tid = late(tid);
   if (tid < C) atomicAdd(dst + tid * stride, racc[tid]);
 }
 // the same row times a per-feature factor (sum_p ubar = gamma * sum_p phibar: the bias gradient needs no sum of its own)
@@ -504,12 +511,12 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       }
     }
     __syncthreads();
-    if (tid < C) {  // gamma_v d gamma_v += sum_{j < 3} Wv[f][128 + j] dWv[f][128 + j]  (the GEMM adds the other 128 columns and bv)
+    if (const int t_ = late(tid); t_ < C) {  // gamma_v d gamma_v += sum_{j < 3} Wv[f][128 + j] dWv[f][128 + j]  (the GEMM adds the other 128 columns and bv)
       const float* racc = reinterpret_cast<const float*>(lds + L_RACC);
-      const f32x4 wx = *reinterpret_cast<const f32x4*>(lds + L_TABS + H_TABV * 4 + tid * 16);
-      const float gv = reinterpret_cast<const float*>(lds + L_FILM2)[tid];  // the head's rows sit in FiLM slot 1
-      atomicAdd(d_gamma + ((size_t)e * 9 + 8) * C + tid,
-                fmaf(wx[0], racc[6 * C + tid], fmaf(wx[1], racc[7 * C + tid], wx[2] * racc[2 * C + tid])) / gv);
+      const f32x4 wx = *reinterpret_cast<const f32x4*>(lds + L_TABS + H_TABV * 4 + t_ * 16);
+      const float gv = reinterpret_cast<const float*>(lds + L_FILM2)[t_];  // the head's rows sit in FiLM slot 1
+      atomicAdd(d_gamma + ((size_t)e * 9 + 8) * C + t_,
+                fmaf(wx[0], racc[6 * C + t_], fmaf(wx[1], racc[7 * C + t_], wx[2] * racc[2 * C + t_])) / gv);
     }
     racc_flush_row(lds, 2, d_small + DS_WVX + 2, 3, tid);
     racc_flush_row(lds, 3, d_small + DS_WRGB + 0 * C, 1, tid);
@@ -845,14 +852,14 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       racc_flush_row(lds, 3, d_small + DS_W0 + 0, 3, tid);
       racc_flush_row(lds, 4, d_small + DS_W0 + 1, 3, tid);
       racc_flush_row(lds, 5, d_small + DS_W0 + 2, 3, tid);
-      if (tid < C) {  // d beta_0 = d b_0 / gamma_0;  gamma_0 d gamma_0 = sum_j W0[f][j] dW0[f][j] + b_0[f] d b_0[f]
+      if (const int t_ = late(tid); t_ < C) {  // d beta_0 = d b_0 / gamma_0;  gamma_0 d gamma_0 = sum_j W0[f][j] dW0[f][j] + b_0[f] d b_0[f]
         const float* racc = reinterpret_cast<const float*>(lds + L_RACC);
-        const f32x4 w = *reinterpret_cast<const f32x4*>(lds + L_TABS + H_TAB0 * 4 + tid * 16);
-        const float ig = 1.0f / reinterpret_cast<const float*>(lds + L_FILM)[tid];  // layer 0's rows sit in FiLM slot 0
-        const float db = racc[1 * C + tid];
-        atomicAdd(d_beta + (size_t)e * 9 * C + tid, db * ig);
-        atomicAdd(d_gamma + (size_t)e * 9 * C + tid,
-                  fmaf(w[0], racc[3 * C + tid], fmaf(w[1], racc[4 * C + tid], fmaf(w[2], racc[5 * C + tid], hdr[H_BIAS + tid] * db))) * ig);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(lds + L_TABS + H_TAB0 * 4 + t_ * 16);
+        const float ig = 1.0f / reinterpret_cast<const float*>(lds + L_FILM)[t_];  // layer 0's rows sit in FiLM slot 0
+        const float db = racc[1 * C + t_];
+        atomicAdd(d_beta + (size_t)e * 9 * C + t_, db * ig);
+        atomicAdd(d_gamma + (size_t)e * 9 * C + t_,
+                  fmaf(w[0], racc[3 * C + t_], fmaf(w[1], racc[4 * C + t_], fmaf(w[2], racc[5 * C + t_], hdr[H_BIAS + t_] * db))) * ig);
       }
     }
     BW_T(11);
