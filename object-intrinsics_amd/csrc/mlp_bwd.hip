@@ -119,6 +119,13 @@ struct WaveScratchB {
   }
 };
 
+// (`tid` goes through an empty asm: the destination address is then formed HERE -- hipcc otherwise computes the 64-bit
+// per-lane addresses of every flush in the kernel's prologue and keeps, i.e. spills, them across both sweeps)
+__device__ __forceinline__ int late(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // Sums over the points of a wave tile (parameter gradients of the FiLM rows, biases and heads).  The point sits on the
 // lane (j = lane & 31), so every value needs a cross-lane sum; done one value at a time (5 DPP adds + a 2-lane LDS atomic
 // behind a branch each) this was half of the instructions of the down sweep.  Instead 16 values (4 groups x 4 features of
@@ -144,10 +151,13 @@ __device__ __forceinline__ float row_transpose_sum16(const float (&v)[16], int l
 }
 // v[4 * rr + k] = value of feature 32 t + 8 rr + 4 h + k at this lane's point -> LDS accumulator row `row`
 struct RowSum {
-  float* lane_base;  // racc + 8 * ((lane & 15) >> 2) + 4 * h + (lane & 3)
+  float* racc;  // the workgroup's reduction rows (wave-uniform)
   int lane;
   __device__ __forceinline__ void add(int row, int t, const float (&v)[16]) const {
-    atomicAdd(lane_base + row * C + 32 * t, row_transpose_sum16(v, lane));
+    // the lane's column, 8 * ((lane & 15) >> 2) + 4 * h + (lane & 3), is formed here (three instructions): kept in a
+    // register from the prologue it was spilled across both sweeps
+    const int l = late(lane);
+    atomicAdd(racc + row * C + 32 * t + 8 * ((l & 15) >> 2) + 4 * (l >> 5) + (l & 3), row_transpose_sum16(v, lane));
   }
 };
 
@@ -156,12 +166,6 @@ __device__ __forceinline__ void racc_zero(char* lds, int tid) {
   for (int i = tid; i < 8 * C; i += BW_THREADS) racc[i] = 0.f;
 }
 // flush `rows` accumulator rows: row r goes to dst[r] (a global base pointer per row)
-// (`tid` goes through an empty asm: the destination address is then formed HERE -- hipcc otherwise computes the 64-bit
-// per-lane addresses of every flush in the kernel's prologue and keeps, i.e. spills, them across both sweeps)
-__device__ __forceinline__ int late(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
 __device__ __forceinline__ void racc_flush_row(char* lds, int row, float* dst, int stride, int tid) {
   const float* racc = reinterpret_cast<const float*>(lds + L_RACC) + row * C;
   tid = late(tid);
@@ -187,7 +191,7 @@ __device__ __forceinline__ FilmRegs film_load(const float* __restrict__ gamma, c
                                               const float* __restrict__ hdr, int e, int l, float inv_img, int tid) {
   // unconditional (the upper half of the workgroup re-reads the same rows): a branch here made hipcc finish the arithmetic
   // on the loaded values inside it, i.e. wait for the loads on the spot
-  const int f = tid & (C - 1);
+  const int f = late(tid) & (C - 1);
   FilmRegs r;
   r.g = gamma[((size_t)e * 9 + l) * C + f];
   r.b = beta[((size_t)e * 9 + l) * C + f];
@@ -197,6 +201,7 @@ __device__ __forceinline__ FilmRegs film_load(const float* __restrict__ gamma, c
 }
 __device__ __forceinline__ void film_store(char* lds, const FilmRegs& r, int tid) {
   float* film = reinterpret_cast<float*>(lds + L_FILM);
+  tid = late(tid);
   if (tid < C) {
     const float gr = r.g * INV_2PI;
     film[tid] = r.g;
@@ -345,7 +350,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   o.l16hi = 16 * lane + 32768;
   asm volatile("" : "+v"(o.h16), "+v"(o.h64), "+v"(o.l16), "+v"(o.l16hi));
 
-  const RowSum rs{reinterpret_cast<float*>(lds + L_RACC) + 8 * ((lane & 15) >> 2) + 4 * h + (lane & 3), lane};
+  const RowSum rs{reinterpret_cast<float*>(lds + L_RACC), lane};
   const long long local = (long long)blockIdx.x * BW_TILE + wave * WAVE_PTS + j;
   const bool valid = local < n_per_elem;
   const long long pt = (long long)e * n_stride + pt_off + (valid ? local : n_per_elem - 1);
