@@ -70,19 +70,20 @@ conv4x4_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
     for (int u = 0; u < 4; ++u) {
       const int r = r0 + 2 * u + h;  // this lane-half's kernel row
       const bool r_ok = r < r_end;
-      const int cin = r >> 2, ky = r & 3;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) a[u][k] = bv[u][k] = 0.f;
-      if (r_ok && n_ok) {
-        const float4 wv = *reinterpret_cast<const float4*>(wrow + r * 4);
-        a[u][0] = wv.x; a[u][1] = wv.y; a[u][2] = wv.z; a[u][3] = wv.w;
-      }
+      const int rs = r_ok ? r : r_begin;  // (a valid row for the lanes past the end: loaded, then zeroed by the selects)
+      const int cin = rs >> 2, ky = rs & 3;
+      // loads are UNCONDITIONAL from clamped addresses, out-of-range lanes are zeroed by selects: `cond ? load : 0` became a
+      // branch around every load with a wait every few -- a chain of memory round trips per trip
+      const float4 wv = *reinterpret_cast<const float4*>(wrow + rs * 4);
+      const bool w_ok = r_ok && n_ok;
+      a[u][0] = w_ok ? wv.x : 0.f; a[u][1] = w_ok ? wv.y : 0.f; a[u][2] = w_ok ? wv.z : 0.f; a[u][3] = w_ok ? wv.w : 0.f;
       const int iy = iy0 + ky;
-      if (r_ok && m_ok && iy >= 0 && iy < H) {
-        const float* xr = xb + ((size_t)cin * H + iy) * W;
+      const bool row_ok = r_ok && m_ok && iy >= 0 && iy < H;
+      const float* xr = xb + ((size_t)cin * H + min(max(iy, 0), H - 1)) * W;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (ix0 + k >= 0 && ix0 + k < W) bv[u][k] = xr[ix0 + k];
+      for (int k = 0; k < 4; ++k) {
+        const float xv = xr[min(max(ix0 + k, 0), W - 1)];
+        bv[u][k] = (row_ok && ix0 + k >= 0 && ix0 + k < W) ? xv : 0.f;
       }
     }
     if (x_slope != 1.0f) {  // the producer left its LeakyReLU to this layer's loads (wave-uniform branch)

@@ -40,7 +40,9 @@ struct WgradArgs {
   long long items;
 };
 
-template <int S>
+// REF: compile-time "A.ref != null" -- tested at run time (a uniform branch per loaded value) it split the loop into blocks
+// with a wait each, and the loads of a trip could not be issued together
+template <int S, bool REF>
 __device__ __forceinline__ void dgrad_body(const DgradArgs& A, long long block) {
   const float* __restrict__ g = A.g;
   const float* __restrict__ ref = A.ref;
@@ -98,11 +100,19 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs& A, long long block) 
 #pragma unroll
         for (int jx = 0; jx < TJ; ++jx) {
           const int kx = cb + S * jx, ox = ox_base - jx;
-          a[u][jy][jx] = (n_ok && c_ok) ? wn[ky * 4 + kx] : 0.f;
+          // loads are UNCONDITIONAL from clamped (always valid) addresses and the out-of-range lanes are zeroed by a select:
+          // `cond ? p[i] : 0` compiles to a branch around every load (s_and_saveexec / s_cbranch_execz) with a wait every
+          // third one -- the loop then is a chain of ~10 memory round trips per trip instead of one
+          const float wt = wn[ky * 4 + kx];
+          a[u][jy][jx] = (n_ok && c_ok) ? wt : 0.f;
           const bool ok = n_ok && pix_ok && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
-          float v = ok ? gn[oy * Wo + ox] : 0.f;
-          if (ref != nullptr && ok && !(ref[gn_off + oy * Wo + ox] > 0.f)) v *= slope;
-          bv[u][jy][jx] = v;
+          const int gi = min(max(oy, 0), Ho - 1) * Wo + min(max(ox, 0), Wo - 1);
+          float v = gn[gi];
+          if constexpr (REF) {
+            const float rv = ref[gn_off + gi];
+            v = rv > 0.f ? v : v * slope;
+          }
+          bv[u][jy][jx] = ok ? v : 0.f;
         }
       }
     }
@@ -129,9 +139,10 @@ __device__ __forceinline__ void dgrad_body(const DgradArgs& A, long long block) 
 // wgrad.  A = G[n][pix] (rows = output channel), B = X gathered for ONE (c, ky) kernel row and the 4 kx
 // taps spread over ... columns j = (c_local * 16 + ky*4 + kx): 32 columns = 2 input channels x 16 taps.
 // ------------------------------------------------------------------------------------------
-template <int S>
-__global__ void __launch_bounds__(256) conv4x4_dgrad_kernel(const DgradArgs A) { dgrad_body<S>(A, blockIdx.x); }
+template <int S, bool REF>
+__global__ void __launch_bounds__(256) conv4x4_dgrad_kernel(const DgradArgs A) { dgrad_body<S, REF>(A, blockIdx.x); }
 
+template <bool REF>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& A, long long block) {
   const float* __restrict__ g = A.g;
   const float* __restrict__ ref = A.ref;
@@ -168,10 +179,17 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& A, long long block) 
       const int pp = p_ok ? p : 0;
       const int b = pp / HW, pl = pp % HW, oy = pl / Wo, ox = pl % Wo;
       const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
-      a[q] = (p_ok && n_ok) ? g[((size_t)b * Cout + n) * HW + pl] : 0.f;
-      if (ref != nullptr && p_ok && n_ok && !(ref[((size_t)b * Cout + n) * HW + pl] > 0.f)) a[q] *= slope;
-      bv[q] = (p_ok && c_ok && iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * Cin + c) * H + iy) * W + ix] : 0.f;
-      if (A.x_slope != 1.0f && !(bv[q] > 0.f)) bv[q] *= A.x_slope;
+      // (unconditional loads from clamped addresses + selects: see the dgrad loop)
+      const size_t gi = ((size_t)b * Cout + (n_ok ? n : 0)) * HW + pl;
+      float av = g[gi];
+      if constexpr (REF) {
+        const float rv = ref[gi];
+        av = rv > 0.f ? av : av * slope;
+      }
+      a[q] = (p_ok && n_ok) ? av : 0.f;
+      float xv = x[(((size_t)b * Cin + (c_ok ? c : 0)) * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)];
+      if (A.x_slope != 1.0f) xv = xv > 0.f ? xv : xv * A.x_slope;
+      bv[q] = (p_ok && c_ok && iy >= 0 && iy < H && ix >= 0 && ix < W) ? xv : 0.f;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bv[q], acc, 0, 0, 0);
@@ -187,15 +205,16 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& A, long long block) 
   }
 }
 
-__global__ void __launch_bounds__(256) conv4x4_wgrad_kernel(const WgradArgs A) { wgrad_body(A, blockIdx.x); }
+template <bool REF>
+__global__ void __launch_bounds__(256) conv4x4_wgrad_kernel(const WgradArgs A) { wgrad_body<REF>(A, blockIdx.x); }
 
 // Both gradients of one layer in ONE launch (they share the incoming gradient and nothing else): the first `blocks_d`
 // workgroups run data-gradient items, the rest weight-gradient items.  At batch 1 a discriminator step is a chain of ~100
 // launches of a few microseconds each; every launch less is ~6 us of a 0.7 ms step.
-template <int S>
+template <int S, bool REF>
 __global__ void __launch_bounds__(256) conv4x4_bwd_kernel(const DgradArgs D, const WgradArgs Wg, int blocks_d) {
-  if ((int)blockIdx.x < blocks_d) dgrad_body<S>(D, blockIdx.x);
-  else wgrad_body(Wg, (long long)blockIdx.x - blocks_d);
+  if ((int)blockIdx.x < blocks_d) dgrad_body<S, REF>(D, blockIdx.x);
+  else wgrad_body<REF>(Wg, (long long)blockIdx.x - blocks_d);
 }
 
 // out = ref > 0 ? v : slope * v     (LeakyReLU forward with ref = v, and its gradient with ref = output)
@@ -226,6 +245,14 @@ extern "C" {
 int oi_conv4x4_dgrad(const float* g, const float* w, float* gx, int B, int Cin, int H, int W, int Cout, int stride,
                      int pad, oi_stream_t stream) {
   return oi_conv4x4_dgrad_masked(g, nullptr, 1.f, w, gx, B, Cin, H, W, Cout, stride, pad, stream);
+}
+
+static void launch_dgrad(const DgradArgs& A, int stride, hipStream_t st) {
+  const dim3 grid(oi::cdiv(A.items, 4)), blk(256);
+  if (stride == 2 && A.ref != nullptr) hipLaunchKernelGGL((conv4x4_dgrad_kernel<2, true>), grid, blk, 0, st, A);
+  else if (stride == 2) hipLaunchKernelGGL((conv4x4_dgrad_kernel<2, false>), grid, blk, 0, st, A);
+  else if (A.ref != nullptr) hipLaunchKernelGGL((conv4x4_dgrad_kernel<1, true>), grid, blk, 0, st, A);
+  else hipLaunchKernelGGL((conv4x4_dgrad_kernel<1, false>), grid, blk, 0, st, A);
 }
 
 static int make_dgrad(DgradArgs& A, const float* g, const float* ref, float slope, const float* w, float* gx, int B, int Cin,
@@ -274,8 +301,7 @@ int oi_conv4x4_dgrad_masked(const float* g, const float* ref, float slope, const
   // rows/cols no tap reaches (e.g. the last row when (H + 2 pad - 4) % stride != 0) keep the zero fill
   hipError_t e = oi::zero_output_async(gx, (size_t)B * Cin * H * W, st);
   if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_dgrad: memset: %s", hipGetErrorString(e));
-  if (stride == 2) hipLaunchKernelGGL(conv4x4_dgrad_kernel<2>, dim3(oi::cdiv(A.items, 4)), dim3(256), 0, st, A);
-  else hipLaunchKernelGGL(conv4x4_dgrad_kernel<1>, dim3(oi::cdiv(A.items, 4)), dim3(256), 0, st, A);
+  launch_dgrad(A, stride, st);
   return oi::check_launch("oi_conv4x4_dgrad");
 }
 
@@ -294,7 +320,8 @@ int oi_conv4x4_wgrad_masked(const float* g, const float* ref, float slope, const
     hipError_t e = oi::zero_output_async(gw, (size_t)Cout * Cin * 16, st);
     if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_wgrad: memset: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(conv4x4_wgrad_kernel, dim3(oi::cdiv(A.items, 4)), dim3(256), 0, st, A);
+  if (A.ref != nullptr) hipLaunchKernelGGL(conv4x4_wgrad_kernel<true>, dim3(oi::cdiv(A.items, 4)), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(conv4x4_wgrad_kernel<false>, dim3(oi::cdiv(A.items, 4)), dim3(256), 0, st, A);
   return oi::check_launch("oi_conv4x4_wgrad");
 }
 
@@ -312,8 +339,7 @@ int oi_conv4x4_dgrad_pre(const float* g, const float* w, const float* x, float x
   hipStream_t st = oi::as_stream(stream);
   hipError_t e = oi::zero_output_async(gx, (size_t)B * Cin * H * W, st);
   if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_dgrad: memset: %s", hipGetErrorString(e));
-  if (stride == 2) hipLaunchKernelGGL(conv4x4_dgrad_kernel<2>, dim3(oi::cdiv(A.items, 4)), dim3(256), 0, st, A);
-  else hipLaunchKernelGGL(conv4x4_dgrad_kernel<1>, dim3(oi::cdiv(A.items, 4)), dim3(256), 0, st, A);
+  launch_dgrad(A, stride, st);
   return oi::check_launch("oi_conv4x4_dgrad_pre");
 }
 
@@ -331,8 +357,11 @@ int oi_conv4x4_bwd_pre(const float* g, const float* ref, float slope, const floa
   if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_conv4x4_bwd: memset: %s", hipGetErrorString(e));
   Wg.accumulate = 1;
   const int blocks_d = oi::cdiv(D.items, 4), blocks_w = oi::cdiv(Wg.items, 4);
-  if (stride == 2) hipLaunchKernelGGL(conv4x4_bwd_kernel<2>, dim3(blocks_d + blocks_w), dim3(256), 0, st, D, Wg, blocks_d);
-  else hipLaunchKernelGGL(conv4x4_bwd_kernel<1>, dim3(blocks_d + blocks_w), dim3(256), 0, st, D, Wg, blocks_d);
+  const dim3 grid(blocks_d + blocks_w), blk(256);
+  if (stride == 2 && ref != nullptr) hipLaunchKernelGGL((conv4x4_bwd_kernel<2, true>), grid, blk, 0, st, D, Wg, blocks_d);
+  else if (stride == 2) hipLaunchKernelGGL((conv4x4_bwd_kernel<2, false>), grid, blk, 0, st, D, Wg, blocks_d);
+  else if (ref != nullptr) hipLaunchKernelGGL((conv4x4_bwd_kernel<1, true>), grid, blk, 0, st, D, Wg, blocks_d);
+  else hipLaunchKernelGGL((conv4x4_bwd_kernel<1, false>), grid, blk, 0, st, D, Wg, blocks_d);
   return oi::check_launch("oi_conv4x4_bwd");
 }
 
