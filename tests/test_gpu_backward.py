@@ -540,9 +540,11 @@ def test_training_trajectory_f16x3_tracks_native_fp32():
     assert np.abs(a - b).max() < 1e-4, np.abs(a - b).max(axis=1)
 
 
-def test_graphed_discriminator_steps_match_eager():
-    """oi_amd.graphed.GraphedDStep (one hipGraphLaunch per discriminator step, shape-static ADA margins) against the eager
-    trainer: three training iterations from identical weights / seeds give the same losses and the same weights."""
+@pytest.mark.parametrize("bs", [1, 2])
+def test_graphed_discriminator_steps_match_eager(bs):
+    """oi_amd.graphed.GraphedDStep (one hipGraphLaunch per discriminator step, shape-static ADA margins, real and fake batch in
+    ONE discriminator pass) against the eager trainer (two passes): three training iterations from identical weights / seeds
+    give the same losses and the same weights."""
     import bench
     from oi_amd.config import build_from_config
     from oi_amd.optim import FusedAdam, FusedRMSprop
@@ -564,7 +566,7 @@ def test_graphed_discriminator_steps_match_eager():
                 "opt_mask_discriminator": FusedRMSprop(mdisc.parameters(), lr=1e-4)}
         tr = Trainer(mods, graph_d_steps=graphed)
         g = torch.Generator(device=dev).manual_seed(9)
-        data = {"image": torch.rand(1, 3, R, R, device=dev, generator=g), "mask": torch.rand(1, 1, R, R, device=dev, generator=g)}
+        data = {"image": torch.rand(bs, 3, R, R, device=dev, generator=g), "mask": torch.rand(bs, 1, R, R, device=dev, generator=g)}
         out = None
         for step in range(3):
             torch.manual_seed(100 + step)
@@ -582,7 +584,7 @@ def test_graphed_discriminator_steps_match_eager():
 @pytest.mark.parametrize("n,B", [(700, 1), (300, 2)])
 def test_mlp_backward_bounded_scratch_chunks_match_single_launch(sdf_sd, col_sd, n, B, monkeypatch):
     """the backward's working memory is a bound (OI_BWD_SCRATCH_MB), not a function of the problem size.  With
-    a cap of ONE 128-point tile per batch element the library walks the points in ceil(n / 128) chunks (ragged last chunk,
+    a cap of ONE workgroup tile (256 points) per batch element the library walks the points in ceil(n / 256) chunks (ragged last chunk,
     per-element offsets); every parameter / FiLM gradient must equal the single-launch result up to the order of the fp32
     atomics."""
     from oi_amd import ops
