@@ -97,6 +97,21 @@ conv4x4_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][k], bv[u][k], acc, 0, 0, 0);
   }
+  // The four waves of a workgroup are four consecutive K splits of ONE output tile when k_splits % 4 == 0 (ks runs fastest):
+  // their partial tiles are summed through LDS and leave as one atomic per element instead of four -- the same-address
+  // atomics of the splits, not the loop, were most of these kernels' time (csrc/disc_bwd.hip, dgrad)
+  const bool wg_sum = (k_splits & 3) == 0;
+  if (wg_sum) {
+    __shared__ float part[3][16][64];
+    const int wv = threadIdx.x >> 6;
+    if (wv != 0)
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) part[wv - 1][rg][lane] = acc[rg];
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) acc[rg] += (part[0][rg][lane] + part[1][rg][lane]) + part[2][rg][lane];
+  }
   // D layout: column = lane & 31 (pixel), row = (reg & 3) + 8 * (reg >> 2) + 4 * h (channel)
   if (!m_ok) return;
 #pragma unroll
@@ -108,6 +123,8 @@ conv4x4_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
     if (k_splits == 1) {
       if (bias != nullptr) v += bias[nn];
       *dst = v > 0.f ? v : v * slope;
+    } else if (wg_sum && k_splits == 4) {
+      *dst = v;   // (all splits were in this workgroup; bias / activation follow in the launcher's pass, as for any split)
     } else {
       atomicAdd(dst, v);
     }
