@@ -1082,6 +1082,9 @@ __device__ __forceinline__ float frag16(const float* sl, int f, int p0, f16x8& h
 #ifndef OI_WGRAD_NT
 #define OI_WGRAD_NT 1
 #endif
+#ifndef OI_WG_TARGET
+#define OI_WG_TARGET 2048  // workgroups of the weight-gradient GEMM (8 matrices x chunks)
+#endif
 #ifndef OI_WG_ABL
 #define OI_WG_ABL 0
 #endif
@@ -1388,7 +1391,7 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
     if (rc != OI_OK) return rc;
     const long long wt_per_elem = (long long)grid.x * BW_NW, n_wt = (long long)B * wt_per_elem;
     // ~2048 workgroups in total; a chunk never straddles two batch elements (per-element FiLM gradients)
-    const int chunk = (int)std::min<long long>(wt_per_elem, std::max<long long>(1, (n_wt * 8 + 2047) / 2048));
+    const int chunk = (int)std::min<long long>(wt_per_elem, std::max<long long>(1, (n_wt * 8 + OI_WG_TARGET - 1) / OI_WG_TARGET));
     dim3 g2(oi::cdiv(wt_per_elem, chunk), 8, B);
     const char* pk = reinterpret_cast<const char*>(packed);
     if constexpr (PREC == OI_PREC_F16X3) {
