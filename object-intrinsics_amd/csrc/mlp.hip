@@ -354,7 +354,17 @@ __global__ void pack_weights_kernel(const float* __restrict__ w0, const float* _
 // MFMA peak, matrix pipe 64 % busy -- profiles/r1_*.)
 // ------------------------------------------------------------------------------------------
 
-template <bool FAST, bool FULL, int SRC, class SCR>
+// REV: the FiLM rows were staged in REVOLUTIONS (gamma / 2pi, beta' / 2pi; sdf-only F16X3 pass): the phase needs one
+// v_fract (exact, keeps v_sin inside its [-256, 256] domain) instead of the four-operation reduction of sincos_, and no
+// cosine exists in that pass -- the form the register-resident kernel (mlp_fwd3.hip) uses.
+#ifndef OI_SDF_REV
+#define OI_SDF_REV 1
+#endif
+template <bool FAST>
+__device__ __forceinline__ float sin_rev(float phi_rev) {
+  return __builtin_amdgcn_sinf(FAST ? phi_rev : __builtin_amdgcn_fractf(phi_rev));
+}
+template <bool FAST, bool FULL, int SRC, class SCR, bool REV = false>
 __device__ __forceinline__ void film_sin2(const char* lds, const LaneOff& o, const LayOff& y, const f32x16 (&acc)[4],
                                           float (&act)[64], const SCR& ws, int slot, int tab_imm, float vx,
                                           float vy, float vz) {
@@ -375,10 +385,14 @@ __device__ __forceinline__ void film_sin2(const char* lds, const LaneOff& o, con
         u = SRC == 1 ? d : acc[t][4 * rr + k] + d;
       }
       const float phi = fmaf(gm[k], u, bt[k]);
-      float s, c;
-      sincos_<FAST>(phi, s, c);
-      act[4 * g + k] = s;
-      cv[k] = gm[k] * c;
+      if constexpr (REV) {
+        act[4 * g + k] = sin_rev<FAST>(phi);
+      } else {
+        float s, c;
+        sincos_<FAST>(phi, s, c);
+        act[4 * g + k] = s;
+        cv[k] = gm[k] * c;
+      }
     }
     if constexpr (FULL) ws.store(slot, g, o, cv);
     // two groups (8 values = 4 packed sin/cos chains) per scheduling window: one group alone leaves the dependent
@@ -392,19 +406,12 @@ __device__ __forceinline__ void film_sin2(const char* lds, const LaneOff& o, con
 // complete while block t's 24 MFMAs are in flight -- its 16 FiLM / sin values per lane are issued two at a time between
 // those MFMAs (independent instructions of the same wave run beside its own in-flight MFMAs); only block 3's FiLM
 // phase is exposed.  The B operand is split into its fp16 limbs once per layer (all 8 k-steps stay in registers).
-template <bool FAST, bool FULL, class SCR>
+template <bool FAST, bool FULL, bool REV, class SCR>
 __device__ __forceinline__ void layer_fwd_pipelined(const char* lds, const LaneOff& o, const LayOff& y,
                                                     f32x16 (&acc)[4], float (&act)[64], const SCR& ws, int slot) {
   f16x8 bh[8], bl[8];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float v = act[8 * s + i];
-      bh[s][i] = (_Float16)v;
-      bl[s][i] = (_Float16)(v - (float)bh[s][i]);
-    }
-  }
+  for (int s = 0; s < 8; ++s) split8_pairs(&act[8 * s], bh[s], bl[s]);
   f32x4 gm, bt, cv;
   // one value (accumulator slot 2s + j of block tb) of the FiLM / sin phase; j = 0, 1
   auto film_val = [&](int tb, int s, int j) {
@@ -414,10 +421,14 @@ __device__ __forceinline__ void layer_fwd_pipelined(const char* lds, const LaneO
       bt = lds_f4(lds, (C + grp_f0(g)) * 4, y.f16);
     }
     const float phi = fmaf(gm[k], acc[tb][2 * s + j], bt[k]);
-    float sn, cs;
-    sincos_<FAST>(phi, sn, cs);
-    act[4 * g + k] = sn;
-    cv[k] = gm[k] * cs;
+    if constexpr (REV) {
+      act[4 * g + k] = sin_rev<FAST>(phi);
+    } else {
+      float sn, cs;
+      sincos_<FAST>(phi, sn, cs);
+      act[4 * g + k] = sn;
+      cv[k] = gm[k] * cs;
+    }
     if constexpr (FULL) {
       if (k == 3) ws.store(slot, g, o, cv);
     }
@@ -505,25 +516,28 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   constexpr int LB = layer_bytes(PREC);
   constexpr bool RING2 = v2_two_slots(PREC, FULL);
   constexpr int NWV = v2_waves(PREC, FULL);
+  constexpr bool REV = OI_SDF_REV && PREC == OI_PREC_F16X3 && !FULL;  // FiLM rows in revolutions (see film_sin2)
   // double-buffered ring: the next image is requested at the START of a layer into the other slot.
   // single slot (BF16X6): it is requested right AFTER the layer's MFMAs, behind a barrier, and lands while the
   // FiLM/sin VALU phase runs.
-  auto stage_early = [&](const char* src, int slot) {
-    if constexpr (RING2) prefetch_image<PREC, NWV>(lds, src, slot, wave, lane);
-  };
-  auto stage_late = [&](const char* src) {
-    if constexpr (!RING2) {
-      __syncthreads();
-      prefetch_image<PREC, NWV>(lds, src, 0, wave, lane);
-    }
-  };
-
   LaneOff o;
   o.h16 = 16 * h;
   o.h64 = 64 * h;
   o.l16 = 16 * lane;
   o.l16hi = 16 * lane + 32768;
   asm volatile("" : "+v"(o.h16), "+v"(o.h64), "+v"(o.l16), "+v"(o.l16hi));
+
+  const __amdgpu_buffer_rsrc_t img_rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mats), 0, NMAT * LB, 0x00020000);
+  auto stage_early = [&](int image, int slot) {
+    if constexpr (RING2) prefetch_image<PREC, NWV>(lds, img_rs, image * LB, slot, wave, o.l16);
+  };
+  auto stage_late = [&](int image) {
+    if constexpr (!RING2) {
+      __syncthreads();
+      prefetch_image<PREC, NWV>(lds, img_rs, image * LB, 0, wave, o.l16);
+    }
+  };
 
   constexpr int NW = NWV, NT = 64 * NW;
   const long long local = (long long)blockIdx.x * (NW * WAVE_PTS) + wave * WAVE_PTS + j;
@@ -541,7 +555,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
 
   // image sequence: i = 0..6 forward layers 1..7 (mats 0..6), i = 7..13 transposed layers 7..1 (mats 13..7),
   // i = 14 colour head (mat 14); image i lives in ring slot i & 1.
-  prefetch_image<PREC, NWV>(lds, mats + 0 * (size_t)LB, 0, wave, lane);
+  prefetch_image<PREC, NWV>(lds, img_rs, 0, 0, wave, o.l16);
   {  // small tables + FiLM rows of all 9 layers (gamma | beta | bias), once
     float* tabs = reinterpret_cast<float*>(lds + V2_TABS);
     for (int i = tid; i < H_TABS_END; i += NT) tabs[i] = hdr[i];
@@ -551,8 +565,9 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       const float gm = gamma[((size_t)e * 9 + l) * C + f];
       // image scale of the layer's MFMA operand folded into the multiplier of u (layer 0 runs on the VALU)
       const float ws = l == 0 ? 1.f : hdr[H_WSCALE + (l < NL_SDF ? l - 1 : 14)];
-      film[l * 256 + f] = gm * ws;
-      film[l * 256 + C + f] = fmaf(gm, hdr[H_BIAS + l * C + f], beta[((size_t)e * 9 + l) * C + f]);
+      constexpr float TO_REV = REV ? 0.15915494309189533577f : 1.f;
+      film[l * 256 + f] = gm * ws * TO_REV;
+      film[l * 256 + C + f] = fmaf(gm, hdr[H_BIAS + l * C + f], beta[((size_t)e * 9 + l) * C + f]) * TO_REV;
     }
   }
   const float px = pts[pt * 3 + 0], py = pts[pt * 3 + 1], pz = pts[pt * 3 + 2];
@@ -569,7 +584,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   // ---- layer 0 (K = 3) on the VALU, overlapping the first image's DMA
   {
     const LayOff y = lay_off<PREC>(o, 0, 0);
-    film_sin2<FAST, FULL, 1>(lds, o, y, acc, act, ws, 0, H_TAB0, px, py, pz);
+    film_sin2<FAST, FULL, 1, FwdScratch<HALF_SCR>, REV>(lds, o, y, acc, act, ws, 0, H_TAB0, px, py, pz);
   }
   PROF_T(0);
   ring_sync();
@@ -579,12 +594,12 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   for (int l = 1; l < NL_SDF; ++l) {
     const int i = l - 1;
     // next image: forward layer l+1, or the first transposed image (layer 7) / nothing for the sdf-only variant
-    const char* next = (l < NL_SDF - 1) ? mats + (size_t)l * LB : (FULL ? mats + (size_t)13 * LB : nullptr);
-    if (next) stage_early(next, (i + 1) & 1);
+    const int next = (l < NL_SDF - 1) ? l : (FULL ? 13 : -1);  // image index, -1: none
+    if (next >= 0) stage_early(next, (i + 1) & 1);
     const LayOff y = lay_off<PREC>(o, RING2 ? (i & 1) : 0, l);
 #if OI_PIPE_FWD
     if constexpr (PREC == OI_PREC_F16X3 && RING2) {
-      layer_fwd_pipelined<FAST, FULL>(lds, o, y, acc, act, ws, l);
+      layer_fwd_pipelined<FAST, FULL, REV>(lds, o, y, acc, act, ws, l);
       PROF_T(1);
     } else
 #endif
@@ -592,9 +607,9 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       zero_acc(acc);
       gemm_layer2<PREC>(lds, y, act, acc);
       PROF_T(1);
-      if (next) stage_late(next);
+      if (next >= 0) stage_late(next);
       PROF_T(2);
-      film_sin2<FAST, FULL, 0>(lds, o, y, acc, act, ws, l, 0, 0.f, 0.f, 0.f);
+      film_sin2<FAST, FULL, 0, FwdScratch<HALF_SCR>, REV>(lds, o, y, acc, act, ws, l, 0, 0.f, 0.f, 0.f);
     }
     PROF_T(3);
     ring_sync();
@@ -675,8 +690,8 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       }
       // next image after the scratch loads have been consumed (an in-flight LDS-DMA would otherwise be
       // drained by the vmcnt wait hipcc places in front of the first use of an ordinary load)
-      const char* next = (l > 1) ? mats + (size_t)(7 + l - 2) * LB : (rgb_out != nullptr ? mats + (size_t)14 * LB : nullptr);
-      if (next) stage_early(next, (i + 1) & 1);
+      const int next = (l > 1) ? 7 + l - 2 : (rgb_out != nullptr ? 14 : -1);
+      if (next >= 0) stage_early(next, (i + 1) & 1);
       const LayOff y = lay_off<PREC>(o, RING2 ? (i & 1) : 0, l);
       zero_acc(acc);
       PROF_T(5);
@@ -685,7 +700,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
         cn[2 * s + 1] = ws.load(l - 1, 2 * s + 1, o);
       });
       PROF_T(6);
-      if (next) stage_late(next);
+      if (next >= 0) stage_late(next);
       PROF_T(7);
 #pragma unroll
       for (int t = 0; t < 4; ++t)

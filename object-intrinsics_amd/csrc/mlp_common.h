@@ -56,10 +56,14 @@ __host__ __device__ __forceinline__ int feat_of(int q, int h) {
 // ------------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-// two fp32 values -> one dword of the hi plane and one of the lo plane: hi = v_cvt_pk_f16_f32 (round to nearest even),
-// residual a - float(hi) in ONE v_fma_mix_f32 per value (fp16 operand read straight from the packed dword; bit-identical
-// to the cvt-back / subtract form, tools/dbg/sin_rev_probe.hip), lo = v_cvt_pk_f16_f32 of the residuals.  Every
-// instruction of this single-wave stream costs ~4.75 issue cycles (tools/dbg/valu_cost.hip): 4 instead of 6 per pair.
+// two fp32 values -> one dword of the hi plane and one of the lo plane: hi = v_cvt_pk_f16_f32 (round to nearest even); the
+// residual a - float(hi) is exact in fp32, and v_fma_mixlo_f16 / v_fma_mixhi_f16 form it (fp16 operand read straight from
+// the packed dword) and round it to fp16 into the low / high half of the lo dword: 3 instructions per pair, bit-identical
+// to the cvt-back / subtract / cvt_pk form (tools/dbg/run_fwd_ab.sh compares whole forward passes bit for bit) and to
+// round 2's v_fma_mix_f32 x 2 + v_cvt_pk (4 per pair, OI_SPLIT_MIXLO=0).
+#ifndef OI_SPLIT_MIXLO
+#define OI_SPLIT_MIXLO 1
+#endif
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
   const f16x2 hv = {(_Float16)a, (_Float16)b};
   hi = __builtin_bit_cast(unsigned, hv);
@@ -69,6 +73,14 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     return;
   }
 #endif
+#if OI_SPLIT_MIXLO
+  // the residual of each value, rounded to fp16 straight into its half of the lo dword (the residual is exact in fp32,
+  // so this is the same single rounding v_cvt_pk_f16_f32 applies): 3 instructions per pair
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(lo)
+      : "v"(hi), "v"(a), "v"(b));
+#else
   float ra, rb;
   asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
       "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
@@ -76,6 +88,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
       : "v"(hi), "v"(a), "v"(b));
   const f16x2 lv = {(_Float16)ra, (_Float16)rb};
   lo = __builtin_bit_cast(unsigned, lv);
+#endif
 }
 // eight fp32 values -> the hi and lo fp16 limb fragments (8 x fp16 each) of an MFMA operand: 16 instructions
 __device__ __forceinline__ void split8_pairs(const float* v, f16x8& hi, f16x8& lo) {
@@ -530,15 +543,22 @@ __host__ __device__ constexpr int v2_lds_total(int prec, bool full) {
 }
 
 
+// One layer image -> ring slot `slot` through the LDS-DMA path (16 B per lane straight into LDS).  `rs` spans the 16
+// images, `src_off` = byte offset of the image in it.  A wave copies a contiguous share, 4 KiB per (M0, soffset) setting:
+// the instruction's immediate offset advances the LDS and the global address alike, so four 1 KiB copies share one
+// M0 / soffset pair and no per-chunk 64-bit address is formed on the VALU.
 template <int PREC, int NWAVES>
-__device__ __forceinline__ void prefetch_image(char* lds, const char* __restrict__ src, int slot, int wave, int lane) {
-  constexpr int NCHUNK = layer_bytes(PREC) / 1024;
+__device__ __forceinline__ void prefetch_image(char* lds, __amdgpu_buffer_rsrc_t rs, int src_off, int slot, int wave, int l16) {
+  constexpr int PER_WAVE = layer_bytes(PREC) / NWAVES;
+  static_assert(PER_WAVE % 4096 == 0, "a wave's share of an image is a multiple of 4 KiB");
 #pragma unroll
-  for (int c0 = 0; c0 < NCHUNK / NWAVES; ++c0) {
-    const int c = c0 * NWAVES + wave;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src + c * 1024 + lane * 16),
-        (__attribute__((address_space(3))) void*)(lds + V2_WBUF + slot * layer_bytes(PREC) + c * 1024), 16, 0, 0);
+  for (int q = 0; q < PER_WAVE / 4096; ++q) {
+    const int c = wave * PER_WAVE + q * 4096;
+    auto* dst = (__attribute__((address_space(3))) void*)(lds + V2_WBUF + slot * layer_bytes(PREC) + c);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, l16, src_off + c, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, l16, src_off + c, 1024, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, l16, src_off + c, 2048, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, l16, src_off + c, 3072, 0);
   }
 }
 

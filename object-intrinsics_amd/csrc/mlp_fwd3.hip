@@ -72,6 +72,61 @@ __device__ __forceinline__ int cu_slot_id() {
   return (int)(xcc * 256 + cu);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Packed fp32 arithmetic of the epilogues.  OI_F3_PK: 0 = scalar source, 1 = 2-vectors (hipcc unpacks v_pk_*_f32 it finds in
+// the shadow of an MFMA on gfx950 again), 2 = the packed instruction as written (inline asm)
+#ifndef OI_F3_PK
+#define OI_F3_PK 1
+#endif
+#ifndef OI_F3_MAX3
+#define OI_F3_MAX3 1
+#endif
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+#if OI_F3_PK == 2
+  f32x2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+#elif OI_F3_PK == 1
+  return __builtin_elementwise_fma(a, b, c);
+#else
+  return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
+#endif
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+#if OI_F3_PK == 2
+  f32x2 r;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
+  return a * b;
+#endif
+}
+// a * s with the scalar s taken from the low dword of its register for both halves
+__device__ __forceinline__ f32x2 pk_mul_s(f32x2 a, float s) {
+#if OI_F3_PK == 2
+  f32x2 r, sv;
+  sv[0] = s;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(sv));
+  return r;
+#else
+  return a * s;
+#endif
+}
+// FiLM phase of an accumulator pair (the rows and the accumulators sit in aligned register pairs)
+__device__ __forceinline__ f32x2 film_phase2(const f32x4& a, const f32x4& b, int k, float acc0, float acc1) {
+  return pk_fma(f32x2{a[k], a[k + 1]}, f32x2{acc0, acc1}, f32x2{b[k], b[k + 1]});
+}
+// max(m, |x|, |y|) in one v_max3_f32
+__device__ __forceinline__ float max3_abs(float m, float x, float y) {
+#if OI_F3_MAX3
+  float r;
+  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(x), "v"(y));
+  return r;
+#else
+  return fmaxf(m, fmaxf(fabsf(x), fabsf(y)));
+#endif
+}
+
 typedef unsigned Limbs[8][4];  // one fp16 limb plane of a B operand: [k-step][dword d] = act indices 8 s + 2 d, 8 s + 2 d + 1
 
 
@@ -242,6 +297,10 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
                      long long n_per_elem) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int LB = 65536;
+#ifdef OI_F3_PROF
+  const unsigned long long t_entry = __builtin_readcyclecounter();
+  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, j = lane & 31;
@@ -307,12 +366,17 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     if (pos >= 2) return;
 #endif
     const int m = pos < 7 ? pos : (pos < 12 ? 20 - pos : (pos < 14 ? pos - 12 : (pos < 16 ? 22 - pos : 14)));
+    // a wave copies 16 consecutive KiB, 4 KiB per (M0, soffset) setting: the instruction's immediate offset advances the
+    // LDS and the global address alike, so four 1 KiB copies share one M0 / soffset pair (6 instead of 16 instructions per
+    // 4 KiB; bit-identical results, -1.3 % kernel time)
 #pragma unroll
-    for (int c0 = 0; c0 < LB / 1024 / F3_WAVES; ++c0) {
-      const int c = c0 * F3_WAVES + wave;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          img_rs, (__attribute__((address_space(3))) void*)(lds + F3_WBUF + (pos & 1) * LB + c * 1024), 16, o.l16,
-          m * LB + c * 1024, 0, 0);
+    for (int q = 0; q < LB / 4096 / F3_WAVES; ++q) {
+      const int c = (wave * (LB / 4096 / F3_WAVES) + q) * 4096;
+      auto* dst = (__attribute__((address_space(3))) void*)(lds + F3_WBUF + (pos & 1) * LB + c);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, m * LB + c, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, m * LB + c, 1024, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, m * LB + c, 2048, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, m * LB + c, 3072, 0);
     }
   };
   auto lay = [&](int pos) {  // A-image lane bases of ring position pos
@@ -369,6 +433,7 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_readcyclecounter();
   const unsigned long long tstart = tprev;
+  pacc[4] = tstart - t_entry;  // prologue: tables, FiLM rows, row maxima, two barriers
 #endif
   float act[64];                 // fp32 staging of an adjoint vector before its normalisation (reverse layers only)
   f32x16 acc[4];
@@ -445,8 +510,8 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         NEXT;                                                                                              \
       }                                                                                                    \
     }                                                                                                      \
-    const float r0 = reduce(fmaf(R.a[k], F3_ACC(tb, 2 * rp), R.b[k]));                                        \
-    const float r1 = reduce(fmaf(R.a[k + 1], F3_ACC(tb, 2 * rp + 1), R.b[k + 1]));                            \
+    const f32x2 ph = film_phase2(R.a, R.b, k, F3_ACC(tb, 2 * rp), F3_ACC(tb, 2 * rp + 1));                 \
+    const float r0 = reduce(ph[0]), r1 = reduce(ph[1]);                                                    \
     PARK(g, k, r0);                                                                                        \
     PARK(g, k + 1, r1);                                                                                    \
     split_pair(f3_sin(r0), f3_sin(r1), NH[2 * tb + (rp >> 2)][rp & 3],       \
@@ -486,10 +551,11 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         NEXT;                                                                                              \
       }                                                                                                    \
     }                                                                                                      \
-    const float v0 = (F3_ACC(tb, 2 * rp) * sg) * (R.c[k] * f3_cos(from_acc(BANK[g][k])));     \
-    const float v1 = (F3_ACC(tb, 2 * rp + 1) * sg) * (R.c[k + 1] * f3_cos(from_acc(BANK[g][k + 1]))); \
-    vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));                                                       \
-    split_pair(v0, v1, NH[2 * tb + (rp >> 2)][rp & 3], NL[2 * tb + (rp >> 2)][rp & 3]);                    \
+    const f32x2 cs = {f3_cos(from_acc(BANK[g][k])), f3_cos(from_acc(BANK[g][k + 1]))};                     \
+    const f32x2 v = pk_mul(pk_mul_s(f32x2{F3_ACC(tb, 2 * rp), F3_ACC(tb, 2 * rp + 1)}, sg),                \
+                           pk_mul(f32x2{R.c[k], R.c[k + 1]}, cs));                                         \
+    vmax = max3_abs(vmax, v[0], v[1]);                                                                     \
+    split_pair(v[0], v[1], NH[2 * tb + (rp >> 2)][rp & 3], NL[2 * tb + (rp >> 2)][rp & 3]);                \
   }
 
   const LayOff y1 = lay(0), y2 = lay(1), y3 = lay(2), y4 = lay(3), y5 = lay(4), y6 = lay(5), y7 = lay(6);
@@ -565,16 +631,18 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         NEXT_G(F6);
       }
     }
-    float v[2];
+    const f32x2 ph = film_phase2(R.a, R.b, k, F3_ACC(tb, 2 * rp), F3_ACC(tb, 2 * rp + 1));
+    f32x2 cs;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const float r = reduce(fmaf(R.a[k + i], F3_ACC(tb, 2 * rp + i), R.b[k + i]));
+      const float r = reduce(ph[i]);
       const float sn = f3_sin(r);
       fv[k + i] = sn;
       sdf_part = fmaf(sn, R.d[k + i], sdf_part);
-      v[i] = (R.c[k + i] * sg7) * f3_cos(r);
+      cs[i] = f3_cos(r);
     }
-    vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+    const f32x2 v = pk_mul(pk_mul_s(f32x2{R.c[k], R.c[k + 1]}, sg7), cs);
+    vmax = max3_abs(vmax, v[0], v[1]);
     split_pair(v[0], v[1], BH[2 * tb + (rp >> 2)][rp & 3], BL[2 * tb + (rp >> 2)][rp & 3]);
     if (k == 2) {
       ws.store(0, g, o, fv);
@@ -627,10 +695,10 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   asm volatile("" : "+v"(one));
   auto pg3 = [&](int tb, int rp) {
     const int g = tb * 4 + (rp >> 1), k = 2 * (rp & 1);
-    const float a0 = F3_ACC(tb, 2 * rp) * one, a1 = F3_ACC(tb, 2 * rp + 1) * one;
-    vmax = fmaxf(vmax, fmaxf(fabsf(a0), fabsf(a1)));
-    P0[g][k] = to_acc(a0);
-    P0[g][k + 1] = to_acc(a1);
+    const f32x2 a = pk_mul_s(f32x2{F3_ACC(tb, 2 * rp), F3_ACC(tb, 2 * rp + 1)}, one);
+    vmax = max3_abs(vmax, a[0], a[1]);
+    P0[g][k] = to_acc(a[0]);
+    P0[g][k + 1] = to_acc(a[1]);
   };
   stream_layer(lds, lay(11), BH, BL, acc, r4, [&]() { vmax = 0.f; }, pg3);   // (V3's own maximum is not needed)
   F3_T(1);
@@ -668,13 +736,10 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         NEXT_G(F1);
       }
     }
-    float v[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float r = reduce(fmaf(R.a[k + i], F3_ACC(tb, 2 * rp + i), R.b[k + i]));
-      v[i] = (from_acc(P0[g][k + i]) * sg2) * (R.c[k + i] * f3_cos(r));
-    }
-    vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+    const f32x2 ph = film_phase2(R.a, R.b, k, F3_ACC(tb, 2 * rp), F3_ACC(tb, 2 * rp + 1));
+    const f32x2 cs = {f3_cos(reduce(ph[0])), f3_cos(reduce(ph[1]))};
+    const f32x2 v = pk_mul(pk_mul_s(f32x2{from_acc(P0[g][k]), from_acc(P0[g][k + 1])}, sg2), pk_mul(f32x2{R.c[k], R.c[k + 1]}, cs));
+    vmax = max3_abs(vmax, v[0], v[1]);
     split_pair(v[0], v[1], AH[2 * tb + (rp >> 2)][rp & 3], AL[2 * tb + (rp >> 2)][rp & 3]);
   };
   stream_layer(lds, z2, BH, BL, acc, f1, NoMid(), f2);
@@ -695,9 +760,10 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     const int g = tb * 4 + (rp >> 1), k = 2 * (rp & 1);
     Rows& R = rw[g & 1];
     if (k == 0 && g < 15) rw[(g + 1) & 1].c = ROW_G(F0, g + 1);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      act[4 * g + k + i] = F3_ACC(tb, 2 * rp + i) * (R.c[k + i] * f3_cos(from_acc(P1[g][k + i])));
+    const f32x2 cs = {f3_cos(from_acc(P1[g][k])), f3_cos(from_acc(P1[g][k + 1]))};
+    const f32x2 v = pk_mul(f32x2{F3_ACC(tb, 2 * rp), F3_ACC(tb, 2 * rp + 1)}, pk_mul(f32x2{R.c[k], R.c[k + 1]}, cs));
+    act[4 * g + k] = v[0];
+    act[4 * g + k + 1] = v[1];
   };
   stream_layer(lds, lay(15), BH, BL, acc, r2, [&]() {}, r1);
   F3_T(1);
@@ -794,6 +860,8 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     for (int i = 0; i < 6; ++i) atomicAdd(&oi_prof3[i], pacc[i]);
     atomicAdd(&oi_prof3[6], __builtin_readcyclecounter() - tstart);
     atomicAdd(&oi_prof3[7], 1ull);
+    atomicAdd(&oi_prof3[8], __builtin_readcyclecounter() - t_entry);          // with [9]: the shader clock in the kernel
+    atomicAdd(&oi_prof3[9], __builtin_amdgcn_s_memrealtime() - rt_entry);
   }
 #endif
 #undef OI_PARK

@@ -20,12 +20,19 @@ with torch.no_grad():
     _, gamma, beta = pack.film(z=torch.randn(1, 64, device="cuda"))
     out = ops.sdf_mlp_fwd(pts, pack.packed(), gamma, beta, 1, pack.prec, pack.fast_trig, True, True, False, None)
     raw.oi_prof3_read(buf, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(5):
         ops.sdf_mlp_fwd(pts, pack.packed(), gamma, beta, 1, pack.prec, pack.fast_trig, True, True, False, out[-1])
+    e1.record()
     raw.oi_prof3_read(buf, 0)
+    print(f"wall per launch {e0.elapsed_time(e1) / 5:.3f} ms (profiled build)")
 names = ["layer 0 (VALU, x2)", "layer products (MFMA windows + overlapped epilogues)", "ring_sync (vmcnt0 + barrier)",
-         "exposed block-3 epilogues", "normalise + fp16 split of adjoints", "heads / gradient / rest"]
+         "exposed block-3 epilogues", "prologue (tables, FiLM rows, maxima; before the tile clock)", "heads / gradient / rest"]
 nw = buf[7]
 print(f"waves {nw}, mean ticks per wave {buf[6] / nw:.0f}")
+if buf[9]:
+    print(f"shader clock inside the kernel: {buf[8] / buf[9] * 100:.0f} MHz (s_memtime ticks per 100 MHz s_memrealtime tick; "
+          f"mean wave lifetime {buf[9] / nw / 100:.1f} us)")
 for i, nm in enumerate(names):
     print(f"  {nm:55s} {buf[i] / nw:10.0f}  {100 * buf[i] / buf[6]:5.1f} %")
