@@ -65,6 +65,7 @@ __device__ __forceinline__ float from_acc(float a) {
 }
 
 constexpr int F3_CU_SLOTS = 4096;  // 16 XCC ids x 256 (SE, SH, CU) codes: an upper bound on distinct physical CUs
+constexpr int F3_WG_SLOTS = 512;   // launches of up to this many workgroups index their scratch by workgroup
 // index of the compute unit this wave runs on: HW_REG_XCC_ID[3:0] and HW_REG_HW_ID[15:8] = {SE_ID[2:0], SH_ID, CU_ID[3:0]}
 __device__ __forceinline__ int cu_slot_id() {
   const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);  // 4 bits at offset 0 of register 20
@@ -326,7 +327,7 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   };
 
   // The features of this wave tile wait in a 16 KiB scratch slot from layer 7 until the albedo head.  Small launches
-  // index the slot by workgroup; large ones by the PHYSICAL compute unit the workgroup runs on (XCC id + the SE / SH / CU
+  // (up to F3_WG_SLOTS workgroups) index the slot by workgroup; large ones by the PHYSICAL compute unit the workgroup runs on (XCC id + the SE / SH / CU
   // bits of HW_ID): a CU holds one workgroup of this kernel at a time (149 KiB of its 160 KiB LDS), so consecutive
   // workgroups of a CU overwrite the same 64 KiB and the whole launch touches 256 x 64 KiB = 16 MiB, which stays in the
   // XCD's L2 instead of streaming 512 B/point through HBM.  (Exclusive use of a slot follows from the LDS budget, not from
@@ -334,7 +335,7 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   FwdScratch<false> ws;
   {
     long long wg = (long long)e * gridDim.x + blockIdx.x;
-    if ((long long)gridDim.x * gridDim.y > F3_CU_SLOTS) wg = cu_slot_id();
+    if ((long long)gridDim.x * gridDim.y > F3_WG_SLOTS) wg = cu_slot_id();
     ws.rs = __builtin_amdgcn_make_buffer_rsrc(scratch + (wg * F3_WAVES + wave) * 16384ll, 0, 16384, 0x00020000);
   }
 
@@ -892,7 +893,7 @@ namespace oimlp {
 
 size_t full3_scratch_bytes(int B, long long n_per_elem) {
   const long long wgs = (long long)B * oi::cdiv(n_per_elem, F3_TILE);
-  return (size_t)(wgs > F3_CU_SLOTS ? F3_CU_SLOTS : wgs) * F3_WAVES * 16384;
+  return (size_t)(wgs > F3_WG_SLOTS ? F3_CU_SLOTS : wgs) * F3_WAVES * 16384;
 }
 
 int launch_full3_f16x3(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf,

@@ -367,7 +367,7 @@ def test_device_sincos_accuracy(ops):
 
 def test_cu_slot_exclusive(ops):
     """The register-resident forward kernel parks features in a scratch slot indexed by the physical CU (XCC id + SE/SH/CU
-    bits of HW_ID) when a launch has more than 4096 workgroups.  On the device: many more workgroups than CUs, each with
+    bits of HW_ID) when a launch has more than 512 workgroups.  On the device: many more workgroups than CUs, each with
     that kernel's LDS footprint, must never find their slot busy, and the ids must spread over many distinct slots."""
     from oi_amd import lib
     L = lib.load()
@@ -387,7 +387,7 @@ def test_cu_slot_exclusive(ops):
 
 
 def test_sdf_mlp_large_launch_uses_cu_slots(ops, packed_all):
-    """> 4096 workgroups (CU-indexed scratch) gives the same result as the same points in small launches."""
+    """> 512 workgroups (CU-indexed scratch; here 6001) gives the same result as the same points in small launches."""
     P, packs = packed_all
     g1 = load_golden("f1_film_siren")
     w, gamma, beta = ops.film_params(P["style_w"], P["style_b"], P["gw"], P["gb"], P["bw"], P["bb"], w=g1["w"][:1].cuda())
