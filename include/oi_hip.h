@@ -411,6 +411,25 @@ int oi_gan_losses_bwd(const float* g_total, const float* d_real, const float* d_
                       const float* aux_w, float reg_w, float* g_real, float* g_fake, float* g_gx, int B, int K, long long N,
                       oi_stream_t stream);
 
+/* The inputs of one captured (hipGraph) step in one launch: n_copies <= 4 device-to-device copies of counts[c] floats
+ * (srcs / dsts / counts: HOST arrays) and n_imm <= 64 floats `imm` (HOST values, carried in the kernel arguments) written to
+ * the device address imm_dst.  Replaces a copy launch per input tensor, the pinned-buffer upload of the augmentation
+ * matrices and a fill per scalar in front of every replay (oi_amd.graphed). */
+int oi_stage_inputs(const float* const* srcs, float* const* dsts, const long long* counts, int n_copies, const float* imm,
+                    int n_imm, float* imm_dst, oi_stream_t stream);
+
+/* The renderer's two derived scalars from the compositing reductions r4[4] (reference: src/models/renderer.py:430-446):
+ * out2 = (r4[0] / (r4[1] + 1e-5), r4[2] * inv_nt), and the gradient w.r.t. r4 (g_err / g_surf: device scalars or NULL). */
+int oi_render_scalars_fwd(const float* r4, float inv_nt, float* out2, oi_stream_t stream);
+int oi_render_scalars_bwd(const float* r4, const float* g_err, const float* g_surf, float inv_nt, float* g_r4,
+                          oi_stream_t stream);
+
+/* total = sum_i weights[i] * *terms[i] over n <= 8 device scalars, and its gradient g_terms[i] = weights[i] * *g_out: the
+ * weighted sum of loss terms of a training step (reference: src/trainers/gan_pose_trainer.py:122-137, one multiply and one
+ * add per term composed from tensor ops).  `terms` and `weights` are HOST arrays (n device pointers / n floats). */
+int oi_weighted_sum_fwd(const float* const* terms, const float* weights, int n, float* out, oi_stream_t stream);
+int oi_weighted_sum_bwd(const float* g_out, const float* weights, int n, float* g_terms, oi_stream_t stream);
+
 /* Outputs that are ACCUMULATED into (the split-K sums of oi_conv4x4_fwd* / oi_conv4x4_wgrad, the scatter-adds of
  * oi_conv4x4_dgrad, oi_affine_grid_sample_bwd, oi_grid_sample_bwd, oi_reflect_pad_bwd) are cleared by their launcher with a
  * fill of their own.  A caller that takes every such output from memory it has already zeroed -- one fill per training step

@@ -86,9 +86,77 @@ gan_losses_bwd_kernel(const float* __restrict__ g_total, const float* __restrict
   }
 }
 
+// total = sum_i w_i * term_i of up to 8 device scalars (the generator's loss: GAN term per discriminator + the weighted
+// regularisers, gan_pose_trainer.py:122-137): one launch instead of a multiply and an add per term, each way
+struct WeightedTerms {
+  const float* p[8];
+  float w[8];
+  int n;
+};
+__global__ void weighted_sum_fwd_kernel(WeightedTerms t, float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = 0; i < t.n; ++i) s = fmaf(t.w[i], t.p[i][0], s);
+  out[0] = s;
+}
+__global__ void weighted_sum_bwd_kernel(WeightedTerms t, const float* __restrict__ g_out, float* __restrict__ g_terms) {
+  if ((int)threadIdx.x < t.n) g_terms[threadIdx.x] = t.w[threadIdx.x] * g_out[0];
+}
+
+// The two scalars the renderer derives from the compositing kernel's reductions r4 = (sum of eikonal errors inside the
+// sphere, number of such samples, sum of |sdf| surface terms, .) -- reference renderer.py:430-446:
+//   gradient_error = r4[0] / (r4[1] + 1e-5),   surface_loss = r4[2] * inv_nt
+__global__ void render_scalars_fwd_kernel(const float* __restrict__ r4, float inv_nt, float* __restrict__ out2) {
+  out2[0] = r4[0] / (r4[1] + 1e-5f);
+  out2[1] = r4[2] * inv_nt;
+}
+__global__ void render_scalars_bwd_kernel(const float* __restrict__ r4, const float* __restrict__ g_err,
+                                          const float* __restrict__ g_surf, float inv_nt, float* __restrict__ g_r4) {
+  const float den = r4[1] + 1e-5f;
+  const float ge = g_err != nullptr ? g_err[0] : 0.f;
+  g_r4[0] = ge / den;
+  g_r4[1] = -ge * r4[0] / (den * den);
+  g_r4[2] = g_surf != nullptr ? g_surf[0] * inv_nt : 0.f;
+  g_r4[3] = 0.f;
+}
+
 }  // namespace
 
 extern "C" {
+
+int oi_render_scalars_fwd(const float* r4, float inv_nt, float* out2, oi_stream_t stream) {
+  OI_REQUIRE(r4 != nullptr && out2 != nullptr, "oi_render_scalars_fwd: null pointer");
+  hipLaunchKernelGGL(render_scalars_fwd_kernel, dim3(1), dim3(1), 0, oi::as_stream(stream), r4, inv_nt, out2);
+  return oi::check_launch("oi_render_scalars_fwd");
+}
+
+int oi_render_scalars_bwd(const float* r4, const float* g_err, const float* g_surf, float inv_nt, float* g_r4,
+                          oi_stream_t stream) {
+  OI_REQUIRE(r4 != nullptr && g_r4 != nullptr, "oi_render_scalars_bwd: null pointer");
+  hipLaunchKernelGGL(render_scalars_bwd_kernel, dim3(1), dim3(1), 0, oi::as_stream(stream), r4, g_err, g_surf, inv_nt, g_r4);
+  return oi::check_launch("oi_render_scalars_bwd");
+}
+
+int oi_weighted_sum_fwd(const float* const* terms, const float* weights, int n, float* out, oi_stream_t stream) {
+  OI_REQUIRE(terms != nullptr && weights != nullptr && out != nullptr && n >= 1 && n <= 8, "oi_weighted_sum_fwd: n=%d (1..8)", n);
+  WeightedTerms t{};
+  t.n = n;
+  for (int i = 0; i < n; ++i) {
+    OI_REQUIRE(terms[i] != nullptr, "oi_weighted_sum_fwd: term %d is null", i);
+    t.p[i] = terms[i];
+    t.w[i] = weights[i];
+  }
+  hipLaunchKernelGGL(weighted_sum_fwd_kernel, dim3(1), dim3(1), 0, oi::as_stream(stream), t, out);
+  return oi::check_launch("oi_weighted_sum_fwd");
+}
+
+int oi_weighted_sum_bwd(const float* g_out, const float* weights, int n, float* g_terms, oi_stream_t stream) {
+  OI_REQUIRE(g_out != nullptr && weights != nullptr && g_terms != nullptr && n >= 1 && n <= 8, "oi_weighted_sum_bwd: n=%d (1..8)", n);
+  WeightedTerms t{};
+  t.n = n;
+  for (int i = 0; i < n; ++i) t.w[i] = weights[i];
+  hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(1), dim3(64), 0, oi::as_stream(stream), t, g_out, g_terms);
+  return oi::check_launch("oi_weighted_sum_bwd");
+}
 
 int oi_gan_losses_fwd(const float* d_real, const float* d_fake, const float* pose, const float* gx, const float* aux_w,
                       float reg_w, float* out6, int B, int K, long long N, oi_stream_t stream) {

@@ -5,6 +5,8 @@
 // src/trainers/gan_pose_trainer.py:142,191) and the EMA lerp of the generator (src/utils/ema.py:26-32) -- which
 // torch runs as 4-6 foreach launches per optimiser.  HBM-bound: reads 16 B and writes 12 B per parameter (Adam).
 // Arithmetic follows torch's single-tensor formulas (torch/optim/adam.py, rmsprop.py; Tensor.lerp) in fp32.
+#include <algorithm>
+
 #include "oi_common.h"
 
 namespace {
@@ -54,9 +56,52 @@ multi_copy_kernel(const oi_mt_chunk* __restrict__ table) {
   for (int i = threadIdx.x; i < c.n; i += 256) c.p[i] = c.g[i];
 }
 
+// The inputs of one captured step in ONE launch: up to 4 device-to-device copies into the graph's static buffers plus up to
+// 64 floats that travel in the kernel arguments (augmentation matrices, scalar weights) -- instead of a copy launch per
+// tensor, a pinned staging buffer + host-to-device copy for the matrices and a fill for every scalar.
+struct StageArgs {
+  const float* src[4];
+  float* dst[4];
+  long long n[4];
+  float imm[64];
+  float* imm_dst;
+  int n_copies, n_imm;
+};
+__global__ void __launch_bounds__(256) stage_inputs_kernel(StageArgs a) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+  if (gid < a.n_imm) a.imm_dst[gid] = a.imm[gid];
+  for (int c = 0; c < a.n_copies; ++c)
+    for (long long i = gid; i < a.n[c]; i += stride) a.dst[c][i] = a.src[c][i];
+}
+
 }  // namespace
 
 extern "C" {
+
+int oi_stage_inputs(const float* const* srcs, float* const* dsts, const long long* counts, int n_copies, const float* imm,
+                    int n_imm, float* imm_dst, oi_stream_t stream) {
+  OI_REQUIRE(n_copies >= 0 && n_copies <= 4 && n_imm >= 0 && n_imm <= 64, "oi_stage_inputs: %d copies (<= 4), %d immediates (<= 64)",
+             n_copies, n_imm);
+  OI_REQUIRE(n_imm == 0 || (imm != nullptr && imm_dst != nullptr), "oi_stage_inputs: immediates without a destination");
+  StageArgs a{};
+  long long most = n_imm;
+  for (int c = 0; c < n_copies; ++c) {
+    OI_REQUIRE(srcs[c] != nullptr && dsts[c] != nullptr && counts[c] >= 0, "oi_stage_inputs: copy %d", c);
+    a.src[c] = srcs[c];
+    a.dst[c] = dsts[c];
+    a.n[c] = counts[c];
+    most = std::max(most, counts[c]);
+  }
+  for (int i = 0; i < n_imm; ++i) a.imm[i] = imm[i];
+  a.imm_dst = imm_dst;
+  a.n_copies = n_copies;
+  a.n_imm = n_imm;
+  if (most == 0) return OI_OK;
+  const int blocks = (int)std::min<long long>(1024, (most + 1023) / 1024);
+  hipLaunchKernelGGL(stage_inputs_kernel, dim3(blocks), dim3(256), 0, oi::as_stream(stream), a);
+  return oi::check_launch("oi_stage_inputs");
+}
+
 
 int oi_mt_chunk_elems(void) { return CHUNK; }
 

@@ -110,11 +110,14 @@ class GraphedDStep:
         self.x_cat = torch.empty(2 * B, *x_real.shape[1:], device=dev) if self._cat else None
         self.x_real = self.x_cat[:B] if self._cat else torch.empty_like(x_real)
         self.x_fake = self.x_cat[B:] if self._cat else torch.empty_like(x_fake)
-        self.th_cat = torch.empty(2 * B, 2, 3, device=dev)
+        # augmentation matrices and the pose-loss weight live in ONE flat buffer: up to 64 floats reach it inside the
+        # arguments of the input-staging launch (ops.stage_inputs), together with the copies of the images
+        self._imm = torch.zeros(12 * B + 1, device=dev)
+        self.th_cat = self._imm[:12 * B].view(2 * B, 2, 3)
         self.th_real, self.th_fake = self.th_cat[:B], self.th_cat[B:]
         self._gsel = None
         self.c2b = None if c2b is None else torch.empty_like(c2b)
-        self.aux_w = torch.zeros((), device=dev)
+        self.aux_w = self._imm[12 * B]
         self._one = torch.ones((), device=dev)
         self._fork = torch.cuda.Stream(device=dev)
         # no geometric augmentation configured: the eager path returns the images untouched (AugmentPipe.forward), so the
@@ -226,6 +229,17 @@ class GraphedDStep:
         return out
 
     def _upload(self, x_real, x_fake, c2b, aux_w):
+        from . import ops
+        copies = [(x_real, self.x_real), (x_fake, self.x_fake), (c2b, self.c2b)]
+        if self._imm.numel() <= 64:  # (batches of up to 5 images: everything in one launch)
+            import numpy as np
+            th = self._thetas(tuple(x_real.shape)) if self._geom else None
+            flat = np.zeros(self._imm.numel(), np.float32)
+            if th is not None:
+                flat[:-1] = np.concatenate([np.asarray(th[0], np.float32).ravel(), np.asarray(th[1], np.float32).ravel()])
+            flat[-1] = float(aux_w)
+            ops.stage_inputs(copies, flat, self._imm)
+            return
         if self._geom:
             th = self._thetas(tuple(x_real.shape))
             i = self._pin_i = (self._pin_i + 1) % len(self._pins)
@@ -237,10 +251,7 @@ class GraphedDStep:
             self.th_cat.copy_(pin.view(-1, 2, 3), non_blocking=True)   # (th_real | th_fake are its halves)
             self._pin_ev[i] = torch.cuda.Event()
             self._pin_ev[i].record()
-        self.x_real.copy_(x_real, non_blocking=True)
-        self.x_fake.copy_(x_fake, non_blocking=True)
-        if self.c2b is not None:
-            self.c2b.copy_(c2b, non_blocking=True)
+        ops.stage_inputs(copies)
         self.aux_w.fill_(float(aux_w))
 
     def capture(self, x_real, x_fake, c2b, aux_w):
@@ -299,6 +310,11 @@ class GraphedDForward:
         return aug.theta_for(G, aug.static_margins(H, W), H, W)
 
     def _upload(self, x):
+        from . import ops
+        if self.theta.numel() <= 64:  # (up to 10 images: the matrices travel in the arguments of the copy launch)
+            th = self._thetas(tuple(x.shape)) if self._geom else None
+            ops.stage_inputs([(x, self.x)], None if th is None else th.ravel(), self.theta)
+            return
         if self._geom:
             th = self._thetas(tuple(x.shape))
             i = self._pin_i = (self._pin_i + 1) % len(self._pins)

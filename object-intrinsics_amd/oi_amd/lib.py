@@ -84,6 +84,11 @@ _SIGS = {
     "oi_light_dir_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "oi_gan_losses_fwd": (_i, [_vp] * 5 + [_f, _vp, _i, _i, _ll, _vp]),
     "oi_gan_losses_bwd": (_i, [_vp] * 6 + [_f, _vp, _vp, _vp, _i, _i, _ll, _vp]),
+    "oi_stage_inputs": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "oi_render_scalars_fwd": (_i, [_vp, _f, _vp, _vp]),
+    "oi_render_scalars_bwd": (_i, [_vp, _vp, _vp, _f, _vp, _vp]),
+    "oi_weighted_sum_fwd": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "oi_weighted_sum_bwd": (_i, [_vp, _vp, _i, _vp, _vp]),
     "oi_affine_grid_sample_fwd": (_i, [_vp] * 3 + [_i] * 6 + [_vp]),
     "oi_affine_grid_sample_bwd": (_i, [_vp] * 3 + [_i] * 6 + [_vp]),
     "oi_fused_bias_act": (_i, [_vp] * 4 + [_i, _i, _f, _f, _ll, _ll, _i, _vp]),

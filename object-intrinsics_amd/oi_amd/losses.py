@@ -58,6 +58,37 @@ class _GanLosses(autograd.Function):
         return g[0], g[1], None, g[2], None, None
 
 
+class _WeightedSum(autograd.Function):
+    """sum_i w_i * term_i over device scalars in one launch each way (oi_weighted_sum_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        from . import ops
+        ctx.weights, ctx.shapes = weights, [t.shape for t in terms]
+        ctx.set_materialize_grads(False)
+        return ops.weighted_sum_fwd([t.detach().reshape(()) for t in terms], weights)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        if g_out is None:
+            return (None,) * (1 + len(ctx.weights))
+        from . import ops
+        g = ops.weighted_sum_bwd(g_out.contiguous(), ctx.weights, g_out.device)
+        return (None,) + tuple(g[i].view(sh) if ctx.needs_input_grad[1 + i] else None for i, sh in enumerate(ctx.shapes))
+
+
+def weighted_sum(terms, weights):
+    """sum_i weights[i] * terms[i] for scalar loss terms (gan_pose_trainer.py:122-137).  On the GPU one launch each way for
+    up to 8 float32 scalars; otherwise (CPU tests, other dtypes) the tensor-op composition of the reference."""
+    if 1 <= len(terms) <= 8 and all(t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 for t in terms):
+        return _WeightedSum.apply(tuple(float(w) for w in weights), *terms)
+    total = None
+    for t, w in zip(terms, weights):
+        v = t if w == 1 else t * w
+        total = v if total is None else total + v
+    return total
+
+
 class _GanLossesCat(autograd.Function):
     """The same for ONE discriminator pass over [real batch; fake batch] (oi_amd.graphed.GraphedDStep): d_all [2B, K], gx_all
     [2B, ...] = d sum(d_all[:B, 0]) / d x_all (its fake half is exactly zero), one gradient tensor per input."""
@@ -99,6 +130,15 @@ def gan_losses(d_real=None, d_fake=None, pose=None, gx=None, aux_w=None, reg_w=0
 
 
 _ONES = {}
+
+
+def ones_scalar(like):
+    """A cached tensor of ones shaped like `like` (the seed of a backward pass: autograd's default is a fill per call)."""
+    key = (tuple(like.shape), like.device)
+    ones = _ONES.get(key)
+    if ones is None:
+        ones = _ONES[key] = torch.ones(like.shape, device=like.device)
+    return ones
 
 
 def grad_wrt_input(d_out, x_in, grad_outputs=None):

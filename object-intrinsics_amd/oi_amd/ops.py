@@ -65,7 +65,8 @@ class ZeroPool:
         n4 = (n + 63) // 64 * 64       # 256-byte granules
         self.need += n4
         if self.buf is None or self.off + n4 > self.buf.numel():
-            return torch.zeros(shape, dtype=torch.float32, device=ref.device)   # measuring pass / overflow: its own fill
+            dev = ref if isinstance(ref, torch.device) else ref.device
+            return torch.zeros(shape, dtype=torch.float32, device=dev)   # measuring pass / overflow: its own fill
         out = self.buf[self.off:self.off + n].view(shape)
         self.off += n4
         return out
@@ -89,7 +90,11 @@ def _new_acc(ref, *shape):
 
 
 def _zeros_split(dev, *shapes):
-    """Several zero-initialised fp32 tensors from ONE fill launch (views of one flat buffer, each 16-byte aligned)."""
+    """Several zero-initialised fp32 tensors from ONE fill launch (views of one flat buffer, each 16-byte aligned) -- or
+    from the step's ZeroPool when one is active (no launch)."""
+    pool = ZeroPool._active
+    if pool is not None:
+        return [pool.take(dev, sh) for sh in shapes]
     sizes = [int(torch.Size(sh).numel()) for sh in shapes]
     offs, tot = [], 0
     for n in sizes:
@@ -123,9 +128,9 @@ def film_params_bwd(d_gamma, d_beta, w, gw, bw, style_w=None, style_b=None, z=No
     B, NL = d_gamma.shape[0], d_gamma.shape[1]
     d_gamma, d_beta, w = _c(d_gamma), _c(d_beta), _c(w)
     out = {"d_gw": torch.empty_like(gw), "d_gb": _new(w, NL, 128), "d_bw": torch.empty_like(bw), "d_bb": _new(w, NL, 128),
-           "d_w": torch.zeros_like(w) if d_w_in is None else d_w_in.contiguous().clone()}
+           "d_w": _zeros_split(w.device, w.shape)[0] if d_w_in is None else d_w_in.contiguous().clone()}
     if z is not None:
-        out["d_style_w"], out["d_style_b"] = torch.zeros_like(style_w), torch.zeros_like(style_b)
+        out["d_style_w"], out["d_style_b"] = _zeros_split(w.device, style_w.shape, style_b.shape)
         if want_dz:
             out["d_z"] = torch.empty_like(z)
     _l.check(L.oi_film_params_bwd(_p(d_gamma), _p(d_beta), _p(w), _p(_c(gw)), _p(_c(bw)), _p(out["d_gw"]), _p(out["d_gb"]),
@@ -139,7 +144,7 @@ def style_bwd(d_w, style_w, style_b, z, want_dz=False):
     """Backward of the style MLP alone (oi_film_params_bwd with no FiLM layer) -> dict(d_style_w, d_style_b [, d_z])."""
     L = _l.load()
     B = z.shape[0]
-    out = {"d_style_w": torch.zeros_like(style_w), "d_style_b": torch.zeros_like(style_b)}
+    out = dict(zip(("d_style_w", "d_style_b"), _zeros_split(z.device, style_w.shape, style_b.shape)))
     if want_dz:
         out["d_z"] = torch.empty_like(z)
     d_w = d_w.contiguous().clone()
@@ -503,6 +508,59 @@ def gan_losses_fwd(d_real, d_fake, pose, gx, aux_w, reg_w):
     _l.check(L.oi_gan_losses_fwd(_p(d_real), _p(d_fake), _p(pose), _p(gx), _p(aux_w), float(reg_w), _p(out), B, K, N, _stream()),
              "oi_gan_losses_fwd")
     return out
+
+
+def stage_inputs(copies, imm=None, imm_dst=None):
+    """One launch for the inputs of a captured step: `copies` = up to 4 (src, dst) pairs of equally sized contiguous float32
+    device tensors; `imm` = up to 64 Python / numpy floats written to the device tensor `imm_dst` (oi_stage_inputs)."""
+    L = _l.load()
+    copies = [(s_, d_) for s_, d_ in copies if s_ is not None]
+    n = len(copies)
+    for s_, d_ in copies:
+        assert s_.numel() == d_.numel(), (tuple(s_.shape), tuple(d_.shape))
+    srcs = (ctypes.c_void_p * max(n, 1))(*[_p(_c(s_.detach())).value for s_, _ in copies])
+    dsts = (ctypes.c_void_p * max(n, 1))(*[_p(d_).value for _, d_ in copies])
+    cnts = (ctypes.c_longlong * max(n, 1))(*[s_.numel() for s_, _ in copies])
+    vals = [] if imm is None else [float(v) for v in imm]
+    assert len(vals) <= 64 and (not vals or imm_dst.numel() >= len(vals))
+    immv = (ctypes.c_float * max(len(vals), 1))(*vals)
+    _l.check(L.oi_stage_inputs(srcs, dsts, cnts, n, immv, len(vals), _p(imm_dst) if vals else None, _stream()), "oi_stage_inputs")
+
+
+def render_scalars_fwd(r4, inv_nt):
+    """(gradient_error, surface_loss) = (r4[0] / (r4[1] + 1e-5), r4[2] * inv_nt) as a [2] tensor."""
+    L = _l.load()
+    out = _new(r4, 2)
+    _l.check(L.oi_render_scalars_fwd(_p(r4), float(inv_nt), _p(out), _stream()), "oi_render_scalars_fwd")
+    return out
+
+
+def render_scalars_bwd(r4, g_err, g_surf, inv_nt):
+    L = _l.load()
+    g = _new(r4, 4)
+    _l.check(L.oi_render_scalars_bwd(_p(r4), _p(g_err), _p(g_surf), float(inv_nt), _p(g), _stream()), "oi_render_scalars_bwd")
+    return g
+
+
+def weighted_sum_fwd(terms, weights):
+    """sum_i weights[i] * terms[i] over up to 8 device scalars (0-dim or 1-element float32 tensors) -> 0-dim tensor."""
+    L = _l.load()
+    n = len(terms)
+    ptrs = (ctypes.c_void_p * n)(*[_p(t).value for t in terms])
+    ws = (ctypes.c_float * n)(*[float(w) for w in weights])
+    out = torch.empty((), dtype=torch.float32, device=terms[0].device)
+    _l.check(L.oi_weighted_sum_fwd(ptrs, ws, n, _p(out), _stream()), "oi_weighted_sum_fwd")
+    return out
+
+
+def weighted_sum_bwd(g_out, weights, device):
+    """-> [n] tensor of weights[i] * g_out (g_out: a device scalar)."""
+    L = _l.load()
+    n = len(weights)
+    ws = (ctypes.c_float * n)(*[float(w) for w in weights])
+    g = torch.empty(n, dtype=torch.float32, device=device)
+    _l.check(L.oi_weighted_sum_bwd(_p(g_out), ws, n, _p(g), _stream()), "oi_weighted_sum_bwd")
+    return g
 
 
 def gan_losses_bwd(g_total, d_real, d_fake, pose, gx, aux_w, reg_w, want_real, want_fake, want_gx, out=None):

@@ -94,6 +94,33 @@ class NeuSRenderer:
         return assemble_render_dict(s, c, self.deviation_network.variance, background_rgb)
 
 
+class _RenderScalars(torch.autograd.Function):
+    """(gradient_error, surface_loss) from the compositing reductions in one launch each way (oi_render_scalars_fwd / _bwd);
+    as tensor ops: add, div, div forward and six launches backward per training render."""
+
+    @staticmethod
+    def forward(ctx, r4, inv_nt):
+        r4 = r4.detach().contiguous()
+        out = ops.render_scalars_fwd(r4, inv_nt)
+        ctx.r4, ctx.inv_nt = r4, inv_nt
+        ctx.set_materialize_grads(False)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_err, g_surf):
+        if g_err is None and g_surf is None:
+            return None, None
+        c = lambda g: None if g is None else g.contiguous()
+        return ops.render_scalars_bwd(ctx.r4, c(g_err), c(g_surf), ctx.inv_nt), None
+
+
+def render_scalars(r4, n_samples_total):
+    """-> (gradient_error, surface_loss) (renderer.py:430-446)."""
+    if r4.is_cuda:
+        return _RenderScalars.apply(r4, 1.0 / float(n_samples_total))
+    return r4[0] / (r4[1] + 1e-5), r4[2] / float(n_samples_total)
+
+
 _INV_S_CACHE = {}
 
 
@@ -120,6 +147,7 @@ def assemble_render_dict(s, c, variance, background_rgb=None, finals=None):
     color = c["color_fine"]
     if background_rgb is not None:
         color = color + background_rgb * (1.0 - c["weight_sum"])
+    gradient_error, surface_loss = (finals[0], finals[1]) if finals is not None else render_scalars(r4, N * T)
     return {
         "s_val": s_val.expand(N, 1),
         "cdf_fine": c["cdf"],
@@ -127,10 +155,10 @@ def assemble_render_dict(s, c, variance, background_rgb=None, finals=None):
         "weight_max": c["weight_max"],
         "gradients": s["gradients"],
         "weights": c["weights"],
-        "gradient_error": r4[0] / (r4[1] + 1e-5) if finals is None else finals[0],
+        "gradient_error": gradient_error,
         "inside_sphere": c["inside_sphere"],
         "mid_z_vals": s["mid_z_vals"],
-        "surface_loss": r4[2] / float(N * T) if finals is None else finals[1],
+        "surface_loss": surface_loss,
         "sdf": s["sdf"],
         "pts_norm": c["pts_norm"],
         "pts": s["pts"],

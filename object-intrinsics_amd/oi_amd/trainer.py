@@ -13,7 +13,7 @@ F9 pins the per-parameter gradients of one iteration assembled from the referenc
 class itself on top of the oi_amd modules stays untested (its module imports tu.loggers / visualisation helpers)."""
 import torch
 
-from .losses import GANLoss, PositionLoss, gan_losses, grad_wrt_input, linear_increase
+from .losses import GANLoss, PositionLoss, gan_losses, grad_wrt_input, linear_increase, ones_scalar, weighted_sum
 
 MODULE_KEYS = ("generator", "discriminator", "mask_discriminator")
 DATA_KEYS = {"generator": ["image"], "discriminator": ["image"], "mask_discriminator": ["mask"]}
@@ -51,10 +51,6 @@ def _cat(tensors):
     """torch.cat along the channel axis; a single tensor is returned as is (both discriminators take ONE map:
     MODULE_KEYS_TO_DATA_KEYS of gan_pose_trainer.py:27-31 -- the reference's cat of one tensor is a copy launch)."""
     return tensors[0] if len(tensors) == 1 else torch.cat(tensors, dim=-3)
-
-
-def _scaled(v, w):
-    return v if w == 1 else v * w
 
 
 def _backward_to(loss, net):
@@ -153,12 +149,15 @@ class Trainer:
         loss_disc, _ = gan_losses(d_real=self.discriminator(x_fake, it=self.it))
         m_fake = _cat([blob["render_out"][k] for k in DATA_KEYS["mask_discriminator"]])
         loss_mask, _ = gan_losses(d_real=self.mask_discriminator(m_fake, it=self.it))
-        loss = _scaled(loss_disc, self.loss_weight["disc_in_gen"]) + _scaled(loss_mask, self.loss_weight["mask_disc_in_gen"])
+        # the weighted sum of the terms (gan_pose_trainer.py:122-137) in one launch each way (losses.weighted_sum)
+        terms, weights = [loss_disc, loss_mask], [self.loss_weight["disc_in_gen"], self.loss_weight["mask_disc_in_gen"]]
         ret = {"generator/loss": loss_disc, "generator/loss_mask": loss_mask}
         for k, v in blob["loss"].items():
-            loss = loss + _scaled(v, self.loss_weight[k])
+            terms.append(v)
+            weights.append(self.loss_weight[k])
             ret[f"generator/{k}"] = v
-        loss.backward()
+        loss = weighted_sum(terms, weights)
+        loss.backward(ones_scalar(loss))  # (a cached 1.0: autograd's default is a fill launch per call)
         return ret
 
     def train_step_discriminator(self, key, real, fake, defer_step=False):

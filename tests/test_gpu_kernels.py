@@ -648,3 +648,46 @@ def test_conv_backward_in_one_launch_matches_the_two_kernels(B, Cin, Cout, H, st
     acc = base.clone()
     _, out = ops.conv4x4_bwd(g, w, x, stride, pad, y, 0.2, acc=acc)
     assert out is acc and float((acc - (base + gw0)).abs().max()) <= 1e-5 * float((base + gw0).abs().max())
+
+
+def test_weighted_sum_and_render_scalars_match_tensor_ops():
+    """Round 3 glue kernels: the weighted sum of scalar loss terms and the renderer's two derived scalars, forward and
+    gradient, against the tensor-op composition they replace (gan_pose_trainer.py:122-137, renderer.py:430-446)."""
+    from oi_amd.losses import weighted_sum
+    from oi_amd.renderer import render_scalars
+    g = torch.Generator().manual_seed(3)
+    vals = [torch.randn((), generator=g).cuda().requires_grad_() for _ in range(5)]
+    vals[3] = torch.randn(1, generator=g).cuda().requires_grad_()   # a 1-element term keeps its shape in the gradient
+    ws = [1.0, 0.1, 10.0, 0.0, -2.5]
+    total = weighted_sum(vals, ws)
+    ref = sum(v.detach().double().reshape(()) * w for v, w in zip(vals, ws))
+    assert abs(float(total) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+    (total * 3.0).backward()
+    for v, w in zip(vals, ws):
+        assert v.grad.shape == v.shape and abs(float(v.grad.reshape(())) - 3.0 * w) < 1e-6
+    r4 = torch.tensor([12.5, 340.0, 7.25, 0.0], device="cuda", requires_grad=True)
+    r4b = r4.detach().clone().requires_grad_()
+    err, surf = render_scalars(r4, 4096)
+    err_o, surf_o = r4b[0] / (r4b[1] + 1e-5), r4b[2] / 4096.0
+    assert maxdiff(err, err_o) < 1e-7 and maxdiff(surf, surf_o) < 1e-9
+    (2.0 * err + 5.0 * surf).backward()
+    (2.0 * err_o + 5.0 * surf_o).backward()
+    assert maxdiff(r4.grad, r4b.grad) < 1e-8
+    r4.grad = None
+    render_scalars(r4, 4096)[0].backward()          # only one of the two outputs used: the other gradient is absent
+    assert abs(float(r4.grad[0]) - 1.0 / (340.0 + 1e-5)) < 1e-9 and float(r4.grad[2]) == 0.0
+
+
+def test_stage_inputs_copies_and_immediates(ops):
+    """oi_stage_inputs: several device copies and up to 64 host floats in one launch (inputs of a captured step)."""
+    g = torch.Generator().manual_seed(4)
+    srcs = [torch.randn(n, generator=g).cuda() for n in (1, 4099, 3 * 64 * 64)]
+    dsts = [torch.full_like(s, -7.0) for s in srcs]
+    imm = np.arange(13, dtype=np.float32) * 0.37 - 1.0
+    flat = torch.full((16,), -7.0, device="cuda")
+    ops.stage_inputs(list(zip(srcs, dsts)) + [(None, None)], imm, flat)
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(s, d)
+    assert torch.equal(flat[:13].cpu(), torch.from_numpy(imm)) and bool((flat[13:] == -7.0).all())
+    ops.stage_inputs([(srcs[1] * 2, dsts[1])])      # copies only
+    assert torch.equal(dsts[1], srcs[1] * 2)

@@ -54,3 +54,18 @@ torch.cuda.synchronize()
 print("ops dispatched from Python per generator step (views excluded):", sum(log.c.values()) / N)
 for (name, where), n in log.c.most_common(70):
     print(f"{n / N:6.1f}  {name:34s} {where}")
+
+
+# the same for the CAPTURED discriminator steps: a fresh trainer, whose first train_step captures both graphs under the log
+# (what the log shows is what every replay launches, plus the per-step host-side glue around the replays)
+if os.environ.get("OI_PROF_DSTEPS", "1") != "0":
+    tr2 = Trainer(mods, graph_d_steps=True)
+    log2 = Log()
+    with log2:
+        tr2.train_step(data)
+    torch.cuda.synchronize()
+    g = sum(n for (name, where), n in log2.c.items())
+    print("\nops dispatched during ONE whole first iteration (captures both discriminator steps; includes its generator step):", g)
+    for (name, where), n in log2.c.most_common(80):
+        if "graphed" in where or "discriminator" in where or "augment" in where or "losses" in where or "autograd" in where:
+            print(f"{n:6d}  {name:34s} {where}")
