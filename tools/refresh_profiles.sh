@@ -36,6 +36,14 @@ for c in "FETCH_SIZE:fetch" "WRITE_SIZE:write"; do
   python $R/tools/prof_summary.py /tmp/p_b$tag $O/${T}_pmc_${tag}_bf16.txt > /dev/null
 done
 python $R/tools/traffic_json.py $O/${T}_pmc_fetch_bf16.txt $O/${T}_pmc_write_bf16.txt "sdf_mlp_kernel<2, true, true>" "bf16:1x64x64:64+64" $O/${T}_traffic.json
+# the same dominant kernel at the C4 per-GPU size (128^2 rays, 128 + 128 samples, 4 up-sampling steps: eight times the points)
+C4="--res 128 --samples 128 --importance 128 --up-steps 4"
+for c in "FETCH_SIZE:fetch" "WRITE_SIZE:write"; do
+  ctr=${c%%:*}; tag=${c##*:}
+  rm -rf /tmp/p_c$tag; rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/p_c$tag -- $BENCH $C4 --steps 3 --warmup 1 --train-steps 0 > /dev/null 2>&1
+  python $R/tools/prof_summary.py /tmp/p_c$tag $O/${T}_pmc_${tag}_c4.txt > /dev/null
+done
+python $R/tools/traffic_json.py $O/${T}_pmc_fetch_c4.txt $O/${T}_pmc_write_c4.txt sdf_mlp_full3_kernel "f16x3:1x128x128:128+128" $O/${T}_traffic.json
 python $R/tools/bench_c5.py > $O/${T}_c5_mlp_microbench.jsonl 2>/dev/null
 # the un-profiled bench lines last: they read the traffic file written above (same sources, same digest)
 cp $O/${T}_traffic.json $R/profiles/${T}_traffic.json
