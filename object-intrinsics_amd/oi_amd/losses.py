@@ -78,15 +78,11 @@ class _WeightedSum(autograd.Function):
 
 
 def weighted_sum(terms, weights):
-    """sum_i weights[i] * terms[i] for scalar loss terms (gan_pose_trainer.py:122-137).  On the GPU one launch each way for
-    up to 8 float32 scalars; otherwise (CPU tests, other dtypes) the tensor-op composition of the reference."""
-    if 1 <= len(terms) <= 8 and all(t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 for t in terms):
-        return _WeightedSum.apply(tuple(float(w) for w in weights), *terms)
-    total = None
-    for t, w in zip(terms, weights):
-        v = t if w == 1 else t * w
-        total = v if total is None else total + v
-    return total
+    """sum_i weights[i] * terms[i] for 1..8 scalar float32 loss terms on the device (gan_pose_trainer.py:122-137): one
+    launch each way.  (No tensor-op fallback: like every op of the path it raises for host tensors.)"""
+    if not 1 <= len(terms) <= 8 or any(t.numel() != 1 for t in terms):
+        raise ValueError(f"weighted_sum: {len(terms)} terms of sizes {[t.numel() for t in terms]} (1..8 scalars)")
+    return _WeightedSum.apply(tuple(float(w) for w in weights), *terms)
 
 
 class _GanLossesCat(autograd.Function):

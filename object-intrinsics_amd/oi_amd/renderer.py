@@ -116,9 +116,7 @@ class _RenderScalars(torch.autograd.Function):
 
 def render_scalars(r4, n_samples_total):
     """-> (gradient_error, surface_loss) (renderer.py:430-446)."""
-    if r4.is_cuda:
-        return _RenderScalars.apply(r4, 1.0 / float(n_samples_total))
-    return r4[0] / (r4[1] + 1e-5), r4[2] / float(n_samples_total)
+    return _RenderScalars.apply(r4, 1.0 / float(n_samples_total))
 
 
 _INV_S_CACHE = {}
