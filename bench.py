@@ -269,8 +269,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Rehearsal switches for a 1-GPU box (tests/test_gpu_bench_dist.py): OI_BENCH_ONE_DEVICE=1 puts every rank on cuda:0,
+    # OI_BENCH_DIST_BACKEND=gloo exchanges through the host (RCCL cannot place two ranks on one device).  Everything else
+    # of the N > 1 path -- self-launch, rendezvous, barriers, MAX / SUM reductions, FlatGradDDP on a communication stream,
+    # captured D steps, the watchdog -- is the code the multi-GPU run executes.
+    backend = os.environ.get("OI_BENCH_DIST_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("OI_BENCH_ONE_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     # OI_BENCH_FORCE_DIST=1 runs the RCCL code paths (process group, barrier, max/sum reductions, FlatGradDDP
     # all-reduce) with a single rank: a smoke test of the N > 1 path on a 1-GPU box.
     distributed = world > 1 or os.environ.get("OI_BENCH_FORCE_DIST") == "1"
@@ -279,7 +285,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", init_method="env://", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", init_method="env://", device_id=device)
+        else:
+            dist.init_process_group(backend, init_method="env://")
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
 
     torch.manual_seed(1234 + rank)
@@ -308,9 +317,16 @@ def main():
             d = None if args.no_disc else disc(out["image"].contiguous(), it=it)
         return out, d
 
+    def dist_barrier():
+        if backend == "nccl":
+            dist.barrier(device_ids=[dev_index])
+        else:
+            dist.barrier()
+
     def barrier():
+        torch.cuda.synchronize()  # (also in front: a host-side backend's barrier does not wait for this rank's stream)
         if distributed:
-            dist.barrier(device_ids=[local_rank])
+            dist_barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -455,8 +471,12 @@ def main():
                 line["extras"] = {"error": f"{type(ex).__name__}: {ex}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.res, args.samples, args.importance, args.up_steps, args.batch)
+        elif world > 1:  # rank-0-at-N=1 measurements: an explicit pointer instead of an absent key
+            line["cpu_baseline"] = "see the N=1 line (the oracle is timed on rank 0 at N=1 only)"
+            line["extras"] = "see the N=1 line (secondary single-GPU legs)"
+            line["dist_backend"] = backend + (" (every rank on cuda:0: rehearsal of the N > 1 path on one GPU)" if os.environ.get("OI_BENCH_ONE_DEVICE") == "1" else "")
     if distributed:
-        dist.barrier(device_ids=[local_rank])
+        dist_barrier()
         dist.destroy_process_group()
     if rank == 0:
         # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which is

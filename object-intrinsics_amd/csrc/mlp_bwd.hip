@@ -14,16 +14,22 @@
 //   down sweep (l down) cbar_l = vbar_l * g_{l+1};  v_l = g_{l+1} * c_l;
 //                       phibar_l = abar_{l+1} cos phi_l - cbar_l gamma_l sin phi_l;  ubar_l = phibar_l gamma_l;
 //                       TWO products per staged image:  g_l = W_l^T v_l  and  abar_l = W_l^T ubar_l;
-//                       parks v_l, ubar_l for the weight-gradient GEMM                                        [14 GEMMs]
+//                       parks v_l / gamma_l, phibar_l for the weight-gradient GEMM (round 4, see below)         [14 GEMMs]
 // Round 3: the FiLM / bias gradients of the MFMA layers are NOT summed in the sweep any more.  phi_l = gamma_l (W_l a + b_l)
 // + beta_l -- and with it every first- and second-order term -- depends on gamma_l, W_l, b_l only through gamma_l W_l and
 // gamma_l b_l, hence per batch element
-//       gamma_l[f] d gamma_l[f] = sum_i W_l[f][i] dW_l[f][i] + b_l[f] db_l[f],     d beta_l[f] = db_l[f] / gamma_l[f],
+//       gamma_l[f] d gamma_l[f] = sum_i W_l[f][i] dW_l[f][i] + b_l[f] db_l[f],     gamma_l[f] d beta_l[f] = db_l[f],
 // and db_l = sum_p ubar_l is a by-product of the weight-gradient GEMM (which reads ubar_l anyway).  That removes 72 of the
 // 112 cross-lane point sums of a tile and the recomputation of u_l (one v_rcp + 4 VALU per element); the parked phase is
 // the REDUCED phase in revolutions (FiLM rows staged pre-multiplied by 1/2pi, as in the forward kernel), so the down sweep
-// and the GEMM feed it to v_sin / v_cos without a range reduction.  (Requires gamma_l[f] != 0; the reference initialises
-// gamma = 15 (...) + 30.)
+// and the GEMM feed it to v_sin / v_cos without a range reduction.
+// Round 4: NO division by gamma.  Both weight-gradient operands carry gamma_l[f] as a factor of row f (v_l = gamma_l g_{l+1}
+// cos phi_l, ubar_l = gamma_l phibar_l), so the sweep parks them WITHOUT it (v_l / gamma_l = g_{l+1} cos phi_l and phibar_l),
+// the GEMM accumulates D_l[f][i] = sum_p (v_l/gamma_l gbar_l^T + phibar_l a_l^T)[f][i] and its epilogue writes
+//       dW_l[f][i] = gamma_l[f] D_l[f][i],   db_l[f] = gamma_l[f] sum_p phibar_l[f],
+//       d gamma_l[f] = sum_i W_l[f][i] D_l[f][i] + b_l[f] sum_p phibar_l[f],   d beta_l[f] = sum_p phibar_l[f]
+// -- exact for gamma = 0 and free of the cancellation a small |gamma| caused (the reference, autograd through
+// fields.py:104-122, has no restriction on gamma either; tests/test_gpu_backward.py::test_mlp_backward_gamma_through_zero).
 // (Round 1 ran four sweeps -- phi up, g down, gbar up, abar down -- and parked 46 slots per point; forming g again in the
 // last sweep instead of parking it, and gbar together with the recomputed activations, leaves 32 slots, 16 of which
 // are read back here: 23.5 -> 16 KB written and 22 -> 9 KB read per point.)
@@ -45,9 +51,9 @@ constexpr int S_PHI = 0;    // 8: phi_l, l = 1..7.  Layer 0 (three input columns
                             //    sweep and the weight-gradient GEMM form phi_0 / vbar_0 again from the point and dL/dgrad,
                             //    which sit in the first KiB of this slot: [32 points][x y z 0 | Gx Gy Gz 0]
 constexpr int S_VB = 8;     // 8: gamma_l vbar_l, vbar_l = W_l gbar_l, l = 1..7   (down sweep: gamma_l cbar_l = . g_{l+1}; wgrad: gbar_{l+1} = . cos phi_l)
-constexpr int S_V = 16;     // 7: v_l,    l = 1..7   (wgrad operand)
-constexpr int S_U = 23;     // 7: ubar_l, l = 1..7   (wgrad operand)
-constexpr int S_UV = 30;    // 1: uvbar (colour head pre-activation gradient)
+constexpr int S_V = 16;     // 7: v_l / gamma_l = g_{l+1} cos phi_l, l = 1..7   (wgrad operand)
+constexpr int S_U = 23;     // 7: phibar_l = ubar_l / gamma_l,       l = 1..7   (wgrad operand)
+constexpr int S_UV = 30;    // 1: phibar_v (colour head: gradient w.r.t. the phase, without gamma_v)
 constexpr int S_AC = 31;    // 1: abar_8 contribution of the colour head
 constexpr int NSLOT_BWD = 32;
 
@@ -172,9 +178,10 @@ __device__ __forceinline__ void racc_flush_row(char* lds, int row, float* dst, i
   if (tid < C) atomicAdd(dst + tid * stride, racc[tid]);
 }
 // the same row times a per-feature factor (sum_p ubar = gamma * sum_p phibar: the bias gradient needs no sum of its own)
-__device__ __forceinline__ void racc_flush_row_scaled(char* lds, int row, const float* factor, float* dst, int tid) {
+__device__ __forceinline__ void racc_flush_row_scaled(char* lds, int row, const float* factor, float* dst, int stride, int tid) {
   const float* racc = reinterpret_cast<const float*>(lds + L_RACC) + row * C;
-  if (tid < C) atomicAdd(dst + tid, racc[tid] * factor[tid]);
+  tid = late(tid);
+  if (tid < C) atomicAdd(dst + tid * stride, racc[tid] * factor[tid]);
 }
 
 // FiLM rows of the backward kernels (one 1536-byte slot): [gamma | G | B2] with the phase in REVOLUTIONS,
@@ -284,10 +291,10 @@ __device__ __forceinline__ float gemm2(const char* lds, const LaneOff& o, float 
 // already takes the per-point maximum of every adjoint vector it feeds to a product; the wave maximum of those is
 // published here (one atomic per wave, layer and operand: non-negative floats order like their bit patterns), so that the
 // weight-gradient GEMM can run on ONE power-of-two scale per operand instead of normalising every 32-point tile.
-constexpr int OM_V = 0;    // 7: max |v_l|,    l = 1..7
-constexpr int OM_U = 7;    // 7: max |ubar_l|, l = 1..7
+constexpr int OM_V = 0;    // 7: max |v_l / gamma_l|, l = 1..7   (the PARKED operands)
+constexpr int OM_U = 7;    // 7: max |phibar_l|,      l = 1..7
 constexpr int OM_G = 14;   // 7: max |gbar_l|, l = 1..7
-constexpr int OM_UV = 21;  // 1: max |uvbar|
+constexpr int OM_UV = 21;  // 1: max |phibar_v|
 // same-address atomics serialise in the L2 (16,384 waves x 22 slots on 22 addresses cost 0.7 ms): 64 replicas of the
 // table, chosen by workgroup; the GEMM takes the maximum over the replicas
 constexpr int OM_STRIDE = 32, OM_REPLICAS = 64;
@@ -454,7 +461,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     // uv -> phiv -> hv; then uvbar.  Point sums kept here: rows 3..5 dWrgb, rows 2 / 6 / 7 dWv[:, 130 / 128 / 129]; the FiLM and
     // bias gradients of the head come out of the weight-gradient GEMM (FiLM-scale identity), the part of it that belongs to
     // the three extra input columns is added at the flush below
-    float dGx = 0.f, dGy = 0.f, dGz = 0.f;
+    float dGx = 0.f, dGy = 0.f, dGz = 0.f, mx_pv = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       float uv16[16], hv16[16];  // the six summed rows are products of these with per-point scalars: formed one at a time
@@ -467,7 +474,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         const f32x4 w0 = lds_f4(lds, L_TABS + (H_RGB + 0 * C + grp_f0(g)) * 4, o.h16);
         const f32x4 w1 = lds_f4(lds, L_TABS + (H_RGB + 1 * C + grp_f0(g)) * 4, o.h16);
         const f32x4 w2 = lds_f4(lds, L_TABS + (H_RGB + 2 * C + grp_f0(g)) * 4, o.h16);
-        f32x4 uvb;
+        f32x4 uvb, pvb;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const f32x4 wx = lds_f4(lds, L_TABS + H_TABV * 4 + (grp_f0(g) + k) * 16, o.h64);
@@ -477,14 +484,16 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           float hv, cv;
           sincos_rev(rev_reduce<FAST, false>(ph), hv, cv);
           const float hvb = w0[k] * rho[0] + w1[k] * rho[1] + w2[k] * rho[2];
-          uvb[k] = hvb * cv * gm[k];
-          uv16[4 * rr + k] = uvb[k];
+          pvb[k] = hvb * cv;        // phibar_v: what is parked and summed (no gamma_v: see the header comment)
+          uvb[k] = pvb[k] * gm[k];  // uvbar = gamma_v phibar_v: what travels on to abar_8 and dL/dgrad
+          mx_pv = fmaxf(mx_pv, fabsf(pvb[k]));
+          uv16[4 * rr + k] = pvb[k];
           hv16[4 * rr + k] = hv;
           dGx = fmaf(uvb[k], wx[0], dGx);
           dGy = fmaf(uvb[k], wx[1], dGy);
           dGz = fmaf(uvb[k], wx[2], dGz);
         }
-        ws.store(S_UV, g, o.l16, uvb);
+        ws.store(S_UV, g, o.l16, pvb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) act[4 * g + k] = uvb[k];
 #if OI_BWD_COL_FENCE
@@ -516,27 +525,28 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       }
     }
     __syncthreads();
-    if (const int t_ = late(tid); t_ < C) {  // gamma_v d gamma_v += sum_{j < 3} Wv[f][128 + j] dWv[f][128 + j]  (the GEMM adds the other 128 columns and bv)
+    // rows 2 / 6 / 7 hold sums of phibar_v (not of uvbar = gamma_v phibar_v):
+    //   d gamma_v += sum_{j < 3} Wv[f][128 + j] R_j   (the GEMM adds the other 128 columns and bv),   dWv[f][128 + j] = gamma_v[f] R_j
+    const float* gv_row = reinterpret_cast<const float*>(lds + L_FILM2);  // the head's rows sit in FiLM slot 1
+    if (const int t_ = late(tid); t_ < C) {
       const float* racc = reinterpret_cast<const float*>(lds + L_RACC);
       const f32x4 wx = *reinterpret_cast<const f32x4*>(lds + L_TABS + H_TABV * 4 + t_ * 16);
-      const float gv = reinterpret_cast<const float*>(lds + L_FILM2)[t_];  // the head's rows sit in FiLM slot 1
       atomicAdd(d_gamma + ((size_t)e * 9 + 8) * C + t_,
-                fmaf(wx[0], racc[6 * C + t_], fmaf(wx[1], racc[7 * C + t_], wx[2] * racc[2 * C + t_])) / gv);
+                fmaf(wx[0], racc[6 * C + t_], fmaf(wx[1], racc[7 * C + t_], wx[2] * racc[2 * C + t_])));
     }
-    racc_flush_row(lds, 2, d_small + DS_WVX + 2, 3, tid);
+    racc_flush_row_scaled(lds, 2, gv_row, d_small + DS_WVX + 2, 3, tid);
     racc_flush_row(lds, 3, d_small + DS_WRGB + 0 * C, 1, tid);
     racc_flush_row(lds, 4, d_small + DS_WRGB + 1 * C, 1, tid);
     racc_flush_row(lds, 5, d_small + DS_WRGB + 2 * C, 1, tid);
-    racc_flush_row(lds, 6, d_small + DS_WVX + 0, 3, tid);
-    racc_flush_row(lds, 7, d_small + DS_WVX + 1, 3, tid);
+    racc_flush_row_scaled(lds, 6, gv_row, d_small + DS_WVX + 0, 3, tid);
+    racc_flush_row_scaled(lds, 7, gv_row, d_small + DS_WVX + 1, 3, tid);
     __syncthreads();
     racc_zero(lds, tid);
     // abar_8 from the colour head: Wv[:, :128]^T uvbar   (transposed colour image, matrix 15: resident in slot 1 since the
     // prologue)
     acc_zero(acc);
-    float mx_uv = 0.f;
-    const float fT = gemm2<PREC, true>(lds, layer_off(1, 1), act, acc, SC ? hdr[H_WSCALE + 15] : 1.f, &mx_uv);
-    if constexpr (SC) publish_max(op_max, OM_UV, mx_uv);
+    const float fT = gemm2<PREC, true>(lds, layer_off(1, 1), act, acc, SC ? hdr[H_WSCALE + 15] : 1.f);
+    if constexpr (SC) publish_max(op_max, OM_UV, mx_pv);  // (of the parked operand: phibar_v)
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       f32x4 v;
@@ -753,9 +763,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           sincos_rev(ph[k], s, c);                                     // parked reduced phase (revolutions)
           const float gn = gnx[k];                                     // g_{l+1}
           const float cb = vb[k] * gn;                                 // gamma_l cbar_l (gamma folded into the parked vbar)
-          vv[k] = gn * c * gm[k];                                      // v_l
-          const float phb = fmaf(abx[k], c, -cb * s);                  // phibar_l
-          ub[k] = phb * gm[k];                                         // ubar_l
+          vv[k] = gn * c;                                              // v_l / gamma_l  (parked without gamma_l, see the header)
+          ub[k] = fmaf(abx[k], c, -cb * s);                            // phibar_l = ubar_l / gamma_l
           gb[4 * g + k] = vv[k];
           act[4 * g + k] = ub[k];
 #if OI_BWD_NW == 8
@@ -825,19 +834,35 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #endif
     BW_T(8);
     if constexpr (!L0) {
+      // the point vectors hold v_l / gamma_l and phibar_l (what was parked); the products want v_l and ubar_l = gamma_l phibar_l.
+      // The launch-wide maxima the weight-gradient GEMM scales its operands with are those of the PARKED vectors.
+      auto times_gamma = [&](float (&v)[64], int om_slot) {
+        float mx = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, ol.h16);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if constexpr (SC) mx = fmaxf(mx, fabsf(v[4 * g + k]));
+            v[4 * g + k] *= gm[k];
+            asm volatile("" : "+v"(v[4 * g + k]));  // (pins the group: see the epilogue above)
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (SC) publish_max(op_max, om_slot, mx);  // (at once: nothing scalar stays live across the next product)
+      };
       const float inv_t = SC ? hdr[H_WSCALE + 7 + l - 1] : 1.f;
+      times_gamma(gb, OM_V + l - 1);
       acc_zero(acc);
       BW_T(9);
-      float mx_v = 0.f, mx_u = 0.f;
-      const float f1 = gemm2<PREC, true>(lds, ol, gb, acc, inv_t, &mx_v);   // g_l = W_l^T v_l
-      if constexpr (SC) publish_max(op_max, OM_V + l - 1, mx_v);  // (at once: nothing scalar stays live across the next product)
+      const float f1 = gemm2<PREC, true>(lds, ol, gb, acc, inv_t);   // g_l = W_l^T v_l
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gb[16 * t + r] = SC ? acc[t][r] * f1 : acc[t][r];
+      times_gamma(act, OM_U + l - 1);
       acc_zero(acc);
-      const float f2 = gemm2<PREC, true>(lds, ol, act, acc, inv_t, &mx_u);  // abar_l = W_l^T ubar_l
-      if constexpr (SC) publish_max(op_max, OM_U + l - 1, mx_u);
+      const float f2 = gemm2<PREC, true>(lds, ol, act, acc, inv_t);  // abar_l = W_l^T ubar_l
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -853,18 +878,20 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     BW_T(10);
     if constexpr (L0) {
       __syncthreads();
-      racc_flush_row(lds, 1, d_small + DS_B, 1, tid);
-      racc_flush_row(lds, 3, d_small + DS_W0 + 0, 3, tid);
-      racc_flush_row(lds, 4, d_small + DS_W0 + 1, 3, tid);
-      racc_flush_row(lds, 5, d_small + DS_W0 + 2, 3, tid);
-      if (const int t_ = late(tid); t_ < C) {  // d beta_0 = d b_0 / gamma_0;  gamma_0 d gamma_0 = sum_j W0[f][j] dW0[f][j] + b_0[f] d b_0[f]
+      // the rows hold sums of phibar_0 / (v_0 / gamma_0) terms, R1 = sum phibar_0, R_{3+j} = sum (phibar_0 x_j + v_0/gamma_0 G_j):
+      //   d b_0 = gamma_0 R1,  d W0[:, j] = gamma_0 R_{3+j},  d beta_0 = R1,  d gamma_0 = sum_j W0[f][j] R_{3+j} + b_0[f] R1
+      const float* g0_row = reinterpret_cast<const float*>(lds + L_FILM);  // layer 0's rows sit in FiLM slot 0
+      racc_flush_row_scaled(lds, 1, g0_row, d_small + DS_B, 1, tid);
+      racc_flush_row_scaled(lds, 3, g0_row, d_small + DS_W0 + 0, 3, tid);
+      racc_flush_row_scaled(lds, 4, g0_row, d_small + DS_W0 + 1, 3, tid);
+      racc_flush_row_scaled(lds, 5, g0_row, d_small + DS_W0 + 2, 3, tid);
+      if (const int t_ = late(tid); t_ < C) {
         const float* racc = reinterpret_cast<const float*>(lds + L_RACC);
         const f32x4 w = *reinterpret_cast<const f32x4*>(lds + L_TABS + H_TAB0 * 4 + t_ * 16);
-        const float ig = 1.0f / reinterpret_cast<const float*>(lds + L_FILM)[t_];  // layer 0's rows sit in FiLM slot 0
-        const float db = racc[1 * C + t_];
-        atomicAdd(d_beta + (size_t)e * 9 * C + t_, db * ig);
+        const float r1 = racc[1 * C + t_];
+        atomicAdd(d_beta + (size_t)e * 9 * C + t_, r1);
         atomicAdd(d_gamma + (size_t)e * 9 * C + t_,
-                  fmaf(w[0], racc[3 * C + t_], fmaf(w[1], racc[4 * C + t_], fmaf(w[2], racc[5 * C + t_], hdr[H_BIAS + t_] * db))) * ig);
+                  fmaf(w[0], racc[3 * C + t_], fmaf(w[1], racc[4 * C + t_], fmaf(w[2], racc[5 * C + t_], hdr[H_BIAS + t_] * r1))));
       }
     }
     BW_T(11);
@@ -926,11 +953,11 @@ constexpr int WG_SLOT_FLOATS = 4096 + 8 * 32;
 
 // FiLM / bias gradients of layer `lrow` (1..7, 8 = colour head) of one batch element from a workgroup's partial results
 // (everything is linear in the partial sums, so every workgroup adds its share):
-//   dwv[t][rg]  partial dW[oo][32 t + i], oo = 32 wave + (rg & 3) + 8 (rg >> 2) + 4 h   (MFMA accumulator layout)
-//   sub         this lane's partial sum of ubar[fo] over the points its MFMA A-fragments cover (the other lane half holds
+//   dwv[t][rg]  partial D[oo][32 t + i], oo = 32 wave + (rg & 3) + 8 (rg >> 2) + 4 h   (MFMA accumulator layout)
+//   sub         this lane's partial sum of phibar[fo] over the points its MFMA A-fragments cover (the other lane half holds
 //               the other points), fo = 32 wave + i
-//   gamma d gamma = sum_i W[f][i] dW[f][i] + b[f] db[f];   d beta = db / gamma;   db = sum_p ubar
-// DW(t, rg) returns the workgroup's partial dW[oo][32 t + i]; it is also what this function adds to the global dW.
+//   d gamma = sum_i W[f][i] D[f][i] + b[f] s[f];   d beta = s;   db = gamma s;   dW[f][i] = gamma[f] D[f][i];   s = sum_p phibar
+// DW(t, rg) returns the workgroup's partial D[oo][32 t + i] (operands parked without gamma: no division anywhere).
 template <class DW>
 __device__ __forceinline__ void film_identity_epilogue(DW dw, float* __restrict__ dst, float sub,
                                                        const float* __restrict__ wplain, const float* __restrict__ bias_row,
@@ -941,11 +968,12 @@ __device__ __forceinline__ void film_identity_epilogue(DW dw, float* __restrict_
 #pragma unroll
   for (int rg = 0; rg < 16; ++rg) {
     const size_t row = (size_t)(32 * wave + (rg & 3) + 8 * (rg >> 2) + 4 * h) * C + i;
+    const float grow = gamma_row[32 * wave + (rg & 3) + 8 * (rg >> 2) + 4 * h];
     float a = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const float v = dw(t, rg);
-      atomicAdd(dst + row + 32 * t, v);
+      atomicAdd(dst + row + 32 * t, v * grow);
       a = fmaf(v, wplain[row + 32 * t], a);
     }
     s[rg] = a;
@@ -957,14 +985,13 @@ __device__ __forceinline__ void film_identity_epilogue(DW dw, float* __restrict_
   if ((lane & 16) == 0) {
     const int r = lane & 15;
     const int oo = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-    atomicAdd(d_gamma_row + oo, v / gamma_row[oo]);
+    atomicAdd(d_gamma_row + oo, v);
   }
   if (h == 0) {
     const int f = 32 * wave + i;
-    const float ig = 1.0f / gamma_row[f];
-    atomicAdd(d_bias_row + f, w);
-    atomicAdd(d_beta_row + f, w * ig);
-    atomicAdd(d_gamma_row + f, bias_row[f] * w * ig);
+    atomicAdd(d_bias_row + f, w * gamma_row[f]);
+    atomicAdd(d_beta_row + f, w);
+    atomicAdd(d_gamma_row + f, bias_row[f] * w);
   }
 }
 

@@ -680,6 +680,71 @@ def test_mlp_backward_wide_dynamic_range_cotangents(sdf_sd, col_sd):
     assert not bad, bad
 
 
+GAMMA_ZERO_TOL = 2e-5
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_mlp_backward_gamma_through_zero(sdf_sd, col_sd, precision):
+    """FiLM scales gamma = 15 lin(w) + 30 that cross zero (a trained mapping network can produce lin(w) = -2): rows with
+    gamma exactly 0, |gamma| < 1e-2 and negative gamma in every layer kind (layer 0, MFMA layers, colour head), gamma spread
+    over about [-20, 80].  The reference (autograd through fields.py:104-122) has no restriction on gamma; the round-3
+    backward divided by it.  Every parameter gradient against fp64 oracle autograd, incl. the FiLM heads'."""
+    from oi_amd.fields import ShapeNetwork, ColorNetwork, FieldPack
+    from oi_amd.autograd import sdf_mlp
+    n, B = 200, 2
+    g = torch.Generator().manual_seed(4321)
+    sdf_sd = {k: v.clone() for k, v in sdf_sd.items()}
+    col_sd = {k: v.clone() for k, v in col_sd.items()}
+    w = O.style_mlp(sdf_sd, torch.randn(B, 64, generator=g))
+
+    def doctor(sd, prefix, rows):
+        # spread: gamma - 30 scaled up so that gamma covers about [-20, 80]; then pin chosen rows to exact targets
+        sd[prefix + "gamma.weight"] = sd[prefix + "gamma.weight"] * 1.0 + 0.2 * torch.randn(128, 64, generator=g)
+        for f, target in rows:
+            sd[prefix + "gamma.weight"][f] = 0.0
+            sd[prefix + "gamma.bias"][f] = (target - 30.0) / 15.0
+    exact = [(3, 0.0), (17, 3e-3), (40, -7e-3), (77, -12.0), (101, 1e-4), (127, 0.0)]
+    for l in (0, 1, 4, 7):
+        doctor(sdf_sd, f"pts_linears.{l}.", exact)
+    doctor(col_sd, "views_linears.", exact)
+    pts = torch.rand(B * n, 3, generator=g) * 2.0 - 1.0
+    cs, cg, cr = torch.randn(B * n, generator=g), 0.1 * torch.randn(B * n, 3, generator=g), torch.randn(B * n, 3, generator=g)
+    loss_o, g_o = _oracle_mlp_grads(sdf_sd, col_sd, pts, w, cs, cg, cr)
+
+    sdf_net = ShapeNetwork(SDF_NPZ, **NET_KW)
+    sdf_net.load_state_dict(sdf_sd)
+    sdf_net = sdf_net.cuda()
+    col_net = ColorNetwork(**NET_KW)
+    col_net.load_state_dict(col_sd)
+    col_net = col_net.cuda()
+    pack = FieldPack(sdf_net, col_net, precision)
+    wh = w.cuda().requires_grad_(True)
+    _, gamma, beta = pack.film(w=wh)
+    gmat = gamma.detach().cpu()
+    assert float(gmat.min()) < -10.0 and float(gmat.max()) > 60.0 and int((gmat == 0).sum()) >= 2 * B, \
+        (float(gmat.min()), float(gmat.max()), int((gmat == 0).sum()))
+    assert int((gmat.abs() < 1e-2).sum()) >= 5 * 4 * B
+    sdf, grad, rgb, _ = sdf_mlp(pack, pts.cuda(), gamma, beta, B, True, True, False)
+    loss = (sdf * cs.cuda()).sum() + (grad * cg.cuda()).sum() + (rgb * cr.cuda()).sum()
+    assert abs(float(loss) - loss_o) < 1e-3 * max(1.0, abs(loss_o))
+    named = [("sdf." + k, v) for k, v in sdf_net.named_parameters() if not k.startswith("style.")] + \
+            [("col." + k, v) for k, v in col_net.named_parameters()] + [("w", wh)]
+    gr = torch.autograd.grad(loss, [v for _, v in named])
+    errs = {}
+    for (name, _), a in zip(named, gr):
+        assert bool(torch.isfinite(a).all()), name
+        errs[name] = rel_err(a, g_o[name])
+        record_margin(f"mlp_backward_gamma_through_zero_vs_fp64_oracle[{precision}]", name, errs[name])
+    bad = {k: v for k, v in errs.items() if v > GAMMA_ZERO_TOL}
+    assert not bad, bad
+    # the pinned rows themselves (d gamma.bias of a row with gamma = 0 is a sum the round-3 identity could not form)
+    for l in (0, 1, 4, 7):
+        a = dict(zip([n_ for n_, _ in named], gr))[f"sdf.pts_linears.{l}.gamma.bias"].cpu().double()
+        b = g_o[f"sdf.pts_linears.{l}.gamma.bias"]
+        rows = [f for f, _ in exact]
+        assert float((a[rows] - b[rows]).abs().max()) < 1e-4 * float(b.abs().max()), (l, a[rows], b[rows])
+
+
 @pytest.mark.parametrize("B", [1, 3])
 def test_discriminator_preactivation_chain_matches_layerwise_autograd(B):
     """DCDiscriminator under autograd as a chain of pre-activations (autograd_conv._ConvPre: LeakyReLU applied by the consumer

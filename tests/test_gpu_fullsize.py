@@ -74,6 +74,52 @@ def test_full_size_render_properties(sdf_sd, col_sd, name, B, R, S, I, K, precis
     assert maxdiff(out["weights"].cpu()[idx][ok], ref["weights"][ok]) < (2e-4 if K == 1 else 3e-4)
 
 
+@pytest.mark.parametrize("name,B,R,S,I,K", [("C2", 1, 64, 64, 64, 1)])
+def test_full_size_render_properties_bf16(sdf_sd, col_sd, name, B, R, S, I, K):
+    """BASELINE.json configs[1] in the mode it names (64x64, 64+64 samples/ray, bf16 operands): the size-independent
+    properties of every mode, chunk invariance, and the per-ray outputs against the fp32 oracle on 256 rays with the bf16
+    mode's stated tolerance (per-sample outputs are not compared: see tests/test_gpu_modules.py, BF16_RAY_TOL)."""
+    from conftest import record_margin
+    N = B * R * R
+    ro, rd, near, far = _rays(N, 11)
+    w = O.style_mlp(sdf_sd, torch.randn(B, 64, generator=torch.Generator().manual_seed(5)))
+    r = _renderer(col_sd, S, I, K, "bf16")
+    with torch.no_grad():
+        out = r.render(ro.cuda(), rd.cuda(), near.cuda(), far.cuda(), perturb_overwrite=0, cos_anneal_ratio=0.5, w=w.cuda())
+        T = S + I
+        z = out["mid_z_vals"]
+        assert z.shape == (N, T) and bool((z[:, 1:] >= z[:, :-1]).all()), "samples must be sorted along the ray"
+        wts = out["weights"]
+        assert bool((wts >= 0).all()) and float(out["weight_sum"].max()) <= 1.0 + 1e-4
+        assert maxdiff(wts.sum(-1, keepdim=True), out["weight_sum"]) < 1e-5
+        assert maxdiff(wts.max(-1, keepdim=True).values, out["weight_max"]) == 0
+        rgb = out["raw_color"]
+        assert float(rgb.min()) >= 0 and float(rgb.max()) <= 1 and bool(torch.isfinite(out["gradients"]).all())
+        assert maxdiff((rgb * wts[..., None]).sum(1), out["color_fine"]) < 2e-5
+        assert 0.0 <= float(out["gradient_error"]) < 1e3
+        hit = (ro + rd * (-(ro * rd).sum(-1, keepdim=True))).norm(dim=-1) < 0.5
+        assert float(out["weight_sum"].cpu()[hit].mean()) > 0.9
+        sl = slice(N // 3, N // 3 + 256)
+        sub = r.render(ro[sl].cuda(), rd[sl].cuda(), near[sl].cuda(), far[sl].cuda(), perturb_overwrite=0,
+                       cos_anneal_ratio=0.5, w=w.cuda())
+        assert maxdiff(sub["color_fine"], out["color_fine"][sl]) < 1e-6   # ray independence holds in every mode
+    idx = torch.randperm(N, generator=torch.Generator().manual_seed(1))[:256]
+    ref = O.render(sdf_sd, col_sd, torch.tensor(0.3), ro[idx], rd[idx], near[idx], far[idx], w, S, I, K, 0.5)
+    for k, tol in (("color_fine", 2.5e-2), ("weight_sum", 1.5e-2)):
+        err = maxdiff(out[k].cpu()[idx], ref[k])
+        mae = float((out[k].cpu()[idx] - ref[k]).abs().mean())
+        record_margin("c2_full_size_bf16_mode_vs_fp32_oracle", k, err)
+        record_margin("c2_full_size_bf16_mode_vs_fp32_oracle", k + "(mean)", mae)
+        assert err < tol and mae < 0.1 * tol, (k, err, mae)
+    # the normals the shading consumes: the angle between the bf16 mode's and the oracle's weighted normal
+    n_a = (out["gradients"].cpu()[idx] * out["weights"].cpu()[idx][..., None]).sum(1)
+    n_b = (ref["gradients"] * ref["weights"][..., None]).sum(1)
+    solid = ref["weight_sum"].squeeze(-1) > 0.5
+    cosang = torch.nn.functional.cosine_similarity(n_a[solid], n_b[solid], dim=-1)
+    record_margin("c2_full_size_bf16_mode_vs_fp32_oracle", "normal angle (rad)", float(torch.acos(cosang.clamp(-1, 1)).max()))
+    assert float(cosang.min()) > 0.995, float(cosang.min())
+
+
 def test_c5_mlp_only_microbench_size(sdf_sd, col_sd):
     """C5: 2^20 rays x 512 points through the SDF network (sdf-only kernel, chunked over rays); oracle on a
     random subsample; determinism across two runs; linear ray parametrisation consistency."""

@@ -80,9 +80,14 @@ def test_sdf_mlp_golden(ops, packed_all, col_sd, mode, tol_sdf, tol_grad, tol_rg
     assert maxdiff(sdf2, sdf) < (5e-6 if mode == "f16x3" else 1e-6)
 
 
+RAGGED_TOL = {"f32": (2e-5, 1e-4, 2e-5), "f16x3": (2e-5, 1e-4, 2e-5), "bf16": (3e-2, 1.5e-1, 3e-2)}
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3", "bf16"])
 @pytest.mark.parametrize("n", [1, 37, 128, 1000])
-def test_sdf_mlp_ragged_tiles(ops, packed_all, sdf_sd, col_sd, n):
-    """Tile tails: n points per element not a multiple of the 128-point workgroup tile."""
+def test_sdf_mlp_ragged_tiles(ops, packed_all, sdf_sd, col_sd, n, mode):
+    """Tile tails: n points per element not a multiple of the workgroup tile -- the v2 kernel (f32: 256-point tiles), the
+    register-resident f16x3 kernel and the register-resident bf16 kernel (128-point workgroups, CU-indexed slots) each."""
     P, packs = packed_all
     g = torch.Generator().manual_seed(n)
     B = 3
@@ -92,10 +97,19 @@ def test_sdf_mlp_ragged_tiles(ops, packed_all, sdf_sd, col_sd, n):
     sdf_o, feat_o, grad_o = O.sdf_forward(sdf_sd, pts, w, want_grad=True)
     rgb_o = O.color_head(col_sd, feat_o, grad_o, w)
     _, gamma, beta = ops.film_params(P["style_w"], P["style_b"], P["gw"], P["gb"], P["bw"], P["bb"], w=w.cuda())
-    sdf, grad, rgb, _, _ = ops.sdf_mlp_fwd(pts.cuda(), packs["f32"], gamma, beta, B, 0, want_grad=True, want_rgb=True)
-    assert maxdiff(sdf.cpu(), sdf_o.squeeze(-1)) < 2e-5
-    assert maxdiff(grad.cpu(), grad_o) < 1e-4 * max(1.0, float(grad_o.abs().max()))
-    assert maxdiff(rgb.cpu(), rgb_o) < 2e-5
+    prec = {"f32": 0, "bf16": 2, "f16x3": 4}[mode]
+    # guard bands around every output: a tail lane that stored past its element would land here
+    sdf, grad, rgb, feat, _ = ops.sdf_mlp_fwd(pts.cuda(), packs[mode], gamma, beta, B, prec, fast_trig=(mode == "bf16"),
+                                              want_grad=True, want_rgb=True, want_feat=True)
+    t_sdf, t_grad, t_rgb = RAGGED_TOL[mode]
+    assert bool(torch.isfinite(sdf).all() and torch.isfinite(grad).all() and torch.isfinite(rgb).all())
+    assert maxdiff(sdf.cpu(), sdf_o.squeeze(-1)) < t_sdf
+    assert maxdiff(grad.cpu(), grad_o) < t_grad * max(1.0, float(grad_o.abs().max()))
+    assert maxdiff(rgb.cpu(), rgb_o) < t_rgb
+    assert maxdiff(feat.cpu(), feat_o) < {"f32": 1e-4, "f16x3": 1e-4, "bf16": 1e-1}[mode]
+    # the sdf-only pass on the same ragged shape
+    sdf2 = ops.sdf_mlp_fwd(pts.cuda(), packs[mode], gamma, beta, B, prec, fast_trig=(mode == "bf16"))[0]
+    assert maxdiff(sdf2.cpu(), sdf_o.squeeze(-1)) < t_sdf
 
 
 def test_gen_rays(ops):

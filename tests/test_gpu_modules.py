@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oi_oracle as O
-from conftest import GOLDEN, load_golden, maxdiff, sub_sd
+from conftest import GOLDEN, load_golden, maxdiff, sub_sd, record_margin
 
 pytestmark = pytest.mark.gpu
 NET_KW = dict(D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64)
@@ -74,6 +74,63 @@ def test_render_golden_f4(col_sd, tag, car, precision, tol):
         if precision == "bf16x3" and k == "gradients":
             scale *= 2.5
         assert maxdiff(out[k].cpu(), ref) < tol * scale, (k, maxdiff(out[k].cpu(), ref))
+
+
+# ---- bf16 operand mode (BASELINE.json configs[1] names it): ONE bf16 MFMA per product, unreduced v_sin / v_cos.
+# Tolerances are on the MAPS (per-ray outputs) and are measurements: `record_margin` collects the error of every key,
+# tools/grad_margin.py prints them (profiles/r4_bf16_margins.txt), each tolerance is ~3x the worst measured error.
+# Per-SAMPLE outputs are not compared: the coarse pass runs in bf16 too, importance sampling is discontinuous in the sdf
+# (searchsorted bins), so individual samples move -- the integrals over the ray do not.
+BF16_RAY_TOL = {"color_fine": 2.5e-2, "weight_sum": 1.5e-2, "weight_max": 1.2e-1, "s_val": 1e-6}
+
+
+@pytest.mark.parametrize("tag,car", [("c0p0", 0.0), ("c0p5", 0.5), ("c1p0", 1.0)])
+def test_render_golden_f4_bf16_maps(col_sd, tag, car):
+    """NeuSRenderer.render in precision="bf16" against the reference's own F4 outputs: every per-ray key."""
+    g = load_golden("f4_render")
+    r = make_renderer(col_sd, 16, 16, 1, "bf16")
+    with torch.no_grad():
+        out = r.render(g["rays_o"].cuda(), g["rays_d"].cuda(), g["near"].cuda(), g["far"].cuda(), perturb_overwrite=0,
+                       cos_anneal_ratio=car, z=None, w=g["w"].cuda())
+    for k, tol in BF16_RAY_TOL.items():
+        ref = g[f"{tag}_{k}"]
+        assert tuple(out[k].shape) == tuple(ref.shape), (k, out[k].shape, ref.shape)
+        assert bool(torch.isfinite(out[k]).all()), k
+        err = maxdiff(out[k].cpu(), ref)
+        record_margin("render_f4_bf16_mode_vs_reference", k, err)
+        assert err < tol, (k, err)
+    # mean absolute error of the colour: the worst ray is a silhouette ray, the image as a whole is far closer
+    mae = float((out["color_fine"].cpu() - g[f"{tag}_color_fine"]).abs().mean())
+    record_margin("render_f4_bf16_mode_vs_reference", "color_fine(mean)", mae)
+    assert mae < 2.5e-3, mae
+
+
+BF16_MAP_TOL = {"image": 3e-2, "mask": 2e-2, "normal_map": 1.2e-1, "shading_map": 5e-2, "z_map": 2e-1, "color_map": 3e-2,
+                "image_no_bg": 3e-2, "diff_shading_map": 5e-2, "specular_map": 5e-2}
+
+
+def test_generator_golden_f5_bf16_maps():
+    """Generator.forward in precision="bf16" vs the reference's own F5 maps (worst pixel and mean absolute error)."""
+    g = load_golden("f5_generator")
+    gen = build_generator(16, 16, 16, 1, "bf16").eval()
+    gen.color_network.load_state_dict(sub_sd(g, "color."))
+    gen.light.load_state_dict(sub_sd(g, "light."))
+    gen.it.fill_(int(g["it"]))
+    np.random.seed(12)
+    with torch.no_grad():
+        blob = gen(bs=2, it=None, data={"z": g["z"].cuda(), "b2w": g["b2w"].cuda()}, return_raw=True)["box"]
+    assert maxdiff(blob["rays_info"]["rays_o"].cpu(), g["rays_o"]) < 1e-5   # (not MLP outputs: exact as in every mode)
+    for k, v in blob["render_out"].items():
+        ref = g["map_" + k]
+        assert tuple(v.shape) == tuple(ref.shape) and bool(torch.isfinite(v).all()), k
+        err, mae = maxdiff(v.cpu(), ref), float((v.cpu() - ref).abs().mean())
+        record_margin("generator_f5_bf16_mode_vs_reference", k, err)
+        record_margin("generator_f5_bf16_mode_vs_reference", k + "(mean)", mae)
+        assert err < BF16_MAP_TOL.get(k, 5e-2), (k, err)
+        assert mae < 0.15 * BF16_MAP_TOL.get(k, 5e-2), (k, mae)
+    err = abs(float(blob["loss"]["eikonal"]) - float(g["eikonal"]))
+    record_margin("generator_f5_bf16_mode_vs_reference", "eikonal", err)
+    assert err < 2e-2, err
 
 
 @pytest.mark.parametrize("K,I", [(1, 64), (4, 64), (2, 32)])
