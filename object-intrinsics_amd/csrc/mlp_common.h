@@ -589,4 +589,8 @@ int launch_full3_f16x3(const float* pts, const void* packed, const float* gamma,
                        float* grad, float* rgb, float* feat, void* scratch, int B, long long n, int fast_trig,
                        hipStream_t st);
 
+// mlp_fwd3b.hip: register-resident BF16 forward with gradient (+ albedo); no scratch
+int launch_full3_bf16(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf, float* grad,
+                      float* rgb, float* feat, int B, long long n, int fast_trig, hipStream_t st);
+
 }  // namespace oimlp

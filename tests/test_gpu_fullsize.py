@@ -105,7 +105,7 @@ def test_full_size_render_properties_bf16(sdf_sd, col_sd, name, B, R, S, I, K):
         assert maxdiff(sub["color_fine"], out["color_fine"][sl]) < 1e-6   # ray independence holds in every mode
     idx = torch.randperm(N, generator=torch.Generator().manual_seed(1))[:256]
     ref = O.render(sdf_sd, col_sd, torch.tensor(0.3), ro[idx], rd[idx], near[idx], far[idx], w, S, I, K, 0.5)
-    for k, tol in (("color_fine", 2.5e-2), ("weight_sum", 1.5e-2)):
+    for k, tol in (("color_fine", 7e-3), ("weight_sum", 1.2e-2)):   # measured 2.1e-3 / 3.9e-3 (means 1.0e-4 / 1.7e-4)
         err = maxdiff(out[k].cpu()[idx], ref[k])
         mae = float((out[k].cpu()[idx] - ref[k]).abs().mean())
         record_margin("c2_full_size_bf16_mode_vs_fp32_oracle", k, err)
@@ -117,7 +117,7 @@ def test_full_size_render_properties_bf16(sdf_sd, col_sd, name, B, R, S, I, K):
     solid = ref["weight_sum"].squeeze(-1) > 0.5
     cosang = torch.nn.functional.cosine_similarity(n_a[solid], n_b[solid], dim=-1)
     record_margin("c2_full_size_bf16_mode_vs_fp32_oracle", "normal angle (rad)", float(torch.acos(cosang.clamp(-1, 1)).max()))
-    assert float(cosang.min()) > 0.995, float(cosang.min())
+    assert float(cosang.min()) > 0.992, float(cosang.min())   # measured: 4.2e-2 rad worst; 0.992 = 0.127 rad
 
 
 def test_c5_mlp_only_microbench_size(sdf_sd, col_sd):

@@ -77,7 +77,9 @@ def test_sdf_mlp_golden(ops, packed_all, col_sd, mode, tol_sdf, tol_grad, tol_rg
     # sdf-only variant agrees with the full variant (f16x3: two kernels, the register-resident one forms the FiLM phase
     # in revolutions: two valid fp32 roundings of the same phase, both within tol_sdf of the reference)
     sdf2, _, _, _, _ = ops.sdf_mlp_fwd(g1["pts"].cuda(), packs[mode], gamma, beta, 2, prec, fast_trig=(mode == "bf16"))
-    assert maxdiff(sdf2, sdf) < (5e-6 if mode == "f16x3" else 1e-6)
+    # (bf16: likewise two kernels -- mlp_fwd3b.hip forms the phase in revolutions and feeds it unreduced to v_sin --, both
+    # within the mode's tolerance of the reference)
+    assert maxdiff(sdf2, sdf) < {"f16x3": 5e-6, "bf16": tol_sdf}.get(mode, 1e-6)
 
 
 RAGGED_TOL = {"f32": (2e-5, 1e-4, 2e-5), "f16x3": (2e-5, 1e-4, 2e-5), "bf16": (3e-2, 1.5e-1, 3e-2)}

@@ -81,7 +81,9 @@ def test_render_golden_f4(col_sd, tag, car, precision, tol):
 # tools/grad_margin.py prints them (profiles/r4_bf16_margins.txt), each tolerance is ~3x the worst measured error.
 # Per-SAMPLE outputs are not compared: the coarse pass runs in bf16 too, importance sampling is discontinuous in the sdf
 # (searchsorted bins), so individual samples move -- the integrals over the ray do not.
-BF16_RAY_TOL = {"color_fine": 2.5e-2, "weight_sum": 1.5e-2, "weight_max": 1.2e-1, "s_val": 1e-6}
+# measured (MI355X, profiles/r4_bf16_margins.txt): color_fine 6.7e-4, weight_sum 1.3e-3, weight_max 1.2e-2 (a single sample's
+# weight: not an integral over the ray), s_val exact
+BF16_RAY_TOL = {"color_fine": 2.5e-3, "weight_sum": 5e-3, "weight_max": 4e-2, "s_val": 1e-6}
 
 
 @pytest.mark.parametrize("tag,car", [("c0p0", 0.0), ("c0p5", 0.5), ("c1p0", 1.0)])
@@ -102,11 +104,14 @@ def test_render_golden_f4_bf16_maps(col_sd, tag, car):
     # mean absolute error of the colour: the worst ray is a silhouette ray, the image as a whole is far closer
     mae = float((out["color_fine"].cpu() - g[f"{tag}_color_fine"]).abs().mean())
     record_margin("render_f4_bf16_mode_vs_reference", "color_fine(mean)", mae)
-    assert mae < 2.5e-3, mae
+    assert mae < 4e-4, mae   # measured 1.0e-4
 
 
-BF16_MAP_TOL = {"image": 3e-2, "mask": 2e-2, "normal_map": 1.2e-1, "shading_map": 5e-2, "z_map": 2e-1, "color_map": 3e-2,
-                "image_no_bg": 3e-2, "diff_shading_map": 5e-2, "specular_map": 5e-2}
+# worst pixel, measured: image 1.4e-3, mask 1.8e-3, normal_map 6.8e-3 (unnormalised gradient, |.| up to ~16), shading 1.4e-3,
+# z_map 2.3e-2 (depth in scene units at a silhouette pixel), colour 9.8e-4, specular 1.3e-3; every mean 15x or more below
+BF16_MAP_TOL = {"image": 5e-3, "mask": 6e-3, "weight_sum_map": 6e-3, "normal_map": 2.5e-2, "shading_map": 5e-3, "z_map": 7e-2,
+                "color_map": 4e-3, "image_no_bg": 5e-3, "diff_shading_map": 5e-3, "specular_map": 5e-3,
+                "no_specular_map": 3e-3, "amb_shading_map": 2e-3, "z_min": 1e-5}
 
 
 def test_generator_golden_f5_bf16_maps():
@@ -126,11 +131,11 @@ def test_generator_golden_f5_bf16_maps():
         err, mae = maxdiff(v.cpu(), ref), float((v.cpu() - ref).abs().mean())
         record_margin("generator_f5_bf16_mode_vs_reference", k, err)
         record_margin("generator_f5_bf16_mode_vs_reference", k + "(mean)", mae)
-        assert err < BF16_MAP_TOL.get(k, 5e-2), (k, err)
-        assert mae < 0.15 * BF16_MAP_TOL.get(k, 5e-2), (k, mae)
+        assert err < BF16_MAP_TOL.get(k, 5e-3), (k, err)
+        assert mae < 0.15 * BF16_MAP_TOL.get(k, 5e-3), (k, mae)
     err = abs(float(blob["loss"]["eikonal"]) - float(g["eikonal"]))
     record_margin("generator_f5_bf16_mode_vs_reference", "eikonal", err)
-    assert err < 2e-2, err
+    assert err < 6e-4, err   # measured 1.7e-4
 
 
 @pytest.mark.parametrize("K,I", [(1, 64), (4, 64), (2, 32)])
