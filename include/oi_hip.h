@@ -433,10 +433,13 @@ int oi_weighted_sum_bwd(const float* g_out, const float* weights, int n, float* 
 /* Outputs that are ACCUMULATED into (the split-K sums of oi_conv4x4_fwd* / oi_conv4x4_wgrad, the scatter-adds of
  * oi_conv4x4_dgrad, oi_affine_grid_sample_bwd, oi_grid_sample_bwd, oi_reflect_pad_bwd) are cleared by their launcher with a
  * fill of their own.  A caller that takes every such output from memory it has already zeroed -- one fill per training step
- * instead of ~90 -- declares so: oi_outputs_prezeroed(1) ... oi_outputs_prezeroed(0).  The setting is process-wide (a
- * backward pass issues its launches from the framework's autograd thread); it returns the previous setting.
+ * instead of ~90 -- declares so FOR ONE STREAM: oi_outputs_prezeroed_stream(s, 1) ... oi_outputs_prezeroed_stream(s, 0).
+ * Only launches on stream `s` skip their fill: a backward pass (issued from the framework's autograd thread, on the forward's
+ * stream) is covered, a second thread working on its own stream is not affected (re-entrant, thread-safe;
+ * tests/test_gpu_ddp.py::test_prezeroed_declaration_is_per_stream).  Returns the previous setting of that stream (0 / 1), or
+ * a negative oi_status when more than 16 streams hold the declaration at once.
  * (oi_amd.ops.ZeroPool does this around a captured discriminator step.) */
-int oi_outputs_prezeroed(int on);
+int oi_outputs_prezeroed_stream(oi_stream_t stream, int on);
 
 /* The whole geometric augmentation of AugmentPipe.forward (src/third_party/ada/augment.py:284-301) for a given sampling
  * grid, in two launches: reflect pad (margins mx0, mx1, my0, my1) + x2 up-FIR | affine bilinear resample + /2 down-FIR.

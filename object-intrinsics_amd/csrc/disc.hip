@@ -908,8 +908,10 @@ int oi_reflect_pad_bwd(const float* gy, float* gx, int BC, int H, int W, int px0
   return oi::check_launch("oi_reflect_pad_bwd");
 }
 
-int oi_outputs_prezeroed(int on) {
-  return oi::outputs_prezeroed().exchange(on != 0);
+int oi_outputs_prezeroed_stream(oi_stream_t stream, int on) {
+  const int was = oi::set_stream_prezeroed(oi::as_stream(stream), on != 0);
+  if (was < 0) return oi::fail(OI_ERR_INVALID_ARG, "oi_outputs_prezeroed_stream: more than %d streams hold the declaration", oi::PREZERO_SLOTS);
+  return was;
 }
 
 int oi_version(void) { return 1; }

@@ -174,6 +174,8 @@ int oi_gan_losses_bwd(const float* g_total, const float* d_real, const float* d_
   OI_REQUIRE((g_real == nullptr || d_real != nullptr) && (g_fake == nullptr || d_fake != nullptr) &&
                  (g_gx == nullptr || gx != nullptr),
              "oi_gan_losses_bwd: a gradient output without its operand");
+  OI_REQUIRE(pose == nullptr || (aux_w != nullptr && d_fake != nullptr && K >= 2),
+             "oi_gan_losses_bwd: a pose target needs its weight (aux_w), the fake logits and K >= 2 (K=%d)", K);
   if (g_gx == nullptr || N == 0) gx = nullptr;  // (the R1 term's gradient is not wanted)
   const long long work = std::max<long long>((long long)B * K, gx != nullptr ? (long long)B * N : 0);
   const int blocks = (int)std::min<long long>(1024, std::max<long long>(1, (work + 255) / 256));

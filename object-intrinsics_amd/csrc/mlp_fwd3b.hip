@@ -152,7 +152,8 @@ __device__ __forceinline__ void run_tail_b(EPI&& epi) {
 
 // -DOI_B3_PROF: per-phase shader-clock accounting
 #ifdef OI_B3_PROF
-__device__ unsigned long long oi_prof3b[16];
+__device__ unsigned long long oi_prof3b[1024][16];  // replicated by workgroup: same-address atomics of 300k waves would
+                                                     // dominate the memory system (and with it the prologue and the DMA waits)
 #define B3_T(i)                                                  \
   do {                                                           \
     const unsigned long long t_ = __builtin_readcyclecounter();  \
@@ -235,7 +236,13 @@ sdf_mlp_full3b_kernel(const float* __restrict__ pts, const char* __restrict__ pa
     }
   };
   constexpr int DMA_PER_IMAGE = LBB / 1024 / B3_WAVES;  // vector-memory instructions per wave and image: 8
-  auto lay = [&](int pos) { return o.l16 + B3_WBUF + (pos & (B3_NSLOT - 1)) * LBB; };
+  // lane base of ring position pos, laundered: the A-fragment reads then are <this VGPR> + a 16-bit immediate (left to
+  // itself hipcc folds the slot base into the immediate, overflows its 16 bits and forms a new address on the VALU per read)
+  auto lay = [&](int pos) {
+    int b = o.l16 + B3_WBUF + (pos & (B3_NSLOT - 1)) * LBB;
+    asm volatile("" : "+v"(b));
+    return b;
+  };
   auto film_base = [&](int l) { return o.h16 + B3_FILM + l * B3_FILM_ROW; };
 
   float px, py, pz;
@@ -571,11 +578,12 @@ sdf_mlp_full3b_kernel(const float* __restrict__ pts, const char* __restrict__ pa
 #ifdef OI_B3_PROF
   B3_T(5);
   if (lane == 0) {
-    for (int i = 0; i < 6; ++i) atomicAdd(&oi_prof3b[i], pacc[i]);
-    atomicAdd(&oi_prof3b[6], __builtin_readcyclecounter() - tstart);
-    atomicAdd(&oi_prof3b[7], 1ull);
-    atomicAdd(&oi_prof3b[8], __builtin_readcyclecounter() - t_entry);  // with [9]: the shader clock in the kernel
-    atomicAdd(&oi_prof3b[9], __builtin_amdgcn_s_memrealtime() - rt_entry);
+    unsigned long long* pr = oi_prof3b[(blockIdx.x * 4 + wave) & 1023];
+    for (int i = 0; i < 6; ++i) atomicAdd(&pr[i], pacc[i]);
+    atomicAdd(&pr[6], __builtin_readcyclecounter() - tstart);
+    atomicAdd(&pr[7], 1ull);
+    atomicAdd(&pr[8], __builtin_readcyclecounter() - t_entry);  // with [9]: the shader clock in the kernel
+    atomicAdd(&pr[9], __builtin_amdgcn_s_memrealtime() - rt_entry);
   }
 #endif
 #undef OI_FWD_EPI
@@ -614,9 +622,14 @@ int launch_full3_bf16(const float* pts, const void* packed, const float* gamma, 
 #ifdef OI_B3_PROF
 extern "C" int oi_prof3b_read(unsigned long long* out, int reset) {
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(oi_prof3b), sizeof(unsigned long long) * 16);
+  static unsigned long long host[1024][16];
+  (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(oi_prof3b), sizeof(host));
+  for (int i = 0; i < 16; ++i) {
+    out[i] = 0;
+    for (int r = 0; r < 1024; ++r) out[i] += host[r][i];
+  }
   if (reset) {
-    unsigned long long z[16] = {0};
+    static unsigned long long z[1024][16];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(oi_prof3b), z, sizeof(z));
   }
   return 0;

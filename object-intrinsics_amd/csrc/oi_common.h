@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdint>
 #include <cstdarg>
 #include <cstdio>
 
@@ -140,16 +141,40 @@ inline hipError_t zero_async(float* p, size_t n_floats, hipStream_t st) {
   return hipGetLastError();
 }
 
-// Accumulate-outputs (split-K sums, scatter-adds) are cleared by their launcher -- unless the caller has declared that it
-// hands every such output out of memory it has already zeroed (oi_outputs_prezeroed: one fill per captured step instead
-// of one per op).  Process-wide, not thread-local: PyTorch runs a backward pass on its autograd worker thread, and the
-// declaration has to cover the launches issued from there.
-inline std::atomic<int>& outputs_prezeroed() {
-  static std::atomic<int> v{0};
+// Accumulate-outputs (split-K sums, scatter-adds) are cleared by their launcher -- unless the caller has declared FOR THE
+// STREAM OF THE LAUNCH that it hands every such output out of memory it has already zeroed (oi_outputs_prezeroed_stream: one
+// fill per captured step instead of one per op).  Keyed by stream, not by thread and not process-wide: PyTorch runs a
+// backward pass on its autograd worker thread but on the forward's stream, so the declaration covers those launches, while
+// another thread working on its own stream ("re-entrant and thread-safe") keeps the default behaviour.
+constexpr int PREZERO_SLOTS = 16;
+inline std::atomic<uintptr_t>* prezeroed_streams() {
+  static std::atomic<uintptr_t> v[PREZERO_SLOTS];  // 0 = free; otherwise (stream handle | 1): the null stream has the key 1
   return v;
 }
+inline bool stream_prezeroed(hipStream_t st) {
+  const uintptr_t key = reinterpret_cast<uintptr_t>(st) | 1u;
+  std::atomic<uintptr_t>* v = prezeroed_streams();
+  for (int i = 0; i < PREZERO_SLOTS; ++i)
+    if (v[i].load(std::memory_order_relaxed) == key) return true;
+  return false;
+}
+// -> previous setting of that stream, or -1 when the table is full
+inline int set_stream_prezeroed(hipStream_t st, bool on) {
+  const uintptr_t key = reinterpret_cast<uintptr_t>(st) | 1u;
+  std::atomic<uintptr_t>* v = prezeroed_streams();
+  for (int i = 0; i < PREZERO_SLOTS; ++i) {
+    uintptr_t cur = key;
+    if (on ? v[i].load(std::memory_order_relaxed) == key : v[i].compare_exchange_strong(cur, 0)) return 1;  // was on
+  }
+  if (!on) return 0;
+  for (int i = 0; i < PREZERO_SLOTS; ++i) {
+    uintptr_t empty = 0;
+    if (v[i].compare_exchange_strong(empty, key)) return 0;
+  }
+  return -1;
+}
 inline hipError_t zero_output_async(float* p, size_t n_floats, hipStream_t st) {
-  return outputs_prezeroed().load(std::memory_order_relaxed) ? hipSuccess : zero_async(p, n_floats, st);
+  return stream_prezeroed(st) ? hipSuccess : zero_async(p, n_floats, st);
 }
 
 }  // namespace oi

@@ -1,6 +1,6 @@
 """Parameter EMA of the generator (src/utils/ema.py:7-41): p_ema <- lerp(p, p_ema, beta), buffers copied.
-On the GPU the parameter loop is ONE launch of `oi_multi_lerp` (oi_amd.optim.ema_update, csrc/optim.hip) instead of
-one lerp + copy per parameter; host-resident modules (unit tests of the host logic) take torch._foreach_lerp_."""
+The parameter loop is ONE launch of `oi_multi_lerp` (oi_amd.optim.ema_update, csrc/optim.hip) instead of one lerp + copy
+per parameter.  Like every op of the path there is no host-tensor branch: parameters that are not on the GPU raise."""
 import copy
 
 import torch
@@ -25,12 +25,9 @@ class EMA:
     @torch.no_grad()
     def update(self, it=None):
         pe, p = list(self.m_ema.parameters()), [q.detach() for q in self.m.parameters()]
-        if pe and all(q.is_cuda for q in pe):
-            from .optim import ema_update
+        if pe:
+            from .optim import ema_update   # p.lerp(p_ema, beta) = p + beta (p_ema - p); rejects host tensors
             ema_update(pe, p, self.beta)
-        else:
-            # p.lerp(p_ema, beta) = p + beta (p_ema - p)  ==  p_ema.lerp_(p, 1 - beta)
-            torch._foreach_lerp_(pe, p, 1.0 - self.beta)
         if hasattr(self.m, "sync_it"):  # Generator keeps its iteration counter on the host between observations
             self.m.sync_it()
         for b_ema, b in zip(self.m_ema.buffers(), self.m.buffers()):

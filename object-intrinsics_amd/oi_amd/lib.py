@@ -79,7 +79,7 @@ _SIGS = {
     "oi_channel_sum": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "oi_upfirdn2d": (_i, [_vp] * 3 + [_i] * 14 + [_f, _vp]),
     "oi_ada_geom_fwd": (_i, [_vp] * 5 + [_i] * 8 + [_vp]),
-    "oi_outputs_prezeroed": (_i, [_i]),
+    "oi_outputs_prezeroed_stream": (_i, [_vp, _i]),
     "oi_light_dir_fwd": (_i, [_vp, _vp, _vp, _i, _vp]),
     "oi_light_dir_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "oi_gan_losses_fwd": (_i, [_vp] * 5 + [_f, _vp, _i, _i, _ll, _vp]),

@@ -43,17 +43,26 @@ class ZeroPool:
     """Pre-zeroed memory for the accumulate-outputs (split-K sums, scatter-adds) of ONE captured step: a single fill at
     the start of the step instead of a fill launch in front of every such op (93 of 631 launches of a training iteration
     were fills).  Bump allocation in call order; while active, the library is told not to clear those outputs itself
-    (oi_outputs_prezeroed).  The first pass only measures (every request is served by its own torch.zeros); the buffer is
+    (oi_outputs_prezeroed_stream, for this stream only).  The first pass only measures (every request is served by its own torch.zeros); the buffer is
     allocated at the next `begin()`.  Slices stay valid until the next `begin()` -- the owner (oi_amd.graphed.GraphedDStep)
     guarantees that nothing outlives its step except what the optimiser reads before the next one starts."""
 
-    _active = None
+    _active = {}   # raw stream handle -> the pool that is active for launches on that stream
 
     def __init__(self):
         self.buf, self.off, self.need = None, 0, 0
 
-    def begin(self, device):
-        """Start of a step: (re)allocate if the last pass asked for more, then ONE fill of what the step will hand out."""
+    def begin(self, device, must_not_alias=()):
+        """Start of a step: (re)allocate if the last pass asked for more, then ONE fill of what the step will hand out.
+        `must_not_alias`: parameters whose `.grad` must not live in the pool any more (a gradient kept across steps --
+        gradient accumulation, zero_grad(set_to_none=False) -- would be zeroed under its owner: fail loudly instead)."""
+        if self.buf is not None and must_not_alias:
+            lo, hi = self.buf.data_ptr(), self.buf.data_ptr() + self.buf.numel() * 4
+            for p_ in must_not_alias:
+                g_ = p_.grad
+                if g_ is not None and lo <= g_.data_ptr() < hi:
+                    raise RuntimeError("ZeroPool.begin: a parameter's .grad still points into the pool of the previous step; call "
+                                       "zero_grad(set_to_none=True) before the step (or clone gradients that must outlive it)")
         if self.buf is None or self.buf.numel() < self.need:
             self.buf = torch.empty(self.need, dtype=torch.float32, device=device) if self.need else None
         self.off, self.need = 0, 0
@@ -72,27 +81,40 @@ class ZeroPool:
         return out
 
     def __enter__(self):
-        assert ZeroPool._active is None, "nested ZeroPool"
-        ZeroPool._active = self
-        self._was = _l.load().oi_outputs_prezeroed(1)
+        # The declaration belongs to the CURRENT STREAM (oi_outputs_prezeroed_stream): the ops of this step -- forward here,
+        # backward on the autograd thread but on the same stream -- take pool memory and skip their fills; any other thread /
+        # stream keeps plain torch.empty outputs that the library clears itself.
+        self._key = _stream().value or 0
+        assert self._key not in ZeroPool._active, "nested ZeroPool on one stream"
+        was = _l.load().oi_outputs_prezeroed_stream(_vp(self._key), 1)
+        if was < 0:
+            _l.check(was, "oi_outputs_prezeroed_stream")
+        self._was = was
+        ZeroPool._active[self._key] = self
         return self
 
     def __exit__(self, *exc):
-        _l.load().oi_outputs_prezeroed(self._was)
-        ZeroPool._active = None
+        _l.load().oi_outputs_prezeroed_stream(_vp(self._key), self._was)
+        del ZeroPool._active[self._key]
         return False
+
+
+def _active_pool():
+    if not ZeroPool._active:
+        return None
+    return ZeroPool._active.get(_stream().value or 0)
 
 
 def _new_acc(ref, *shape):
     """Output buffer of an op that ACCUMULATES into it: plain memory (the launcher clears it) unless a ZeroPool is active."""
-    pool = ZeroPool._active
+    pool = _active_pool()
     return torch.empty(shape, dtype=torch.float32, device=ref.device) if pool is None else pool.take(ref, shape)
 
 
 def _zeros_split(dev, *shapes):
     """Several zero-initialised fp32 tensors from ONE fill launch (views of one flat buffer, each 16-byte aligned) -- or
     from the step's ZeroPool when one is active (no launch)."""
-    pool = ZeroPool._active
+    pool = _active_pool()
     if pool is not None:
         return [pool.take(dev, sh) for sh in shapes]
     sizes = [int(torch.Size(sh).numel()) for sh in shapes]
@@ -385,7 +407,7 @@ def conv4x4_fwd(x, w, bias=None, stride=2, pad=1, slope=0.2, out=None, x_slope=1
     # `zero_tail`: floats of the arena behind `out` that this launch also clears (oi_conv4x4_fwd_arena);
     # `out_is_zero`: whether `out` already holds zeros (default: it does when given)
     zero = (out is not None) if out_is_zero is None else bool(out_is_zero)
-    if out is not None and not zero and ZeroPool._active is not None:
+    if out is not None and not zero and _active_pool() is not None:
         out.zero_()  # under a ZeroPool the library clears nothing: a caller-owned output that is not yet zero is cleared here
         zero = True
     _l.check(L.oi_conv4x4_fwd_arena(_p(x), _p(w), _p(_c(bias)), _p(y), B, Cin, H, W, Cout, stride, pad, float(slope),
@@ -497,14 +519,34 @@ def light_dir_bwd(d, w2b, g_n):
     return g_d
 
 
+def _gan_shapes(d_real, d_fake, pose, gx, aux_w):
+    """(B, K, N) of the fused GAN-loss launches, with the shape checks the ATen composition they replace performed on its
+    own (torch.split / mse_loss raise on a mismatch; the kernels index raw pointers)."""
+    ref = d_real if d_real is not None else d_fake
+    if ref is None or ref.dim() != 2:
+        raise ValueError("gan_losses: logits must be [B, K]")
+    B, K = ref.shape
+    for name, t in (("d_real", d_real), ("d_fake", d_fake)):
+        if t is not None and tuple(t.shape) != (B, K):
+            raise ValueError(f"gan_losses: {name} is {tuple(t.shape)}, expected {(B, K)}")
+    if pose is not None:
+        if d_fake is None:
+            raise ValueError("gan_losses: a pose target needs the fake logits")
+        if tuple(pose.shape) != (B, K - 1):
+            raise ValueError(f"gan_losses: pose is {tuple(pose.shape)}, expected {(B, K - 1)} (logits [:, 1:], position.py:4-12)")
+        if aux_w is None or aux_w.numel() != 1:
+            raise ValueError("gan_losses: a pose target needs its weight (one device scalar)")
+    if gx is not None and (gx.dim() < 1 or gx.shape[0] != B):
+        raise ValueError(f"gan_losses: the R1 gradient has leading dimension {tuple(gx.shape)[:1]}, expected {B}")
+    return B, K, (0 if gx is None else gx.numel() // B)
+
+
 def gan_losses_fwd(d_real, d_fake, pose, gx, aux_w, reg_w):
     """-> out6 = (total, real + fake, reg, fake, real, aux): see oi_gan_losses_fwd.  d_real / d_fake [B, K] (or None),
     pose [B, K-1] (or None), gx [B, ...] (or None), aux_w a device scalar tensor (or None)."""
     L = _l.load()
-    ref = d_real if d_real is not None else d_fake
-    B, K = ref.shape
-    N = 0 if gx is None else gx.numel() // B
-    out = _new(ref, 6)
+    B, K, N = _gan_shapes(d_real, d_fake, pose, gx, aux_w)
+    out = _new(d_real if d_real is not None else d_fake, 6)
     _l.check(L.oi_gan_losses_fwd(_p(d_real), _p(d_fake), _p(pose), _p(gx), _p(aux_w), float(reg_w), _p(out), B, K, N, _stream()),
              "oi_gan_losses_fwd")
     return out
@@ -566,9 +608,7 @@ def weighted_sum_bwd(g_out, weights, device):
 def gan_losses_bwd(g_total, d_real, d_fake, pose, gx, aux_w, reg_w, want_real, want_fake, want_gx, out=None):
     """out: optional (g_real, g_fake, g_gx) destinations (contiguous; e.g. slices of one tensor)."""
     L = _l.load()
-    ref = d_real if d_real is not None else d_fake
-    B, K = ref.shape
-    N = 0 if gx is None else gx.numel() // B
+    B, K, N = _gan_shapes(d_real, d_fake, pose, gx, aux_w)
     if out is not None:
         g_real, g_fake, g_gx = out
     else:

@@ -112,6 +112,18 @@ class _StepCounts:
         super().load_state_dict(state_dict)
         self.__dict__["_steps"] = {}
 
+    # pickle / copy.deepcopy go through __getstate__ (torch.optim.Optimizer: defaults, state, param_groups): the counts are
+    # written into the state first, and the copy starts from the state alone (a deep copy's parameters are new objects:
+    # the Python-side dictionary keyed on the old ones would be stale, i.e. bias correction restarted at step 1).
+    def __getstate__(self):
+        self._flush_steps()
+        return super().__getstate__()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__["_steps"] = {}
+        self.__dict__.setdefault("_tables", {})
+
 
 class FusedAdam(_StepCounts, torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):

@@ -147,7 +147,7 @@ def assemble_render_dict(s, c, variance, background_rgb=None, finals=None):
         color = color + background_rgb * (1.0 - c["weight_sum"])
     gradient_error, surface_loss = (finals[0], finals[1]) if finals is not None else render_scalars(r4, N * T)
     return {
-        "s_val": s_val.expand(N, 1),
+        "s_val": s_val.detach().expand(N, 1),   # a report without a graph (stated deviation: see _inv_s)
         "cdf_fine": c["cdf"],
         "weight_sum": c["weight_sum"],
         "weight_max": c["weight_max"],

@@ -133,13 +133,15 @@ class Trainer:
         """ONE fill for the split-K / scatter outputs of the step's discriminator passes (ops.ZeroPool: ~20 fill launches of
         the generator step otherwise; sized by the first step, valid until the next one begins)."""
         from . import ops
-        dev = next(_unwrap(self.generator).parameters()).device
+        params = list(_unwrap(self.generator).parameters())
+        dev = params[0].device
         if dev.type != "cuda":
-            import contextlib
-            return contextlib.nullcontext()
+            raise RuntimeError("oi_amd.trainer.Trainer: the modules must be on the GPU (there is no host-tensor path)")
         if getattr(self, "_gpool", None) is None:
             self._gpool = ops.ZeroPool()
-        self._gpool.begin(dev)
+        # Gradients taken from pool slices become `.grad` of leaf parameters (AccumulateGrad steals them): begin() zeroes that
+        # memory again, which is only right because _zero_grad(set_to_none=True) ran first -- checked, not assumed.
+        self._gpool.begin(dev, must_not_alias=params)
         return self._gpool
 
     def _generator_loss_backward(self, bs):

@@ -707,3 +707,64 @@ def test_stage_inputs_copies_and_immediates(ops):
     assert torch.equal(flat[:13].cpu(), torch.from_numpy(imm)) and bool((flat[13:] == -7.0).all())
     ops.stage_inputs([(srcs[1] * 2, dsts[1])])      # copies only
     assert torch.equal(dsts[1], srcs[1] * 2)
+
+
+def test_prezeroed_declaration_is_per_stream(ops):
+    """the boundary is re-entrant and thread-safe.  While one thread works inside a ZeroPool (the library
+    skips the fills of accumulate-outputs launched on THAT stream), a second thread on its own stream calls
+    oi_conv4x4_wgrad into memory full of garbage and must get the right sums -- the round-3 flag was process-wide and the
+    second thread would have accumulated onto the garbage."""
+    import threading
+    from oi_amd import lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 16, 16, 16, generator=g).cuda()
+    gy = torch.randn(2, 32, 8, 8, generator=g).cuda()
+    ref = torch.nn.grad.conv2d_weight(x.double().cpu(), (32, 16, 4, 4), gy.double().cpu(), stride=2, padding=1)
+    torch.cuda.synchronize()
+    s_main, s_other = torch.cuda.Stream(), torch.cuda.Stream()
+    inside, release, result = threading.Event(), threading.Event(), {}
+
+    def pool_owner():
+        with torch.cuda.stream(s_main):
+            pool = ops.ZeroPool()
+            for _ in range(2):   # the first pass measures, the second hands out pool memory
+                pool.begin(x.device)
+                with pool:
+                    gw = ops.conv4x4_wgrad(gy, x, 2, 1)
+                    if pool.buf is not None:
+                        assert gw.data_ptr() >= pool.buf.data_ptr() and gw.data_ptr() < pool.buf.data_ptr() + pool.buf.numel() * 4
+                        inside.set()
+                        assert release.wait(60)
+            s_main.synchronize()
+            result["owner"] = gw.detach().cpu()
+
+    def bystander():
+        assert inside.wait(60)
+        try:
+            with torch.cuda.stream(s_other):
+                junk = torch.full((32, 16, 4, 4), 1.0e9, device="cuda")   # the allocator hands this block out again below
+                s_other.synchronize()
+                ptr = junk.data_ptr()
+                del junk
+                gw = ops.conv4x4_wgrad(gy, x, 2, 1)
+                s_other.synchronize()
+                result["reused_garbage_block"] = gw.data_ptr() == ptr
+                result["bystander"] = gw.detach().cpu()
+                # and through the raw C-ABI, into memory this thread filled itself
+                raw = torch.full((32, 16, 4, 4), -7.0e8, device="cuda")
+                s_other.synchronize()
+                lib.check(L.oi_conv4x4_wgrad(ops._p(gy), ops._p(x), ops._p(raw), 2, 16, 16, 16, 32, 2, 1, ops._stream()), "oi_conv4x4_wgrad")
+                s_other.synchronize()
+                result["raw"] = raw.cpu()
+        finally:
+            release.set()
+
+    ta, tb = threading.Thread(target=pool_owner), threading.Thread(target=bystander)
+    ta.start(); tb.start(); ta.join(120); tb.join(120)
+    assert "owner" in result and "bystander" in result and "raw" in result, result.keys()
+    for k in ("owner", "bystander", "raw"):
+        err = float((result[k].double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-5, (k, err)
+    # the declaration is gone with the pool
+    assert L.oi_outputs_prezeroed_stream(ops._vp(s_main.cuda_stream), 0) == 0

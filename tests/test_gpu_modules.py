@@ -49,6 +49,22 @@ def test_shape_network_api(col_sd):
         assert maxdiff(gr.cpu(), g["grad"]) < 1e-4 * float(g["grad"].abs().max())
 
 
+def test_s_val_is_a_reported_value_and_the_variance_gradient_comes_from_compositing(col_sd):
+    """Stated deviation (renderer._inv_s): the reference's `s_val` entry carries a graph to the variance parameter
+    (renderer.py:404) that no loss of the path uses; ours is a detached, cached report.  The variance gradient itself is
+    owned by the compositing kernel and arrives through every differentiable output."""
+    g = load_golden("f4_render")
+    r = make_renderer(col_sd, 16, 16, 1, "f16x3")
+    r.deviation_network.variance.requires_grad_(True)
+    out = r.render(g["rays_o"].cuda(), g["rays_d"].cuda(), g["near"].cuda(), g["far"].cuda(), perturb_overwrite=0,
+                   cos_anneal_ratio=0.5, z=None, w=g["w"].cuda())
+    assert not out["s_val"].requires_grad and out["s_val"].grad_fn is None
+    assert abs(float(out["s_val"][0, 0]) - float(torch.exp(torch.tensor(-3.0)))) < 1e-6   # 1 / exp(10 * 0.3)
+    (out["color_fine"].sum() + out["weight_sum"].sum()).backward()
+    gv = r.deviation_network.variance.grad
+    assert gv is not None and bool(torch.isfinite(gv).all()) and float(gv.abs().sum()) > 0
+
+
 KEYS = ("s_val", "cdf_fine", "weight_sum", "weight_max", "gradients", "weights", "gradient_error", "inside_sphere",
         "mid_z_vals", "surface_loss", "sdf", "pts_norm", "pts", "color_fine", "raw_color")
 
@@ -348,6 +364,54 @@ def test_fused_optimizer_matches_torch(kind):
     # a torch optimiser checkpoint loads into the fused one (and keeps stepping)
     oa.load_state_dict(sb)
     oa.step()
+
+
+def test_fused_adam_deepcopy_and_pickle_keep_the_step_counts():
+    """The step counts live in Python ints between observations (optim._StepCounts): copy.deepcopy / pickle must see them
+    -- a copy that restarted Adam's bias correction at step 1 with warm moments would take a different third step."""
+    import copy, pickle
+    from oi_amd.optim import FusedAdam
+    pa, pb = _param_set(2), _param_set(2)
+    oa, ob = FusedAdam(pa, lr=1e-3, betas=(0.5, 0.9)), torch.optim.Adam(pb, lr=1e-3, betas=(0.5, 0.9))
+    g = torch.Generator().manual_seed(4)
+    grads = [[torch.randn(x.shape, generator=g).cuda() for x in pa] for _ in range(3)]
+    for it in range(2):
+        for x, y, gr in zip(pa, pb, grads[it]):
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    oc = copy.deepcopy(oa)
+    od = pickle.loads(pickle.dumps(oa))
+    for o in (oc, od):
+        steps = {float(st["step"]) for st in o.state.values()}
+        assert steps == {2.0}, steps
+    for y, gr in zip(pb, grads[2]):
+        y.grad = gr.clone()
+    ob.step()
+    for o in (oc, od):
+        ps = [p for grp in o.param_groups for p in grp["params"]]
+        for x, gr in zip(ps, grads[2]):
+            x.grad = gr.clone()
+        o.step()
+        for x, y in zip(ps, pb):
+            assert maxdiff(x, y) <= 2e-7 * max(1.0, float(y.abs().max())), (x.shape, maxdiff(x, y))
+
+
+def test_ema_update_matches_reference_rule():
+    """p_ema <- p.lerp(p_ema, beta), buffers copied (src/utils/ema.py:26-32): one oi_multi_lerp launch."""
+    from oi_amd.ema import EMA
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(40, 30), torch.nn.BatchNorm1d(30), torch.nn.Linear(30, 7)).cuda()
+    ema = EMA(m, 0.9)
+    before = [p.clone() for p in ema.module.parameters()]
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn_like(p))
+        m[1].running_mean.add_(1.5)
+    ema.update(0)
+    for pe, b, p in zip(ema.module.parameters(), before, m.parameters()):
+        assert maxdiff(pe, p.detach().lerp(b, 0.9)) <= 2e-7 * max(1.0, float(p.abs().max()))
+    assert maxdiff(ema.module[1].running_mean, m[1].running_mean) == 0.0
 
 
 def test_fused_step_invalidates_packed_weight_images():
