@@ -177,6 +177,24 @@ int oi_gen_rays_light(const float* c2b, const float* kinv, const float* offs, in
  * a8: coarse samples.  z[r][i] = near + (far-near) i/(S-1) (+ (jitter[r]-0.5)*2/S if jitter),
  * pts[r][i] = o + d z.   NeuSRenderer.render, renderer.py:359-373, 391.
  */
+/* Everything a render needs before its first MLP pass, in ONE launch: oi_gen_rays_light + oi_film_params + oi_coarse_samples,
+ * with the pose block passed BY VALUE (no host-to-device copy in front).  Host arrays: b2w / w2b / c2b [B][16] (row-major
+ * 4x4), offs [B][2] (crop offsets, generator.py:262-268), bg [B][3]; B <= OI_PREP_MAX_B.  Device inputs: kinv [3][3],
+ * light_direction [3] (raw parameter; NULL with light_dir NULL), jitter [B R R] or NULL, and oi_film_params' inputs.
+ * Outputs: pose_out [53 B] = b2w [B][16] | w2b [B][16] | c2b [B][16] | offs [B][2] | bg [B][3] (device copies for the pose
+ * loss / compositing), rays_o / rays_d
+ * [B R R][3], near_ / far_ [B R R], light_dir [B][3], z_coarse [B R R][S], pts_coarse [B R R][S][3], w_out / gamma / beta as
+ * oi_film_params.  Results are bit-identical to the three separate entry points (tests/test_gpu_kernels.py). */
+#define OI_PREP_MAX_B 8
+typedef struct oi_prep_params {
+  float b2w[OI_PREP_MAX_B][16], w2b[OI_PREP_MAX_B][16], c2b[OI_PREP_MAX_B][16], offs[OI_PREP_MAX_B][2], bg[OI_PREP_MAX_B][3];
+  int B, R, S, NL;
+  const float *kinv, *light_direction, *jitter;
+  const float *style_w, *style_b, *z, *gw, *gb, *bw, *bb;
+  float *pose_out, *rays_o, *rays_d, *near_, *far_, *light_dir, *z_coarse, *pts_coarse, *w_out, *gamma, *beta;
+} oi_prep_params;
+int oi_prep_render(const oi_prep_params* p, oi_stream_t stream);
+
 int oi_coarse_samples(const float* rays_o, const float* rays_d, const float* near, const float* far,
                       const float* jitter, long long N, int S, float* z, float* pts,
                       oi_stream_t stream);
@@ -193,6 +211,13 @@ int oi_upsample(const float* rays_o, const float* rays_d, const float* z, const 
                 float* z_merged, oi_stream_t stream);
 
 /* a11 when more up-sampling steps follow: merge (z, sdf) with (z_new, sdf_new), ascending in z. */
+/* oi_upsample with merge AND the section mid-points of the merged list (oi_midpoints) in the same launch: the last
+ * up-sampling step of a render.  z_merged [N][Sc+n_new], dists / mid_z [N][Sc+n_new], pts_mid [N][Sc+n_new][3];
+ * last_dist as in oi_midpoints.  Results are bit-identical to oi_upsample followed by oi_midpoints. */
+int oi_upsample_mid(const float* rays_o, const float* rays_d, const float* z, const float* sdf, long long N, int Sc, int n_new,
+                    float inv_s, float* z_new, float* pts_new, float* z_merged, float last_dist, float* dists, float* mid_z,
+                    float* pts_mid, oi_stream_t stream);
+
 int oi_merge_sorted(const float* z, const float* sdf, const float* z_new, const float* sdf_new,
                     long long N, int Sc, int n_new, float* z_out, float* sdf_out, oi_stream_t stream);
 
@@ -256,6 +281,14 @@ typedef struct oi_composite_params {
    * workspace into totals + derived scalars.  (1024 blocks adding onto three addresses with atomics cost more than
    * the rest of the kernel: 37 us vs 16 us at N = 4096.) */
   float* block_partials;
+  /* round 4 (appended: older callers that zero-initialise the struct keep the old behaviour)
+   *   stats16 + stats_ticket: the launch ALSO does oi_render_stats' work -- the last workgroup to finish sums block_partials
+   *     in oi_render_stats' order (bit-identical) and writes out16 to stats16.  stats_ticket: one device word, zero before
+   *     the first launch (the kernel leaves it zero); it must not be shared by launches that may overlap (one per stream).
+   *   image_planar != 0: `image` is written as [B][3][N / B] (the (B, 3, H, W) map itself) instead of [N][3]. */
+  float* stats16;
+  unsigned* stats_ticket;
+  int image_planar;
 } oi_composite_params;
 
 int oi_composite_fwd(const oi_composite_params* p, oi_stream_t stream);

@@ -31,6 +31,51 @@ __device__ __forceinline__ float linspace_at(float start, float end, int n, int 
   return i < n / 2 ? start + step * (float)i : end - step * (float)(n - 1 - i);
 }
 
+// Ray set-up arithmetic shared by the stand-alone kernels and the fused prep_render_kernel.  Floating-point contraction is OFF
+// inside these helpers: left to the compiler, a*b + c becomes an fma in one kernel and a multiply + add in another (it
+// depends on what surrounds the expression after inlining), and "the same expressions" would differ in the last bit.
+struct RayOD {
+  float o[3], d[3], near_, far_;
+};
+__device__ __forceinline__ RayOD make_ray(const float* __restrict__ M /* c2b 4x4 */, const float* __restrict__ kinv, float offx,
+                                          float offy, int R, int x, int y) {
+#pragma clang fp contract(off)
+  RayOD r;
+  // build_rays: pixels = linspace(0,1,R) * recp_size + offset   (generator.py:325-329)
+  const float px = linspace_at(0.f, 1.f, R, x) * (float)R + offx;
+  const float py = linspace_at(0.f, 1.f, R, y) * (float)R + offy;
+  float p[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) p[i] = kinv[i * 3 + 0] * px + kinv[i * 3 + 1] * py + kinv[i * 3 + 2];
+  const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+  p[0] /= nrm;
+  p[1] /= nrm;
+  p[2] /= nrm;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    r.d[i] = M[i * 4 + 0] * p[0] + M[i * 4 + 1] * p[1] + M[i * 4 + 2] * p[2];
+    r.o[i] = M[i * 4 + 3];
+  }
+  // near_far_from_sphere (generator.py:336-342)
+  const float a = r.d[0] * r.d[0] + r.d[1] * r.d[1] + r.d[2] * r.d[2];
+  const float bb = 2.0f * (r.o[0] * r.d[0] + r.o[1] * r.d[1] + r.o[2] * r.d[2]);
+  const float mid = 0.5f * (-bb) / a;
+  r.near_ = mid - 1.0f;
+  r.far_ = mid + 1.0f;
+  return r;
+}
+// coarse sample i of S on [near, far] (+ the per-ray jitter): renderer.py:359-360, 372-373
+__device__ __forceinline__ float coarse_z_at(float nr, float fr, int S, int i, const float* __restrict__ jitter, long long r) {
+#pragma clang fp contract(off)
+  float zv = nr + (fr - nr) * linspace_at(0.f, 1.f, S, i);
+  if (jitter != nullptr) zv = zv + (jitter[r] - 0.5f) * 2.0f / (float)S;
+  return zv;
+}
+__device__ __forceinline__ float along_ray(float o, float d, float z) {
+#pragma clang fp contract(off)
+  return o + d * z;
+}
+
 // ------------------------------------------------------------------------------------------
 // a13 + a14: rays of the object crop
 // ------------------------------------------------------------------------------------------
@@ -52,34 +97,132 @@ __global__ void gen_rays_kernel(const float* __restrict__ c2b, const float* __re
     for (int i = 0; i < 3; ++i)
       light_dir[b * 3 + i] = Wb[i * 4 + 0] * (l0 / ln) + Wb[i * 4 + 1] * (l1 / ln) + Wb[i * 4 + 2] * (l2 / ln);
   }
-  // build_rays: pixels = linspace(0,1,R) * recp_size + offset   (generator.py:325-329)
-  const float px = linspace_at(0.f, 1.f, R, x) * (float)R + offs[b * 2 + 0];
-  const float py = linspace_at(0.f, 1.f, R, y) * (float)R + offs[b * 2 + 1];
-  float p[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) p[i] = kinv[i * 3 + 0] * px + kinv[i * 3 + 1] * py + kinv[i * 3 + 2];
-  const float nrm = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
-  p[0] /= nrm;
-  p[1] /= nrm;
-  p[2] /= nrm;
-  const float* M = c2b + b * 16;
-  float d[3], o[3];
+  const RayOD ry = make_ray(c2b + b * 16, kinv, offs[b * 2 + 0], offs[b * 2 + 1], R, x, y);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    d[i] = M[i * 4 + 0] * p[0] + M[i * 4 + 1] * p[1] + M[i * 4 + 2] * p[2];
-    o[i] = M[i * 4 + 3];
+    rays_d[idx * 3 + i] = ry.d[i];
+    rays_o[idx * 3 + i] = ry.o[i];
   }
+  near_[idx] = ry.near_;
+  far_[idx] = ry.far_;
+}
+
+// ------------------------------------------------------------------------------------------
+// Everything a render needs before its first MLP pass, ONE launch (round 4): the pose block arrives BY VALUE in the kernel
+// arguments (no host-to-device copy on the stream: 4.5 us each on this part), the first workgroups evaluate the style MLP +
+// the FiLM parameters of all layers (a1, a2: film_params_kernel's work), the others generate the crop's rays (a13, a14), their
+// near / far and the coarse samples with their points (a8).  Replaces four dependent launches (copy, oi_gen_rays_light,
+// oi_film_params, oi_coarse_samples) of ~5-10 us each; every value is computed by the same expressions as in those kernels.
+// ------------------------------------------------------------------------------------------
+constexpr int PREP_RAYS = 16;  // rays per ray workgroup (256 threads: 16 rays x S samples written coalesced)
+
+__device__ __forceinline__ void style_film_block(const float* __restrict__ style_w, const float* __restrict__ style_b,
+                                                 const float* __restrict__ z, float* __restrict__ w_out,
+                                                 const float* __restrict__ gw, const float* __restrict__ gb,
+                                                 const float* __restrict__ bw, const float* __restrict__ bb,
+                                                 float* __restrict__ gamma, float* __restrict__ beta, int NL, int e, int l,
+                                                 float (*h)[64]) {
+  // (csrc/mlp.hip film_params_kernel, same operations in the same order; threads >= 128 only keep the barriers)
+  const int t = threadIdx.x;
+  if (z != nullptr) {
+    if (t < 64) h[0][t] = z[e * 64 + t];
+    __syncthreads();
+    int cur = 0;
+    for (int ly = 0; ly < 3; ++ly) {
+      if (t < 64) {
+        const float* wr = style_w + (ly * 64 + t) * 64;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) acc = fmaf(h[cur][k], wr[k], acc);
+        acc += style_b[ly * 64 + t];
+        h[cur ^ 1][t] = acc > 0.f ? acc : 0.2f * acc;
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+    if (t < 64 && l == 0) w_out[e * 64 + t] = h[cur][t];
+    if (cur != 0) {
+      if (t < 64) h[0][t] = h[1][t];
+    }
+    __syncthreads();
+  } else {
+    if (t < 64) h[0][t] = w_out[e * 64 + t];
+    __syncthreads();
+  }
+  if (l < NL && t < 128) {
+    const float* g = gw + ((size_t)l * 128 + t) * 64;
+    const float* b = bw + ((size_t)l * 128 + t) * 64;
+    float ag = 0.f, ab = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) {
+      ag = fmaf(h[0][k], g[k], ag);
+      ab = fmaf(h[0][k], b[k], ab);
+    }
+    gamma[((size_t)e * NL + l) * 128 + t] = 15.0f * (ag + gb[l * 128 + t]) + 30.0f;
+    beta[((size_t)e * NL + l) * 128 + t] = 0.25f * (ab + bb[l * 128 + t]) + 0.0f;
+  }
+}
+
+__global__ void __launch_bounds__(256) prep_render_kernel(const oi_prep_params p) {
+  __shared__ float h[2][64];
+  __shared__ float ray[PREP_RAYS][8];  // o xyz, d xyz, near, far
+  const int nl1 = p.NL > 0 ? p.NL : 1;
+  const int n_film = p.B * nl1;
+  if ((int)blockIdx.x < n_film) {
+    style_film_block(p.style_w, p.style_b, p.z, p.w_out, p.gw, p.gb, p.bw, p.bb, p.gamma, p.beta, p.NL, blockIdx.x / nl1,
+                     blockIdx.x % nl1, h);
+    return;
+  }
+  const int rb = blockIdx.x - n_film, t = threadIdx.x, R = p.R;
+  const long long n = (long long)p.B * R * R;
+  if (rb == 0) {  // the pose block for later consumers (pose loss, compositing): b2w [B][16] | w2b | c2b | offs [B][2] | bg [B][3]
+    const int B = p.B;
+    for (int i = t; i < B * 53; i += 256) {
+      float v;
+      if (i < 16 * B) v = p.b2w[i / 16][i % 16];
+      else if (i < 32 * B) v = p.w2b[(i - 16 * B) / 16][(i - 16 * B) % 16];
+      else if (i < 48 * B) v = p.c2b[(i - 32 * B) / 16][(i - 32 * B) % 16];
+      else if (i < 50 * B) v = p.offs[(i - 48 * B) / 2][(i - 48 * B) % 2];
+      else v = p.bg[(i - 50 * B) / 3][(i - 50 * B) % 3];
+      p.pose_out[i] = v;
+    }
+    if (p.light_dir != nullptr && t < p.B) {  // light direction in each box frame: w2b[:3,:3] (d / |d|)   (lighting.py:62-64, 115-119)
+      const float l0 = p.light_direction[0], l1 = p.light_direction[1], l2 = p.light_direction[2];
+      const float ln = sqrtf(l0 * l0 + l1 * l1 + l2 * l2);
+      const float* Wb = p.w2b[t];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    rays_d[idx * 3 + i] = d[i];
-    rays_o[idx * 3 + i] = o[i];
+      for (int i = 0; i < 3; ++i)
+        p.light_dir[t * 3 + i] = Wb[i * 4 + 0] * (l0 / ln) + Wb[i * 4 + 1] * (l1 / ln) + Wb[i * 4 + 2] * (l2 / ln);
+    }
   }
-  // near_far_from_sphere (generator.py:336-342)
-  const float a = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-  const float bb = 2.0f * (o[0] * d[0] + o[1] * d[1] + o[2] * d[2]);
-  const float mid = 0.5f * (-bb) / a;
-  near_[idx] = mid - 1.0f;
-  far_[idx] = mid + 1.0f;
+  const long long r0 = (long long)rb * PREP_RAYS;
+  if (t < PREP_RAYS && r0 + t < n) {  // gen_rays_kernel's expressions
+    const long long idx = r0 + t;
+    const int x = idx % R, y = (idx / R) % R, b = idx / ((long long)R * R);
+    const RayOD ry = make_ray(p.c2b[b], p.kinv, p.offs[b][0], p.offs[b][1], R, x, y);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      p.rays_d[idx * 3 + i] = ry.d[i];
+      p.rays_o[idx * 3 + i] = ry.o[i];
+      ray[t][i] = ry.o[i];
+      ray[t][3 + i] = ry.d[i];
+    }
+    p.near_[idx] = ray[t][6] = ry.near_;
+    p.far_[idx] = ray[t][7] = ry.far_;
+  }
+  __syncthreads();
+  // coarse_samples_kernel's expressions, 16 rays x S samples, consecutive threads on consecutive samples
+  const int S = p.S;
+  for (int i = t; i < PREP_RAYS * S; i += 256) {
+    const int lr = i / S, k = i % S;
+    const long long r = r0 + lr;
+    if (r >= n) break;
+    const float zv = coarse_z_at(ray[lr][6], ray[lr][7], S, k, p.jitter, r);
+    const long long o_ = r * S + k;
+    p.z_coarse[o_] = zv;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p.pts_coarse[o_ * 3 + c] = along_ray(ray[lr][c], ray[lr][3 + c], zv);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -93,12 +236,10 @@ __global__ void coarse_samples_kernel(const float* __restrict__ rays_o, const fl
   if (idx >= N * S) return;
   const long long r = idx / S;
   const int i = idx % S;
-  const float nr = near_[r], fr = far_[r];
-  float zv = nr + (fr - nr) * linspace_at(0.f, 1.f, S, i);                   // renderer.py:359-360
-  if (jitter != nullptr) zv = zv + (jitter[r] - 0.5f) * 2.0f / (float)S;     // renderer.py:372-373
+  const float zv = coarse_z_at(near_[r], far_[r], S, i, jitter, r);
   z[idx] = zv;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) pts[idx * 3 + k] = rays_o[r * 3 + k] + rays_d[r * 3 + k] * zv;
+  for (int k = 0; k < 3; ++k) pts[idx * 3 + k] = along_ray(rays_o[r * 3 + k], rays_d[r * 3 + k], zv);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -165,7 +306,8 @@ __device__ __forceinline__ float upsample_alpha(const float* zs, const float* ss
 __global__ void __launch_bounds__(256)
 upsample_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ z,
                 const float* __restrict__ sdf, long long N, int Sc, int n_new, float inv_s,
-                float* __restrict__ z_new, float* __restrict__ pts_new, float* __restrict__ z_merged) {
+                float* __restrict__ z_new, float* __restrict__ pts_new, float* __restrict__ z_merged,
+                float last_dist, float* __restrict__ mid_dists, float* __restrict__ mid_z, float* __restrict__ mid_pts) {
   extern __shared__ float smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long long r = (long long)blockIdx.x * RAYS_PER_BLOCK + wave;
@@ -250,9 +392,31 @@ upsample_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays
   __syncthreads();
   // a11: rank merge of the two ascending lists (== cat + sort, renderer.py:187-188)
   const int Tm = Sc + n_new;
-  if (live) {
-    for (int i = lane; i < Sc; i += 64) z_merged[r * Tm + i + count_lt(zn, n_new, zs[i])] = zs[i];
-    for (int jn = lane; jn < n_new; jn += 64) z_merged[r * Tm + jn + count_le(zs, Sc, zn[jn])] = zn[jn];
+  if (mid_dists == nullptr) {
+    if (live) {
+      for (int i = lane; i < Sc; i += 64) z_merged[r * Tm + i + count_lt(zn, n_new, zs[i])] = zs[i];
+      for (int jn = lane; jn < n_new; jn += 64) z_merged[r * Tm + jn + count_le(zs, Sc, zn[jn])] = zn[jn];
+    }
+    return;
+  }
+  // ... and, on the last step, the section mid-points of the merged list in the same launch (midpoints_kernel: renderer.py
+  // :219-235): the merged list is formed in LDS (zm: Tm floats behind the four arrays), every lane then has its neighbour
+  float* zm = smem + RAYS_PER_BLOCK * (3 * Sc + n_new) + wave * Tm;
+  for (int i = lane; i < Sc; i += 64) zm[i + count_lt(zn, n_new, zs[i])] = zs[i];
+  for (int jn = lane; jn < n_new; jn += 64) zm[jn + count_le(zs, Sc, zn[jn])] = zn[jn];
+  __syncthreads();
+  if (!live) return;
+  for (int i = lane; i < Tm; i += 64) {
+    const float zi = zm[i];
+    const float d = i + 1 < Tm ? zm[i + 1] - zi : last_dist;
+    const float m = zi + d * 0.5f;
+    const long long k = r * Tm + i;
+    z_merged[k] = zi;
+    mid_dists[k] = d;
+    mid_z[k] = m;
+    mid_pts[k * 3 + 0] = ox + dx * m;
+    mid_pts[k * 3 + 1] = oy + dy * m;
+    mid_pts[k * 3 + 2] = oz + dz * m;
   }
 }
 
@@ -293,6 +457,47 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z, float e
   x /= n;
   y /= n;
   z /= n;
+}
+
+// Sums the per-block partials of composite_fwd_kernel in a fixed order (256 threads: block-strided partial sums, wave sums,
+// four waves) and derives the scalars the reference gets from ~8 tiny tensor launches:  out[0..3] = reduce4 totals,
+// out[4..7] = ray sums, out[8] = gradient_error = out[0] / (out[1] + 1e-5), out[9] = surface_loss = out[2] / (N T),
+// out[10..12] = means over rays of cdf[:,0], weight_max, weight_sum.  AGENT: the partials were written by other workgroups
+// of the SAME launch (agent-scope loads bypass this CU's L1).
+template <bool AGENT>
+__device__ __forceinline__ void stats_reduce(const float* __restrict__ block_partials, int n_blocks, float n_rays,
+                                             float n_samples, float* __restrict__ out) {
+  __shared__ float sred[4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) {
+    const float* src = block_partials + (size_t)i * 8;
+    if constexpr (AGENT) {
+#pragma unroll
+      for (int t = 0; t < 7; ++t)
+        if (t != 3) s[t] += __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const float4 a = reinterpret_cast<const float4*>(src)[0], b = reinterpret_cast<const float4*>(src)[1];
+      s[0] += a.x; s[1] += a.y; s[2] += a.z;
+      s[4] += b.x; s[5] += b.y; s[6] += b.z;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) s[t] = oi::wave_sum(s[t]);
+  if (lane == 0) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) sred[wave][t] = s[t];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) out[t] = s[t] = sred[0][t] + sred[1][t] + sred[2][t] + sred[3][t];
+  out[8] = s[0] / (s[1] + 1e-5f);
+  out[9] = s[2] / n_samples;
+  out[10] = s[4] / n_rays;
+  out[11] = s[5] / n_rays;
+  out[12] = s[6] / n_rays;
+  out[13] = out[14] = out[15] = 0.f;
 }
 
 __global__ void __launch_bounds__(256)
@@ -406,9 +611,16 @@ composite_fwd_kernel(const oi_composite_params p) {
     if (p.image) {
       const float t = 1.0f - a_wsum;  // generator.py:159
       const float b0 = p.bg ? p.bg[e * 3 + 0] : 0.f, b1 = p.bg ? p.bg[e * 3 + 1] : 0.f, b2 = p.bg ? p.bg[e * 3 + 2] : 0.f;
-      p.image[r * 3] = a_i0 + b0 * t;
-      p.image[r * 3 + 1] = a_i1 + b1 * t;
-      p.image[r * 3 + 2] = a_i2 + b2 * t;
+      if (p.image_planar) {  // [B][3][N / B]: the (B, 3, H, W) map the discriminator reads, no strided-to-contiguous copy
+        const long long hw = p.N / p.B, px_ = r - (long long)e * hw;
+        p.image[((long long)e * 3 + 0) * hw + px_] = a_i0 + b0 * t;
+        p.image[((long long)e * 3 + 1) * hw + px_] = a_i1 + b1 * t;
+        p.image[((long long)e * 3 + 2) * hw + px_] = a_i2 + b2 * t;
+      } else {
+        p.image[r * 3] = a_i0 + b0 * t;
+        p.image[r * 3 + 1] = a_i1 + b1 * t;
+        p.image[r * 3 + 2] = a_i2 + b2 * t;
+      }
     }
     if (p.shading) p.shading[r] = a_sh;
     if (p.normal) { p.normal[r * 3] = a_n0; p.normal[r * 3 + 1] = a_n1; p.normal[r * 3 + 2] = a_n2; }
@@ -436,46 +648,39 @@ composite_fwd_kernel(const oi_composite_params p) {
         // parked per block and summed by render_stats_kernel: 1024 blocks adding onto the same three addresses with
         // atomics cost more than the rest of this kernel (37 us vs 16 us at N = 4096)
         const int slot = threadIdx.x < 3 ? threadIdx.x : threadIdx.x + 1;
-        p.block_partials[(size_t)blockIdx.x * 8 + slot] = v;
+        // (stats16 given: the LAST block to arrive sums the partials in this launch -- the partials then are agent-scope
+        //  write-through stores, which the ticket below may follow once they are acknowledged)
+        if (p.stats16 != nullptr) __hip_atomic_store(p.block_partials + (size_t)blockIdx.x * 8 + slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else p.block_partials[(size_t)blockIdx.x * 8 + slot] = v;
       } else if (threadIdx.x < 3) {
         atomicAdd(p.reduce4 + threadIdx.x, v);
       }
     }
   }
+  if (p.stats16 != nullptr && p.block_partials != nullptr) {
+    // render_stats_kernel's work by the last block of THIS launch (one launch and ~4.5 us less per render).  Hand-off per
+    // MI355X_MICROARCH.md ("valid forms"): write-through (sc1) payload stores -> s_waitcnt vmcnt(0) -> agent-scope ticket;
+    // the last arriver reads the payload with agent-scope (L1-bypassing) loads.  No block waits for another one.
+    __shared__ int is_last;
+    if (wave == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        const unsigned t = __hip_atomic_fetch_add(p.stats_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = t == gridDim.x - 1;
+      }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    stats_reduce<true>(p.block_partials, (int)gridDim.x, (float)p.N, (float)p.N * (float)p.T, p.stats16);
+    if (threadIdx.x == 0) __hip_atomic_store(p.stats_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  }
 }
 
-// Sums the per-block partials of composite_fwd_kernel in a fixed order and derives the scalars the reference gets from
-// ~8 tiny tensor launches:  out[0..3] = reduce4 totals, out[4..7] = ray sums, out[8] = gradient_error =
-// out[0] / (out[1] + 1e-5), out[9] = surface_loss = out[2] / (N T), out[10..12] = means over rays of cdf[:,0],
-// weight_max, weight_sum.
+// stand-alone form of stats_reduce (callers that keep the two launches)
 __global__ void __launch_bounds__(256)
 render_stats_kernel(const float* __restrict__ block_partials, int n_blocks, float n_rays, float n_samples,
                     float* __restrict__ out) {
-  __shared__ float red[4][8];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) {
-    const float4* src = reinterpret_cast<const float4*>(block_partials + (size_t)i * 8);
-    const float4 a = src[0], b = src[1];
-    s[0] += a.x; s[1] += a.y; s[2] += a.z;
-    s[4] += b.x; s[5] += b.y; s[6] += b.z;
-  }
-#pragma unroll
-  for (int t = 0; t < 8; ++t) s[t] = oi::wave_sum(s[t]);
-  if (lane == 0) {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) red[wave][t] = s[t];
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) out[t] = s[t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-  out[8] = s[0] / (s[1] + 1e-5f);
-  out[9] = s[2] / n_samples;
-  out[10] = s[4] / n_rays;
-  out[11] = s[5] / n_rays;
-  out[12] = s[6] / n_rays;
-  out[13] = out[14] = out[15] = 0.f;
+  stats_reduce<false>(block_partials, n_blocks, n_rays, n_samples, out);
 }
 
 }  // namespace
@@ -504,6 +709,21 @@ int oi_gen_rays_light(const float* c2b, const float* kinv, const float* offs, in
   return oi::check_launch("oi_gen_rays_light");
 }
 
+int oi_prep_render(const oi_prep_params* p, oi_stream_t stream) {
+  OI_REQUIRE(p != nullptr, "oi_prep_render: null params");
+  OI_REQUIRE(p->B > 0 && p->B <= OI_PREP_MAX_B && p->R > 0 && p->S > 0 && p->NL >= 0, "oi_prep_render: B=%d (<= %d) R=%d S=%d NL=%d",
+             p->B, OI_PREP_MAX_B, p->R, p->S, p->NL);
+  OI_REQUIRE(p->kinv && p->pose_out && p->rays_o && p->rays_d && p->near_ && p->far_ && p->z_coarse && p->pts_coarse && p->w_out,
+             "oi_prep_render: null pointer");
+  OI_REQUIRE((p->light_dir == nullptr) == (p->light_direction == nullptr), "oi_prep_render: light_dir needs light_direction");
+  OI_REQUIRE(p->NL == 0 || (p->gw && p->gb && p->bw && p->bb && p->gamma && p->beta), "oi_prep_render: null FiLM pointer");
+  OI_REQUIRE(p->z == nullptr || (p->style_w && p->style_b), "oi_prep_render: z given without style weights");
+  const long long n = (long long)p->B * p->R * p->R;
+  const int blocks = p->B * (p->NL > 0 ? p->NL : 1) + (int)oi::cdiv(n, PREP_RAYS);
+  hipLaunchKernelGGL(prep_render_kernel, dim3(blocks), dim3(256), 0, oi::as_stream(stream), *p);
+  return oi::check_launch("oi_prep_render");
+}
+
 int oi_coarse_samples(const float* rays_o, const float* rays_d, const float* near_, const float* far_,
                       const float* jitter, long long N, int S, float* z, float* pts, oi_stream_t stream) {
   OI_REQUIRE(rays_o && rays_d && near_ && far_ && z && pts, "oi_coarse_samples: null pointer");
@@ -529,8 +749,22 @@ int oi_upsample(const float* rays_o, const float* rays_d, const float* z, const 
   OI_REQUIRE(Sc <= MAX_SC && n_new <= MAX_SC, "oi_upsample: at most %d samples per ray", MAX_SC);
   const size_t sh = (size_t)RAYS_PER_BLOCK * (3 * Sc + n_new) * sizeof(float);
   hipLaunchKernelGGL(upsample_kernel, dim3(oi::cdiv(N, RAYS_PER_BLOCK)), dim3(256), sh, oi::as_stream(stream), rays_o,
-                     rays_d, z, sdf, N, Sc, n_new, inv_s, z_new, pts_new, z_merged);
+                     rays_d, z, sdf, N, Sc, n_new, inv_s, z_new, pts_new, z_merged, 0.f, nullptr, nullptr, nullptr);
   return oi::check_launch("oi_upsample");
+}
+
+int oi_upsample_mid(const float* rays_o, const float* rays_d, const float* z, const float* sdf, long long N, int Sc, int n_new,
+                    float inv_s, float* z_new, float* pts_new, float* z_merged, float last_dist, float* dists, float* mid_z,
+                    float* pts_mid, oi_stream_t stream) {
+  OI_REQUIRE(rays_o && rays_d && z && sdf && z_new && pts_new && z_merged && dists && mid_z && pts_mid, "oi_upsample_mid: null pointer");
+  OI_REQUIRE(N > 0 && Sc >= 2 && n_new > 0, "oi_upsample_mid: N=%lld Sc=%d n_new=%d", N, Sc, n_new);
+  OI_REQUIRE(Sc <= MAX_SC && n_new <= MAX_SC, "oi_upsample_mid: at most %d samples per ray", MAX_SC);
+  const size_t sh = (size_t)RAYS_PER_BLOCK * (3 * Sc + n_new + Sc + n_new) * sizeof(float);  // + the merged list
+  auto k = upsample_kernel;
+  if (sh > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  hipLaunchKernelGGL(k, dim3(oi::cdiv(N, RAYS_PER_BLOCK)), dim3(256), sh, oi::as_stream(stream), rays_o, rays_d, z, sdf, N, Sc,
+                     n_new, inv_s, z_new, pts_new, z_merged, last_dist, dists, mid_z, pts_mid);
+  return oi::check_launch("oi_upsample_mid");
 }
 
 int oi_merge_sorted(const float* z, const float* sdf, const float* z_new, const float* sdf_new, long long N, int Sc,
@@ -551,6 +785,8 @@ int oi_composite_fwd(const oi_composite_params* p, oi_stream_t stream) {
              "oi_composite_fwd: null input pointer");
   OI_REQUIRE(p->N > 0 && p->T > 0 && p->B > 0 && p->N % p->B == 0, "oi_composite_fwd: N=%lld T=%d B=%d", p->N, p->T,
              p->B);
+  OI_REQUIRE(p->stats16 == nullptr || (p->stats_ticket != nullptr && p->block_partials != nullptr),
+             "oi_composite_fwd: stats16 needs stats_ticket (one zero-initialised word) and block_partials");
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(oi::cdiv(p->N, RAYS_PER_BLOCK)), dim3(256), 0, oi::as_stream(stream),
                      *p);
   return oi::check_launch("oi_composite_fwd");

@@ -106,11 +106,13 @@ def sdf_mlp(pack, pts, gamma, beta, B, want_grad, want_rgb, want_feat, scratch=N
 # ------------------------------------------------------------------------------------------
 
 def composite(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light, cos_anneal_ratio, B,
-              outputs=None):
+              outputs=None, image_planar=False):
+    """`image_planar` applies to the no-grad path only (the backward kernel reads gradients of the (N, 3) form): callers
+    check the shape they get back."""
     if _needs_grad(sdf, grad, rgb, variance, light, light_dir):
         from .autograd_render import CompositeFunction
         return CompositeFunction.run(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light,
                                      cos_anneal_ratio, B, outputs)
     with torch.no_grad():
         return ops.composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light,
-                                 cos_anneal_ratio, B, outputs)
+                                 cos_anneal_ratio, B, outputs, image_planar=image_planar)

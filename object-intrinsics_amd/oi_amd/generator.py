@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from . import ops
 from .config import build_from_config
+from .lib import PREP_MAX_B
 from .renderer import assemble_render_dict
 
 import weakref
@@ -115,28 +116,62 @@ class Generator(nn.Module):
         else:
             # Poses come from the host RNG: do the 4x4 algebra that depends only on them (rigid inverse, camera-to-box,
             # crop offsets; ~20 tiny device kernels in the reference) on the host in fp32 and ship ONE staged buffer.
-            b2w_h = np.ascontiguousarray(self.pose_prior(bs), dtype=np.float32)
-            cam = self._camera_host()
-            Rt = b2w_h[:, :3, :3].transpose(0, 2, 1)
-            w2b_h = np.zeros_like(b2w_h)
-            w2b_h[:, :3, :3] = Rt
-            w2b_h[:, :3, 3:4] = -(Rt @ b2w_h[:, :3, 3:4])
-            w2b_h[:, 3, 3] = 1.0
-            c2b_h = w2b_h @ cam["c2w"]
-            xy_h = self._crop_offsets_host(b2w_h, cam)
-            # the background colour is the next numpy draw of the forward (generator.py:161): same order, same upload
-            bg_h = None if "bg_color" in data else np.asarray(self.bg_color(bs), dtype=np.float32)
+            b2w_h, w2b_h, c2b_h, xy_h, bg_h = self._sample_prior_host(bs, data)
             parts = [b2w_h.ravel(), w2b_h.ravel(), c2b_h.ravel(), xy_h.ravel()] + ([] if bg_h is None else [bg_h.ravel()])
-            flat = self._h2d(np.concatenate(parts))
-            n = bs * 16
-            b2w, w2b, c2b = flat[:n].view(bs, 4, 4), flat[n:2 * n].view(bs, 4, 4), flat[2 * n:3 * n].view(bs, 4, 4)
-            self._xy_off = flat[3 * n:3 * n + 2 * bs].view(bs, 2)
-            self._bg_dev = None if bg_h is None else flat[3 * n + 2 * bs:].view(bs, 3)
-            return {"c2b": c2b, "b2w": b2w, "w2b": w2b, "light": self.light.batch_transform(w2b=w2b)}
+            return self._prior_from_flat(self._h2d(np.concatenate(parts)), bs, bg_h is not None)
         self._xy_off = self._bg_dev = None
         w2b = invert_rot_t(b2w)
         c2b = torch.einsum("bij,jk->bik", w2b, self.camera.c2w)
         return {"c2b": c2b, "b2w": b2w, "w2b": w2b, "light": self.light.batch_transform(w2b=w2b)}
+
+    def _sample_prior_host(self, bs, data):
+        """The host half of sample_prior: poses from the numpy RNG and the 4x4 algebra that depends only on them."""
+        b2w_h = np.ascontiguousarray(self.pose_prior(bs), dtype=np.float32)
+        cam = self._camera_host()
+        Rt = b2w_h[:, :3, :3].transpose(0, 2, 1)
+        w2b_h = np.zeros_like(b2w_h)
+        w2b_h[:, :3, :3] = Rt
+        w2b_h[:, :3, 3:4] = -(Rt @ b2w_h[:, :3, 3:4])
+        w2b_h[:, 3, 3] = 1.0
+        c2b_h = w2b_h @ cam["c2w"]
+        xy_h = self._crop_offsets_host(b2w_h, cam)
+        # the background colour is the next numpy draw of the forward (generator.py:161): same order, same upload
+        bg_h = None if "bg_color" in data else np.asarray(self.bg_color(bs), dtype=np.float32)
+        return b2w_h, w2b_h, c2b_h, xy_h, bg_h
+
+    def _prior_from_flat(self, flat, bs, has_bg):
+        """Views of the device pose block  b2w [bs][16] | w2b | c2b | offs [bs][2] | bg [bs][3]  -> prior_info."""
+        n = bs * 16
+        b2w, w2b, c2b = flat[:n].view(bs, 4, 4), flat[n:2 * n].view(bs, 4, 4), flat[2 * n:3 * n].view(bs, 4, 4)
+        self._xy_off = flat[3 * n:3 * n + 2 * bs].view(bs, 2)
+        self._bg_dev = flat[3 * n + 2 * bs:3 * n + 5 * bs].view(bs, 3) if has_bg else None
+        return {"c2b": c2b, "b2w": b2w, "w2b": w2b, "light": self.light.batch_transform(w2b=w2b)}
+
+    def _kinv(self, dev):
+        ki = self.camera.intrinsics_inv
+        kkey = (ki.data_ptr(), ki._version)
+        kinv = getattr(self, "_kinv33", None)
+        if kinv is None or kinv.device != dev or getattr(self, "_kinv33_key", None) != kkey:
+            kinv, self._kinv33_key = ki[:3, :3].contiguous(), kkey
+            self._kinv33 = kinv
+        return kinv
+
+    def _prep_fused(self, bs, data):
+        """No-grad forward with host-sampled poses: pose upload, rays, light direction, style MLP + FiLM parameters and the
+        coarse samples in ONE launch (ops.prep_render); the torch draws keep their order (latent, then the per-ray jitter).
+        -> (prior, latent, rays, film, coarse)"""
+        dev = self.it.device
+        b2w_h, w2b_h, c2b_h, xy_h, bg_h = self._sample_prior_host(bs, data)
+        latent = self.sample_latent(bs, data)
+        R, S = self.resolution, self.renderer.n_samples
+        perturb = self.renderer.perturb if self.training else 0
+        jitter = torch.rand([bs * R * R, 1], device=dev) if perturb > 0 else None   # renderer.py:372
+        pre = ops.prep_render(b2w_h, w2b_h, c2b_h, xy_h, bg_h, self._kinv(dev), R, S, jitter, self.light.param_direction,
+                              self.renderer.pack.film_stacked(differentiable=False), latent["z"])
+        prior = self._prior_from_flat(pre["pose"], bs, True)
+        rays = {"x_offset": self._xy_off[:, 0], "y_offset": self._xy_off[:, 1], "light_dir": pre["light_dir"],
+                "rays_o": pre["rays_o"], "rays_d": pre["rays_d"], "near": pre["near"], "far": pre["far"]}
+        return prior, latent, rays, (pre["w"], pre["gamma"], pre["beta"]), (pre["z_coarse"], pre["pts_coarse"])
 
     def _camera_host(self):
         # host copies of the camera buffers, keyed on (address, version) of the device buffers: load_state_dict / .to()
@@ -178,12 +213,7 @@ class Generator(nn.Module):
             cy = self.camera.cam_dist / b2c_t[..., 2] * b2c_t[..., 1] * R / 2 + 0.5 * self.scene_resolution
             xy = torch.stack([cx - R / 2, cy - R / 2], -1)
         x_off, y_off = xy[:, 0], xy[:, 1]
-        ki = self.camera.intrinsics_inv
-        kkey = (ki.data_ptr(), ki._version)
-        kinv = getattr(self, "_kinv33", None)
-        if kinv is None or kinv.device != b2w.device or getattr(self, "_kinv33_key", None) != kkey:
-            kinv, self._kinv33_key = ki[:3, :3].contiguous(), kkey
-            self._kinv33 = kinv
+        kinv = self._kinv(b2w.device)
         out = {"x_offset": x_off, "y_offset": y_off}
         if with_light:
             ro, rd, near, far, out["light_dir"] = ops.gen_rays(prior_info["c2b"], kinv, xy, R, w2b=prior_info["w2b"],
@@ -199,13 +229,20 @@ class Generator(nn.Module):
             it = self.iteration()
         if int(it) != self.iteration():
             self._it_host, self._it_dirty = int(it), True
-        prior = self.sample_prior(bs, data)
-        latent = self.sample_latent(bs, data)
-        # the light direction needs the tensor path only when a gradient has to reach param_direction
-        grad_light = torch.is_grad_enabled() and self.light.param_direction.requires_grad
-        rays = self.gen_rays_at(data, prior, with_light=not grad_light)
         h = w = self.resolution
         n_rays = bs * h * w
+        film = coarse = None
+        fused = (not torch.is_grad_enabled() and self.it.is_cuda and bs <= PREP_MAX_B and bs * h * w <= MAX_RAY_BATCH_SIZE
+                 and not any(k in data for k in ("b2w", "z", "w", "bg_color")))
+        if fused:
+            prior, latent, rays, film, coarse = self._prep_fused(bs, data)
+            grad_light = False
+        else:
+            prior = self.sample_prior(bs, data)
+            latent = self.sample_latent(bs, data)
+            # the light direction needs the tensor path only when a gradient has to reach param_direction
+            grad_light = torch.is_grad_enabled() and self.light.param_direction.requires_grad
+            rays = self.gen_rays_at(data, prior, with_light=not grad_light)
         cos_anneal_ratio = min(1.0, self._it_host / self.anneal_end)
         # "bg_color": optional (bs, 3) device tensor -- an extension used by the HIP-graph wrapper (oi_amd.graphed), whose
         # inputs must live at fixed device addresses; the reference always draws it from numpy (generator.py:161)
@@ -230,7 +267,8 @@ class Generator(nn.Module):
         if n_chunks > 1:
             assert not self.training, (n_rays, chunk)
         # style MLP (generator.py:235-238) + FiLM parameters of all 9 layers: ONE launch, shared by every chunk
-        film = self.renderer.pack.film(z=None if "w" in latent else latent["z"], w=latent.get("w"))
+        if film is None:
+            film = self.renderer.pack.film(z=None if "w" in latent else latent["z"], w=latent.get("w"))
         latent["w"] = film[0]
         outs = []
         for ci in range(n_chunks):
@@ -239,7 +277,8 @@ class Generator(nn.Module):
             s, c = self.renderer.render_full(flat(ro_all), flat(rd_all), flat(near_all), flat(far_all),
                                              perturb_overwrite=-1 if self.training else 0,
                                              cos_anneal_ratio=cos_anneal_ratio, z=latent["z"], w=latent["w"],
-                                             light=lpk, light_dir=ldir, bg=bg, film=film)
+                                             light=lpk, light_dir=ldir, bg=bg, film=film, coarse=coarse,
+                                             image_planar=(n_chunks == 1 and not torch.is_grad_enabled()))
             outs.append((s, c))
         if n_chunks == 1:
             s, c = outs[0]
@@ -257,6 +296,8 @@ class Generator(nn.Module):
             render_out["surface_loss"] = None
 
         def to_map(x):
+            if x.dim() == 3:  # the compositing kernel wrote the (bs, 3, h * w) map itself (no-grad path: `image`)
+                return x.view(bs, -1, h, w)
             return x.reshape(bs, h, w, -1).permute(0, 3, 1, 2)
 
         new = {

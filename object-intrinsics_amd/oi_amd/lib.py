@@ -27,7 +27,21 @@ class CompositeParams(ctypes.Structure):
                 [("cos_anneal_ratio", _f), ("N", _ll), ("T", _i), ("B", _i)] +
                 [(n, _vp) for n in ("weights", "cdf", "alpha", "inside_sphere", "pts_norm", "weight_sum", "weight_max",
                                     "color_fine", "image_no_bg", "image", "shading", "normal", "mask", "z_map",
-                                    "specular_map", "diffuse_map", "reduce4", "block_partials")])
+                                    "specular_map", "diffuse_map", "reduce4", "block_partials", "stats16", "stats_ticket")] +
+                [("image_planar", _i)])
+
+
+PREP_MAX_B = 8
+
+
+class PrepParams(ctypes.Structure):
+    """Mirror of `oi_prep_params` (include/oi_hip.h)."""
+    _fields_ = ([(n, (_f * 16) * PREP_MAX_B) for n in ("b2w", "w2b", "c2b")] +
+                [("offs", (_f * 2) * PREP_MAX_B), ("bg", (_f * 3) * PREP_MAX_B)] +
+                [(n, _i) for n in ("B", "R", "S", "NL")] +
+                [(n, _vp) for n in ("kinv", "light_direction", "jitter", "style_w", "style_b", "z", "gw", "gb", "bw", "bb",
+                                    "pose_out", "rays_o", "rays_d", "near_", "far_", "light_dir", "z_coarse", "pts_coarse",
+                                    "w_out", "gamma", "beta")])
 
 
 class CompositeGrads(ctypes.Structure):
@@ -61,7 +75,9 @@ _SIGS = {
     "oi_gen_rays": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "oi_gen_rays_light": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "oi_coarse_samples": (_i, [_vp] * 5 + [_ll, _i, _vp, _vp, _vp]),
+    "oi_prep_render": (_i, [_vp, _vp]),
     "oi_upsample": (_i, [_vp] * 4 + [_ll, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "oi_upsample_mid": (_i, [_vp] * 4 + [_ll, _i, _i, _f, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "oi_merge_sorted": (_i, [_vp] * 4 + [_ll, _i, _i, _vp, _vp, _vp]),
     "oi_midpoints": (_i, [_vp] * 3 + [_ll, _i, _f, _vp, _vp, _vp, _vp]),
     "oi_composite_fwd": (_i, [ctypes.POINTER(CompositeParams), _vp]),

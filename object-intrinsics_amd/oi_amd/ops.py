@@ -6,6 +6,7 @@ Autograd structure lives in `oi_amd.autograd`."""
 import ctypes
 import os
 
+import numpy as np
 import torch
 
 from . import lib as _l
@@ -144,6 +145,36 @@ def film_params(style_w, style_b, gw, gb, bw, bb, z=None, w=None):
     return w_out, gamma, beta
 
 
+def prep_render(b2w, w2b, c2b, offs, bg, kinv, R, S, jitter, light_direction, film_P, z):
+    """ONE launch for everything a render needs before its first MLP pass (oi_prep_render): the pose block (numpy, host) goes
+    BY VALUE in the kernel arguments; rays, near / far, light direction, coarse samples + points and the style MLP + FiLM
+    parameters come back.  -> dict(pose (53 B: b2w | w2b | c2b | offs | bg blocks), rays_o, rays_d, near, far, light_dir, z_coarse, pts_coarse, w, gamma, beta)."""
+    L = _l.load()
+    B = b2w.shape[0]
+    assert B <= _l.PREP_MAX_B and z is not None
+    dev = z.device
+    P = _l.PrepParams()
+    for name, arr, n in (("b2w", b2w, 16), ("w2b", w2b, 16), ("c2b", c2b, 16), ("offs", offs, 2), ("bg", bg, 3)):
+        a = np.ascontiguousarray(arr, dtype=np.float32).reshape(B, n)
+        dst = np.frombuffer(getattr(P, name), dtype=np.float32).reshape(_l.PREP_MAX_B, n)
+        dst[:B] = a
+    NL = film_P["gw"].shape[0]
+    N = B * R * R
+    f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    out = {"pose": f(B * 53), "rays_o": f(B, R, R, 3), "rays_d": f(B, R, R, 3), "near": f(N, 1), "far": f(N, 1),
+           "light_dir": f(B, 3), "z_coarse": f(N, S), "pts_coarse": f(N, S, 3), "w": f(B, 64), "gamma": f(B, NL, 128),
+           "beta": f(B, NL, 128)}
+    P.B, P.R, P.S, P.NL = B, int(R), int(S), NL
+    keep = [_c(kinv), _c(light_direction), _c(jitter), _c(z)] + [_c(film_P[k]) for k in ("style_w", "style_b", "gw", "gb", "bw", "bb")]
+    P.kinv, P.light_direction, P.jitter, P.z = (_p(t) for t in keep[:4])
+    P.style_w, P.style_b, P.gw, P.gb, P.bw, P.bb = (_p(t) for t in keep[4:])
+    P.pose_out, P.rays_o, P.rays_d, P.near_, P.far_ = (_p(out[k]) for k in ("pose", "rays_o", "rays_d", "near", "far"))
+    P.light_dir, P.z_coarse, P.pts_coarse = _p(out["light_dir"]), _p(out["z_coarse"]), _p(out["pts_coarse"])
+    P.w_out, P.gamma, P.beta = _p(out["w"]), _p(out["gamma"]), _p(out["beta"])
+    _l.check(L.oi_prep_render(ctypes.byref(P), _stream()), "oi_prep_render")
+    return out
+
+
 def film_params_bwd(d_gamma, d_beta, w, gw, bw, style_w=None, style_b=None, z=None, d_w_in=None, want_dz=False):
     """Backward of film_params -> dict(d_gw, d_gb, d_bw, d_bb, d_w [, d_style_w, d_style_b, d_z])."""
     L = _l.load()
@@ -268,10 +299,19 @@ def coarse_samples(rays_o, rays_d, near, far, S, jitter=None):
     return z, pts
 
 
-def upsample(rays_o, rays_d, z, sdf, n_new, inv_s, merge=True):
+def upsample(rays_o, rays_d, z, sdf, n_new, inv_s, merge=True, mid_last_dist=None):
+    """-> z_new, pts_new, z_merged [, (dists, mid_z, pts_mid) when `mid_last_dist` is given: the section mid-points of the
+    merged list from the same launch (oi_upsample_mid = oi_upsample + oi_midpoints, bit-identical)]."""
     L = _l.load()
     N, Sc = z.shape
     z_new, pts_new = _new(z, N, n_new), _new(z, N, n_new, 3)
+    if mid_last_dist is not None:
+        T = Sc + n_new
+        z_merged, dists, mid_z, pts = _new(z, N, T), _new(z, N, T), _new(z, N, T), _new(z, N, T, 3)
+        _l.check(L.oi_upsample_mid(_p(_c(rays_o)), _p(_c(rays_d)), _p(_c(z)), _p(_c(sdf)), N, Sc, n_new, float(inv_s),
+                                   _p(z_new), _p(pts_new), _p(z_merged), float(mid_last_dist), _p(dists), _p(mid_z), _p(pts),
+                                   _stream()), "oi_upsample_mid")
+        return z_new, pts_new, z_merged, (dists, mid_z, pts)
     z_merged = _new(z, N, Sc + n_new) if merge else None
     _l.check(L.oi_upsample(_p(_c(rays_o)), _p(_c(rays_d)), _p(_c(z)), _p(_c(sdf)), N, Sc, n_new, float(inv_s),
                            _p(z_new), _p(pts_new), _p(z_merged), _stream()), "oi_upsample")
@@ -302,11 +342,26 @@ PER_RAY_OUT = {"weight_sum": 1, "weight_max": 1, "color_fine": 3, "image_no_bg":
                "normal": 3, "mask": 1, "z_map": 1, "specular_map": 1, "diffuse_map": 1}
 
 
+_STATS_TICKETS = {}
+FUSED_STATS = True   # oi_composite_fwd also does oi_render_stats' work (its last workgroup); False: two launches
+
+
+def _stats_ticket(dev):
+    """One zero-initialised device word per (device, stream): the arrival counter of the compositing launch's last-block
+    reduction (the kernel leaves it at zero; launches that may overlap must not share one)."""
+    key = (dev, _stream().value or 0)
+    t = _STATS_TICKETS.get(key)
+    if t is None:
+        t = _STATS_TICKETS[key] = torch.zeros(4, dtype=torch.int32, device=dev)
+    return t
+
+
 def composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light, cos_anneal_ratio,
-                  B, outputs=None):
+                  B, outputs=None, image_planar=False):
     """Returns dict of requested outputs (default: all) + 'reduce4' = [sum m*(|g|-1)^2, sum m, sum exp(-100|sdf|), 0].
-    With 'reduce4' come two forward-only extras from the same reduction launch (oi_render_stats): 'ray_sums'
-    = [sum cdf[:,0], sum weight_max, sum weight_sum, 0] and 'finals' = [gradient_error, surface_loss, the three means]."""
+    With 'reduce4' come two forward-only extras from the SAME launch (its last workgroup does oi_render_stats' sums):
+    'ray_sums' = [sum cdf[:,0], sum weight_max, sum weight_sum, 0] and 'finals' = [gradient_error, surface_loss, the three
+    means].  `image_planar`: 'image' comes back as (B, 3, N / B) -- the (B, 3, H, W) map itself -- instead of (N, 3)."""
     L = _l.load()
     N, T = dists.shape
     P = _l.CompositeParams()
@@ -327,17 +382,22 @@ def composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, v
         setattr(P, name, _p(out.get(name)))
     for name, c in PER_RAY_OUT.items():
         if name in want:
-            out[name] = _new(dists, N, c)
+            out[name] = _new(dists, B, 3, N // B) if (name == "image" and image_planar) else _new(dists, N, c)
         setattr(P, name, _p(out.get(name)))
-    partials = None
-    if "reduce4" in want:  # per-block partial sums (no atomics), reduced below
+    P.image_planar = int(bool(image_planar))
+    partials = out16 = None
+    if "reduce4" in want:  # per-block partial sums (no atomics), reduced by the launch's last workgroup in a fixed order
         partials = _new(dists, L.oi_composite_num_blocks(N), 8)
+        out16 = _new(dists, 16)
+        if FUSED_STATS:
+            ticket = _stats_ticket(dists.device)
+            P.stats16, P.stats_ticket = _p(out16), _vp(ticket.data_ptr())
     P.reduce4 = None
     P.block_partials = _p(partials)
     _l.check(L.oi_composite_fwd(ctypes.byref(P), _stream()), "oi_composite_fwd")
     if partials is not None:
-        out16 = _new(dists, 16)
-        _l.check(L.oi_render_stats(_p(partials), partials.shape[0], N, T, _p(out16), _stream()), "oi_render_stats")
+        if not FUSED_STATS:  # the two-launch form (kept as the yardstick of tests/test_gpu_kernels.py)
+            _l.check(L.oi_render_stats(_p(partials), partials.shape[0], N, T, _p(out16), _stream()), "oi_render_stats")
         out["reduce4"], out["ray_sums"], out["finals"] = out16[0:4], out16[4:8], out16[8:13]
     return out
 

@@ -33,27 +33,35 @@ class NeuSRenderer:
         self.pack = FieldPack(sdf_network, color_network, precision, fast_trig)
 
     # -- stages -----------------------------------------------------------------------------
-    def sample_z(self, rays_o, rays_d, near, far, gamma, beta, B, perturb):
-        """Hierarchical sampling (no grad, as in the reference: renderer.py:390, 180).  -> z (N, S+I)."""
+    def sample_z(self, rays_o, rays_d, near, far, gamma, beta, B, perturb, with_mid=False, coarse=None):
+        """Hierarchical sampling (no grad, as in the reference: renderer.py:390, 180).  -> z (N, S+I) [, (dists, mid_z, pts):
+        the section mid-points, which the last up-sampling launch produces as well (None when there is no such launch)]."""
         S, I, K = self.n_samples, self.n_importance, self.up_sample_steps
         N = rays_o.shape[0]
+        mid = None
         with torch.no_grad():
-            jitter = torch.rand([N, 1], device=rays_o.device) if perturb > 0 else None  # renderer.py:372
-            z, pts = ops.coarse_samples(rays_o, rays_d, near, far, S, jitter)
+            if coarse is not None:   # (z, pts) of the coarse samples from the caller's fused launch (jitter already drawn)
+                z, pts = coarse
+            else:
+                jitter = torch.rand([N, 1], device=rays_o.device) if perturb > 0 else None  # renderer.py:372
+                z, pts = ops.coarse_samples(rays_o, rays_d, near, far, S, jitter)
             if I > 0:
                 sdf = sdf_mlp(self.pack, pts.view(-1, 3), gamma, beta, B, False, False, False)[0].view(N, S)
                 for i in range(K):
                     last = i + 1 == K
+                    if last and with_mid:
+                        _, _, z, mid = ops.upsample(rays_o, rays_d, z, sdf, I // K, 64.0 * 2 ** i, mid_last_dist=2.0 / S)
+                        break
                     z_new, pts_new, z_merged = ops.upsample(rays_o, rays_d, z, sdf, I // K, 64.0 * 2 ** i, merge=last)
                     if last:
                         z = z_merged
                     else:
                         sdf_new = sdf_mlp(self.pack, pts_new.view(-1, 3), gamma, beta, B, False, False, False)[0]
                         z, sdf = ops.merge_sorted(z, sdf, z_new, sdf_new.view(N, -1))
-        return z
+        return (z, mid) if with_mid else z
 
     def render_full(self, rays_o, rays_d, near, far, perturb_overwrite=-1, cos_anneal_ratio=0.0, z=None, w=None,
-                    light=None, light_dir=None, bg=None, outputs=None, film=None):
+                    light=None, light_dir=None, bg=None, outputs=None, film=None, image_planar=False, coarse=None):
         """Shared implementation: returns (per-sample/per-ray dict, composite dict)."""
         from .autograd import composite
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
@@ -67,17 +75,22 @@ class NeuSRenderer:
             raise ValueError(f"NeuSRenderer.render: {N} rays cannot be split over {B} latent codes (rows of one batch "
                              "element are contiguous, fields.py:55)")
         perturb = self.perturb if perturb_overwrite < 0 else perturb_overwrite
-        zv = self.sample_z(rays_o, rays_d, near, far, gamma.detach(), beta.detach(), B, perturb)
+        zv, mid = self.sample_z(rays_o, rays_d, near, far, gamma.detach(), beta.detach(), B, perturb, with_mid=True,
+                                 coarse=coarse)
         T = zv.shape[1]
-        with torch.no_grad():
-            dists, mid_z, pts = ops.midpoints(rays_o, rays_d, zv, 2.0 / self.n_samples)
+        if mid is not None:
+            dists, mid_z, pts = mid
+        else:  # no importance samples: the coarse list itself
+            with torch.no_grad():
+                dists, mid_z, pts = ops.midpoints(rays_o, rays_d, zv, 2.0 / self.n_samples)
         sdf, grad, rgb, _ = sdf_mlp(self.pack, pts.view(-1, 3), gamma, beta, B, True, True, False)
         dev = rays_o.device
         if light is None:
             light = torch.tensor([0.0, 0.0, 1.0], device=dev)
             light_dir = torch.tensor([[0.0, 0.0, -1.0]], device=dev).expand(B, 3)
         comp = composite(sdf.view(N, T), grad.view(N, T, 3), rgb.view(N, T, 3), dists, mid_z, rays_o, rays_d,
-                         light_dir, bg, self.deviation_network.variance, light, cos_anneal_ratio, B, outputs)
+                         light_dir, bg, self.deviation_network.variance, light, cos_anneal_ratio, B, outputs,
+                         image_planar=image_planar)
         samples = {"sdf": sdf.view(N, T), "gradients": grad.view(N, T, 3), "raw_color": rgb.view(N, T, 3),
                    "mid_z_vals": mid_z, "pts": pts, "dists": dists, "z_vals": zv}
         return samples, comp

@@ -768,3 +768,55 @@ def test_prezeroed_declaration_is_per_stream(ops):
         assert err < 2e-5, (k, err)
     # the declaration is gone with the pool
     assert L.oi_outputs_prezeroed_stream(ops._vp(s_main.cuda_stream), 0) == 0
+
+
+# ---------------------------------------------------------------- round 4: fused small launches are bit-identical to the chains
+def _ray_batch(N, seed):
+    g = torch.Generator().manual_seed(seed)
+    ro = torch.tensor([0.0, 0.0, -3.0]).expand(N, 3) + 0.05 * torch.randn(N, 3, generator=g)
+    rd = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + 0.15 * torch.randn(N, 3, generator=g), dim=-1)
+    near, far = O.near_far_from_sphere(ro, rd)
+    return ro.cuda().contiguous(), rd.cuda().contiguous(), near.cuda(), far.cuda(), g
+
+
+@pytest.mark.parametrize("N,Sc,n_new", [(1, 16, 16), (37, 64, 64), (130, 40, 96), (64, 112, 16)])
+def test_upsample_mid_matches_upsample_then_midpoints(ops, N, Sc, n_new):
+    """oi_upsample_mid (the render's last up-sampling step + the section mid-points in one launch) against oi_upsample
+    followed by oi_midpoints: every output bit for bit, ragged ray counts, n_new > Sc included."""
+    ro, rd, near, far, g = _ray_batch(N, N + Sc)
+    z, _ = ops.coarse_samples(ro, rd, near, far, Sc, torch.rand(N, 1, generator=g).cuda())
+    sdf = (torch.rand(N, Sc, generator=g) - 0.4).cumsum(-1).neg().add(2.0).cuda() * 0.1
+    zn_a, pn_a, zm_a = ops.upsample(ro, rd, z, sdf, n_new, 64.0, merge=True)
+    d_a, m_a, p_a = ops.midpoints(ro, rd, zm_a, 2.0 / Sc)
+    zn_b, pn_b, zm_b, (d_b, m_b, p_b) = ops.upsample(ro, rd, z, sdf, n_new, 64.0, mid_last_dist=2.0 / Sc)
+    for a, b in ((zn_a, zn_b), (pn_a, pn_b), (zm_a, zm_b), (d_a, d_b), (m_a, m_b), (p_a, p_b)):
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,T", [(3, 16), (4096, 128), (1001, 70)])
+def test_composite_last_block_statistics_match_render_stats(ops, N, T, monkeypatch):
+    """The compositing launch's last workgroup sums the per-block partials itself (agent-scope hand-off inside ONE launch):
+    reduce4 / ray sums / finals bit-identical to the separate oi_render_stats launch, repeatedly (the arrival counter
+    resets itself), and the planar `image` equals the (N, 3) form."""
+    g = torch.Generator().manual_seed(N)
+    B = 1
+    ro, rd, near, far, _ = _ray_batch(N, N)
+    z = torch.sort(near.cpu() + (far - near).cpu() * torch.rand(N, T, generator=g), -1).values.cuda()
+    dists, mid_z, _ = ops.midpoints(ro, rd, z, 2.0 / T)
+    sdf = (1.0 - mid_z + 0.05 * torch.randn(N, T, generator=g).cuda()) * 0.3
+    grad = torch.nn.functional.normalize(torch.randn(N, T, 3, generator=g), dim=-1).cuda() * 1.1
+    rgb = torch.rand(N, T, 3, generator=g).cuda()
+    light = torch.tensor([-0.7, 0.2, 8.0]).cuda()
+    args = (sdf, grad, rgb, dists, mid_z, ro, rd, torch.tensor([[0.2, -0.4, -0.9]]).cuda(), torch.rand(B, 3, generator=g).cuda(),
+            torch.tensor(0.3).cuda(), light, 0.5, B)
+    monkeypatch.setattr(ops, "FUSED_STATS", False)
+    ref = ops.composite_fwd(*args)
+    monkeypatch.setattr(ops, "FUSED_STATS", True)
+    for rep in range(3):
+        out = ops.composite_fwd(*args, image_planar=(rep == 1))
+        torch.cuda.synchronize()
+        for k in ("reduce4", "ray_sums", "finals", "weights", "color_fine", "mask"):
+            assert torch.equal(out[k], ref[k]), (k, rep)
+        img = out["image"] if rep != 1 else out["image"].view(B, 3, N // B).permute(0, 2, 1).reshape(N, 3)
+        assert torch.equal(img, ref["image"]), rep
+    assert int(ops._stats_ticket(sdf.device)[0]) == 0

@@ -245,6 +245,38 @@ def test_generator_golden_f5(precision):
         assert abs(float(blob["stats"][k]) - float(g["stat_" + k.replace("/", "_")])) < 1e-5, k
 
 
+@pytest.mark.parametrize("bs,train", [(1, True), (2, True), (2, False)])
+def test_generator_fused_prep_launch_matches_the_separate_launches(monkeypatch, bs, train):
+    """No-grad forward with host-sampled poses: pose upload + rays + light direction + style MLP / FiLM parameters + coarse
+    samples in ONE launch (oi_prep_render, pose block by value) against the copy + oi_gen_rays_light + oi_film_params +
+    oi_coarse_samples chain: same numpy / torch draws, every map, statistic and pose tensor bit for bit."""
+    import oi_amd.generator as G
+    gen = build_generator(16, 16, 16, 1, "f16x3")
+    gen = gen.train() if train else gen.eval()
+
+    def run(fused):
+        monkeypatch.setattr(G, "PREP_MAX_B", 8 if fused else 0)
+        np.random.seed(5)
+        torch.manual_seed(5)
+        with torch.no_grad():
+            return gen(bs=bs, it=3, data={}, return_raw=True)["box"]
+
+    a, b = run(True), run(False)
+    assert a["render_out"]["image"].is_contiguous()
+    for k in a["render_out"]:
+        assert torch.equal(a["render_out"][k], b["render_out"][k]), k
+    for k in ("c2b", "b2w", "w2b"):
+        assert torch.equal(a["prior_info"][k], b["prior_info"][k]), k
+    for k in ("rays_o", "rays_d", "near", "far", "light_dir", "x_offset", "y_offset"):
+        assert torch.equal(a["rays_info"][k], b["rays_info"][k]), k
+    assert torch.equal(a["latent_info"]["w"], b["latent_info"]["w"]) and torch.equal(a["latent_info"]["z"], b["latent_info"]["z"])
+    for k in ("weights", "mid_z_vals", "sdf", "gradients"):
+        assert torch.equal(a["raw_render_out"][k], b["raw_render_out"][k]), k
+    for k, v in a["stats"].items():
+        assert torch.equal(torch.as_tensor(v), torch.as_tensor(b["stats"][k])), k
+    assert torch.equal(a["loss"]["eikonal"], b["loss"]["eikonal"])
+
+
 def test_generator_multi_chunk_matches_single(monkeypatch):
     """Eval-time ray chunking (generator.py:281-305) does not change the image."""
     import oi_amd.generator as G
@@ -609,7 +641,7 @@ def test_k4_sampling_stage_by_stage_golden_f10(col_sd, S):
                 assert maxdiff(zo.cpu(), g[f"{t}z_after{i}"]) == 0.0
                 assert maxdiff(so.cpu(), g[f"{t}sdf_after{i}"]) < 2e-5
         z_fin = g[f"{t}z_after3"].cuda()
-        r.sample_z = lambda *a, **k: z_fin          # the final stage on the reference's own samples
+        r.sample_z = lambda *a, **k: (z_fin, None) if k.get("with_mid") else z_fin   # the final stage on the reference's own samples
         out = r.render(ro, rd, g["near"].cuda(), g["far"].cuda(), perturb_overwrite=0,
                        cos_anneal_ratio=float(g["cos_anneal_ratio"]), w=w)
     for k in KEYS:
