@@ -474,6 +474,25 @@ int oi_weighted_sum_bwd(const float* g_out, const float* weights, int n, float* 
  * (oi_amd.ops.ZeroPool does this around a captured discriminator step.) */
 int oi_outputs_prezeroed_stream(oi_stream_t stream, int on);
 
+/* First half of oi_ada_geom_fwd alone: canvas [B C][2 (H + my0 + my1)][2 (W + mx0 + mx1)] = reflect pad + x2 up-FIR of x. */
+int oi_ada_pad_up2(const float* x, const float* f, float* canvas, int B, int C, int H, int W, int mx0, int mx1, int my0, int my1,
+                   oi_stream_t stream);
+
+/* Discriminator forward at batch 1-4 in FIVE launches (csrc/disc_small.hip): AugmentPipe's geometric augmentation (given its
+ * sampling matrix theta [B][2][3] and reflect margins, as oi_ada_geom_fwd) + the four 4x4 stride-2 LeakyReLU blocks + the 4x4
+ * head of DCDiscriminator(img_size 64, n_feat 512) -- reference src/models/discriminator.py:57-85, ada/augment.py:284-301.
+ *   x [B][C][64][64];  theta_host: HOST array, passed to the kernel by value (no copy on the stream) | theta_dev: device
+ *   array (captured graphs) | both NULL: no augmentation;  f12: Hz_geom (12 taps);  w1..w4 [Cout][Cin][4][4] (C -> 64 -> 128 ->
+ *   256 -> 512), whead [out_dim][512][4][4], bhead [out_dim] or NULL;  logits [B][out_dim].
+ *   workspace: oi_disc_fwd_small_workspace_floats(...) floats;  ticket: one zero-initialised device word (left zero; not to
+ *   be shared by launches that may overlap).  Fixed summation order: results are bit-reproducible.
+ * OI_ERR_UNSUPPORTED for any other shape (B > 4, other sizes): callers then take the general path. */
+size_t oi_disc_fwd_small_workspace_floats(int B, int C, int mx0, int mx1, int my0, int my1);
+int oi_disc_fwd_small(const float* x, const float* theta_host, const float* theta_dev, const float* f12, int mx0, int mx1, int my0,
+                      int my1, const float* w1, const float* w2, const float* w3, const float* w4, const float* whead,
+                      const float* bhead, float* workspace, unsigned* ticket, float* logits, int B, int C, int H, int W, int n_feat,
+                      int out_dim, float slope, oi_stream_t stream);
+
 /* The whole geometric augmentation of AugmentPipe.forward (src/third_party/ada/augment.py:284-301) for a given sampling
  * grid, in two launches: reflect pad (margins mx0, mx1, my0, my1) + x2 up-FIR | affine bilinear resample + /2 down-FIR.
  *   x [B][C][H][W], theta [B][2][3] (the matrix F.affine_grid receives, augment.py:297), f: the 12 taps of Hz_geom

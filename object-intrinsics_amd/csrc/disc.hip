@@ -681,6 +681,20 @@ ada_resample_down2_kernel(const float* __restrict__ canvas, const float* __restr
 
 extern "C" {
 
+int oi_ada_pad_up2(const float* x, const float* f, float* canvas, int B, int C, int H, int W, int mx0, int mx1, int my0, int my1,
+                   oi_stream_t stream) {
+  OI_REQUIRE(x && f && canvas, "oi_ada_pad_up2: null pointer");
+  OI_REQUIRE(B > 0 && C > 0 && H > 1 && W > 1, "oi_ada_pad_up2: bad shape");
+  OI_REQUIRE(mx0 >= 0 && mx1 >= 0 && my0 >= 0 && my1 >= 0 && mx0 < W && mx1 < W && my0 < H && my1 < H,
+             "oi_ada_pad_up2: reflect margins must be in [0, size)");
+  const long long BC = (long long)B * C;
+  const int Hp = H + my0 + my1, Wp = W + mx0 + mx1;
+  OI_REQUIRE(BC <= 65535 && 2 * Hp <= 65535, "oi_ada_pad_up2: launch grid");
+  hipLaunchKernelGGL(ada_pad_up2_kernel, dim3(oi::cdiv(2 * Wp, ADA_UW), oi::cdiv(2 * Hp, ADA_UH), (unsigned)BC), dim3(256), 0,
+                     oi::as_stream(stream), x, f, canvas, (int)BC, H, W, mx0, my0, Hp, Wp);
+  return oi::check_launch("oi_ada_pad_up2");
+}
+
 int oi_ada_geom_fwd(const float* x, const float* theta, const float* f, float* y, float* canvas, int B, int C, int H, int W,
                     int mx0, int mx1, int my0, int my1, oi_stream_t stream) {
   OI_REQUIRE(x && theta && f && y && canvas, "oi_ada_geom_fwd: null pointer");

@@ -1,0 +1,371 @@
+// DC discriminator forward at batch 1-4 (the per-GPU batch of training and of the D-images/s metric), gfx950.
+//
+// Replaces, for the 64 x 64 / n_feat 512 network of configs/train.yaml (reference src/models/discriminator.py:57-85 with
+// AugmentPipe.forward, src/third_party/ada/augment.py:284-301, in front), the nine dependent launches of the general path
+// (csrc/disc.hip: pad + up-FIR | resample + down-FIR | five split-K MFMA convolutions | copies) by FIVE:
+//     ada_pad_up2_kernel (disc.hip)                         canvas
+//     d_aug_conv1_kernel       resample + down-FIR + conv 1 + LeakyReLU           (C -> 64, 64^2 -> 32^2)
+//     d_conv_small_kernel x 3  conv 2, conv 3, conv 4 (+ the 4 x 4 head)          (64 -> 128 -> 256 -> 512 -> out_dim)
+// At these sizes a layer is a weight stream (0.5 / 2 / 8 MB) against 0.03 GFLOP and a handful of output pixels: what
+// matters is that every load of a layer is in flight at once and that nothing waits on another workgroup.
+//   * d_conv_small_kernel: one workgroup per output channel; the INPUT CHANNEL sits on the lane (64 per wave), a wave owns
+//     16 output pixels and one 64-channel block of the K sum: 4 weight loads + <= 32 input loads per lane, all issued
+//     before the first multiply -- ONE memory round trip per layer instead of one per K chunk (the split-K MFMA kernel
+//     walks its K range in trips of 8 kernel rows, each a full round trip: 8 us per layer at batch 1).  The 16 pixel sums
+//     of a wave are reduced over the lanes with a transposed butterfly, then over the waves through LDS: fixed summation
+//     order, no atomics, bit-reproducible.  fp32 FMA on the vector units: with <= 64 output pixels per image the 32-wide
+//     matrix-core tile would be 3/4 padding, and the layer is bandwidth-bound either way (the batch >= 16 path of disc.hip
+//     stays on the matrix cores).
+//   * the head (512 x 4 x 4 -> out_dim) rides on conv 4: every workgroup adds its channel's share of the logits to a
+//     partial table, the LAST workgroup to arrive sums the table in channel order (agent-scope write-through hand-off as in
+//     render.hip's compositing statistics; nobody spins).
+//   * d_aug_conv1_kernel: an 8 x 8 tile of the augmented image (+ the convolution's halo) is resampled from the canvas into
+//     LDS (30 x 30 grid points per channel), filtered down (12 taps, both axes) and convolved (4 x 4 stride 2, 64 channels)
+//     without leaving the workgroup; the sampling matrix arrives BY VALUE in the kernel arguments (no host-to-device copy).
+#include "oi_common.h"
+
+namespace {
+
+// ---- shared with disc.hip (same expressions) ------------------------------------------------------------------------
+__device__ __forceinline__ void affine_src_s(const float* th, int ox, int oy, int Wo, int Ho, int Wi, int Hi, float& ix,
+                                             float& iy) {
+  const float xn = (2.0f * ox + 1.0f) / Wo - 1.0f;  // affine_grid base grid, align_corners=False
+  const float yn = (2.0f * oy + 1.0f) / Ho - 1.0f;
+  const float gx = th[0] * xn + th[1] * yn + th[2];
+  const float gy = th[3] * xn + th[4] * yn + th[5];
+  ix = ((gx + 1.0f) * Wi - 1.0f) * 0.5f;  // grid_sampler unnormalize, align_corners=False
+  iy = ((gy + 1.0f) * Hi - 1.0f) * 0.5f;
+}
+
+constexpr int DS_MAX_B = 4, DS_MAX_C = 4;
+constexpr int DA_T = 4;                    // augmented-image tile edge (-> 2 x 2 outputs of conv 1): 256 workgroups per image
+constexpr int DA_P = DA_T + 2;             // 6: + the convolution's halo (pad 1, 4 taps, stride 2)
+constexpr int DA_TAPS = 12, DA_PAD = 6;    // Hz_geom; the resampled grid is 2 (H + 6) x 2 (W + 6)
+constexpr int DA_G = 2 * DA_P + DA_TAPS - 2;  // 22 grid points per axis under a patch
+
+struct ThetaArg {
+  float t[DS_MAX_B][6];
+};
+
+// x [B][C][H][W] (theta_on = 0: no augmentation) or canvas [B][C][Hc][Wc] -> y [B][C1][H/2][W/2] = lrelu(conv1(aug(x)))
+__global__ void __launch_bounds__(256)
+d_aug_conv1_kernel(const float* __restrict__ src, const ThetaArg th, const float* __restrict__ theta_dev, int theta_on,
+                   const float* __restrict__ f,
+                   const float* __restrict__ w1, float* __restrict__ y, int C, int H, int W, int Hc, int Wc, int C1, float slope) {
+  __shared__ float g[DS_MAX_C][DA_G][DA_G + 1];   // resampled grid patch
+  __shared__ float gv[DS_MAX_C][DA_P][DA_G + 1];  // after the vertical pass
+  __shared__ float aug[DS_MAX_C][DA_P][DA_P + 1]; // augmented patch (zero outside the image: the convolution's padding)
+  __shared__ float fs[DA_TAPS];
+  const int tid = threadIdx.x, b = blockIdx.z;
+  const int ay0 = blockIdx.y * DA_T - 1, ax0 = blockIdx.x * DA_T - 1;  // patch origin in the augmented image
+  if (theta_on) {
+    if (tid < DA_TAPS) fs[tid] = f[tid];  // flip_filter = True: the correlation taps are the filter itself
+    const int Ho = 2 * (H + DA_PAD), Wo = 2 * (W + DA_PAD);
+    const int gy0 = 2 * ay0 + 1, gx0 = 2 * ax0 + 1;  // aug[a][b] = sum_{k,l} f[k] f[l] G[2 a + k + 1][2 b + l + 1]
+    for (int i = tid; i < DA_G * DA_G; i += 256) {
+      const int r = i / DA_G, c = i % DA_G;
+      const int gyi = gy0 + r, gxi = gx0 + c;
+      const bool in = gyi >= 0 && gyi < Ho && gxi >= 0 && gxi < Wo;
+      float ix, iy;
+      float tb[6];   // the sampling matrix: by value (eager callers) or from device memory (captured graphs)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) tb[q] = theta_dev != nullptr ? theta_dev[b * 6 + q] : th.t[b][q];
+      affine_src_s(tb, in ? gxi : 0, in ? gyi : 0, Wo, Ho, Wc, Hc, ix, iy);
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int x0 = (int)fx, y0 = (int)fy;
+      const float tx = ix - fx, ty = iy - fy;
+      // unconditional loads from clamped addresses, out-of-range taps zeroed through their weights (a branch per tap made
+      // the four loads of a point four dependent round trips)
+      const bool xa = x0 >= 0 && x0 < Wc, xb = x0 + 1 >= 0 && x0 + 1 < Wc, ya = y0 >= 0 && y0 < Hc, yb = y0 + 1 >= 0 && y0 + 1 < Hc;
+      const int cx0 = min(max(x0, 0), Wc - 1), cx1 = min(max(x0 + 1, 0), Wc - 1);
+      const int cy0 = min(max(y0, 0), Hc - 1), cy1 = min(max(y0 + 1, 0), Hc - 1);
+      const float w00 = (in && xa && ya) ? (1.f - tx) * (1.f - ty) : 0.f, w01 = (in && xb && ya) ? tx * (1.f - ty) : 0.f;
+      const float w10 = (in && xa && yb) ? (1.f - tx) * ty : 0.f, w11 = (in && xb && yb) ? tx * ty : 0.f;
+      for (int c_ = 0; c_ < C; ++c_) {
+        const float* cp = src + ((size_t)b * C + c_) * Hc * Wc;
+        const float v00 = cp[(size_t)cy0 * Wc + cx0], v01 = cp[(size_t)cy0 * Wc + cx1];
+        const float v10 = cp[(size_t)cy1 * Wc + cx0], v11 = cp[(size_t)cy1 * Wc + cx1];
+        float v = 0.f;   // (the order of disc.hip's ada_resample_down2_kernel)
+        v += v00 * w00;
+        v += v01 * w01;
+        v += v10 * w10;
+        v += v11 * w11;
+        g[c_][r][c] = v;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < C * DA_P * DA_G; i += 256) {  // vertical pass
+      const int c_ = i / (DA_P * DA_G), t = (i / DA_G) % DA_P, c = i % DA_G;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < DA_TAPS; ++k) s = fmaf(fs[k], g[c_][2 * t + k][c], s);
+      gv[c_][t][c] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < C * DA_P * DA_P; i += 256) {  // horizontal pass
+      const int c_ = i / (DA_P * DA_P), t = (i / DA_P) % DA_P, u = i % DA_P;
+      float s = 0.f;
+#pragma unroll
+      for (int l = 0; l < DA_TAPS; ++l) s = fmaf(fs[l], gv[c_][t][2 * u + l], s);
+      const int ay = ay0 + t, ax = ax0 + u;
+      aug[c_][t][u] = (ay >= 0 && ay < H && ax >= 0 && ax < W) ? s : 0.f;
+    }
+  } else {
+    for (int i = tid; i < C * DA_P * DA_P; i += 256) {
+      const int c_ = i / (DA_P * DA_P), t = (i / DA_P) % DA_P, u = i % DA_P;
+      const int ay = ay0 + t, ax = ax0 + u;
+      const bool in = ay >= 0 && ay < H && ax >= 0 && ax < W;
+      const float v = src[(((size_t)b * C + c_) * H + min(max(ay, 0), H - 1)) * W + min(max(ax, 0), W - 1)];
+      aug[c_][t][u] = in ? v : 0.f;
+    }
+  }
+  __syncthreads();
+  // conv 1: C1 channels x (DA_T / 2)^2 outputs of this tile; K = 16 C taps per output, summed (c, ky, kx)-major.
+  // Output in the layout the next layer reads with the input channel on the lane: y[b][oy][ox / 4][ch][ox % 4]
+  constexpr int OT = DA_T / 2;
+  const int Ho1 = H / 2, Wo1 = W / 2;
+  for (int o = tid; o < C1 * OT * OT; o += 256) {
+    const int ch = o / (OT * OT), py = (o / OT) % OT, px = o % OT;
+    const float* wr = w1 + (size_t)ch * C * 16;
+    float acc = 0.f;
+    for (int c_ = 0; c_ < C; ++c_) {
+#pragma unroll
+      for (int ky = 0; ky < 4; ++ky) {
+        const float4 wv = *reinterpret_cast<const float4*>(wr + c_ * 16 + ky * 4);
+        const float* ar = &aug[c_][2 * py + ky][2 * px];
+        acc = fmaf(wv.x, ar[0], acc);
+        acc = fmaf(wv.y, ar[1], acc);
+        acc = fmaf(wv.z, ar[2], acc);
+        acc = fmaf(wv.w, ar[3], acc);
+      }
+    }
+    const int oy = blockIdx.y * OT + py, ox = blockIdx.x * OT + px;
+    if (oy < Ho1 && ox < Wo1) y[((((size_t)b * Ho1 + oy) * (Wo1 / 4) + ox / 4) * C1 + ch) * 4 + (ox & 3)] = acc > 0.f ? acc : acc * slope;
+  }
+}
+
+// ---- conv 2 .. 4 ------------------------------------------------------------------------------------------------------
+// sum over the 64 lanes of v[i], i < 16: lane l returns the total of v[l & 15] (transposed butterfly: at step s two registers
+// become one -- each lane keeps the partial sum of the value its lane bit s selects)
+__device__ __forceinline__ float xpose_sum16(const float (&v)[16], int lane) {
+  float a[8], b[4], c[2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bool bit = lane & 1;
+    const float keep = bit ? v[2 * i + 1] : v[2 * i], give = bit ? v[2 * i] : v[2 * i + 1];
+    a[i] = keep + __shfl_xor(give, 1, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool bit = lane & 2;
+    const float keep = bit ? a[2 * i + 1] : a[2 * i], give = bit ? a[2 * i] : a[2 * i + 1];
+    b[i] = keep + __shfl_xor(give, 2, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const bool bit = lane & 4;
+    const float keep = bit ? b[2 * i + 1] : b[2 * i], give = bit ? b[2 * i] : b[2 * i + 1];
+    c[i] = keep + __shfl_xor(give, 4, 64);
+  }
+  const bool bit = lane & 8;
+  float d = (bit ? c[1] : c[0]) + __shfl_xor(bit ? c[0] : c[1], 8, 64);
+  d += __shfl_xor(d, 16, 64);
+  d += __shfl_xor(d, 32, 64);
+  return d;   // value index (lane & 15): bit s of the index was selected by lane bit s
+}
+
+// Activations between the layers live in the layout  A[b][y][x / 4][channel][x % 4]:  with the input channel on the lane a
+// wave's float4 load of (y, x / 4) is 1 KiB of consecutive memory (channel-major planes gave 64 different cache lines per
+// load instruction: the address path, not the data, then set the layer's time).
+//   x A[B][HIN][HIN/4][CIN][4] -> y A[B][HO][HO/4][COUT][4] = lrelu(conv4x4 s2 p1 (x, w)), w [COUT][CIN][4][4], HO = HIN / 2.
+// grid (COUT / NCH, wave tasks / WPB); block 64 WPB.  A wave task = (64-channel block cb of the K sum, 16 consecutive output
+// pixels) for NCH output channels (they share the input registers); the tasks of one pixel group sit in one workgroup.
+// HEAD (HIN = 8 only): logits[b][k] = bhead[k] + sum_{n, p} whead[k][n][p] y[b][n][p] (4 x 4 valid convolution), combined
+// by the last workgroup to arrive.
+template <int CIN, int HIN, int WPB, int NCH, bool HEAD>
+__global__ void __launch_bounds__(64 * WPB)
+d_conv_small_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int B, int COUT, float slope,
+                    const float* __restrict__ whead, const float* __restrict__ bhead, int KOUT, float* __restrict__ partials,
+                    unsigned* __restrict__ ticket, float* __restrict__ logits) {
+  constexpr int HO = HIN / 2, CW = CIN / 64;
+  constexpr int RPP = 16 / HO;            // output rows per wave task: 1 (HO 16), 2 (HO 8), 4 (HO 4)
+  constexpr int NIR = 2 * RPP + 2;        // input rows under them
+  constexpr int Q = HIN / 4;              // float4 per input row
+  constexpr int NG = WPB / CW;            // pixel groups per workgroup
+  static_assert(RPP * HO == 16 && WPB % CW == 0, "wave task = 16 output pixels x one 64-channel block");
+  __shared__ float red[WPB][NCH][16];
+  __shared__ float act[DS_MAX_B][NCH][16];
+  __shared__ float hsum[256];
+  __shared__ int is_last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * NCH;
+  const int task = blockIdx.y * WPB + wave, cb = task % CW, grp = task / CW;  // pixel group: output rows grp RPP ..
+  const int cin = cb * 64 + lane;
+  const int oy0 = grp * RPP, iy0 = 2 * oy0 - 1;
+  // every load of the task is issued before the first multiply: one round trip per layer
+  float wk[NCH][16];
+#pragma unroll
+  for (int c_ = 0; c_ < NCH; ++c_) {
+    const float4* wp = reinterpret_cast<const float4*>(w + ((size_t)(n0 + c_) * CIN + cin) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = wp[q];
+      wk[c_][4 * q] = v.x; wk[c_][4 * q + 1] = v.y; wk[c_][4 * q + 2] = v.z; wk[c_][4 * q + 3] = v.w;
+    }
+  }
+  for (int b = 0; b < B; ++b) {
+    float xin[NIR][HIN + 2];
+#pragma unroll
+    for (int r = 0; r < NIR; ++r) {
+      const int iy = iy0 + r;
+      const bool ok = iy >= 0 && iy < HIN;
+      const float4* rp = reinterpret_cast<const float4*>(x + (((size_t)b * HIN + min(max(iy, 0), HIN - 1)) * Q * CIN + cin) * 4);
+      xin[r][0] = 0.f;
+      xin[r][HIN + 1] = 0.f;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const float4 v = rp[(size_t)q * CIN];
+        xin[r][1 + 4 * q] = ok ? v.x : 0.f;
+        xin[r][2 + 4 * q] = ok ? v.y : 0.f;
+        xin[r][3 + 4 * q] = ok ? v.z : 0.f;
+        xin[r][4 + 4 * q] = ok ? v.w : 0.f;
+      }
+    }
+#pragma unroll
+    for (int c_ = 0; c_ < NCH; ++c_) {
+      float acc[16];
+#pragma unroll
+      for (int r = 0; r < RPP; ++r)
+#pragma unroll
+        for (int ox = 0; ox < HO; ++ox) {
+          float s = 0.f;
+#pragma unroll
+          for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) s = fmaf(wk[c_][4 * ky + kx], xin[2 * r + ky][2 * ox + kx], s);  // column 2 ox - 1 + kx (+ 1: border)
+          acc[r * HO + ox] = s;
+        }
+      const float tot = xpose_sum16(acc, lane);
+      if (lane < 16) red[wave][c_][lane] = tot;
+    }
+    __syncthreads();
+    // pixel group g of this workgroup = waves g CW .. g CW + CW - 1, summed in that order
+    for (int i = threadIdx.x; i < NG * NCH * 16; i += 64 * WPB) {
+      const int gl = i / (NCH * 16), c_ = (i >> 4) % NCH, p = i & 15;
+      float s = red[gl * CW][c_][p];
+#pragma unroll
+      for (int k = 1; k < CW; ++k) s += red[gl * CW + k][c_][p];
+      s = s > 0.f ? s : s * slope;
+      const int g_ = blockIdx.y * NG + gl;
+      const int oy = g_ * RPP + p / HO, ox = p % HO;
+      constexpr int QO = HO / 4;
+      y[((((size_t)b * HO + oy) * QO + ox / 4) * COUT + n0 + c_) * 4 + (ox & 3)] = s;
+      if (HEAD) act[b][c_][p] = s;
+    }
+    __syncthreads();
+  }
+  if constexpr (HEAD) {
+    const int t = threadIdx.x;
+    const int nv = B * KOUT;   // <= 32 logits
+    if (t < nv) {
+      const int b = t / KOUT, k = t % KOUT;
+      float s = 0.f;
+#pragma unroll
+      for (int c_ = 0; c_ < NCH; ++c_) {
+        const float* wh = whead + ((size_t)k * COUT + n0 + c_) * 16;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) s = fmaf(wh[p], act[b][c_][p], s);
+      }
+      __hip_atomic_store(partials + (size_t)blockIdx.x * 32 + t, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (t < 32) {
+      __hip_atomic_store(partials + (size_t)blockIdx.x * 32 + t, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (unused columns: defined)
+    }
+    if (wave == 0) {  // (the stores above are this wave's)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // the last workgroup sums the table [gridDim.x][32] in a fixed order: 8 threads per logit take every 8th row (all
+    // loads independent), then a fixed 8-term sum per logit
+    {
+      const int v = t & 31, part = t >> 5;  // 256 threads = 32 logits x 8 parts of NROWS / 8 consecutive rows
+      constexpr int NROWS = 512 / NCH, PER = NROWS / 8;   // (the head exists for the 512-channel layer only: gridDim.x = NROWS)
+      float vals[PER];
+#pragma unroll
+      for (int j = 0; j < PER; ++j)   // all loads in flight at once (a run-time trip count made this a chain of round trips)
+        vals[j] = __hip_atomic_load(partials + (size_t)(part * PER + j) * 32 + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) s += vals[j];
+      hsum[t] = v < nv ? s : 0.f;
+    }
+    __syncthreads();
+    if (t < nv) {
+      float s = bhead != nullptr ? bhead[t % KOUT] : 0.f;
+#pragma unroll
+      for (int part = 0; part < 8; ++part) s += hsum[part * 32 + t];
+      logits[t] = s;
+    }
+    if (t == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+}  // namespace
+
+// disc.hip: the canvas of the augmentation (reflect pad + x2 up-FIR) for a given stream
+extern "C" int oi_ada_pad_up2(const float* x, const float* f, float* canvas, int B, int C, int H, int W, int mx0, int mx1, int my0,
+                              int my1, oi_stream_t stream);
+
+extern "C" {
+
+size_t oi_disc_fwd_small_workspace_floats(int B, int C, int mx0, int mx1, int my0, int my1) {
+  const size_t canvas = (size_t)B * C * (2 * (64 + my0 + my1)) * (2 * (64 + mx0 + mx1));
+  return (canvas + 63) / 64 * 64 + (size_t)B * (64 * 32 * 32 + 128 * 16 * 16 + 256 * 8 * 8) + (size_t)512 * DS_MAX_B * 8;
+}
+
+int oi_disc_fwd_small(const float* x, const float* theta_host, const float* theta_dev, const float* f12, int mx0, int mx1, int my0,
+                      int my1, const float* w1, const float* w2, const float* w3, const float* w4, const float* whead,
+                      const float* bhead, float* workspace, unsigned* ticket, float* logits, int B, int C, int H, int W, int n_feat,
+                      int out_dim, float slope, oi_stream_t stream) {
+  OI_REQUIRE(x && f12 && w1 && w2 && w3 && w4 && whead && workspace && ticket && logits, "oi_disc_fwd_small: null pointer");
+  OI_REQUIRE(theta_host == nullptr || theta_dev == nullptr, "oi_disc_fwd_small: theta_host and theta_dev are alternatives");
+  if (!(B >= 1 && B <= DS_MAX_B && C >= 1 && C <= DS_MAX_C && H == 64 && W == 64 && n_feat == 512 && out_dim >= 1 && out_dim <= 8))
+    return oi::fail(OI_ERR_UNSUPPORTED, "oi_disc_fwd_small: only B <= %d, C <= %d, 64 x 64, n_feat 512, out_dim <= 8 (got B=%d C=%d %dx%d n_feat=%d out_dim=%d)",
+                    DS_MAX_B, DS_MAX_C, B, C, H, W, n_feat, out_dim);
+  hipStream_t st = oi::as_stream(stream);
+  const bool aug = theta_host != nullptr || theta_dev != nullptr;
+  float* canvas = workspace;
+  const int Hp = H + my0 + my1, Wp = W + mx0 + mx1;
+  const size_t canvas_n = aug ? (size_t)B * C * (2 * Hp) * (2 * Wp) : 0;
+  float* a1 = workspace + (canvas_n + 63) / 64 * 64;   // conv 1 out; dead after conv 2: conv 4's output lands here again
+  float* a2 = a1 + (size_t)B * 64 * 32 * 32;
+  float* a3 = a2 + (size_t)B * 128 * 16 * 16;
+  float* partials = a3 + (size_t)B * 256 * 8 * 8;
+  ThetaArg th = {};
+  int rc = OI_OK;
+  if (aug) {
+    if (theta_host != nullptr)
+      for (int b = 0; b < B; ++b)
+        for (int i = 0; i < 6; ++i) th.t[b][i] = theta_host[b * 6 + i];
+    rc = oi_ada_pad_up2(x, f12, canvas, B, C, H, W, mx0, mx1, my0, my1, stream);
+    if (rc != OI_OK) return rc;
+  }
+  hipLaunchKernelGGL(d_aug_conv1_kernel, dim3(W / DA_T, H / DA_T, B), dim3(256), 0, st, aug ? canvas : x, th, theta_dev, aug ? 1 : 0,
+                     f12, w1, a1, C, H, W, 2 * Hp, 2 * Wp, 64, slope);
+  rc = oi::check_launch("oi_disc_fwd_small(aug + conv1)");
+  if (rc != OI_OK) return rc;
+  hipLaunchKernelGGL((d_conv_small_kernel<64, 32, 8, 2, false>), dim3(128 / 2, 2), dim3(512), 0, st, a1, w2, a2, B, 128, slope, nullptr,
+                     nullptr, 0, nullptr, nullptr, nullptr);
+  rc = oi::check_launch("oi_disc_fwd_small(conv2)");
+  if (rc != OI_OK) return rc;
+  hipLaunchKernelGGL((d_conv_small_kernel<128, 16, 8, 2, false>), dim3(256 / 2, 1), dim3(512), 0, st, a2, w3, a3, B, 256, slope, nullptr,
+                     nullptr, 0, nullptr, nullptr, nullptr);
+  rc = oi::check_launch("oi_disc_fwd_small(conv3)");
+  if (rc != OI_OK) return rc;
+  hipLaunchKernelGGL((d_conv_small_kernel<256, 8, 4, 2, true>), dim3(512 / 2, 1), dim3(256), 0, st, a3, w4, a1, B, 512, slope, whead, bhead,
+                     out_dim, partials, ticket, logits);
+  return oi::check_launch("oi_disc_fwd_small(conv4 + head)");
+}
+
+}  // extern "C"

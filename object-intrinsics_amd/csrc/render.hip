@@ -34,12 +34,18 @@ __device__ __forceinline__ float linspace_at(float start, float end, int n, int 
 // Ray set-up arithmetic shared by the stand-alone kernels and the fused prep_render_kernel.  Floating-point contraction is OFF
 // inside these helpers: left to the compiler, a*b + c becomes an fma in one kernel and a multiply + add in another (it
 // depends on what surrounds the expression after inlining), and "the same expressions" would differ in the last bit.
+// -DOI_RAY_CONTRACT_DEFAULT: the compiler's default contraction inside the helpers (debug A/B only)
+#ifdef OI_RAY_CONTRACT_DEFAULT
+#define OI_RAY_FP_CONTRACT
+#else
+#define OI_RAY_FP_CONTRACT _Pragma("clang fp contract(off)")
+#endif
 struct RayOD {
   float o[3], d[3], near_, far_;
 };
 __device__ __forceinline__ RayOD make_ray(const float* __restrict__ M /* c2b 4x4 */, const float* __restrict__ kinv, float offx,
                                           float offy, int R, int x, int y) {
-#pragma clang fp contract(off)
+OI_RAY_FP_CONTRACT
   RayOD r;
   // build_rays: pixels = linspace(0,1,R) * recp_size + offset   (generator.py:325-329)
   const float px = linspace_at(0.f, 1.f, R, x) * (float)R + offx;
@@ -66,13 +72,13 @@ __device__ __forceinline__ RayOD make_ray(const float* __restrict__ M /* c2b 4x4
 }
 // coarse sample i of S on [near, far] (+ the per-ray jitter): renderer.py:359-360, 372-373
 __device__ __forceinline__ float coarse_z_at(float nr, float fr, int S, int i, const float* __restrict__ jitter, long long r) {
-#pragma clang fp contract(off)
+OI_RAY_FP_CONTRACT
   float zv = nr + (fr - nr) * linspace_at(0.f, 1.f, S, i);
   if (jitter != nullptr) zv = zv + (jitter[r] - 0.5f) * 2.0f / (float)S;
   return zv;
 }
 __device__ __forceinline__ float along_ray(float o, float d, float z) {
-#pragma clang fp contract(off)
+OI_RAY_FP_CONTRACT
   return o + d * z;
 }
 

@@ -11,6 +11,8 @@ import torch.nn as nn
 from .autograd_disc import conv4x4_lrelu
 from .config import build_from_config
 
+SMALL_PATH = True   # batch <= 4 no-grad forwards of the 64 x 64 network take csrc/disc_small.hip (False: the general chain)
+
 
 class _ConvParam(nn.Module):
     """Holds `weight` (and optional `bias`) under the same names as nn.Conv2d(…, 4, s, p)."""
@@ -58,9 +60,21 @@ class DCDiscriminator(nn.Module):
             off += n
         return x
 
+    def _small_ok(self, x):
+        """The five-launch forward of csrc/disc_small.hip: no gradient, batch <= 4, the 64 x 64 / n_feat 512 network."""
+        return (SMALL_PATH and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.shape[0] <= 4 and x.shape[1] <= 4
+                and tuple(x.shape[2:]) == (64, 64) and len(self.blocks) == 4 and self.blocks[0].weight.shape[0] == 64
+                and self.blocks[3].weight.shape[0] == 512 and self.out_dim <= 8)
+
+    def _forward_small(self, x, **aug):
+        from . import ops
+        return ops.disc_fwd_small(x.float(), [l.weight for l in self.blocks], self.conv_out.weight, self.conv_out.bias, **aug)
+
     def forward(self, x, **kwargs):
         batch_size = x.shape[0]
         assert x.shape[1] == self.in_dim, x.shape
+        if self._small_ok(x):
+            return self._forward_small(x)
         if not torch.is_grad_enabled():
             return self._forward_nograd(x.float()).reshape(batch_size, self.out_dim)
         from . import autograd_conv as AC
@@ -93,6 +107,19 @@ class ADADiscriminator(DCDiscriminator):
 
     def forward(self, x, aug_theta=None, **kwargs):
         """`aug_theta`: precomputed sampling grid for the shape-static augmentation (see AugmentPipe.forward)."""
+        from .augment import AugmentPipe
+        aug = self.aug
+        if (self._small_ok(x) and type(aug).forward is AugmentPipe.forward and "forward" not in aug.__dict__
+                and aug.Hz_geom.shape[0] == 12):
+            # augmentation + network in five launches; the sampling matrix goes to the kernel by value (no upload)
+            H, W = x.shape[2:]
+            if aug_theta is not None:
+                return self._forward_small(x, f12=aug.Hz_geom, theta_dev=aug_theta, margins=aug.static_margins(H, W))
+            G_inv = aug.sample_G_inv(x, None)
+            if G_inv is None:
+                return self._forward_small(x)
+            margins = aug.margins_for(G_inv, H, W)
+            return self._forward_small(x, f12=aug.Hz_geom, theta_np=aug.theta_for(G_inv, margins, H, W), margins=margins)
         return super().forward(self.aug(x) if aug_theta is None else self.aug(x, theta=aug_theta), **kwargs)
 
 

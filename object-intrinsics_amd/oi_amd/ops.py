@@ -703,6 +703,37 @@ def upfirdn2d(x, f, upx=1, upy=1, downx=1, downy=1, padx0=0, padx1=0, pady0=0, p
     return y
 
 
+_DISC_TICKETS = {}
+
+
+def disc_fwd_small(x, weights, whead, bhead, f12=None, theta_np=None, theta_dev=None, margins=(0, 0, 0, 0), slope=0.2):
+    """DCDiscriminator(img_size 64, n_feat 512) forward at batch <= 4 in five launches (oi_disc_fwd_small): optional ADA
+    geometry (theta_np: (B, 2, 3) numpy, passed by value | theta_dev: device tensor; margins (mx0, my0, mx1, my1) as
+    AugmentPipe.margins_for returns them) + four conv blocks + head.  -> logits (B, out_dim)."""
+    L = _l.load()
+    x = _c(x)
+    B, C, H, W = x.shape
+    mx0, my0, mx1, my1 = (int(v) for v in margins)
+    n = L.oi_disc_fwd_small_workspace_floats(B, C, mx0, mx1, my0, my1)
+    ws = torch.empty(n, dtype=torch.float32, device=x.device)
+    key = (x.device, _stream().value or 0)
+    ticket = _DISC_TICKETS.get(key)
+    if ticket is None:
+        ticket = _DISC_TICKETS[key] = torch.zeros(4, dtype=torch.int32, device=x.device)
+    out_dim = whead.shape[0]
+    logits = _new(x, B, out_dim)
+    th_host = th_arr = None
+    if theta_np is not None:
+        th_arr = np.ascontiguousarray(theta_np, dtype=np.float32).reshape(-1)   # alive during the call: the C side copies the
+        assert th_arr.size == 6 * B                                             # values into the kernel arguments
+        th_host = th_arr.ctypes.data_as(ctypes.c_void_p)
+    ws_ = [_c(w) for w in weights]
+    _l.check(L.oi_disc_fwd_small(_p(x), th_host, _p(_c(theta_dev)), _p(_c(f12)) if f12 is not None else _p(x), mx0, mx1, my0, my1,
+                                 *[_p(w) for w in ws_], _p(_c(whead)), _p(_c(bhead)), _p(ws), _vp(ticket.data_ptr()), _p(logits),
+                                 B, C, H, W, int(ws_[3].shape[0]), int(out_dim), float(slope), _stream()), "oi_disc_fwd_small")
+    return logits
+
+
 def ada_geom_fwd(x, theta, f12, margins):
     """reflect pad + x2 up-FIR + affine resample + /2 down-FIR (AugmentPipe geometry) in two launches; see oi_ada_geom_fwd."""
     L = _l.load()
