@@ -34,7 +34,17 @@ constexpr int B3_FILM = 0;
 constexpr int B3_FILM_ROW = 3 * C * 4;                      // bytes per FiLM layer
 constexpr int B3_TABS = B3_FILM + 10 * B3_FILM_ROW;         // 15360
 constexpr int B3_WBUF = B3_TABS + H_TABS_END * 4;           // 21632
-constexpr int B3_LDS = B3_WBUF + B3_NSLOT * LBB;            // 152,704 of the CU's 163,840 bytes
+// Two small A images for the K = 128 -> 3 products at the ends of the network (d sdf/dx = W0^T v0; rgb = Wrgb sin(phi_v)): rows
+// 0..2 = the bf16 hi limb of the three output rows, 3..5 their lo limbs, 6..7 zero; [k-step 8][lane half 2][row 8][8 x bf16].
+// (Lanes read row (lane & 7): MFMA output rows >= 8 then hold copies nobody reads.)
+constexpr int B3_SIMG = B3_WBUF + B3_NSLOT * LBB;           // 152,704
+constexpr int SIMG_BYTES = 8 * 2 * 8 * 16;                  // 2 KiB each
+constexpr int B3_LDS = B3_SIMG + 2 * SIMG_BYTES;            // 156,800 of the CU's 163,840 bytes
+// The three-input-column products (layer 0, the albedo head's gradient columns), the three-output-row products (d sdf/dx, rgb)
+// on the matrix cores instead of the VALU: 1 = on (default), 0 = the round-4a VALU forms (A/B switch)
+#ifndef OI_B3_MFMA_EDGES
+#define OI_B3_MFMA_EDGES 1
+#endif
 
 typedef unsigned Limb[8][4];   // bf16 B operand of one layer: [k-step][dword d] = act indices 8 s + 2 d, 8 s + 2 d + 1
 typedef unsigned BankB[16][2];  // one parked 128-vector of cos(phi) as fp16 pairs: [group g][pair] <-> act[4 g + 2 pair (+1)]
@@ -97,9 +107,13 @@ template <> struct is_no_tail_b<NoTailB> { static constexpr bool value = true; }
 //   blocks 1..3             EPI(t - 1, s): this layer's epilogue pair s of the block that has just completed
 // This layer's own block-3 pairs are left to the caller: the next layer's TAIL, or run_tail_b().
 // An epilogue pair (tb, rp) consumes accumulator slots 2 rp, 2 rp + 1 of block tb = act indices 16 tb + 2 rp (+1).
-template <class TAIL, class EPI>
+struct NoPost {
+  __device__ __forceinline__ void operator()(int, f32x16&) const {}
+};
+// POST(t, acc[t]) runs right after block t's eight MFMAs (the albedo head adds its three gradient columns there: one more MFMA)
+template <class TAIL, class EPI, class POST = NoPost>
 __device__ __forceinline__ void stream_layer_b(const char* lds, int wl, const Limb& bh, f32x16 (&acc)[4], TAIL&& tail,
-                                               EPI&& epi) {
+                                               EPI&& epi, POST&& post = POST()) {
   constexpr bool HAS_TAIL = !is_no_tail_b<std::remove_cv_t<std::remove_reference_t<TAIL>>>::value;
   constexpr int AD = OI_B3_ADIST;
   f32x4 a[AD + 1];
@@ -137,6 +151,7 @@ __device__ __forceinline__ void stream_layer_b(const char* lds, int wl, const Li
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    post(t, acc[t]);
   }
 }
 // block 3's epilogue with nothing to hide behind: two pairs (four independent chains) per window
@@ -267,6 +282,26 @@ sdf_mlp_full3b_kernel(const float* __restrict__ pts, const char* __restrict__ pa
       if (l == 7) film[9 * (B3_FILM_ROW / 4) + f] = gm * hdr[H_SIG + f];
     }
   }
+#if OI_B3_MFMA_EDGES
+  {  // the two 3-row A images: entry (image, k-step s, half hh, row i): 8 bf16 = M[i][feat_of(8 s + j, hh)], j = 0..7
+    const int img = tid >> 7, s_ = (tid >> 4) & 7, hh = (tid >> 3) & 1, i = tid & 7;
+    const int c = i < 3 ? i : i - 3;
+    unsigned d[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[2];
+#pragma unroll
+      for (int e_ = 0; e_ < 2; ++e_) {
+        const int f = feat_of(8 * s_ + 2 * q + e_, hh);
+        const float w = i < 6 ? (img == 0 ? hdr[H_TAB0 + 4 * f + c] : hdr[H_RGB + c * C + f]) : 0.f;
+        const float whi = (float)(__bf16)w;
+        v[e_] = i < 3 ? whi : w - whi;
+      }
+      d[q] = pk_bf16(v[0], v[1]);
+    }
+    *reinterpret_cast<u32x4*>(lds + B3_SIMG + img * SIMG_BYTES + ((s_ * 2 + hh) * 8 + i) * 16) = u32x4{d[0], d[1], d[2], d[3]};
+  }
+#endif
   // (the prologue's loads are complete: hipcc waits with vmcnt(0) for them before the LDS writes above -- the image DMA is
   //  issued behind them so that those waits do not drain it)
   prefetch(0);
@@ -333,6 +368,39 @@ sdf_mlp_full3b_kernel(const float* __restrict__ pts, const char* __restrict__ pa
     }
   };
 
+  // B fragment of a three-column product: the 3-vector v as bf16 hi + lo limbs in the K slots
+  //   half 0: (vh.x vh.y vh.z | vl.x vl.y vl.z | 0 0)   half 1: (vh.x vh.y vh.z | 0 ..)
+  // against A rows  half 0: (wh.x wh.y wh.z | wh.x wh.y wh.z | 0 0)   half 1: (wl.x wl.y wl.z | 0 ..):  vh wh + vl wh + vh wl
+  auto frag3_b = [&](float vx, float vy, float vz) {
+    const float hx = (float)(__bf16)vx, hy = (float)(__bf16)vy, hz = (float)(__bf16)vz;
+    const unsigned d0 = pk_bf16(hx, hy);
+    const unsigned d1 = h == 0 ? pk_bf16(hz, vx - hx) : pk_bf16(hz, 0.f);
+    const unsigned d2 = h == 0 ? pk_bf16(vy - hy, vz - hz) : 0u;
+    return __builtin_bit_cast(bf16x8, u32x4{d0, d1, d2, 0u});
+  };
+  // A fragment of output block t from a [128][4] fp32 table (w.x w.y w.z 0 per feature) at LDS offset TAB
+  auto frag3_a = [&](int tab, int t) {
+    const f32x4 w = lds_f4(lds, tab + t * 32 * 16, 16 * (lane & 31));
+    const float hx = (float)(__bf16)w[0], hy = (float)(__bf16)w[1], hz = (float)(__bf16)w[2];
+    const float ax = h == 0 ? hx : w[0] - hx, ay = h == 0 ? hy : w[1] - hy, az = h == 0 ? hz : w[2] - hz;
+    const unsigned d0 = pk_bf16(ax, ay);
+    const unsigned d1 = h == 0 ? pk_bf16(az, hx) : pk_bf16(az, 0.f);
+    const unsigned d2 = h == 0 ? pk_bf16(hy, hz) : 0u;
+    return __builtin_bit_cast(bf16x8, u32x4{d0, d1, d2, 0u});
+  };
+  // A fragment (k-step s) of one of the two small 3-row images
+  auto simg = [&](int img, int s_) {
+    return __builtin_bit_cast(bf16x8, lds_f4(lds, B3_SIMG + img * SIMG_BYTES + s_ * 256, 128 * h + 16 * (lane & 7)));
+  };
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // rows 0..2 (hi limb) + rows 3..5 (lo limb) of a 3-row product: row = (reg & 3) + 8 (reg >> 2) + 4 h
+  auto rows3 = [&](const f32x16& a, float& r0, float& r1, float& r2) {
+    const float u0 = __shfl_xor(a[0], 32, 64), u1 = __shfl_xor(a[1], 32, 64);  // rows 4, 5 sit in the other lane half
+    r0 = a[0] + a[3];
+    r1 = a[1] + u0;
+    r2 = a[2] + u1;   // (valid in the half-0 lanes: they hold rows 0..3 and receive rows 4, 5)
+  };
+
   // Epilogue pair (tb, rp) of a forward FiLM layer whose rows sit at lane base FB: sin(phi) -> next limb set NH,
   // cos(phi) -> BANK.  REQ: requester of this layer's rows; NEXT: requester of the rows of whatever epilogue follows.
 #define OI_FWD_EPI(FB, NH, BANK, NEXT)                                                                     \
@@ -374,9 +442,28 @@ sdf_mlp_full3b_kernel(const float* __restrict__ pts, const char* __restrict__ pa
             F5 = film_base(5), F6 = film_base(6), F7 = film_base(7), F8 = film_base(8), F9 = film_base(9);
 
   // ================= forward, layers 0..7 =================
+#if OI_B3_MFMA_EDGES
+  {  // layer 0 (K = 3) on the matrix cores: one MFMA per output block, then the ordinary forward epilogue
+    REQ_AB(F0)(0);
+    REQ_AB(F0)(1);
+    const bf16x8 bp = frag3_b(px, py, pz);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag3_a(B3_TABS + H_TAB0 * 4, t), bp, zero16, 0, 0, 0);
+    auto e0 = OI_FWD_EPI(F0, AH, P0, REQ_AB(F1));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int rp = 0; rp < 8; ++rp) {
+        e0(t, rp);
+        if (rp & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#else
   layer0(AH);
   REQ_AB(F1)(0);
   REQ_AB(F1)(1);
+#endif
   B3_T(0);
   ring_sync_b<2 * DMA_PER_IMAGE>();  // image 0 resident (1 and 2 may still be in flight)
   B3_T(2);
@@ -496,6 +583,28 @@ sdf_mlp_full3b_kernel(const float* __restrict__ pts, const char* __restrict__ pa
   B3_T(1);
   ring_sync_b<DMA_PER_IMAGE>();      // image 13 resident
   B3_T(2);
+#if OI_B3_MFMA_EDGES
+  // transposed layer 1: V0 = g1 * G0 cos(phi0) as limbs; then d sdf/dx = W0^T V0 (K = 128 -> 3 rows) as eight MFMAs against
+  // the small image
+  auto r1 = OI_REV_EPI(F0, P0, AH, req_none);
+  stream_layer_b(lds, lay(13), BH, acc, r2, r1);
+  B3_T(1);
+  run_tail_b(r1);
+  B3_T(3);
+  float gx, gy, gz;
+  {
+    f32x16 a0 = zero16;
+#pragma unroll
+    for (int s_ = 0; s_ < 8; ++s_) {
+      const u32x4 ub = {AH[s_][0], AH[s_][1], AH[s_][2], AH[s_][3]};
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(simg(0, s_), __builtin_bit_cast(bf16x8, ub), a0, 0, 0, 0);
+    }
+    rows3(a0, gx, gy, gz);
+    gx = __shfl(gx, lane & 31, 64);  // both halves of the point need the gradient (the albedo head's B fragment)
+    gy = __shfl(gy, lane & 31, 64);
+    gz = __shfl(gz, lane & 31, 64);
+  }
+#else
   // transposed layer 1: v0 = g1 * G0 cos(phi0) stays fp32 (layer 0's transposed product, K = 128 -> 3, runs on the VALU)
   float act[64];
   auto r1 = [&](int tb, int rp) {
@@ -526,6 +635,7 @@ sdf_mlp_full3b_kernel(const float* __restrict__ pts, const char* __restrict__ pa
   gx += __shfl_xor(gx, 32, 64);
   gy += __shfl_xor(gy, 32, 64);
   gz += __shfl_xor(gz, 32, 64);
+#endif
   bool valid;
   const long long pt = point_of(valid);
   if (valid && h == 0) {
@@ -538,9 +648,37 @@ sdf_mlp_full3b_kernel(const float* __restrict__ pts, const char* __restrict__ pa
     // ---- albedo head: sigmoid(Wrgb sin(gv * (Wv [feat, grad] + bv) + bv') + brgb)   (fields.py:89-101)
     ring_sync_b<0>();  // image 14 resident
     float r0 = 0.f, r1c = 0.f, r2c = 0.f;
-    f32x4 w0, w1, w2;
     REQ_AB(F8)(0);
     REQ_AB(F8)(1);
+#if OI_B3_MFMA_EDGES
+    // the head's three gradient columns are a ninth MFMA of every output block; its activations sin(phi_v) go on as bf16 limbs
+    // (AH: free) and rgb = Wrgb sin(phi_v) is eight MFMAs against the second small image
+    const bf16x8 bg3 = frag3_b(gx, gy, gz);
+    auto post = [&](int t, f32x16& a) { a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag3_a(B3_TABS + H_TABV * 4, t), bg3, a, 0, 0, 0); };
+    auto ec = [&](int tb, int rp) {
+      const int g = tb * 4 + (rp >> 1), k = 2 * (rp & 1);
+      const Rows& R = rw[g & 3];
+      if (k == 0 && g + 2 < 16) REQ_AB(F8)(g + 2);
+      const float s0 = __builtin_amdgcn_sinf(reduce(fmaf(R.a[k], acc[tb][2 * rp], R.b[k])));
+      const float s1 = __builtin_amdgcn_sinf(reduce(fmaf(R.a[k + 1], acc[tb][2 * rp + 1], R.b[k + 1])));
+      AH[2 * tb + (rp >> 2)][rp & 3] = pk_bf16(s0, s1);
+    };
+    B3_T(5);
+    stream_layer_b(lds, lay(14), CH, acc, NoTailB(), ec, post);
+    B3_T(1);
+    run_tail_b(ec);
+    {
+      f32x16 a0 = zero16;
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_) {
+        const u32x4 ub = {AH[s_][0], AH[s_][1], AH[s_][2], AH[s_][3]};
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(simg(1, s_), __builtin_bit_cast(bf16x8, ub), a0, 0, 0, 0);
+      }
+      rows3(a0, r0, r1c, r2c);
+    }
+    B3_T(3);
+#else
+    f32x4 w0, w1, w2;
     auto ec = [&](int tb, int rp) {
       const int g = tb * 4 + (rp >> 1), k = 2 * (rp & 1);
       const Rows& R = rw[g & 3];
@@ -568,6 +706,7 @@ sdf_mlp_full3b_kernel(const float* __restrict__ pts, const char* __restrict__ pa
     r0 += __shfl_xor(r0, 32, 64);
     r1c += __shfl_xor(r1c, 32, 64);
     r2c += __shfl_xor(r2c, 32, 64);
+#endif
     if (valid && h == 0 && rgb_out != nullptr) {
       const float* brgb = reinterpret_cast<const float*>(lds + B3_TABS + (H_RGB + 3 * C) * 4);
       rgb_out[pt * 3 + 0] = oi::sigmoidf_(r0 + brgb[0]);

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Runs ON the GPU box (gpurun): regenerates every file profiles/ holds for the default (f16x3) mode into gpurun_out/.
 #   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'
-# then copy gpurun_out/r3_* into profiles/.  Counter passes are separate runs (--pmc never combined with other traces).
+# then copy gpurun_out/r4_* into profiles/.  Counter passes are separate runs (--pmc never combined with other traces).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
-T=${OI_PROFILE_TAG:-r3}
+T=${OI_PROFILE_TAG:-r4}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bf16 --no-extras --min-seconds 0.2"
@@ -29,13 +29,18 @@ python $R/tools/train_launches.py /tmp/p_t10 10 /tmp/p_t30 30 > $O/${T}_timeline
 rm -rf /tmp/p_dist; OI_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29555 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_dist -- $TRAIN --train-steps 10 > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/p_dist $O/${T}_kernel_stats_train_rccl_1rank.txt > /dev/null
 python $R/tools/traffic_json.py $O/${T}_pmc_fetch_f16x3.txt $O/${T}_pmc_write_f16x3.txt sdf_mlp_full3_kernel "f16x3:1x64x64:64+64" $O/${T}_traffic.json
-# the bf16 throughput mode's dominant kernel (sdf_mlp_kernel<2, true, true>: precision 2, fast trig, full pass)
+# the bf16 mode's dominant kernel (sdf_mlp_full3b_kernel<true>: register-resident, fast trig) + its kernel stats / timeline
 for c in "FETCH_SIZE:fetch" "WRITE_SIZE:write"; do
   ctr=${c%%:*}; tag=${c##*:}
   rm -rf /tmp/p_b$tag; rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/p_b$tag -- $BENCH --precision bf16 --steps 5 --warmup 2 --train-steps 0 > /dev/null 2>&1
   python $R/tools/prof_summary.py /tmp/p_b$tag $O/${T}_pmc_${tag}_bf16.txt > /dev/null
 done
-python $R/tools/traffic_json.py $O/${T}_pmc_fetch_bf16.txt $O/${T}_pmc_write_bf16.txt "sdf_mlp_kernel<2, true, true>" "bf16:1x64x64:64+64" $O/${T}_traffic.json
+python $R/tools/traffic_json.py $O/${T}_pmc_fetch_bf16.txt $O/${T}_pmc_write_bf16.txt "sdf_mlp_full3b_kernel" "bf16:1x64x64:64+64" $O/${T}_traffic.json
+rm -rf /tmp/p_bks; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bks -- $BENCH --precision bf16 --train-steps 0 > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/p_bks $O/${T}_kernel_stats_bf16.txt > /dev/null
+python $R/tools/dbg/timeline.py /tmp/p_bks $O/${T}_timeline_step_bf16.txt > /dev/null
+rm -rf /tmp/p_bsq; rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_bsq -- $BENCH --precision bf16 --steps 5 --warmup 2 --train-steps 0 > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/p_bsq $O/${T}_pmc_sq_bf16.txt > /dev/null
 # the same dominant kernel at the C4 per-GPU size (128^2 rays, 128 + 128 samples, 4 up-sampling steps: eight times the points)
 C4="--res 128 --samples 128 --importance 128 --up-steps 4"
 for c in "FETCH_SIZE:fetch" "WRITE_SIZE:write"; do
@@ -45,6 +50,7 @@ for c in "FETCH_SIZE:fetch" "WRITE_SIZE:write"; do
 done
 python $R/tools/traffic_json.py $O/${T}_pmc_fetch_c4.txt $O/${T}_pmc_write_c4.txt sdf_mlp_full3_kernel "f16x3:1x128x128:128+128" $O/${T}_traffic.json
 python $R/tools/bench_c5.py > $O/${T}_c5_mlp_microbench.jsonl 2>/dev/null
+python $R/tools/grad_margin.py $O/${T}_margins.json > $O/${T}_gradient_margins.txt 2>/dev/null   # (incl. the bf16-mode map margins)
 # the un-profiled bench lines last: they read the traffic file written above (same sources, same digest)
 cp $O/${T}_traffic.json $R/profiles/${T}_traffic.json
 python $R/bench.py 2>/dev/null | tail -1 > $O/${T}_bench_f16x3.json
