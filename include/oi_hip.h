@@ -232,6 +232,9 @@ int oi_midpoints(const float* rays_o, const float* rays_d, const float* z, long 
  * Replaces NeuSRenderer.render_core after the network calls (renderer.py:266-311, 338) and
  * Generator.render_maps + lighting.diffuse/specular (generator.py:80-174; lighting.py:126-225).
  */
+/* arrival counters of the launches that finish with a reduction by their last workgroup (two-level: csrc/oi_common.h) */
+#define OI_TICKET_WORDS 4097
+
 typedef struct oi_composite_params {
   /* per sample [N][T] / [N][T][3] */
   const float* sdf;
@@ -283,8 +286,8 @@ typedef struct oi_composite_params {
   float* block_partials;
   /* round 4 (appended: older callers that zero-initialise the struct keep the old behaviour)
    *   stats16 + stats_ticket: the launch ALSO does oi_render_stats' work -- the last workgroup to finish sums block_partials
-   *     in oi_render_stats' order (bit-identical) and writes out16 to stats16.  stats_ticket: one device word, zero before
-   *     the first launch (the kernel leaves it zero); it must not be shared by launches that may overlap (one per stream).
+   *     in oi_render_stats' order (bit-identical) and writes out16 to stats16.  stats_ticket: OI_TICKET_WORDS device words, zero
+   *     before the first launch (the kernel leaves them zero); not to be shared by launches that may overlap (one per stream).
    *   image_planar != 0: `image` is written as [B][3][N / B] (the (B, 3, H, W) map itself) instead of [N][3]. */
   float* stats16;
   unsigned* stats_ticket;
@@ -484,8 +487,8 @@ int oi_ada_pad_up2(const float* x, const float* f, float* canvas, int B, int C, 
  *   x [B][C][64][64];  theta_host: HOST array, passed to the kernel by value (no copy on the stream) | theta_dev: device
  *   array (captured graphs) | both NULL: no augmentation;  f12: Hz_geom (12 taps);  w1..w4 [Cout][Cin][4][4] (C -> 64 -> 128 ->
  *   256 -> 512), whead [out_dim][512][4][4], bhead [out_dim] or NULL;  logits [B][out_dim].
- *   workspace: oi_disc_fwd_small_workspace_floats(...) floats;  ticket: one zero-initialised device word (left zero; not to
- *   be shared by launches that may overlap).  Fixed summation order: results are bit-reproducible.
+  *   workspace: oi_disc_fwd_small_workspace_floats(...) floats;  ticket: OI_TICKET_WORDS zero-initialised device words (left
+ *   zero; not to be shared by launches that may overlap).  Fixed summation order: results are bit-reproducible.
  * OI_ERR_UNSUPPORTED for any other shape (B > 4, other sizes): callers then take the general path. */
 size_t oi_disc_fwd_small_workspace_floats(int B, int C, int mx0, int mx1, int my0, int my1);
 int oi_disc_fwd_small(const float* x, const float* theta_host, const float* theta_dev, const float* f12, int mx0, int mx1, int my0,

@@ -282,7 +282,7 @@ d_conv_small_kernel(const float* __restrict__ x, const float* __restrict__ w, fl
     }
     if (wave == 0) {  // (the stores above are this wave's)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+      if (lane == 0) is_last = oi::last_arriver(ticket, blockIdx.x, gridDim.x);
     }
     __syncthreads();
     if (!is_last) return;
@@ -307,7 +307,6 @@ d_conv_small_kernel(const float* __restrict__ x, const float* __restrict__ w, fl
       for (int part = 0; part < 8; ++part) s += hsum[part * 32 + t];
       logits[t] = s;
     }
-    if (t == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

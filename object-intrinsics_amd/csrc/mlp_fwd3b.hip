@@ -95,6 +95,12 @@ template <> struct is_no_tail_b<NoTailB> { static constexpr bool value = true; }
 #ifndef OI_B3_GROUPS
 #define OI_B3_GROUPS 1
 #endif
+#ifndef OI_B3_WINSTEPS
+#define OI_B3_WINSTEPS 1
+#endif
+#ifndef OI_B3_VALU_PER_MFMA
+#define OI_B3_VALU_PER_MFMA 8
+#endif
 // timing ablations (results garbage): 1 = no epilogue work, 2 = additionally no A-fragment reads after the first
 #ifndef OI_B3_ABL
 #define OI_B3_ABL 0
@@ -145,11 +151,20 @@ __device__ __forceinline__ void stream_layer_b(const char* lds, int wl, const Li
       const u32x4 ub = {bh[s][0], bh[s][1], bh[s][2], bh[s][3]};
       const bf16x8 v = __builtin_bit_cast(bf16x8, ub);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, v, s == 0 ? zero : acc[t], 0, 0, 0);
-      if (OI_B3_GROUPS && npairs >= 1) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // the MFMA opens the window, the epilogue fills its shadow
-        __builtin_amdgcn_sched_group_barrier(0x002, 32, 0);
+      // OI_B3_WINSTEPS k-steps per scheduling window: with 2, two epilogue pairs (independent chains) share a window and fill
+      // each other's wait states (accvgpr read -> use, v_fma_mix -> v_cvt_pk: an s_nop each when a pair is alone)
+      if (OI_B3_WINSTEPS == 1 || (s % OI_B3_WINSTEPS) == OI_B3_WINSTEPS - 1) {
+        if (OI_B3_GROUPS && npairs >= 1) {
+#pragma unroll
+          for (int q = 0; q + 1 < OI_B3_WINSTEPS; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // an MFMA opens each part, the epilogue fills its shadow
+            __builtin_amdgcn_sched_group_barrier(0x002, OI_B3_VALU_PER_MFMA, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 64, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
     post(t, acc[t]);
   }

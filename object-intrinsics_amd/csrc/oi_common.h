@@ -141,6 +141,25 @@ inline hipError_t zero_async(float* p, size_t n_floats, hipStream_t st) {
   return hipGetLastError();
 }
 
+// "Am I the last workgroup of this launch to get here?"  Called by ONE lane per workgroup after the workgroup's payload stores
+// (agent-scope write-through: __hip_atomic_store relaxed / agent) have been acknowledged (s_waitcnt vmcnt(0)); the workgroup
+// for which it returns true may read every other workgroup's payload with agent-scope loads.  Two levels of arrival counters
+// -- groups of LA_GROUP workgroups, then one counter over the groups: a single word takes ~88 same-address atomics per
+// microsecond on this part, i.e. 12 us for the 1024 workgroups of a C2 compositing launch (measured: the fused statistics
+// cost 7 us more than the launch they saved until the counter was split).  Nobody waits for anybody; every counter is left
+// at zero.  `ticket`: 1 + ceil(nblocks / LA_GROUP) zero-initialised words, not shared by launches that may overlap.
+constexpr int LA_GROUP = 32;
+constexpr int LA_WORDS = 1 + 4096;   // callers allocate this many words (up to 131,072 workgroups)
+__device__ __forceinline__ bool last_arriver(unsigned* ticket, unsigned block, unsigned nblocks) {
+  const unsigned ngroups = (nblocks + LA_GROUP - 1) / LA_GROUP, g = block / LA_GROUP;
+  const unsigned gsize = g + 1 == ngroups ? nblocks - g * LA_GROUP : LA_GROUP;
+  if (__hip_atomic_fetch_add(ticket + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gsize - 1) return false;
+  __hip_atomic_store(ticket + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ngroups - 1) return false;
+  __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
 // Accumulate-outputs (split-K sums, scatter-adds) are cleared by their launcher -- unless the caller has declared FOR THE
 // STREAM OF THE LAUNCH that it hands every such output out of memory it has already zeroed (oi_outputs_prezeroed_stream: one
 // fill per captured step instead of one per op).  Keyed by stream, not by thread and not process-wide: PyTorch runs a

@@ -476,14 +476,30 @@ __device__ __forceinline__ void stats_reduce(const float* __restrict__ block_par
   __shared__ float sred[4][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) {
-    const float* src = block_partials + (size_t)i * 8;
-    if constexpr (AGENT) {
+  if constexpr (AGENT) {
+    // four rows per trip, all 24 loads issued before the first add (one at a time they are a chain of L2 round trips: 10 us
+    // for the 1024 rows of a C2 launch); the adds keep the row order of the plain loop below: same bits
+    for (int i0 = threadIdx.x; i0 < n_blocks; i0 += 4 * blockDim.x) {
+      float v[4][6];
 #pragma unroll
-      for (int t = 0; t < 7; ++t)
-        if (t != 3) s[t] += __hip_atomic_load(src + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      const float4 a = reinterpret_cast<const float4*>(src)[0], b = reinterpret_cast<const float4*>(src)[1];
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * blockDim.x;
+        const float* src = block_partials + (size_t)(i < n_blocks ? i : i0) * 8;
+#pragma unroll
+        for (int t = 0; t < 6; ++t) v[u][t] = __hip_atomic_load(src + t + (t >= 3 ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i0 + u * (int)blockDim.x < n_blocks) {
+#pragma unroll
+          for (int t = 0; t < 6; ++t) s[t + (t >= 3 ? 1 : 0)] += v[u][t];
+        }
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) {
+      const float4* src = reinterpret_cast<const float4*>(block_partials + (size_t)i * 8);
+      const float4 a = src[0], b = src[1];
       s[0] += a.x; s[1] += a.y; s[2] += a.z;
       s[4] += b.x; s[5] += b.y; s[6] += b.z;
     }
@@ -670,15 +686,11 @@ composite_fwd_kernel(const oi_composite_params p) {
     __shared__ int is_last;
     if (wave == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) {
-        const unsigned t = __hip_atomic_fetch_add(p.stats_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = t == gridDim.x - 1;
-      }
+      if (lane == 0) is_last = oi::last_arriver(p.stats_ticket, blockIdx.x, gridDim.x);
     }
     __syncthreads();
     if (!is_last) return;
     stats_reduce<true>(p.block_partials, (int)gridDim.x, (float)p.N, (float)p.N * (float)p.T, p.stats16);
-    if (threadIdx.x == 0) __hip_atomic_store(p.stats_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
   }
 }
 

@@ -343,7 +343,11 @@ PER_RAY_OUT = {"weight_sum": 1, "weight_max": 1, "color_fine": 3, "image_no_bg":
 
 
 _STATS_TICKETS = {}
-FUSED_STATS = True   # oi_composite_fwd also does oi_render_stats' work (its last workgroup); False: two launches
+# oi_composite_fwd can do oi_render_stats' work itself (its last workgroup sums the partials: stats16 / stats_ticket).  Measured
+# at C2 (1024 workgroups, rocprofv3): 25.7 us for the one launch against 14.4 + 4.7 us for the two -- the reduction then sits
+# behind the slowest workgroup as a chain of round trips (store acknowledgement, two arrival counters, the loads) that costs
+# more than the launch boundary it replaces.  Default: two launches; the one-launch form stays tested (bit-identical).
+FUSED_STATS = False
 
 
 def _stats_ticket(dev):
@@ -352,7 +356,7 @@ def _stats_ticket(dev):
     key = (dev, _stream().value or 0)
     t = _STATS_TICKETS.get(key)
     if t is None:
-        t = _STATS_TICKETS[key] = torch.zeros(4, dtype=torch.int32, device=dev)
+        t = _STATS_TICKETS[key] = torch.zeros(4097, dtype=torch.int32, device=dev)   # OI_TICKET_WORDS
     return t
 
 
@@ -719,7 +723,7 @@ def disc_fwd_small(x, weights, whead, bhead, f12=None, theta_np=None, theta_dev=
     key = (x.device, _stream().value or 0)
     ticket = _DISC_TICKETS.get(key)
     if ticket is None:
-        ticket = _DISC_TICKETS[key] = torch.zeros(4, dtype=torch.int32, device=x.device)
+        ticket = _DISC_TICKETS[key] = torch.zeros(4097, dtype=torch.int32, device=x.device)   # OI_TICKET_WORDS
     out_dim = whead.shape[0]
     logits = _new(x, B, out_dim)
     th_host = th_arr = None

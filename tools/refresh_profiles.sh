@@ -12,7 +12,7 @@ BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bf16 --no
 rm -rf /tmp/p_ks; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_ks -- $BENCH > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/p_ks $O/${T}_kernel_stats_f16x3.txt > /dev/null
 rm -rf /tmp/p_tl; rocprofv3 --kernel-trace --output-format csv -d /tmp/p_tl -- $BENCH --train-steps 0 > /dev/null 2>&1
-python $R/tools/dbg/timeline.py /tmp/p_tl $O/${T}_timeline_step_f16x3.txt > /dev/null
+python $R/tools/dbg/timeline.py /tmp/p_tl $O/${T}_timeline_step_f16x3.txt prep_render_kernel > /dev/null
 for c in "FETCH_SIZE:fetch" "WRITE_SIZE:write" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE:sq"; do
   ctr=${c%%:*}; tag=${c##*:}
   rm -rf /tmp/p_$tag; rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/p_$tag -- $BENCH --steps 5 --warmup 2 --train-steps 4 > /dev/null 2>&1
@@ -38,7 +38,7 @@ done
 python $R/tools/traffic_json.py $O/${T}_pmc_fetch_bf16.txt $O/${T}_pmc_write_bf16.txt "sdf_mlp_full3b_kernel" "bf16:1x64x64:64+64" $O/${T}_traffic.json
 rm -rf /tmp/p_bks; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bks -- $BENCH --precision bf16 --train-steps 0 > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/p_bks $O/${T}_kernel_stats_bf16.txt > /dev/null
-python $R/tools/dbg/timeline.py /tmp/p_bks $O/${T}_timeline_step_bf16.txt > /dev/null
+python $R/tools/dbg/timeline.py /tmp/p_bks $O/${T}_timeline_step_bf16.txt prep_render_kernel > /dev/null
 rm -rf /tmp/p_bsq; rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_bsq -- $BENCH --precision bf16 --steps 5 --warmup 2 --train-steps 0 > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/p_bsq $O/${T}_pmc_sq_bf16.txt > /dev/null
 # the same dominant kernel at the C4 per-GPU size (128^2 rays, 128 + 128 samples, 4 up-sampling steps: eight times the points)
