@@ -113,15 +113,82 @@ constexpr int L_TOTAL_BWD = L_FILM2 + 1536;
 #ifndef OI_BWD_LD_LAST
 #define OI_BWD_LD_LAST OI_BWD_NT_LD
 #endif
-struct WaveScratchB {
+// Round 4, measured and NOT adopted as the default (-DOI_BWD_PACK24=1 builds it): the parked vectors crossing HBM as 24-bit
+// values (F16X3 mode, accurate trig) -- 12 instead of 16 KiB per slot, a quarter of the 19 GB a backward moves.
+//   phase slots   the reduced phase r in [0, 1) as 24-bit FIXED point (2^-24 absolute: finer than fp32's own spacing near 1)
+//   every other   fp32 with the mantissa rounded to 15 stored bits (2^-16 relative)
+// Four values = three dwords, moved by v_perm_b32 (3 to pack + 4 rounding adds, 4 to unpack).  Same box, 30 training
+// iterations: 9.68 -> 9.31 ms per iteration (render forward + backward 5.88 -> 5.57 ms).  The price: the worst parameter-
+// gradient error of the seven f16x3 gradient tests goes from 0.5-1.2e-5 to 1.4-1.8e-5 against a bar of 2e-5 (tools/dbg/
+// run_q24.sh: every slot family contributes -- gamma vbar 1.7e-5, v / phibar 1.5e-5, the colour pair 1.2e-5 on its own); a
+// format that keeps the bar's margin (24-bit fixed point relative to a per-lane maximum) costs 11 + 8 instead of 7 + 4
+// instructions per four values and needs the maxima before the stores: estimated to return less than half of the 0.37 ms.
+#ifndef OI_BWD_PACK24
+#define OI_BWD_PACK24 0
+#endif
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ u32x3 pack24f(f32x4 v) {
+  // (element copies first: __builtin_bit_cast applied to a vector-element lvalue read element 0 four times -- hipcc 7.2)
+  const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+  const unsigned b0 = __builtin_bit_cast(unsigned, x0) + 0x80u, b1 = __builtin_bit_cast(unsigned, x1) + 0x80u;
+  const unsigned b2 = __builtin_bit_cast(unsigned, x2) + 0x80u, b3 = __builtin_bit_cast(unsigned, x3) + 0x80u;
+  // bytes 1..3 of every value: {b0.1 b0.2 b0.3 b1.1} {b1.2 b1.3 b2.1 b2.2} {b2.3 b3.1 b3.2 b3.3}
+  return u32x3{__builtin_amdgcn_perm(b1, b0, 0x05030201u), __builtin_amdgcn_perm(b2, b1, 0x06050302u),
+               __builtin_amdgcn_perm(b3, b2, 0x07060503u)};
+}
+__device__ __forceinline__ f32x4 unpack24f(u32x3 d) {
+  const unsigned b0 = __builtin_amdgcn_perm(0u, d[0], 0x0201000cu), b1 = __builtin_amdgcn_perm(d[1], d[0], 0x0504030cu);
+  const unsigned b2 = __builtin_amdgcn_perm(d[2], d[1], 0x0403020cu), b3 = __builtin_amdgcn_perm(0u, d[2], 0x0302010cu);
+  return f32x4{__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1), __builtin_bit_cast(float, b2),
+               __builtin_bit_cast(float, b3)};
+}
+__device__ __forceinline__ u32x3 pack24q(f32x4 r) {  // r in [0, 1)
+  const unsigned q0 = (unsigned)(r[0] * 16777216.f), q1 = (unsigned)(r[1] * 16777216.f);
+  const unsigned q2 = (unsigned)(r[2] * 16777216.f), q3 = (unsigned)(r[3] * 16777216.f);
+  return u32x3{__builtin_amdgcn_perm(q1, q0, 0x04020100u), __builtin_amdgcn_perm(q2, q1, 0x05040201u),
+               __builtin_amdgcn_perm(q3, q2, 0x06050402u)};
+}
+__device__ __forceinline__ f32x4 unpack24q(u32x3 d) {
+  const unsigned q0 = __builtin_amdgcn_perm(0u, d[0], 0x0c020100u), q1 = __builtin_amdgcn_perm(d[1], d[0], 0x0c050403u);
+  const unsigned q2 = __builtin_amdgcn_perm(d[2], d[1], 0x0c040302u), q3 = __builtin_amdgcn_perm(0u, d[2], 0x0c030201u);
+  constexpr float S = 1.0f / 16777216.f;
+  return f32x4{(float)q0 * S, (float)q1 * S, (float)q2 * S, (float)q3 * S};
+}
+
+template <bool PACK>
+struct WaveScratchT {
   __amdgpu_buffer_rsrc_t rs;
+  int l12;  // 12 * lane (PACK)
+  // (stores: the wave-uniform offset is folded into voffset, soffset = 0: the >64-bit store hazard of oi::buffer_store_b128)
   template <int AUX = OI_BWD_ST_LOCAL>
   __device__ __forceinline__ void store(int slot, int g, int l16, f32x4 v) const {
-    oi::buffer_store_b128<AUX>(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024);
+#ifdef OI_BWD_Q24_SET  // precision experiment (32-bit slots): round the families in the mask to the 24-bit float format
+    {
+      const int fam = slot >= S_UV ? 3 : (slot >= S_V ? 2 : 1);
+      if ((OI_BWD_Q24_SET >> fam) & 1) v = unpack24f(pack24f(v));
+    }
+#endif
+    if constexpr (PACK) __builtin_amdgcn_raw_buffer_store_b96(pack24f(v), rs, l12 + (slot * 16384 + g * 768), 0, AUX);
+    else oi::buffer_store_b128<AUX>(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024);
   }
+  template <int AUX = OI_BWD_ST_LOCAL>
+  __device__ __forceinline__ void store_phase(int slot, int g, int l16, f32x4 v) const {
+    if constexpr (PACK) __builtin_amdgcn_raw_buffer_store_b96(pack24q(v), rs, l12 + (slot * 16384 + g * 768), 0, AUX);
+    else oi::buffer_store_b128<AUX>(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024);
+  }
+  // A parked fragment as it arrives (3 or 4 dwords); unpacked where it is USED -- the ring of the down sweep requests
+  // fragments a layer ahead, and an unpack next to the load would wait for it on the spot
+  using Frag = std::conditional_t<PACK, u32x3, f32x4>;
   template <int AUX = OI_BWD_LD_LAST>
-  __device__ __forceinline__ f32x4 load(int slot, int g, int l16) const {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, l16, slot * 16384 + g * 1024, AUX));
+  __device__ __forceinline__ Frag load(int slot, int g, int l16) const {
+    if constexpr (PACK) return __builtin_amdgcn_raw_buffer_load_b96(rs, l12, slot * 16384 + g * 768, AUX);
+    else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, l16, slot * 16384 + g * 1024, AUX));
+  }
+  static __device__ __forceinline__ f32x4 value(const Frag& f) {
+    if constexpr (PACK) return unpack24f(f); else return f;
+  }
+  static __device__ __forceinline__ f32x4 phase(const Frag& f) {
+    if constexpr (PACK) return unpack24q(f); else return f;
   }
 };
 
@@ -365,7 +432,10 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   const __amdgpu_buffer_rsrc_t img_rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mats), 0, NMAT * layer_bytes(PREC), 0x00020000);
 
-  WaveScratchB ws;
+  constexpr bool PK = OI_BWD_PACK24 && PREC == OI_PREC_F16X3 && !FAST;  // (fast trig parks unreduced phases: not fixed point)
+  WaveScratchT<PK> ws;
+  ws.l12 = 12 * lane;
+  asm volatile("" : "+v"(ws.l12));
   {
     const long long wt = ((long long)e * gridDim.x + blockIdx.x) * BW_NW + wave;
     ws.rs = __builtin_amdgcn_make_buffer_rsrc(scratch + wt * (long long)(NSLOT_BWD * 16384), 0, NSLOT_BWD * 16384,
@@ -655,7 +725,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           gb[4 * g + k] *= c;
         }
       }
-      if (!(OI_BWD_ABL & 4)) ws.store(S_PHI + l, g, o.l16, ph);
+      if (!(OI_BWD_ABL & 4)) ws.store_phase(S_PHI + l, g, o.l16, ph);
       if constexpr (LAST)
         if ((g & 3) == 3) rs.add(3, g >> 2, wsig_row);
       __builtin_amdgcn_sched_barrier(0);
@@ -682,7 +752,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   // (a ring of PF groups: with 512 registers a whole layer, PF = 16, is in flight across the two products)
   constexpr int PF = PREC == OI_PREC_F32 ? OI_BWD_PF_F32 : OI_BWD_PF, CARRY = OI_BWD_CARRY;
   static_assert(PF >= 1 && PF <= 16 && (PF & (PF - 1)) == 0 && CARRY >= 1 && CARRY <= PF, "OI_BWD_PF / OI_BWD_CARRY");
-  f32x4 phn[PF], vbn[PF];
+  using Frag = typename WaveScratchT<PK>::Frag;
+  Frag phn[PF], vbn[PF];
   f32x4 abl_sink;  // (OI_BWD_ABL & 8)
   constexpr int PFT = PF < 4 ? PF : 4;  // ring depth of the top layer (its point vectors carry phi_7 / vbar_7 as well)
 #if !OI_BWD_AC_REGS
@@ -739,8 +810,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           ph = f32x4{act[4 * g], act[4 * g + 1], act[4 * g + 2], act[4 * g + 3]};
           vb = f32x4{gb[4 * g], gb[4 * g + 1], gb[4 * g + 2], gb[4 * g + 3]};
         } else {
-          ph = phn[g & (PF - 1)];
-          vb = vbn[g & (PF - 1)];
+          ph = ws.phase(phn[g & (PF - 1)]);
+          vb = ws.value(vbn[g & (PF - 1)]);
         }
         f32x4 gnx, abx;  // g_{l+1}, abar_{l+1}
         if constexpr (TOP) {
@@ -748,7 +819,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #if OI_BWD_AC_REGS
           const f32x4 a8 = {ac[4 * g], ac[4 * g + 1], ac[4 * g + 2], ac[4 * g + 3]};
 #else
-          const f32x4 a8 = phn[g & (PFT - 1)];
+          const f32x4 a8 = ws.value(phn[g & (PFT - 1)]);
 #endif
 #pragma unroll
           for (int k = 0; k < 4; ++k) abx[k] = has_col ? fmaf(gs, gnx[k], a8[k]) : gs * gnx[k];  // abar_8
@@ -775,8 +846,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         }
 #if !OI_BWD_STORES_LAST
         if constexpr (!L0 && !(OI_BWD_ABL & 1)) {
-          ws.store<OI_BWD_ST_WGRAD>(S_V + l - 1, g, o.l16, vv);
-          ws.store<OI_BWD_ST_WGRAD>(S_U + l - 1, g, o.l16, ub);
+          ws.template store<OI_BWD_ST_WGRAD>(S_V + l - 1, g, o.l16, vv);
+          ws.template store<OI_BWD_ST_WGRAD>(S_U + l - 1, g, o.l16, ub);
         }
 #endif
         // this group's fragments are consumed: request the same group of the NEXT layer into the same registers -- the loads
@@ -827,8 +898,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     if constexpr (!L0 && !(OI_BWD_ABL & 1)) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        ws.store<OI_BWD_ST_WGRAD>(S_V + l - 1, g, o.l16, f32x4{gb[4 * g], gb[4 * g + 1], gb[4 * g + 2], gb[4 * g + 3]});
-        ws.store<OI_BWD_ST_WGRAD>(S_U + l - 1, g, o.l16, f32x4{act[4 * g], act[4 * g + 1], act[4 * g + 2], act[4 * g + 3]});
+        ws.template store<OI_BWD_ST_WGRAD>(S_V + l - 1, g, o.l16, f32x4{gb[4 * g], gb[4 * g + 1], gb[4 * g + 2], gb[4 * g + 3]});
+        ws.template store<OI_BWD_ST_WGRAD>(S_U + l - 1, g, o.l16, f32x4{act[4 * g], act[4 * g + 1], act[4 * g + 2], act[4 * g + 3]});
       }
     }
 #endif
@@ -1195,19 +1266,24 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
   // the top of the tile and waited: a full memory round trip exposed per tile and workgroup, 4.4 TB/s).
   //   both Y operands of a layer matrix come from the SAME parked phase (reduced, in revolutions): one read, one sin / cos
   //   pair 0: Y = gbar_l = (gamma vbar)_{l-1} cos(phi_{l-1})      pair 1: Y = a_l = sin(phi_{l-1})
-  struct Stage {  // the five slots of one wave tile as they arrive: 80 registers (48 for the colour head)
-    f32x4 xall[2][4], ph4[4], vb4[4];
+  constexpr bool PK = OI_BWD_PACK24 && !FAST;  // the sweep parked 24-bit values (see WaveScratchT): 60 staging registers
+  using WS = WaveScratchT<PK>;
+  using Frag = typename WS::Frag;
+  struct Stage {  // the five slots of one wave tile as they arrive: 80 registers (48 for the colour head); 60 (36) packed
+    Frag xall[2][4], ph4[4], vb4[4];
+    f32x4 pt[2];  // FIRST: the point and dL/dgrad of this thread's lane (raw fp32)
   };
   Stage stA, stB;
   // through a buffer descriptor over the wave tile (512 KiB): the tile base and the slot offsets travel in SGPRs, the lane
   // offset in ONE VGPR -- with flat pointers hipcc kept 20 address pairs live across the loop and spilled
-  const int t16 = tid * 16;
+  const int t16 = tid * (PK ? 12 : 16);
   auto request = [&](long long wt, Stage& st) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(scratch) + wt * (long long)(NSLOT_BWD * 16384), 0, NSLOT_BWD * 16384, 0x00020000);
-    auto ld = [&](int slot, int it) {
-      return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, t16, slot * 16384 + it * 4096,
-                                                                             OI_WGRAD_NT ? 2 : 0));
+    auto ld = [&](int slot, int it) -> Frag {   // granule q = it 256 + tid of the slot: group q / 64, lane q % 64
+      if constexpr (PK) return __builtin_amdgcn_raw_buffer_load_b96(rs, t16, slot * 16384 + it * 3072, OI_WGRAD_NT ? 2 : 0);
+      else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, t16, slot * 16384 + it * 4096,
+                                                                                  OI_WGRAD_NT ? 2 : 0));
     };
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -1221,8 +1297,8 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
     if constexpr (FIRST) {  // this thread's point (lane j = point j): (x y z .), (Gx Gy Gz .)
 #pragma unroll
       for (int q = 0; q < 2; ++q)
-        st.ph4[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * (tid & 31), S_PHI * 16384 + 16 * q,
-                                                                                   OI_WGRAD_NT ? 2 : 0));
+        st.pt[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, 32 * (tid & 31), S_PHI * 16384 + 16 * q,
+                                                                                  OI_WGRAD_NT ? 2 : 0));
     }
   };
   // fragments of one pair out of the fp32 LDS copies: this wave's column tile of Y -> shared fp16 fragments sb[pr], its
@@ -1267,7 +1343,8 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
       for (int it = 0; it < 4; ++it)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          z += st.ph4[it & (FIRST ? 1 : 3)][k] + st.xall[0][it][k] + (COL ? 0.f : (FIRST ? 0.f : st.vb4[it][k]) + st.xall[1][it][k]);
+          z += (FIRST ? st.pt[it & 1][k] : WS::phase(st.ph4[it])[k]) + WS::value(st.xall[0][it])[k] +
+               (COL ? 0.f : (FIRST ? 0.f : WS::value(st.vb4[it])[k]) + WS::value(st.xall[1][it])[k]);
       sub += z;
       __builtin_amdgcn_sched_barrier(0);
       if (wt + 2 < t_end) request(wt + 2, st);
@@ -1281,10 +1358,10 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
     for (int it = 0; it < 4; ++it) {
       f32x4 vb4;
       if constexpr (FIRST) {
-        l0_phase_vb<FAST>(l0tab, st.ph4[0], st.ph4[1], grp_f0(4 * it + wave) + 4 * h, ph4[it], vb4);
+        l0_phase_vb<FAST>(l0tab, st.pt[0], st.pt[1], grp_f0(4 * it + wave) + 4 * h, ph4[it], vb4);
       } else {
-        ph4[it] = st.ph4[it];
-        vb4 = st.vb4[it];
+        ph4[it] = WS::phase(st.ph4[it]);
+        if constexpr (!COL) vb4 = WS::value(st.vb4[it]);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k)  // colour head (one pair): Y = a_8 = sin
@@ -1297,7 +1374,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
     for (int it = 0; it < 4; ++it) {
       const int q = it * 256 + tid;
       const int dq = q + (q >> 5);  // + 4 floats per 32-point block
-      reinterpret_cast<f32x4*>(sx)[dq] = st.xall[0][it] * scx[0];
+      reinterpret_cast<f32x4*>(sx)[dq] = WS::value(st.xall[0][it]) * scx[0];
       reinterpret_cast<f32x4*>(sy)[dq] = y0[it];
     }
     WG_T(2);
@@ -1311,7 +1388,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
       for (int it = 0; it < 4; ++it) {
         const int q = it * 256 + tid;
         const int dq = q + (q >> 5);
-        reinterpret_cast<f32x4*>(sx)[dq] = st.xall[1][it] * scx[1];
+        reinterpret_cast<f32x4*>(sx)[dq] = WS::value(st.xall[1][it]) * scx[1];
         f32x4 y1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) y1[k] = __builtin_amdgcn_sinf(ph4[it][k]) * scy[1];
