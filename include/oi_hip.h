@@ -447,6 +447,10 @@ int oi_gan_losses_bwd(const float* g_total, const float* d_real, const float* d_
                       const float* aux_w, float reg_w, float* g_real, float* g_fake, float* g_gx, int B, int K, long long N,
                       oi_stream_t stream);
 
+/* Zero fill of n_floats floats as a kernel launch on `stream` (the one fill a step's pool of accumulate-outputs gets,
+ * oi_outputs_prezeroed_stream; a kernel node, not a memset node: see oi_common.h on memset nodes under hipGraph replay). */
+int oi_zero_fill(float* p, long long n_floats, oi_stream_t stream);
+
 /* The inputs of one captured (hipGraph) step in one launch: n_copies <= 4 device-to-device copies of counts[c] floats
  * (srcs / dsts / counts: HOST arrays) and n_imm <= 64 floats `imm` (HOST values, carried in the kernel arguments) written to
  * the device address imm_dst.  Replaces a copy launch per input tensor, the pinned-buffer upload of the augmentation
@@ -457,6 +461,15 @@ int oi_stage_inputs(const float* const* srcs, float* const* dsts, const long lon
 /* The renderer's two derived scalars from the compositing reductions r4[4] (reference: src/models/renderer.py:430-446):
  * out2 = (r4[0] / (r4[1] + 1e-5), r4[2] * inv_nt), and the gradient w.r.t. r4 (g_err / g_surf: device scalars or NULL). */
 int oi_render_scalars_fwd(const float* r4, float inv_nt, float* out2, oi_stream_t stream);
+
+/* The scalar glue of a forward in ONE launch (round 4; ~10 tensor-op launches of 0-dim tensors per parameter version before):
+ *   out5    = [inv_s, 1 / inv_s, sigmoid(param_ambient), 1 - sigmoid(param_ambient), max(param_specular, 0)]
+ *             inv_s = clamp(exp(10 variance), 1e-6, 1e6) (renderer.py:404; `s_val` of :448 is out5[1]); the light colours are the
+ *             logging scalars of generator.py:214-222 (lighting.py:50-60 before the expand(3))
+ *   packed3 = [param_ambient, param_specular, param_shininess], the `light` block oi_composite_fwd reads.
+ * All six pointers: single floats / small arrays on the device. */
+int oi_scalar_glue(const float* variance, const float* param_ambient, const float* param_specular, const float* param_shininess,
+                   float* out5, float* packed3, oi_stream_t stream);
 int oi_render_scalars_bwd(const float* r4, const float* g_err, const float* g_surf, float inv_nt, float* g_r4,
                           oi_stream_t stream);
 

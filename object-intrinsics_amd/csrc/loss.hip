@@ -119,9 +119,34 @@ __global__ void render_scalars_bwd_kernel(const float* __restrict__ r4, const fl
   g_r4[3] = 0.f;
 }
 
+// The scalar glue of a render: what the reference derives from four 0-dim parameters with ~10 tensor ops per forward.
+__global__ void scalar_glue_kernel(const float* __restrict__ variance, const float* __restrict__ ambient,
+                                   const float* __restrict__ specular, const float* __restrict__ shininess,
+                                   float* __restrict__ out5, float* __restrict__ packed3) {
+  const float inv_s = fminf(fmaxf(expf(variance[0] * 10.0f), 1e-6f), 1e6f);   // renderer.py:404
+  const float amb = 1.0f / (1.0f + expf(-ambient[0]));                          // lighting.py:50-60
+  out5[0] = inv_s;
+  out5[1] = 1.0f / inv_s;
+  out5[2] = amb;
+  out5[3] = 1.0f - amb;
+  out5[4] = fmaxf(specular[0], 0.f);
+  packed3[0] = ambient[0];
+  packed3[1] = specular[0];
+  packed3[2] = shininess[0];
+}
+
 }  // namespace
 
 extern "C" {
+
+int oi_scalar_glue(const float* variance, const float* param_ambient, const float* param_specular, const float* param_shininess,
+                   float* out5, float* packed3, oi_stream_t stream) {
+  OI_REQUIRE(variance != nullptr && param_ambient != nullptr && param_specular != nullptr && param_shininess != nullptr &&
+             out5 != nullptr && packed3 != nullptr, "oi_scalar_glue: null pointer");
+  hipLaunchKernelGGL(scalar_glue_kernel, dim3(1), dim3(1), 0, oi::as_stream(stream), variance, param_ambient, param_specular,
+                     param_shininess, out5, packed3);
+  return oi::check_launch("oi_scalar_glue");
+}
 
 int oi_render_scalars_fwd(const float* r4, float inv_nt, float* out2, oi_stream_t stream) {
   OI_REQUIRE(r4 != nullptr && out2 != nullptr, "oi_render_scalars_fwd: null pointer");

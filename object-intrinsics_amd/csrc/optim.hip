@@ -103,6 +103,12 @@ int oi_stage_inputs(const float* const* srcs, float* const* dsts, const long lon
 }
 
 
+int oi_zero_fill(float* p, long long n_floats, oi_stream_t stream) {
+  OI_REQUIRE(n_floats >= 0 && (p != nullptr || n_floats == 0), "oi_zero_fill: null pointer");
+  if (oi::zero_async(p, (size_t)n_floats, oi::as_stream(stream)) != hipSuccess) return oi::check_launch("oi_zero_fill");
+  return OI_OK;
+}
+
 int oi_mt_chunk_elems(void) { return CHUNK; }
 
 int oi_multi_adam(const oi_mt_chunk* table, int n_chunks, float lr, float beta1, float beta2, float eps,

@@ -76,7 +76,9 @@ composite_bwd_kernel(const oi_composite_params p, const oi_composite_grads q) {
       carry *= __shfl(incl, 63, 64);
     }
   }
-  const float gi0 = ld(q.g_image, r * 3), gi1 = ld(q.g_image, r * 3 + 1), gi2 = ld(q.g_image, r * 3 + 2);
+  // d image: [N][3], or the [B][3][N / B] map layout the forward wrote (p.image_planar)
+  const long long hw_ = p.image_planar ? p.N / p.B : 1, gi_base = p.image_planar ? (long long)e * 3 * hw_ + (r - (long long)e * hw_) : r * 3;
+  const float gi0 = ld(q.g_image, gi_base), gi1 = ld(q.g_image, gi_base + hw_), gi2 = ld(q.g_image, gi_base + 2 * hw_);
   const float b0 = p.bg ? p.bg[e * 3] : 0.f, b1 = p.bg ? p.bg[e * 3 + 1] : 0.f, b2 = p.bg ? p.bg[e * 3 + 2] : 0.f;
   const float gW = ld(q.g_weight_sum, r) + ((W > 1e-3f && W < 1.0f - 1e-3f) ? ld(q.g_mask, r) : 0.f) -
                    (gi0 * b0 + gi1 * b1 + gi2 * b2);

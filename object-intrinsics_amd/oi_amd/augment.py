@@ -258,5 +258,10 @@ class AugmentPipe(torch.nn.Module):
         if G_inv is None:
             return images
         margins = self.margins_for(G_inv, H, W)
-        th = torch.from_numpy(self.theta_for(G_inv, margins, H, W)).to(images.device, non_blocking=True)
+        th = self.theta_for(G_inv, margins, H, W)
+        if images.is_cuda and th.size <= 64:   # (up to 10 images: in the arguments of one small launch, no pageable copy)
+            from . import ops
+            th = ops.upload_small(th, images.device)
+        else:
+            th = torch.from_numpy(th).to(images.device, non_blocking=True)
         return self.apply_theta(images, th, margins)

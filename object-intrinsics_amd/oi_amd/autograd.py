@@ -107,12 +107,12 @@ def sdf_mlp(pack, pts, gamma, beta, B, want_grad, want_rgb, want_feat, scratch=N
 
 def composite(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light, cos_anneal_ratio, B,
               outputs=None, image_planar=False):
-    """`image_planar` applies to the no-grad path only (the backward kernel reads gradients of the (N, 3) form): callers
-    check the shape they get back."""
+    """`image_planar`: 'image' comes back as (B, 3, N / B) -- the (B, 3, H, W) map itself -- and its gradient is read in that
+    form.  With a gradient recorded the dict also carries 'finals' / 'ray_sums' (no gradient: logging scalars)."""
     if _needs_grad(sdf, grad, rgb, variance, light, light_dir):
         from .autograd_render import CompositeFunction
         return CompositeFunction.run(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light,
-                                     cos_anneal_ratio, B, outputs)
+                                     cos_anneal_ratio, B, outputs, image_planar)
     with torch.no_grad():
         return ops.composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light,
                                  cos_anneal_ratio, B, outputs, image_planar=image_planar)

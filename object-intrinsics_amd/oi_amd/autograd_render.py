@@ -4,33 +4,34 @@ from torch.autograd.function import once_differentiable
 
 from . import ops
 
-OUT_KEYS = ops.PER_SAMPLE_OUT + tuple(ops.PER_RAY_OUT) + ("reduce4",)
-NON_DIFF = ("cdf", "alpha", "inside_sphere", "pts_norm", "weight_max")
+OUT_KEYS = ops.PER_SAMPLE_OUT + tuple(ops.PER_RAY_OUT) + ("reduce4", "ray_sums", "finals")
+NON_DIFF = ("cdf", "alpha", "inside_sphere", "pts_norm", "weight_max", "ray_sums", "finals")
 
 
 class CompositeFunction(torch.autograd.Function):
     @staticmethod
     def run(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light, cos_anneal_ratio, B,
-            outputs=None):
+            outputs=None, image_planar=False):
         # the kernel normalises the light direction; doing it here too (idempotent) lets autograd own the
         # Jacobian of the normalisation, the kernel returns d/d(unit vector)
         # (a direction from DirectionalLight.batch_direction_unit is already that, with its own backward)
         ldir_n = light_dir if getattr(light_dir, "_oi_unit", False) else torch.nn.functional.normalize(light_dir, dim=-1, eps=1e-6)
         outs = CompositeFunction.apply(sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg,
-                                       float(cos_anneal_ratio), B)
+                                       float(cos_anneal_ratio), B, bool(image_planar))
         res = dict(zip(OUT_KEYS, outs))
-        if outputs is not None:
-            res = {k: v for k, v in res.items() if k in outputs}
+        if outputs is not None:   # ('finals' / 'ray_sums' come with 'reduce4', as from ops.composite_fwd)
+            res = {k: v for k, v in res.items() if k in outputs or (k in ("ray_sums", "finals") and "reduce4" in outputs)}
         return res
 
     @staticmethod
-    def forward(ctx, sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg, car, B):
-        out = ops.composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, ldir_n, bg, variance, light, car, B)
+    def forward(ctx, sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg, car, B, planar):
+        out = ops.composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, ldir_n, bg, variance, light, car, B,
+                                image_planar=planar)
         # ~20 outputs of which a loss touches a few: absent upstream gradients arrive as None (a null pointer for the kernel),
         # not as one zero-filled tensor -- one fill launch -- each
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg)
-        ctx.car, ctx.B = car, B
+        ctx.car, ctx.B, ctx.planar = car, B, planar
         ctx.mark_non_differentiable(*[out[k] for k in NON_DIFF])
         return tuple(out[k] for k in OUT_KEYS)
 
@@ -40,5 +41,6 @@ class CompositeFunction(torch.autograd.Function):
         sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg = ctx.saved_tensors
         g = {k: v for k, v in zip(OUT_KEYS, gouts) if k in ops.GRAD_IN and v is not None}
         d_sdf, d_grad, d_rgb, d_var, d_light, d_ldir = ops.composite_bwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d,
-                                                                         ldir_n, bg, variance, light, ctx.car, ctx.B, g)
-        return (d_sdf, d_grad, d_rgb, d_var.reshape(variance.shape), d_light, d_ldir) + (None,) * 7
+                                                                         ldir_n, bg, variance, light, ctx.car, ctx.B, g,
+                                                                         image_planar=ctx.planar)
+        return (d_sdf, d_grad, d_rgb, d_var.reshape(variance.shape), d_light, d_ldir) + (None,) * 8

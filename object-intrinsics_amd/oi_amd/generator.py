@@ -89,6 +89,8 @@ class Generator(nn.Module):
         arr = np.ascontiguousarray(arr, dtype=np.float32)
         if dev.type != "cuda":
             return torch.from_numpy(arr).to(dev)
+        if arr.size <= 64:   # (batches of one: the whole pose block travels in the arguments of one small launch)
+            return ops.upload_small(arr, dev)
         ring = _STAGE_RINGS.setdefault(self, {"bufs": [], "events": [], "i": 0})  # not in __dict__: deepcopy (EMA)
         n = arr.size
         if not ring["bufs"] or ring["bufs"][0].numel() < n:
@@ -146,6 +148,19 @@ class Generator(nn.Module):
         self._xy_off = flat[3 * n:3 * n + 2 * bs].view(bs, 2)
         self._bg_dev = flat[3 * n + 2 * bs:3 * n + 5 * bs].view(bs, 3) if has_bg else None
         return {"c2b": c2b, "b2w": b2w, "w2b": w2b, "light": self.light.batch_transform(w2b=w2b)}
+
+    def _glue(self):
+        """Scalar glue of a forward -- inv_s / s_val, the three logging colours of the light, the light block the compositing
+        kernel reads -- in ONE launch per parameter version (ops.scalar_glue; as tensor ops: exp, clamp, reciprocal, two muls,
+        sigmoid, rsub, clamp and a stack).  -> (out5, packed3)"""
+        lt = self.light
+        ps = (self.deviation_network.variance, lt.param_ambient, lt.param_specular, lt.param_shininess)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        hit = self.__dict__.get("_glue_cache")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = self.__dict__["_glue_cache"] = (key,) + tuple(ops.scalar_glue(*ps))
+        return hit[1], hit[2]
 
     def _kinv(self, dev):
         ki = self.camera.intrinsics_inv
@@ -258,7 +273,11 @@ class Generator(nn.Module):
             ldir._oi_unit = True   # (CompositeFunction.run: already normalised, Jacobian owned by the producer)
         else:
             ldir = prior["light"].direction() if grad_light else rays["light_dir"]
-        lpk = self.light.packed()
+        glue5, lpk = self._glue()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in (self.light.param_ambient, self.light.param_specular,
+                                                                     self.light.param_shininess)):
+            from .lighting import PackLight
+            lpk = PackLight.apply(self.light.param_ambient, self.light.param_specular, self.light.param_shininess, lpk)
 
         ro_all, rd_all = rays["rays_o"].view(bs, h * w, 3), rays["rays_d"].view(bs, h * w, 3)
         near_all, far_all = rays["near"].view(bs, h * w, 1), rays["far"].view(bs, h * w, 1)
@@ -278,7 +297,7 @@ class Generator(nn.Module):
                                              perturb_overwrite=-1 if self.training else 0,
                                              cos_anneal_ratio=cos_anneal_ratio, z=latent["z"], w=latent["w"],
                                              light=lpk, light_dir=ldir, bg=bg, film=film, coarse=coarse,
-                                             image_planar=(n_chunks == 1 and not torch.is_grad_enabled()))
+                                             image_planar=(n_chunks == 1))
             outs.append((s, c))
         if n_chunks == 1:
             s, c = outs[0]
@@ -290,13 +309,16 @@ class Generator(nn.Module):
         # no gradient recorded: gradient_error, surface_loss and the three per-ray logging means come out of the
         # compositing reduction itself (oi_render_stats); with autograd they are tensor expressions of reduce4
         finals = c.get("finals") if n_chunks == 1 else None
-        render_out = assemble_render_dict(s, c, self.deviation_network.variance, finals=finals)
+        # (with a gradient recorded gradient_error / surface_loss are autograd expressions of reduce4; the logging means still
+        # come from the launch's own reduction)
+        render_out = assemble_render_dict(s, c, self.deviation_network.variance,
+                                          finals=None if torch.is_grad_enabled() else finals, s_val=glue5[1])
         if n_chunks > 1:
             render_out["gradient_error"] = None
             render_out["surface_loss"] = None
 
         def to_map(x):
-            if x.dim() == 3:  # the compositing kernel wrote the (bs, 3, h * w) map itself (no-grad path: `image`)
+            if x.dim() == 3:  # the compositing kernel wrote the (bs, 3, h * w) map itself (`image`, unchunked)
                 return x.view(bs, -1, h, w)
             return x.reshape(bs, h, w, -1).permute(0, 3, 1, 2)
 
@@ -309,7 +331,9 @@ class Generator(nn.Module):
             "mask": to_map(c["mask"]),
         }
         if return_raw:
-            amb = torch.sigmoid(self.light.param_ambient)
+            amb = glue5[2]
+            if torch.is_grad_enabled() and self.light.param_ambient.requires_grad:
+                amb = torch.sigmoid(self.light.param_ambient)   # (keeps its graph, as in the reference; nothing trains on it)
             new.update({
                 "amb_shading_map": (amb * to_map(c["weight_sum"])).expand(bs, 3, h, w),
                 "diff_shading_map": to_map(c["diffuse_map"]).expand(bs, 3, h, w),
@@ -326,7 +350,7 @@ class Generator(nn.Module):
             ray_stats = finals[2:5]
         else:
             ray_stats = torch.cat([render_out["cdf_fine"][:, :1], render_out["weight_max"], render_out["weight_sum"]], 1).mean(0)
-        amb, diff, spec = self.light.stats()
+        amb, diff, spec = glue5[2], glue5[3], glue5[4]
         blob = {
             "loss": {"eikonal": render_out["gradient_error"]},
             "stats": {

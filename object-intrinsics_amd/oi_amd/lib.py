@@ -105,6 +105,8 @@ _SIGS = {
     "oi_gan_losses_bwd": (_i, [_vp] * 6 + [_f, _vp, _vp, _vp, _i, _i, _ll, _vp]),
     "oi_stage_inputs": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "oi_render_scalars_fwd": (_i, [_vp, _f, _vp, _vp]),
+    "oi_zero_fill": (_i, [_vp, _ll, _vp]),
+    "oi_scalar_glue": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "oi_render_scalars_bwd": (_i, [_vp, _vp, _vp, _f, _vp, _vp]),
     "oi_weighted_sum_fwd": (_i, [_vp, _vp, _i, _vp, _vp]),
     "oi_weighted_sum_bwd": (_i, [_vp, _vp, _i, _vp, _vp]),

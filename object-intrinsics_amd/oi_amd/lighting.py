@@ -77,6 +77,20 @@ class DirectionalLightWithSpecularFixInit(nn.Module):
         return BatchLight(self, w2b)
 
 
+class PackLight(torch.autograd.Function):
+    """[param_ambient, param_specular, param_shininess] -> the (3,) block the compositing kernel reads, WITHOUT a launch: the block
+    was written by oi_scalar_glue (oi_amd.generator.Generator._glue); this node only routes the gradient back (torch.stack: a
+    copy kernel per call)."""
+
+    @staticmethod
+    def forward(ctx, amb, spec, shin, packed):
+        return packed.view(3)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[0], g[1], g[2], None
+
+
 class _LightDir(torch.autograd.Function):
     @staticmethod
     def forward(ctx, d, w2b):

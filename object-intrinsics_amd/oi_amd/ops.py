@@ -68,7 +68,7 @@ class ZeroPool:
             self.buf = torch.empty(self.need, dtype=torch.float32, device=device) if self.need else None
         self.off, self.need = 0, 0
         if self.buf is not None:
-            self.buf.zero_()
+            _l.check(_l.load().oi_zero_fill(_p(self.buf), self.buf.numel(), _stream()), "oi_zero_fill")
 
     def take(self, ref, shape):
         n = int(torch.Size(shape).numel())
@@ -411,9 +411,9 @@ GRAD_IN = ("weights", "weight_sum", "color_fine", "image_no_bg", "image", "shadi
 
 
 def composite_bwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, variance, light, cos_anneal_ratio, B,
-                  gouts):
+                  gouts, image_planar=False):
     """gouts: dict name -> upstream gradient (missing / None = zero).  -> d_sdf, d_grad, d_rgb, d_variance (1,),
-    d_light (3,), d_light_dir (B,3)."""
+    d_light (3,), d_light_dir (B,3).  `image_planar`: gouts["image"] is (B, 3, N / B), the layout the forward wrote."""
     L = _l.load()
     N, T = dists.shape
     P = _l.CompositeParams()
@@ -426,6 +426,7 @@ def composite_bwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, light_dir, bg, v
         setattr(P, name, _p(t))
     P.cos_anneal_ratio = float(cos_anneal_ratio)
     P.N, P.T, P.B = N, T, B
+    P.image_planar = int(bool(image_planar))
     G = _l.CompositeGrads()
     for name in GRAD_IN:
         t = _c(gouts.get(name))
@@ -631,6 +632,27 @@ def stage_inputs(copies, imm=None, imm_dst=None):
     assert len(vals) <= 64 and (not vals or imm_dst.numel() >= len(vals))
     immv = (ctypes.c_float * max(len(vals), 1))(*vals)
     _l.check(L.oi_stage_inputs(srcs, dsts, cnts, n, immv, len(vals), _p(imm_dst) if vals else None, _stream()), "oi_stage_inputs")
+
+
+def scalar_glue(variance, ambient, specular, shininess):
+    """-> (out5 = [inv_s, 1 / inv_s, ambient colour, diffuse colour, specular colour], packed3 = the compositing kernel's light
+    block) from the four 0-dim parameters: one launch (oi_scalar_glue)."""
+    L = _l.load()
+    out5, packed = _new(variance, 5), _new(variance, 3)
+    ps = [_p(t.detach().reshape(1)) for t in (variance, ambient, specular, shininess)]
+    _l.check(L.oi_scalar_glue(*ps, _p(out5), _p(packed), _stream()), "oi_scalar_glue")
+    return out5, packed
+
+
+def upload_small(values, device):
+    """numpy / Python floats (<= 64 of them) -> a new float32 device tensor of the same shape, through the ARGUMENTS of one launch
+    (oi_stage_inputs): no pageable host-to-device copy -- which makes the host wait for everything queued on the stream -- and
+    no pinned staging ring."""
+    import numpy as np
+    arr = np.ascontiguousarray(values, dtype=np.float32)
+    out = torch.empty(arr.shape, dtype=torch.float32, device=device)
+    stage_inputs([], arr.ravel(), out)
+    return out
 
 
 def render_scalars_fwd(r4, inv_nt):

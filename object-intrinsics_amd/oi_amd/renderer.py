@@ -149,18 +149,20 @@ def _inv_s(variance):
     return hit[1], hit[2]
 
 
-def assemble_render_dict(s, c, variance, background_rgb=None, finals=None):
+def assemble_render_dict(s, c, variance, background_rgb=None, finals=None, s_val=None):
     """Same keys/shapes as NeuSRenderer.render's return value (renderer.py:448-473).  `finals`: the derived scalars
-    of ops.composite_fwd (gradient_error and surface_loss already divided, no extra launches; no-grad callers only)."""
+    of ops.composite_fwd (gradient_error and surface_loss already divided, no extra launches; no-grad callers only).
+    `s_val`: 1 / inv_s when the caller already has it (Generator._glue: one launch per parameter version for all scalar glue)."""
     N, T = s["sdf"].shape
     r4 = c["reduce4"]
-    _, s_val = _inv_s(variance)
+    if s_val is None:
+        _, s_val = _inv_s(variance)
     color = c["color_fine"]
     if background_rgb is not None:
         color = color + background_rgb * (1.0 - c["weight_sum"])
     gradient_error, surface_loss = (finals[0], finals[1]) if finals is not None else render_scalars(r4, N * T)
     return {
-        "s_val": s_val.detach().expand(N, 1),   # a report without a graph (stated deviation: see _inv_s)
+        "s_val": s_val.detach().reshape(1, 1).expand(N, 1),   # a report without a graph (stated deviation: see _inv_s)
         "cdf_fine": c["cdf"],
         "weight_sum": c["weight_sum"],
         "weight_max": c["weight_max"],

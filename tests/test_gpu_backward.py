@@ -180,6 +180,20 @@ def test_composite_backward_vs_oracle(sdf_sd, col_sd):
     for name, a, b in zip(("sdf", "grad", "rgb", "variance", "ambient", "specular", "shininess", "direction"), g_h, g_o):
         record_margin("composite_backward_vs_fp64_oracle", name, rel_err(a, b))
         assert rel_err(a, b) < COMPOSITE_BWD_TOL, (name, rel_err(a, b), a.flatten()[:4], b.flatten()[:4])
+    # the map layout (image written / its gradient read as (B, 3, H W): what Generator.forward uses) is the same arithmetic:
+    # bit-identical image and gradients; with a gradient recorded the launch's own logging reductions come along
+    out_p = CompositeFunction.run(sdf_h, grad_h, rgb_h, dists.cuda(), mid.cuda(), ro.cuda(), rd.cuda(), ldir, bg.cuda(),
+                                  var_h, light, car, B, image_planar=True)
+    assert tuple(out_p["image"].shape) == (B, 3, H * W) and torch.equal(out_p["image"].view(B, 3, H, W), m["image"])
+    assert not out_p["finals"].requires_grad and torch.equal(out_p["finals"], out["finals"])
+    assert abs(float(out_p["finals"][0]) - float(eik_h)) <= 1e-6 * abs(float(eik_h))
+    out_q = CompositeFunction.run(sdf_h, grad_h, rgb_h, dists.cuda(), mid.cuda(), ro.cuda(), rd.cuda(), ldir, bg.cuda(),
+                                  var_h, light, car, B)   # (a fresh graph: the first one was consumed above)
+    loss_p = (out_p["image"].view(B, 3, H, W) * cot["image"].cuda()).sum()
+    loss_q = (to_map(out_q["image"]) * cot["image"].cuda()).sum()
+    leaves_h = [sdf_h, grad_h, rgb_h, var_h, lp["param_ambient"], lp["param_specular"], lp["param_shininess"]]
+    for a, b in zip(torch.autograd.grad(loss_p, leaves_h), torch.autograd.grad(loss_q, leaves_h)):
+        assert torch.equal(a, b)
 
 
 # ---------------------------------------------------------------------------------------------

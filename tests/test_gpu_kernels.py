@@ -820,3 +820,19 @@ def test_composite_last_block_statistics_match_render_stats(ops, N, T, monkeypat
         img = out["image"] if rep != 1 else out["image"].view(B, 3, N // B).permute(0, 2, 1).reshape(N, 3)
         assert torch.equal(img, ref["image"]), rep
     assert int(ops._stats_ticket(sdf.device)[0]) == 0
+
+
+def test_scalar_glue_and_small_upload():
+    """oi_scalar_glue: the 0-dim glue of a forward in one launch (renderer.py:404,448; lighting.py:50-60) against the tensor
+    expressions it replaces; ops.upload_small: values reach the device through the arguments of one launch."""
+    from oi_amd import ops
+    for var, amb, spec, shin in ((0.3, -0.66, 0.01, 10.0), (-2.0, 1.5, -0.2, 3.0), (1.5, 0.0, 0.7, 30.0)):
+        t = [torch.tensor(v, device="cuda") for v in (var, amb, spec, shin)]
+        out5, packed = ops.scalar_glue(*t)
+        inv_s = torch.exp(t[0] * 10.0).clamp(1e-6, 1e6)
+        ref = torch.stack([inv_s, 1.0 / inv_s, torch.sigmoid(t[1]), 1 - torch.sigmoid(t[1]), t[2].clamp(min=0)])
+        assert torch.allclose(out5, ref, rtol=2e-6, atol=0), (out5, ref)
+        assert torch.equal(packed, torch.stack(t[1:]))
+    vals = np.random.default_rng(0).normal(size=(3, 2, 3)).astype(np.float32)
+    up = ops.upload_small(vals, torch.device("cuda"))
+    assert up.shape == (3, 2, 3) and np.array_equal(up.cpu().numpy(), vals)
