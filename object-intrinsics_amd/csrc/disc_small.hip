@@ -24,6 +24,10 @@
 //     without leaving the workgroup; the sampling matrix arrives BY VALUE in the kernel arguments (no host-to-device copy).
 #include "oi_common.h"
 
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
 namespace {
 
 // ---- shared with disc.hip (same expressions) ------------------------------------------------------------------------
@@ -47,21 +51,130 @@ struct ThetaArg {
   float t[DS_MAX_B][6];
 };
 
-// x [B][C][H][W] (theta_on = 0: no augmentation) or canvas [B][C][Hc][Wc] -> y [B][C1][H/2][W/2] = lrelu(conv1(aug(x)))
+__device__ __forceinline__ int reflect_idx_s(int i, int n) {   // (disc.hip's reflect_idx)
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+// FOLD: the canvas (reflect pad + x2 up-FIR: disc.hip's ada_pad_up2_kernel) is not read from memory -- the workgroup builds the
+// canvas pixels its 22 x 22 grid points touch (their bounding box, <= DA_CT per axis) in LDS from the source image, with the
+// SAME two passes and the same association of the sums as that kernel (bit-identical), and resamples from there: one launch
+// and its boundary less.  The launcher checks on the host that the footprint fits (fold_fits), else it takes the canvas form.
+constexpr int DA_CT = 40;                  // canvas tile capacity per axis (identity scale needs 24; scale 0.57 fills it)
+constexpr int DA_PS = DA_CT / 2 + 6;       // 26: padded-image rows / columns under a canvas tile
+
+// x [B][C][H][W] (theta_on = 0: no augmentation; FOLD: the image the canvas is built from) or canvas [B][C][Hc][Wc]
+//   -> y [B][C1][H/2][W/2] = lrelu(conv1(aug(x)))
+template <bool FOLD>
 __global__ void __launch_bounds__(256)
 d_aug_conv1_kernel(const float* __restrict__ src, const ThetaArg th, const float* __restrict__ theta_dev, int theta_on,
                    const float* __restrict__ f,
-                   const float* __restrict__ w1, float* __restrict__ y, int C, int H, int W, int Hc, int Wc, int C1, float slope) {
-  __shared__ float g[DS_MAX_C][DA_G][DA_G + 1];   // resampled grid patch
-  __shared__ float gv[DS_MAX_C][DA_P][DA_G + 1];  // after the vertical pass
+                   const float* __restrict__ w1, float* __restrict__ y, int C, int H, int W, int Hc, int Wc, int C1, float slope,
+                   int mx0, int my0) {
   __shared__ float aug[DS_MAX_C][DA_P][DA_P + 1]; // augmented patch (zero outside the image: the convolution's padding)
   __shared__ float fs[DA_TAPS];
+  // g: resampled grid patch; gv: after the vertical pass.  FOLD adds cv (canvas tile), ps (padded-image patch), tm (after the
+  // row pass); ps and tm are dead before g / gv are written and share their memory
+  constexpr int G_FLOATS = DS_MAX_C * DA_G * (DA_G + 1), GV_FLOATS = DS_MAX_C * DA_P * (DA_G + 1);
+  constexpr int TM_FLOATS = FOLD ? DS_MAX_C * DA_PS * (DA_CT + 1) : 0, PS_FLOATS = FOLD ? DS_MAX_C * DA_PS * (DA_PS + 1) : 0;
+  __shared__ float pool_a[G_FLOATS > TM_FLOATS ? G_FLOATS : TM_FLOATS];
+  __shared__ float pool_b[GV_FLOATS > PS_FLOATS ? GV_FLOATS : PS_FLOATS];
+  __shared__ float cv_[FOLD ? DS_MAX_C * DA_CT * (DA_CT + 1) : 1];
+  __shared__ float fr[FOLD ? DA_TAPS : 1];
+  float (*g)[DA_G][DA_G + 1] = reinterpret_cast<float (*)[DA_G][DA_G + 1]>(pool_a);
+  float (*gv)[DA_P][DA_G + 1] = reinterpret_cast<float (*)[DA_P][DA_G + 1]>(pool_b);
+  float (*tm)[DA_PS][DA_CT + 1] = reinterpret_cast<float (*)[DA_PS][DA_CT + 1]>(pool_a);
+  float (*ps)[DA_PS][DA_PS + 1] = reinterpret_cast<float (*)[DA_PS][DA_PS + 1]>(pool_b);
+  float (*cv)[DA_CT][DA_CT + 1] = reinterpret_cast<float (*)[DA_CT][DA_CT + 1]>(cv_);
   const int tid = threadIdx.x, b = blockIdx.z;
   const int ay0 = blockIdx.y * DA_T - 1, ax0 = blockIdx.x * DA_T - 1;  // patch origin in the augmented image
   if (theta_on) {
     if (tid < DA_TAPS) fs[tid] = f[tid];  // flip_filter = True: the correlation taps are the filter itself
     const int Ho = 2 * (H + DA_PAD), Wo = 2 * (W + DA_PAD);
     const int gy0 = 2 * ay0 + 1, gx0 = 2 * ax0 + 1;  // aug[a][b] = sum_{k,l} f[k] f[l] G[2 a + k + 1][2 b + l + 1]
+    int u0 = 0, v0 = 0;   // FOLD: canvas coordinates of cv[.][0][0] (even)
+    if constexpr (FOLD) {
+      if (tid < DA_TAPS) fr[tid] = 2.0f * f[DA_TAPS - 1 - tid];  // up-FIR correlation taps: reversed, sqrt(gain) = 2 per axis
+      // bounding box of the canvas pixels the tile's grid points touch: the map is affine, so the extremes sit at the corners of
+      // the in-range part of the 22 x 22 grid patch (points outside the grid carry zero weights: what they read is unused)
+      int bbox[4] = {0x7fffffff, 0x7fffffff, -1, -1};   // [min y, min x, max y, max x]
+      {
+        float tb[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) tb[q] = theta_dev != nullptr ? theta_dev[b * 6 + q] : th.t[b][q];
+        const int ya = max(gy0, 0), yb = min(gy0 + DA_G - 1, Ho - 1), xa = max(gx0, 0), xb = min(gx0 + DA_G - 1, Wo - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float ix, iy;
+          affine_src_s(tb, (k & 1) ? xb : xa, (k & 2) ? yb : ya, Wo, Ho, Wc, Hc, ix, iy);
+          const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
+          bbox[0] = min(bbox[0], min(max(y0, 0), Hc - 1));
+          bbox[1] = min(bbox[1], min(max(x0, 0), Wc - 1));
+          bbox[2] = max(bbox[2], min(max(y0 + 1, 0), Hc - 1));
+          bbox[3] = max(bbox[3], min(max(x0 + 1, 0), Wc - 1));
+        }
+      }
+      u0 = bbox[0] & ~1;
+      v0 = bbox[1] & ~1;
+      const int TH = min(bbox[2] - u0 + 1, DA_CT), TW = min(bbox[3] - v0 + 1, DA_CT);   // (<= DA_CT: checked by the launcher)
+      const int r_min = u0 / 2 - 3, c_min = v0 / 2 - 3;       // padded-image index of the first tap of canvas row u0 / column v0
+      const int NR = TH / 2 + 6, NC = TW / 2 + 6;             // rows / columns of the padded image under the tile (<= DA_PS)
+      const int Hp = Hc / 2, Wp = Wc / 2;
+      // thread -> (row, column) with power-of-two strides: run-time divisors cost more than the idle lanes
+      {
+        const int bb = tid & 31, a0 = tid >> 5;               // 32 columns x 8 rows per step (NC <= 26)
+        const int c = c_min + bb;
+        const bool c_ok = bb < NC && c >= 0 && c < Wp;
+        const int cs = reflect_idx_s(min(max(c, 0), Wp - 1) - mx0, W);
+        float pv[4][DS_MAX_C];                                // every load of the patch in flight before the first store
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                         // (NR <= 26 = 4 steps of 8 rows; rows past NR: a clamped, harmless load)
+          const int r = r_min + a0 + 8 * k;
+          const int rs = reflect_idx_s(min(max(r, 0), Hp - 1) - my0, H);
+#pragma unroll
+          for (int c_ = 0; c_ < DS_MAX_C; ++c_)
+            pv[k][c_] = c_ < C ? src[(((size_t)b * C + c_) * H + rs) * W + cs] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int a = a0 + 8 * k, r = r_min + a;
+          const bool ok = c_ok && r >= 0 && r < Hp;
+          if (a < NR && bb < NC)
+#pragma unroll
+            for (int c_ = 0; c_ < DS_MAX_C; ++c_)
+              if (c_ < C) ps[c_][a][bb] = ok ? pv[k][c_] : 0.f;
+        }
+      }
+      __syncthreads();
+      {
+        const int vl = tid & 63, a0 = tid >> 6;               // 64 columns (TW <= 40) x 4 rows per step
+        const int kv = vl & 1, pl = (vl + kv) / 2;
+        if (vl < TW)
+          for (int a = a0; a < NR; a += 4)                    // rows: the six taps k = kv, kv + 2, .. (ada_pad_up2_kernel's order)
+            for (int c_ = 0; c_ < C; ++c_) {
+              float s_ = 0.f;
+#pragma unroll
+              for (int q = 0; q < 6; ++q) s_ = fmaf(fr[kv + 2 * q], ps[c_][a][pl + q], s_);
+              tm[c_][a][vl] = s_;
+            }
+      }
+      __syncthreads();
+      {
+        const int vl = tid & 63, ul0 = tid >> 6;
+        if (vl < TW)
+          for (int ul = ul0; ul < TH; ul += 4) {              // columns
+            const int ku = ul & 1, pl = (ul + ku) / 2;
+            for (int c_ = 0; c_ < C; ++c_) {
+              float acc = 0.f;
+#pragma unroll
+              for (int q = 0; q < 6; ++q) acc = fmaf(fr[ku + 2 * q], tm[c_][pl + q][vl], acc);
+              cv[c_][ul][vl] = acc;
+            }
+          }
+      }
+      __syncthreads();   // (tm is dead: g may be written)
+    }
     for (int i = tid; i < DA_G * DA_G; i += 256) {
       const int r = i / DA_G, c = i % DA_G;
       const int gyi = gy0 + r, gxi = gx0 + c;
@@ -82,9 +195,17 @@ d_aug_conv1_kernel(const float* __restrict__ src, const ThetaArg th, const float
       const float w00 = (in && xa && ya) ? (1.f - tx) * (1.f - ty) : 0.f, w01 = (in && xb && ya) ? tx * (1.f - ty) : 0.f;
       const float w10 = (in && xa && yb) ? (1.f - tx) * ty : 0.f, w11 = (in && xb && yb) ? tx * ty : 0.f;
       for (int c_ = 0; c_ < C; ++c_) {
-        const float* cp = src + ((size_t)b * C + c_) * Hc * Wc;
-        const float v00 = cp[(size_t)cy0 * Wc + cx0], v01 = cp[(size_t)cy0 * Wc + cx1];
-        const float v10 = cp[(size_t)cy1 * Wc + cx0], v11 = cp[(size_t)cy1 * Wc + cx1];
+        float v00, v01, v10, v11;
+        if constexpr (FOLD) {
+          const int ly0 = min(max(cy0 - u0, 0), DA_CT - 1), ly1 = min(max(cy1 - u0, 0), DA_CT - 1);
+          const int lx0 = min(max(cx0 - v0, 0), DA_CT - 1), lx1 = min(max(cx1 - v0, 0), DA_CT - 1);
+          v00 = cv[c_][ly0][lx0]; v01 = cv[c_][ly0][lx1];
+          v10 = cv[c_][ly1][lx0]; v11 = cv[c_][ly1][lx1];
+        } else {
+          const float* cp = src + ((size_t)b * C + c_) * Hc * Wc;
+          v00 = cp[(size_t)cy0 * Wc + cx0]; v01 = cp[(size_t)cy0 * Wc + cx1];
+          v10 = cp[(size_t)cy1 * Wc + cx0]; v11 = cp[(size_t)cy1 * Wc + cx1];
+        }
         float v = 0.f;   // (the order of disc.hip's ada_resample_down2_kernel)
         v += v00 * w00;
         v += v01 * w01;
@@ -312,6 +433,24 @@ d_conv_small_kernel(const float* __restrict__ x, const float* __restrict__ w, fl
 
 }  // namespace
 
+// Does every tile's canvas footprint fit d_aug_conv1_kernel<true>'s LDS tile?  Conservative: over the 21 grid steps of a tile
+// the source coordinate moves by at most 21 Wc (|t0| / Wo + |t1| / Ho) canvas pixels (affine_src_s), the touched pixels are
+// floor + 1, and the tile origin is rounded down to an even pixel.
+static bool fold_fits(const float* theta, int B, int H, int W, int Hp, int Wp) {
+  const float Ho = 2.0f * (H + DA_PAD), Wo = 2.0f * (W + DA_PAD), Hc = 2.0f * Hp, Wc = 2.0f * Wp;
+  for (int b = 0; b < B; ++b) {
+    const float* t = theta + b * 6;
+    const float dx = (DA_G - 1) * Wc * (fabsf(t[0]) / Wo + fabsf(t[1]) / Ho), dy = (DA_G - 1) * Hc * (fabsf(t[3]) / Wo + fabsf(t[4]) / Ho);
+    if (!(dx + 4.0f <= DA_CT && dy + 4.0f <= DA_CT)) return false;   // (also false for NaN)
+  }
+  return true;
+}
+// OI_DISC_FOLD=0: always the canvas form (the yardstick of the bit-identity test)
+static int flags_fold_mode() {
+  static const int v = [] { const char* e = getenv("OI_DISC_FOLD"); return e != nullptr && e[0] == '0' ? 0 : 1; }();
+  return v;
+}
+
 // disc.hip: the canvas of the augmentation (reflect pad + x2 up-FIR) for a given stream
 extern "C" int oi_ada_pad_up2(const float* x, const float* f, float* canvas, int B, int C, int H, int W, int mx0, int mx1, int my0,
                               int my1, oi_stream_t stream);
@@ -343,15 +482,23 @@ int oi_disc_fwd_small(const float* x, const float* theta_host, const float* thet
   float* partials = a3 + (size_t)B * 256 * 8 * 8;
   ThetaArg th = {};
   int rc = OI_OK;
+  // the canvas built inside d_aug_conv1_kernel (one launch less) when the host can see that every tile's footprint fits
+  const bool fold = aug && theta_host != nullptr && (flags_fold_mode() != 0) && fold_fits(theta_host, B, H, W, Hp, Wp);
   if (aug) {
     if (theta_host != nullptr)
       for (int b = 0; b < B; ++b)
         for (int i = 0; i < 6; ++i) th.t[b][i] = theta_host[b * 6 + i];
-    rc = oi_ada_pad_up2(x, f12, canvas, B, C, H, W, mx0, mx1, my0, my1, stream);
-    if (rc != OI_OK) return rc;
+    if (!fold) {
+      rc = oi_ada_pad_up2(x, f12, canvas, B, C, H, W, mx0, mx1, my0, my1, stream);
+      if (rc != OI_OK) return rc;
+    }
   }
-  hipLaunchKernelGGL(d_aug_conv1_kernel, dim3(W / DA_T, H / DA_T, B), dim3(256), 0, st, aug ? canvas : x, th, theta_dev, aug ? 1 : 0,
-                     f12, w1, a1, C, H, W, 2 * Hp, 2 * Wp, 64, slope);
+  if (fold)
+    hipLaunchKernelGGL(d_aug_conv1_kernel<true>, dim3(W / DA_T, H / DA_T, B), dim3(256), 0, st, x, th, theta_dev, 1, f12, w1, a1, C, H, W,
+                       2 * Hp, 2 * Wp, 64, slope, mx0, my0);
+  else
+    hipLaunchKernelGGL(d_aug_conv1_kernel<false>, dim3(W / DA_T, H / DA_T, B), dim3(256), 0, st, aug ? canvas : x, th, theta_dev,
+                       aug ? 1 : 0, f12, w1, a1, C, H, W, 2 * Hp, 2 * Wp, 64, slope, mx0, my0);
   rc = oi::check_launch("oi_disc_fwd_small(aug + conv1)");
   if (rc != OI_OK) return rc;
   hipLaunchKernelGGL((d_conv_small_kernel<64, 32, 8, 2, false>), dim3(128 / 2, 2), dim3(512), 0, st, a1, w2, a2, B, 128, slope, nullptr,
@@ -365,6 +512,149 @@ int oi_disc_fwd_small(const float* x, const float* theta_host, const float* thet
   hipLaunchKernelGGL((d_conv_small_kernel<256, 8, 4, 2, true>), dim3(512 / 2, 1), dim3(256), 0, st, a3, w4, a1, B, 512, slope, whead, bhead,
                      out_dim, partials, ticket, logits);
   return oi::check_launch("oi_disc_fwd_small(conv4 + head)");
+}
+
+}  // extern "C"
+
+// ---- the same launches as ONE hipGraph whose per-call inputs are kernel-node PARAMETERS -----------------------------------
+// A graph captured by the framework has its input pointer and the sampling matrices baked in, so every replay needs a staging
+// launch in front (copy the image to the static buffer, write the matrices: 4.5 us of a 41 us replay).  Here the library owns
+// the graph: captured once from oi_disc_fwd_small on a private stream, and before each launch the nodes that read per-call
+// data get them through hipGraphExecKernelNodeSetParams -- the image POINTER (first node) and the matrices BY VALUE (ThetaArg
+// of d_aug_conv1_kernel).  Nothing else changes between launches; weights, workspace, ticket and logits are fixed addresses.
+// With the augmentation there are two captured variants: canvas built inside d_aug_conv1_kernel (4 nodes), or by
+// ada_pad_up2_kernel in front (5 nodes) for matrices whose footprint does not fit the LDS tile (fold_fits, decided per launch).
+namespace {
+constexpr int N_ARGS_PAD = 10, N_ARGS_AUG = 17;   // ada_pad_up2_kernel / d_aug_conv1_kernel
+struct GraphVariant {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int n_nodes = 0;                                  // leading nodes that take per-call parameters
+  hipGraphNode_t node[2] = {nullptr, nullptr};
+  hipKernelNodeParams kp[2] = {};
+  std::vector<void*> args[2];
+};
+}  // namespace
+
+struct oi_disc_graph {
+  GraphVariant v[2];          // aug: [0] folded, [1] canvas form; no aug: [0] only
+  const float* x_arg = nullptr;
+  ThetaArg th_arg = {};
+  int aug = 0, B = 0, H = 0, W = 0, Hp = 0, Wp = 0;
+  // everything oi_disc_fwd_small takes besides the image and the matrices (oi_disc_graph_launch_eager)
+  const float *f12 = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr, *w4 = nullptr, *whead = nullptr, *bhead = nullptr;
+  float* workspace = nullptr;
+  unsigned* ticket = nullptr;
+  float* logits = nullptr;
+  int C = 0, mx0 = 0, mx1 = 0, my0 = 0, my1 = 0, n_feat = 0, out_dim = 0;
+  float slope = 0.f;
+};
+
+static void graph_variant_free(GraphVariant& v) {
+  if (v.exec) (void)hipGraphExecDestroy(v.exec);
+  if (v.graph) (void)hipGraphDestroy(v.graph);
+  v.exec = nullptr;
+  v.graph = nullptr;
+}
+
+extern "C" {
+
+int oi_disc_graph_create(oi_disc_graph** out, int aug, const float* f12, int mx0, int mx1, int my0, int my1, const float* w1,
+                         const float* w2, const float* w3, const float* w4, const float* whead, const float* bhead,
+                         float* workspace, unsigned* ticket, float* logits, int B, int C, int H, int W, int n_feat, int out_dim,
+                         float slope) {
+  OI_REQUIRE(out != nullptr && workspace != nullptr, "oi_disc_graph_create: null pointer");
+  OI_REQUIRE(B >= 1 && B <= DS_MAX_B, "oi_disc_graph_create: B=%d (1..%d)", B, DS_MAX_B);
+  *out = nullptr;
+  hipStream_t cs = nullptr;
+  if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_disc_graph_create: stream");
+  oi_disc_graph* g = new oi_disc_graph();
+  g->aug = aug ? 1 : 0;
+  g->B = B; g->H = H; g->W = W; g->Hp = H + my0 + my1; g->Wp = W + mx0 + mx1;
+  g->f12 = f12; g->w1 = w1; g->w2 = w2; g->w3 = w3; g->w4 = w4; g->whead = whead; g->bhead = bhead;
+  g->workspace = workspace; g->ticket = ticket; g->logits = logits;
+  g->C = C; g->mx0 = mx0; g->mx1 = mx1; g->my0 = my0; g->my1 = my1; g->n_feat = n_feat; g->out_dim = out_dim; g->slope = slope;
+  int rc = OI_OK;
+  const char* what = nullptr;
+  for (int vi = 0; vi < (g->aug ? 2 : 1) && rc == OI_OK && what == nullptr; ++vi) {
+    GraphVariant& v = g->v[vi];
+    // placeholders for the per-call arguments (nothing runs at capture time): `workspace` as the image pointer; a zero matrix
+    // (fits: the folded form is captured) or an enormous one (does not fit: the canvas form)
+    float th0[DS_MAX_B * 6] = {};
+    if (vi == 1)
+      for (int b = 0; b < B; ++b) th0[b * 6] = 1e9f;
+    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) { what = hipGetErrorString(e); break; }
+    rc = oi_disc_fwd_small(workspace, g->aug ? th0 : nullptr, nullptr, f12 != nullptr ? f12 : workspace, mx0, mx1, my0, my1, w1, w2, w3,
+                           w4, whead, bhead, workspace, ticket, logits, B, C, H, W, n_feat, out_dim, slope,
+                           reinterpret_cast<oi_stream_t>(cs));
+    e = hipStreamEndCapture(cs, &v.graph);
+    if (rc != OI_OK) break;
+    if (e != hipSuccess || v.graph == nullptr) { what = hipGetErrorString(e); break; }
+    if (hipGraphInstantiate(&v.exec, v.graph, nullptr, nullptr, 0) != hipSuccess) { what = "hipGraphInstantiate"; break; }
+    size_t n_root = 1;
+    if (hipGraphGetRootNodes(v.graph, &v.node[0], &n_root) != hipSuccess || n_root != 1) { what = "root node"; break; }
+    v.n_nodes = (g->aug && vi == 1) ? 2 : 1;
+    if (v.n_nodes == 2) {
+      size_t n_dep = 1;
+      if (hipGraphNodeGetDependentNodes(v.node[0], &v.node[1], &n_dep) != hipSuccess || n_dep != 1) { what = "second node"; break; }
+    }
+    for (int i = 0; i < v.n_nodes && what == nullptr; ++i) {
+      if (hipGraphKernelNodeGetParams(v.node[i], &v.kp[i]) != hipSuccess || v.kp[i].kernelParams == nullptr) { what = "kernel node parameters"; break; }
+      const int n_args = (v.n_nodes == 2 && i == 0) ? N_ARGS_PAD : N_ARGS_AUG;
+      v.args[i].assign(v.kp[i].kernelParams, v.kp[i].kernelParams + n_args);
+      v.kp[i].kernelParams = v.args[i].data();
+    }
+    if (what != nullptr) break;
+    v.args[0][0] = &g->x_arg;                                   // the image pointer: first argument of the first kernel
+    if (g->aug) v.args[v.n_nodes - 1][1] = &g->th_arg;          // d_aug_conv1_kernel(src, ThetaArg th, ...)
+  }
+  (void)hipStreamDestroy(cs);
+  if (rc != OI_OK || what != nullptr) {
+    graph_variant_free(g->v[0]);
+    graph_variant_free(g->v[1]);
+    delete g;
+    return rc != OI_OK ? rc : oi::fail(OI_ERR_LAUNCH, "oi_disc_graph_create: %s", what);
+  }
+  *out = g;
+  return OI_OK;
+}
+
+int oi_disc_graph_launch(oi_disc_graph* g, const float* x, const float* theta_host, oi_stream_t stream) {
+  OI_REQUIRE(g != nullptr && x != nullptr, "oi_disc_graph_launch: null pointer");
+  OI_REQUIRE((theta_host != nullptr) == (g->aug != 0), "oi_disc_graph_launch: the graph was created %s augmentation", g->aug ? "with" : "without");
+  g->x_arg = x;
+  int vi = 0;
+  if (g->aug) {
+    for (int b = 0; b < g->B; ++b)
+      for (int i = 0; i < 6; ++i) g->th_arg.t[b][i] = theta_host[b * 6 + i];
+    vi = (flags_fold_mode() != 0 && fold_fits(theta_host, g->B, g->H, g->W, g->Hp, g->Wp)) ? 0 : 1;
+  }
+  GraphVariant& v = g->v[vi];
+  for (int i = 0; i < v.n_nodes; ++i) {
+    const hipError_t e = hipGraphExecKernelNodeSetParams(v.exec, v.node[i], &v.kp[i]);
+    if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_disc_graph_launch: hipGraphExecKernelNodeSetParams: %s", hipGetErrorString(e));
+  }
+  const hipError_t e = hipGraphLaunch(v.exec, oi::as_stream(stream));
+  if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_disc_graph_launch: hipGraphLaunch: %s", hipGetErrorString(e));
+  return OI_OK;
+}
+
+// The same launches issued one by one on `stream` (no graph): a graph launch costs ~5 us of GPU time between two replays on
+// this runtime, four eager launches from one call cost host time instead (which one wins depends on the host).
+int oi_disc_graph_launch_eager(oi_disc_graph* g, const float* x, const float* theta_host, oi_stream_t stream) {
+  OI_REQUIRE(g != nullptr && x != nullptr, "oi_disc_graph_launch_eager: null pointer");
+  OI_REQUIRE((theta_host != nullptr) == (g->aug != 0), "oi_disc_graph_launch_eager: the object was created %s augmentation", g->aug ? "with" : "without");
+  return oi_disc_fwd_small(x, theta_host, nullptr, g->f12 != nullptr ? g->f12 : g->workspace, g->mx0, g->mx1, g->my0, g->my1, g->w1, g->w2,
+                           g->w3, g->w4, g->whead, g->bhead, g->workspace, g->ticket, g->logits, g->B, g->C, g->H, g->W, g->n_feat,
+                           g->out_dim, g->slope, stream);
+}
+
+void oi_disc_graph_destroy(oi_disc_graph* g) {
+  if (g == nullptr) return;
+  graph_variant_free(g->v[0]);
+  graph_variant_free(g->v[1]);
+  delete g;
 }
 
 }  // extern "C"

@@ -326,9 +326,33 @@ class GraphedDForward:
             self._pin_ev[i].record()
         self.x.copy_(x, non_blocking=True)
 
+    def _library_graph(self, x):
+        """Batch <= 4 of the 64 x 64 network: the library's own graph (ops.DiscGraph) -- image pointer and sampling matrices are
+        node parameters, so a call is the host-side draw + ONE graph launch (no staging launch)."""
+        from . import ops
+        from .augment import AugmentPipe
+        d = self.disc
+        aug = getattr(d, "aug", None)
+        with torch.no_grad():
+            ok = d._small_ok(x)
+        if not ok or os.environ.get("OI_GRAPH_D_LIBRARY", "1") == "0":
+            return None
+        if aug is not None and (type(aug).forward is not AugmentPipe.forward or "forward" in aug.__dict__ or aug.Hz_geom.shape[0] != 12):
+            return None
+        geom = aug is not None and _has_geometric(aug)
+        H, W = x.shape[2:]
+        return ops.DiscGraph(tuple(x.shape), x.device, [l.weight for l in d.blocks], d.conv_out.weight, d.conv_out.bias,
+                             f12=aug.Hz_geom if geom else None, margins=aug.static_margins(H, W) if geom else None), geom
+
     def capture(self, x):
         import numpy as np
         B = x.shape[0]
+        lib = self._library_graph(x)
+        if lib is not None:
+            self._lib, self._geom = lib
+            self.x, self.graph = torch.empty(x.shape, device="meta"), "library"   # (shape bookkeeping only)
+            return self
+        self._lib = None
         self.x = torch.empty_like(x)
         self.theta = torch.empty(B, 2, 3, device=x.device)
         self._pins = [torch.empty(B, 2, 3, pin_memory=True) for _ in range(8)]
@@ -354,6 +378,8 @@ class GraphedDForward:
     def __call__(self, x):
         if self.graph is None or tuple(x.shape) != tuple(self.x.shape):
             self.capture(x)
+        if self._lib is not None:
+            return self._lib(x.float(), self._thetas(tuple(x.shape)) if self._geom else None)
         self._upload(x)
         self.graph.replay()
         return self.out

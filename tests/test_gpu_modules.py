@@ -696,6 +696,45 @@ def test_graphed_discriminator_forward_matches_eager():
         assert maxdiff(got, want) < 2e-4 * max(1.0, float(want.abs().max())), (i, maxdiff(got, want))
 
 
+@pytest.mark.parametrize("B,with_aug,launch", [(1, True, "graph"), (3, True, "graph"), (2, False, "graph"), (1, True, "eager"),
+                                               (4, False, "eager")])
+def test_library_graph_discriminator_forward_bit_identical(B, with_aug, launch, monkeypatch):
+    """oi_disc_graph_*: the batch <= 4 forward of the 64 x 64 network as a hipGraph owned by the library; the image pointer and
+    the augmentation matrices are kernel-node parameters updated per launch.  Against the five eager launches
+    (oi_disc_fwd_small, static margins) from the same numpy state: bit-identical, over calls with different images AT
+    DIFFERENT ADDRESSES and different draws; GraphedDForward takes this path for such shapes."""
+    from oi_amd.config import build_from_config
+    from oi_amd.graphed import GraphedDForward
+    from oi_amd import ops
+    net = lambda t, **kw: {"__target__": t, "kwargs": kw}
+    torch.manual_seed(4)
+    cfg = dict(img_size=64, in_dim=3, last_bias=True, n_feat=512, out_dim=7)
+    if with_aug:
+        disc = build_from_config(net("src.models.discriminator.ADADiscriminatorView", out_dim_latent=0, out_dim_position=6,
+                                     aug=net("src.third_party.ada.augment.AugmentPipe", scale=1, xint=1), aug_p=1, **cfg)).cuda().eval()
+    else:
+        disc = build_from_config(net("src.models.discriminator.DCDiscriminator", **cfg)).cuda().eval()
+    monkeypatch.setenv("OI_DISC_LAUNCH", launch)   # "graph": hipGraph replay with updated node parameters | "eager": launch by launch
+    gd = GraphedDForward(disc)
+    g = torch.Generator().manual_seed(6)
+    keep = []
+    for i in range(4):
+        x = torch.rand(B, 3, 64, 64, generator=g).cuda()
+        keep.append(x)   # (keeps every image alive: each call sees a new pointer)
+        np.random.seed(200 + i)
+        with torch.no_grad():
+            if with_aug:
+                th = disc.aug.theta_for(disc.aug.sample_G_inv(x, None), disc.aug.static_margins(64, 64), 64, 64)
+                want = disc._forward_small(x, f12=disc.aug.Hz_geom, theta_np=th, margins=disc.aug.static_margins(64, 64)).clone()
+            else:
+                want = disc(x).clone()
+        np.random.seed(200 + i)
+        got = gd(x).clone()
+        assert gd._lib is not None and isinstance(gd._lib, ops.DiscGraph) and gd._lib.eager == (launch == "eager")
+        assert torch.equal(got, want), (i, maxdiff(got, want))
+    assert len({t.data_ptr() for t in keep}) == 4
+
+
 def test_stack_cache_equals_torch_stack_forward_and_backward():
     """params.StackCache (one gather launch per parameter version, no launch for the differentiable stack) against
     params.stack_field_params (torch.stack): same values, same per-parameter gradients, refreshed after an optimiser step,
@@ -807,3 +846,15 @@ def test_small_batch_discriminator_forward_vs_oracle_and_general_path(monkeypatc
     with torch.no_grad():
         a_dev = D(x0.cuda(), aug_theta=th)
     assert maxdiff(a_dev.cpu(), ref_a) < 5e-5 * scale
+    # (d) canvas built inside the first kernel (matrix by value, footprint fits: 4 launches) == canvas from memory (matrix in
+    # device memory: 5 launches), bit for bit, over scales from 0.6 to 1.7 and integer shifts; a scale whose footprint does not
+    # fit the LDS tile (0.4) takes the canvas form by itself
+    m = D.aug.static_margins(H, W)
+    for i, (sc, tx, ty) in enumerate([(1.0, 0.0, 0.0), (0.62, 1.0, -1.0), (1.7, -1.0, 0.0), (0.85, 0.0, 1.0), (0.4, 1.0, 1.0)]):
+        Gs = O.ada_G_inv(B, 64, 64, torch.tensor([[tx * 0.124, ty * 0.124]], dtype=torch.float64).expand(B, 2),
+                         torch.full((B,), sc, dtype=torch.float64), dtype=torch.float64).numpy().astype(np.float32)
+        th_np = D.aug.theta_for(Gs, m, H, W)
+        with torch.no_grad():
+            by_value = D._forward_small(x0.cuda(), f12=D.aug.Hz_geom, theta_np=th_np, margins=m)
+            from_mem = D._forward_small(x0.cuda(), f12=D.aug.Hz_geom, theta_dev=torch.from_numpy(th_np).cuda(), margins=m)
+        assert torch.equal(by_value, from_mem), (i, sc, maxdiff(by_value, from_mem))
