@@ -343,7 +343,8 @@ def main():
                 disc(x, it=0)
         barrier()
         d_img_s_eager = B * args.steps / (time.perf_counter() - t0)
-        # the same forward replayed from one captured hipGraph (augmentation parameters still drawn per call on the host)
+        # the same forward through GraphedDForward (batch <= 4: the library's plan; else a captured hipGraph); augmentation
+        # parameters still drawn per call on the host
         gd = GraphedDForward(disc)
         for _ in range(3):
             gd(x)
@@ -659,8 +660,11 @@ def build_line(args, value, dt, world, timer, d_img_s, train, distributed, bf16_
                        "rays_per_step_per_gpu": B * R * R, "points_per_step_per_gpu": n_pts,
                        "parallelism": f"dp{world} (independent renders, no data-path collective)"},
             "d_images_per_s": d_img_s,
-            "d_images_per_s_what": "ADADiscriminatorView forward, batch 1 per GPU, replayed from a captured hipGraph "
-                                   "(oi_amd.graphed.GraphedDForward); d_images_per_s_eager = the same launch by launch",
+            "d_images_per_s_what": "ADADiscriminatorView forward, batch 1 per GPU, through oi_amd.graphed.GraphedDForward: at batch "
+                                   "<= 4 a plan held by the library (oi_disc_graph_*: four launches per image, image pointer and "
+                                   "augmentation matrices passed per call; OI_DISC_LAUNCH=graph replays them as one hipGraph), "
+                                   "augmentation parameters drawn per call on the host; d_images_per_s_eager = the module's own "
+                                   "forward, call by call",
             "d_images_per_s_eager": getattr(args, "_d_images_per_s_eager", None),
             "training": train,
             "bf16_mode": bf16_mode,

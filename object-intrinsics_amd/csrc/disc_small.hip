@@ -89,6 +89,18 @@ d_aug_conv1_kernel(const float* __restrict__ src, const ThetaArg th, const float
   float (*cv)[DA_CT][DA_CT + 1] = reinterpret_cast<float (*)[DA_CT][DA_CT + 1]>(cv_);
   const int tid = threadIdx.x, b = blockIdx.z;
   const int ay0 = blockIdx.y * DA_T - 1, ax0 = blockIdx.x * DA_T - 1;  // patch origin in the augmented image
+  // conv 1 weights of this thread's output channel: requested now, used after the last barrier (their round trip would
+  // otherwise sit at the end of the kernel, behind everything)
+  constexpr int OTT = (DA_T / 2) * (DA_T / 2);
+  float4 wq[DS_MAX_C][4];
+  {
+    const int ch = min(tid / OTT, C1 - 1);
+#pragma unroll
+    for (int c_ = 0; c_ < DS_MAX_C; ++c_)
+#pragma unroll
+      for (int ky = 0; ky < 4; ++ky)
+        wq[c_][ky] = c_ < C ? *reinterpret_cast<const float4*>(w1 + ((size_t)ch * C + c_) * 16 + ky * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (theta_on) {
     if (tid < DA_TAPS) fs[tid] = f[tid];  // flip_filter = True: the correlation taps are the filter itself
     const int Ho = 2 * (H + DA_PAD), Wo = 2 * (W + DA_PAD);
@@ -245,19 +257,22 @@ d_aug_conv1_kernel(const float* __restrict__ src, const ThetaArg th, const float
   // Output in the layout the next layer reads with the input channel on the lane: y[b][oy][ox / 4][ch][ox % 4]
   constexpr int OT = DA_T / 2;
   const int Ho1 = H / 2, Wo1 = W / 2;
-  for (int o = tid; o < C1 * OT * OT; o += 256) {
-    const int ch = o / (OT * OT), py = (o / OT) % OT, px = o % OT;
-    const float* wr = w1 + (size_t)ch * C * 16;
+  static_assert(OT * OT * 64 == 256, "one conv 1 output per thread (C1 = 64)");
+  if (tid < C1 * OT * OT) {
+    const int ch = tid / (OT * OT), py = (tid / OT) % OT, px = tid % OT;
     float acc = 0.f;
-    for (int c_ = 0; c_ < C; ++c_) {
 #pragma unroll
-      for (int ky = 0; ky < 4; ++ky) {
-        const float4 wv = *reinterpret_cast<const float4*>(wr + c_ * 16 + ky * 4);
-        const float* ar = &aug[c_][2 * py + ky][2 * px];
-        acc = fmaf(wv.x, ar[0], acc);
-        acc = fmaf(wv.y, ar[1], acc);
-        acc = fmaf(wv.z, ar[2], acc);
-        acc = fmaf(wv.w, ar[3], acc);
+    for (int c_ = 0; c_ < DS_MAX_C; ++c_) {
+      if (c_ < C) {
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+          const float4 wv = wq[c_][ky];
+          const float* ar = &aug[c_][2 * py + ky][2 * px];
+          acc = fmaf(wv.x, ar[0], acc);
+          acc = fmaf(wv.y, ar[1], acc);
+          acc = fmaf(wv.z, ar[2], acc);
+          acc = fmaf(wv.w, ar[3], acc);
+        }
       }
     }
     const int oy = blockIdx.y * OT + py, ox = blockIdx.x * OT + px;
