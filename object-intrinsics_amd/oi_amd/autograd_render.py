@@ -17,23 +17,24 @@ class CompositeFunction(torch.autograd.Function):
         # (a direction from DirectionalLight.batch_direction_unit is already that, with its own backward)
         ldir_n = light_dir if getattr(light_dir, "_oi_unit", False) else torch.nn.functional.normalize(light_dir, dim=-1, eps=1e-6)
         outs = CompositeFunction.apply(sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg,
-                                       float(cos_anneal_ratio), B, bool(image_planar))
-        res = dict(zip(OUT_KEYS, outs))
-        if outputs is not None:   # ('finals' / 'ray_sums' come with 'reduce4', as from ops.composite_fwd)
-            res = {k: v for k, v in res.items() if k in outputs or (k in ("ray_sums", "finals") and "reduce4" in outputs)}
+                                       float(cos_anneal_ratio), B, bool(image_planar),
+                                       None if outputs is None else tuple(outputs))
+        # (outputs nobody asked for are not computed: null pointers for the kernel, None here; 'finals' / 'ray_sums' come with
+        # 'reduce4', as from ops.composite_fwd)
+        res = {k: v for k, v in zip(OUT_KEYS, outs) if v is not None}
         return res
 
     @staticmethod
-    def forward(ctx, sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg, car, B, planar):
+    def forward(ctx, sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg, car, B, planar, want):
         out = ops.composite_fwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d, ldir_n, bg, variance, light, car, B,
-                                image_planar=planar)
+                                outputs=want, image_planar=planar)
         # ~20 outputs of which a loss touches a few: absent upstream gradients arrive as None (a null pointer for the kernel),
         # not as one zero-filled tensor -- one fill launch -- each
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(sdf, grad, rgb, variance, light, ldir_n, dists, mid_z, rays_o, rays_d, bg)
         ctx.car, ctx.B, ctx.planar = car, B, planar
-        ctx.mark_non_differentiable(*[out[k] for k in NON_DIFF])
-        return tuple(out[k] for k in OUT_KEYS)
+        ctx.mark_non_differentiable(*[out[k] for k in NON_DIFF if k in out])
+        return tuple(out.get(k) for k in OUT_KEYS)
 
     @staticmethod
     @once_differentiable
@@ -43,4 +44,4 @@ class CompositeFunction(torch.autograd.Function):
         d_sdf, d_grad, d_rgb, d_var, d_light, d_ldir = ops.composite_bwd(sdf, grad, rgb, dists, mid_z, rays_o, rays_d,
                                                                          ldir_n, bg, variance, light, ctx.car, ctx.B, g,
                                                                          image_planar=ctx.planar)
-        return (d_sdf, d_grad, d_rgb, d_var.reshape(variance.shape), d_light, d_ldir) + (None,) * 8
+        return (d_sdf, d_grad, d_rgb, d_var.reshape(variance.shape), d_light, d_ldir) + (None,) * 9

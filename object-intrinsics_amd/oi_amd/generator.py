@@ -240,6 +240,14 @@ class Generator(nn.Module):
 
     # -- forward --------------------------------------------------------------------------------
     def forward(self, bs, it, data, return_raw=False):
+        pack = self.renderer.pack
+        pack.hold(True)   # (parameters cannot change inside one forward: one version walk over ~65 parameters instead of four)
+        try:
+            return self._forward(bs, it, data, return_raw)
+        finally:
+            pack.hold(False)
+
+    def _forward(self, bs, it, data, return_raw):
         if it is None:  # eval / inference callers only (one D2H read after a checkpoint load); training passes `it`
             it = self.iteration()
         if int(it) != self.iteration():
@@ -289,6 +297,9 @@ class Generator(nn.Module):
         if film is None:
             film = self.renderer.pack.film(z=None if "w" in latent else latent["z"], w=latent.get("w"))
         latent["w"] = film[0]
+        # without return_raw the per-sample compositing outputs (weights, cdf, alpha, inside_sphere, pts_norm: 2 MB each at C2)
+        # and the extra maps reach nobody: the launch is not asked for them
+        want = None if (return_raw or n_chunks > 1) else ("weight_sum", "color_fine", "image_no_bg", "image", "shading", "mask", "reduce4")
         outs = []
         for ci in range(n_chunks):
             sl = slice(ci * chunk, (ci + 1) * chunk)
@@ -297,7 +308,7 @@ class Generator(nn.Module):
                                              perturb_overwrite=-1 if self.training else 0,
                                              cos_anneal_ratio=cos_anneal_ratio, z=latent["z"], w=latent["w"],
                                              light=lpk, light_dir=ldir, bg=bg, film=film, coarse=coarse,
-                                             image_planar=(n_chunks == 1))
+                                             image_planar=(n_chunks == 1), outputs=want)
             outs.append((s, c))
         if n_chunks == 1:
             s, c = outs[0]

@@ -161,19 +161,21 @@ def assemble_render_dict(s, c, variance, background_rgb=None, finals=None, s_val
     if background_rgb is not None:
         color = color + background_rgb * (1.0 - c["weight_sum"])
     gradient_error, surface_loss = (finals[0], finals[1]) if finals is not None else render_scalars(r4, N * T)
+    # (entries the caller did not ask the compositing launch for -- Generator.forward without return_raw, which hands this dict
+    # to nobody -- are None)
     return {
         "s_val": s_val.detach().reshape(1, 1).expand(N, 1),   # a report without a graph (stated deviation: see _inv_s)
-        "cdf_fine": c["cdf"],
+        "cdf_fine": c.get("cdf"),
         "weight_sum": c["weight_sum"],
-        "weight_max": c["weight_max"],
+        "weight_max": c.get("weight_max"),
         "gradients": s["gradients"],
-        "weights": c["weights"],
+        "weights": c.get("weights"),
         "gradient_error": gradient_error,
-        "inside_sphere": c["inside_sphere"],
+        "inside_sphere": c.get("inside_sphere"),
         "mid_z_vals": s["mid_z_vals"],
         "surface_loss": surface_loss,
         "sdf": s["sdf"],
-        "pts_norm": c["pts_norm"],
+        "pts_norm": c.get("pts_norm"),
         "pts": s["pts"],
         "color_fine": color,
         "raw_color": s["raw_color"],
