@@ -735,6 +735,30 @@ def test_library_graph_discriminator_forward_bit_identical(B, with_aug, launch, 
     assert len({t.data_ptr() for t in keep}) == 4
 
 
+@pytest.mark.parametrize("launch", ["graph", "eager"])
+def test_library_graph_takes_the_canvas_form_when_the_footprint_does_not_fit(launch):
+    """ops.DiscGraph holds two captured variants with the augmentation: canvas built inside the first kernel (footprint fits its
+    LDS tile) and canvas from memory (it does not: e.g. a zoom-out by 2.5).  The choice is made per launch from the matrices;
+    both give what oi_disc_fwd_small gives with the matrices in device memory (always the canvas form), bit for bit, also when
+    the two kinds of launch alternate."""
+    from oi_amd import ops
+    D = _ada_disc(3, 7).cuda().eval()
+    H = W = 64
+    m = D.aug.static_margins(H, W)
+    plan = ops.DiscGraph((2, 3, H, W), torch.device("cuda"), [l.weight for l in D.blocks], D.conv_out.weight, D.conv_out.bias,
+                         f12=D.aug.Hz_geom, margins=m, launch=launch)
+    g = torch.Generator().manual_seed(11)
+    for i, scales in enumerate([(1.0, 0.4), (0.4, 0.4), (1.1, 0.9), (0.4, 1.0)]):   # per image of the batch
+        x = torch.rand(2, 3, H, W, generator=g).cuda()
+        Gs = O.ada_G_inv(2, 64, 64, torch.tensor([[0.124, 0.0], [0.0, -0.124]], dtype=torch.float64),
+                         torch.tensor(scales, dtype=torch.float64), dtype=torch.float64).numpy().astype(np.float32)
+        th = D.aug.theta_for(Gs, m, H, W)
+        got = plan(x, th).clone()
+        with torch.no_grad():
+            want = D._forward_small(x, f12=D.aug.Hz_geom, theta_dev=torch.from_numpy(th).cuda(), margins=m)
+        assert torch.equal(got, want), (i, scales, maxdiff(got, want))
+
+
 def test_stack_cache_equals_torch_stack_forward_and_backward():
     """params.StackCache (one gather launch per parameter version, no launch for the differentiable stack) against
     params.stack_field_params (torch.stack): same values, same per-parameter gradients, refreshed after an optimiser step,
