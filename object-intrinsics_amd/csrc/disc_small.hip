@@ -349,6 +349,23 @@ d_conv_small_kernel(const float* __restrict__ x, const float* __restrict__ w, fl
       wk[c_][4 * q] = v.x; wk[c_][4 * q + 1] = v.y; wk[c_][4 * q + 2] = v.z; wk[c_][4 * q + 3] = v.w;
     }
   }
+  // the head's weights of this thread's logit: requested with everything else (their round trip would otherwise start after
+  // the convolution, in front of the hand-off)
+  float whr[HEAD ? NCH : 1][16];
+  if constexpr (HEAD) {
+    const int t = threadIdx.x;
+    if (t < B * KOUT) {
+#pragma unroll
+      for (int c_ = 0; c_ < NCH; ++c_) {
+        const float4* wh4 = reinterpret_cast<const float4*>(whead + ((size_t)(t % KOUT) * COUT + n0 + c_) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = wh4[q];
+          whr[c_][4 * q] = v.x; whr[c_][4 * q + 1] = v.y; whr[c_][4 * q + 2] = v.z; whr[c_][4 * q + 3] = v.w;
+        }
+      }
+    }
+  }
   for (int b = 0; b < B; ++b) {
     float xin[NIR][HIN + 2];
 #pragma unroll
@@ -407,11 +424,9 @@ d_conv_small_kernel(const float* __restrict__ x, const float* __restrict__ w, fl
       const int b = t / KOUT, k = t % KOUT;
       float s = 0.f;
 #pragma unroll
-      for (int c_ = 0; c_ < NCH; ++c_) {
-        const float* wh = whead + ((size_t)k * COUT + n0 + c_) * 16;
+      for (int c_ = 0; c_ < NCH; ++c_)
 #pragma unroll
-        for (int p = 0; p < 16; ++p) s = fmaf(wh[p], act[b][c_][p], s);
-      }
+        for (int p = 0; p < 16; ++p) s = fmaf(whr[c_][p], act[b][c_][p], s);
       __hip_atomic_store(partials + (size_t)blockIdx.x * 32 + t, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if (t < 32) {
       __hip_atomic_store(partials + (size_t)blockIdx.x * 32 + t, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (unused columns: defined)
