@@ -509,9 +509,10 @@ int oi_disc_fwd_small(const float* x, const float* theta_host, const float* thet
                       const float* bhead, float* workspace, unsigned* ticket, float* logits, int B, int C, int H, int W, int n_feat,
                       int out_dim, float slope, oi_stream_t stream);
 
-/* The same forward as a hipGraph OWNED BY THE LIBRARY (round 4): oi_disc_graph_create captures oi_disc_fwd_small once (private
- * stream; arguments as there -- weights, workspace, ticket and logits are fixed addresses from then on; `aug` != 0: with the
- * augmentation at the given STATIC margins), oi_disc_graph_launch replays it on `stream` for a new image pointer `x` and a new
+/* The same forward as a PLAN OWNED BY THE LIBRARY (round 4): oi_disc_graph_create stores the arguments of oi_disc_fwd_small
+ * (weights, workspace, ticket and logits are fixed addresses from then on; `aug` != 0: with the augmentation at the given STATIC
+ * margins; no HIP call is made: an object may be created while its caller captures a stream).  oi_disc_graph_launch captures
+ * oi_disc_fwd_small once (first call; private stream) and replays that hipGraph on `stream` for a new image pointer `x` and a new
  * HOST array of sampling matrices theta_host [B][2][3] (NULL iff aug == 0): both reach the kernels as updated kernel-node
  * parameters (hipGraphExecKernelNodeSetParams) -- no staging copy, no upload.  Results: bit-identical to oi_disc_fwd_small.
  * One graph object serves one stream at a time (its workspace and logits are shared by its launches, which the stream orders).
@@ -522,8 +523,9 @@ int oi_disc_graph_create(oi_disc_graph** out, int aug, const float* f12, int mx0
                          float* workspace, unsigned* ticket, float* logits, int B, int C, int H, int W, int n_feat, int out_dim,
                          float slope);
 int oi_disc_graph_launch(oi_disc_graph* g, const float* x, const float* theta_host, oi_stream_t stream);
-/* the same launches issued one by one (no graph replay) from the object's stored arguments */
-int oi_disc_graph_launch_eager(oi_disc_graph* g, const float* x, const float* theta_host, oi_stream_t stream);
+/* the same launches issued one by one (no graph replay) from the object's stored arguments; `logits`: where this call's
+ * [B][out_dim] result goes (NULL: the buffer given at creation) */
+int oi_disc_graph_launch_eager(oi_disc_graph* g, const float* x, const float* theta_host, float* logits, oi_stream_t stream);
 void oi_disc_graph_destroy(oi_disc_graph* g);
 
 /* The whole geometric augmentation of AugmentPipe.forward (src/third_party/ada/augment.py:284-301) for a given sampling

@@ -593,17 +593,27 @@ int oi_disc_graph_create(oi_disc_graph** out, int aug, const float* f12, int mx0
                          const float* w2, const float* w3, const float* w4, const float* whead, const float* bhead,
                          float* workspace, unsigned* ticket, float* logits, int B, int C, int H, int W, int n_feat, int out_dim,
                          float slope) {
-  OI_REQUIRE(out != nullptr && workspace != nullptr, "oi_disc_graph_create: null pointer");
-  OI_REQUIRE(B >= 1 && B <= DS_MAX_B, "oi_disc_graph_create: B=%d (1..%d)", B, DS_MAX_B);
+  OI_REQUIRE(out != nullptr && workspace != nullptr && ticket != nullptr && logits != nullptr && w1 && w2 && w3 && w4 && whead,
+             "oi_disc_graph_create: null pointer");
+  OI_REQUIRE(!aug || f12 != nullptr, "oi_disc_graph_create: augmentation without the filter taps");
   *out = nullptr;
-  hipStream_t cs = nullptr;
-  if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_disc_graph_create: stream");
+  if (!(B >= 1 && B <= DS_MAX_B && C >= 1 && C <= DS_MAX_C && H == 64 && W == 64 && n_feat == 512 && out_dim >= 1 && out_dim <= 8))
+    return oi::fail(OI_ERR_UNSUPPORTED, "oi_disc_graph_create: only B <= %d, C <= %d, 64 x 64, n_feat 512, out_dim <= 8", DS_MAX_B, DS_MAX_C);
   oi_disc_graph* g = new oi_disc_graph();
   g->aug = aug ? 1 : 0;
   g->B = B; g->H = H; g->W = W; g->Hp = H + my0 + my1; g->Wp = W + mx0 + mx1;
   g->f12 = f12; g->w1 = w1; g->w2 = w2; g->w3 = w3; g->w4 = w4; g->whead = whead; g->bhead = bhead;
   g->workspace = workspace; g->ticket = ticket; g->logits = logits;
   g->C = C; g->mx0 = mx0; g->mx1 = mx1; g->my0 = my0; g->my1 = my1; g->n_feat = n_feat; g->out_dim = out_dim; g->slope = slope;
+  *out = g;   // (the hipGraph variants are captured by the first oi_disc_graph_launch: an object that is only ever launched
+  return OI_OK;   //  eagerly makes no capture -- and can therefore be created while its caller is capturing)
+}
+
+// captures the variants (private stream, relaxed mode) on first use
+static int graph_capture(oi_disc_graph* g) {
+  if (g->v[0].exec != nullptr) return OI_OK;
+  hipStream_t cs = nullptr;
+  if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_disc_graph_launch: stream");
   int rc = OI_OK;
   const char* what = nullptr;
   for (int vi = 0; vi < (g->aug ? 2 : 1) && rc == OI_OK && what == nullptr; ++vi) {
@@ -612,12 +622,12 @@ int oi_disc_graph_create(oi_disc_graph** out, int aug, const float* f12, int mx0
     // (fits: the folded form is captured) or an enormous one (does not fit: the canvas form)
     float th0[DS_MAX_B * 6] = {};
     if (vi == 1)
-      for (int b = 0; b < B; ++b) th0[b * 6] = 1e9f;
+      for (int b = 0; b < g->B; ++b) th0[b * 6] = 1e9f;
     hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) { what = hipGetErrorString(e); break; }
-    rc = oi_disc_fwd_small(workspace, g->aug ? th0 : nullptr, nullptr, f12 != nullptr ? f12 : workspace, mx0, mx1, my0, my1, w1, w2, w3,
-                           w4, whead, bhead, workspace, ticket, logits, B, C, H, W, n_feat, out_dim, slope,
-                           reinterpret_cast<oi_stream_t>(cs));
+    rc = oi_disc_fwd_small(g->workspace, g->aug ? th0 : nullptr, nullptr, g->f12 != nullptr ? g->f12 : g->workspace, g->mx0, g->mx1, g->my0,
+                           g->my1, g->w1, g->w2, g->w3, g->w4, g->whead, g->bhead, g->workspace, g->ticket, g->logits, g->B, g->C, g->H,
+                           g->W, g->n_feat, g->out_dim, g->slope, reinterpret_cast<oi_stream_t>(cs));
     e = hipStreamEndCapture(cs, &v.graph);
     if (rc != OI_OK) break;
     if (e != hipSuccess || v.graph == nullptr) { what = hipGetErrorString(e); break; }
@@ -643,16 +653,18 @@ int oi_disc_graph_create(oi_disc_graph** out, int aug, const float* f12, int mx0
   if (rc != OI_OK || what != nullptr) {
     graph_variant_free(g->v[0]);
     graph_variant_free(g->v[1]);
-    delete g;
-    return rc != OI_OK ? rc : oi::fail(OI_ERR_LAUNCH, "oi_disc_graph_create: %s", what);
+    return rc != OI_OK ? rc : oi::fail(OI_ERR_LAUNCH, "oi_disc_graph_launch: capture: %s", what);
   }
-  *out = g;
   return OI_OK;
 }
 
 int oi_disc_graph_launch(oi_disc_graph* g, const float* x, const float* theta_host, oi_stream_t stream) {
   OI_REQUIRE(g != nullptr && x != nullptr, "oi_disc_graph_launch: null pointer");
   OI_REQUIRE((theta_host != nullptr) == (g->aug != 0), "oi_disc_graph_launch: the graph was created %s augmentation", g->aug ? "with" : "without");
+  {
+    const int rc = graph_capture(g);
+    if (rc != OI_OK) return rc;
+  }
   g->x_arg = x;
   int vi = 0;
   if (g->aug) {
@@ -672,12 +684,12 @@ int oi_disc_graph_launch(oi_disc_graph* g, const float* x, const float* theta_ho
 
 // The same launches issued one by one on `stream` (no graph): a graph launch costs ~5 us of GPU time between two replays on
 // this runtime, four eager launches from one call cost host time instead (which one wins depends on the host).
-int oi_disc_graph_launch_eager(oi_disc_graph* g, const float* x, const float* theta_host, oi_stream_t stream) {
+int oi_disc_graph_launch_eager(oi_disc_graph* g, const float* x, const float* theta_host, float* logits, oi_stream_t stream) {
   OI_REQUIRE(g != nullptr && x != nullptr, "oi_disc_graph_launch_eager: null pointer");
   OI_REQUIRE((theta_host != nullptr) == (g->aug != 0), "oi_disc_graph_launch_eager: the object was created %s augmentation", g->aug ? "with" : "without");
   return oi_disc_fwd_small(x, theta_host, nullptr, g->f12 != nullptr ? g->f12 : g->workspace, g->mx0, g->mx1, g->my0, g->my1, g->w1, g->w2,
-                           g->w3, g->w4, g->whead, g->bhead, g->workspace, g->ticket, g->logits, g->B, g->C, g->H, g->W, g->n_feat,
-                           g->out_dim, g->slope, stream);
+                           g->w3, g->w4, g->whead, g->bhead, g->workspace, g->ticket, logits != nullptr ? logits : g->logits, g->B, g->C,
+                           g->H, g->W, g->n_feat, g->out_dim, g->slope, stream);
 }
 
 void oi_disc_graph_destroy(oi_disc_graph* g) {

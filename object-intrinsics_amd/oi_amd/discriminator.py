@@ -66,9 +66,26 @@ class DCDiscriminator(nn.Module):
                 and tuple(x.shape[2:]) == (64, 64) and len(self.blocks) == 4 and self.blocks[0].weight.shape[0] == 64
                 and self.blocks[3].weight.shape[0] == 512 and self.out_dim <= 8)
 
-    def _forward_small(self, x, **aug):
+    def _forward_small(self, x, f12=None, theta_np=None, theta_dev=None, margins=None):
+        """theta_dev (captured graphs): the plain entry.  Otherwise a plan held by the library (ops.DiscGraph, launch by launch):
+        everything but the image pointer and the matrices is marshalled once per (shape, stream, weight addresses), not per
+        call -- 50 us of host time per forward less."""
         from . import ops
-        return ops.disc_fwd_small(x.float(), [l.weight for l in self.blocks], self.conv_out.weight, self.conv_out.bias, **aug)
+        if theta_dev is not None:
+            return ops.disc_fwd_small(x.float(), [l.weight for l in self.blocks], self.conv_out.weight, self.conv_out.bias, f12=f12,
+                                      theta_dev=theta_dev, margins=margins)
+        ws = [l.weight for l in self.blocks] + [self.conv_out.weight] + ([] if self.conv_out.bias is None else [self.conv_out.bias])
+        key = (tuple(x.shape), x.device.index, ops._stream().value or 0, None if theta_np is None else tuple(int(v) for v in margins),
+               tuple(w.data_ptr() for w in ws))
+        plans = self.__dict__.setdefault("_small_plans", {})
+        plan = plans.get(key)
+        if plan is None:
+            if len(plans) >= 8:
+                plans.clear()   # (weights moved, many shapes: start over rather than grow)
+            plan = plans[key] = ops.DiscGraph(tuple(x.shape), x.device, [l.weight for l in self.blocks], self.conv_out.weight,
+                                              self.conv_out.bias, f12=f12 if theta_np is not None else None,
+                                              margins=margins if theta_np is not None else None, launch="eager")
+        return plan(x.float(), theta_np, fresh=True)
 
     def forward(self, x, **kwargs):
         batch_size = x.shape[0]
@@ -118,7 +135,9 @@ class ADADiscriminator(DCDiscriminator):
             G_inv = aug.sample_G_inv(x, None)
             if G_inv is None:
                 return self._forward_small(x)
-            margins = aug.margins_for(G_inv, H, W)
+            # the largest margins the transform's own clamp allows (static: one plan serves every draw; the same pixels are
+            # sampled as with margins fitted to the draw, augment.py:272-282)
+            margins = aug.static_margins(H, W)
             return self._forward_small(x, f12=aug.Hz_geom, theta_np=aug.theta_for(G_inv, margins, H, W), margins=margins)
         return super().forward(self.aug(x) if aug_theta is None else self.aug(x, theta=aug_theta), **kwargs)
 

@@ -790,7 +790,8 @@ class DiscGraph:
                                         _vp(self.ticket.data_ptr()), _p(self.logits), B, C, H, W, int(self.keep[3].shape[0]),
                                         int(whead.shape[0]), float(slope)), "oi_disc_graph_create")
 
-    def __call__(self, x, theta_np=None):
+    def __call__(self, x, theta_np=None, fresh=False):
+        """`fresh` (eager launches only): the result goes to a new tensor instead of the plan's own buffer."""
         assert tuple(x.shape) == self.shape and (theta_np is not None) == self.aug
         x = _c(x)
         th = None
@@ -799,8 +800,12 @@ class DiscGraph:
             assert th_arr.size == 6 * self.shape[0]
             th = th_arr.ctypes.data_as(ctypes.c_void_p)
         L = _l.load()
-        fn = L.oi_disc_graph_launch_eager if self.eager else L.oi_disc_graph_launch
-        _l.check(fn(self.handle, _p(x), th, _stream()), "oi_disc_graph_launch")
+        if self.eager:
+            out = torch.empty_like(self.logits) if fresh else self.logits
+            _l.check(L.oi_disc_graph_launch_eager(self.handle, _p(x), th, _p(out), _stream()), "oi_disc_graph_launch_eager")
+            return out
+        assert not fresh, "a graph replay writes the buffer it was captured with"
+        _l.check(L.oi_disc_graph_launch(self.handle, _p(x), th, _stream()), "oi_disc_graph_launch")
         return self.logits
 
     def __del__(self):
