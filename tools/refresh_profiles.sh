@@ -9,7 +9,9 @@ T=${OI_PROFILE_TAG:-r4}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bf16 --no-extras --min-seconds 0.2"
-rm -rf /tmp/p_ks; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_ks -- $BENCH > /dev/null 2>&1
+# (forward steps only: the with-gradient renders of the training leg run the same kernel with the feature stores on, and would
+#  pull its average away from what bench.py's HIP events measure; the training kernels are in ${T}_kernel_stats_train.txt)
+rm -rf /tmp/p_ks; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_ks -- $BENCH --train-steps 0 > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/p_ks $O/${T}_kernel_stats_f16x3.txt > /dev/null
 rm -rf /tmp/p_tl; rocprofv3 --kernel-trace --output-format csv -d /tmp/p_tl -- $BENCH --train-steps 0 > /dev/null 2>&1
 python $R/tools/dbg/timeline.py /tmp/p_tl $O/${T}_timeline_step_f16x3.txt prep_render_kernel > /dev/null
