@@ -11,6 +11,9 @@ import torch.nn as nn
 from .autograd_disc import conv4x4_lrelu
 from .config import build_from_config
 
+import weakref
+
+_SMALL_PLANS = weakref.WeakKeyDictionary()
 SMALL_PATH = True   # batch <= 4 no-grad forwards of the 64 x 64 network take csrc/disc_small.hip (False: the general chain)
 
 
@@ -77,7 +80,7 @@ class DCDiscriminator(nn.Module):
         ws = [l.weight for l in self.blocks] + [self.conv_out.weight] + ([] if self.conv_out.bias is None else [self.conv_out.bias])
         key = (tuple(x.shape), x.device.index, ops._stream().value or 0, None if theta_np is None else tuple(int(v) for v in margins),
                tuple(w.data_ptr() for w in ws))
-        plans = self.__dict__.setdefault("_small_plans", {})
+        plans = _SMALL_PLANS.setdefault(self, {})   # (not in __dict__: the plans hold library handles; copy.deepcopy(module) must work)
         plan = plans.get(key)
         if plan is None:
             if len(plans) >= 8:

@@ -733,6 +733,14 @@ def test_library_graph_discriminator_forward_bit_identical(B, with_aug, launch, 
         assert gd._lib is not None and isinstance(gd._lib, ops.DiscGraph) and gd._lib.eager == (launch == "eager")
         assert torch.equal(got, want), (i, maxdiff(got, want))
     assert len({t.data_ptr() for t in keep}) == 4
+    # the module's own forward keeps its plans outside its attributes: a discriminator that has run still deep-copies
+    import copy
+    with torch.no_grad():
+        disc(keep[0])
+        twin = copy.deepcopy(disc)
+        np.random.seed(5); a = disc(keep[1]).clone()
+        np.random.seed(5); b = twin(keep[1]).clone()
+    assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("launch", ["graph", "eager"])
