@@ -494,7 +494,8 @@ int oi_outputs_prezeroed_stream(oi_stream_t stream, int on);
 int oi_ada_pad_up2(const float* x, const float* f, float* canvas, int B, int C, int H, int W, int mx0, int mx1, int my0, int my1,
                    oi_stream_t stream);
 
-/* Discriminator forward at batch 1-4 in FIVE launches (csrc/disc_small.hip): AugmentPipe's geometric augmentation (given its
+/* Discriminator forward at batch 1-4 in FOUR launches -- five when the matrices are in device memory or a tile's canvas
+ * footprint does not fit the first kernel's LDS tile -- (csrc/disc_small.hip): AugmentPipe's geometric augmentation (given its
  * sampling matrix theta [B][2][3] and reflect margins, as oi_ada_geom_fwd) + the four 4x4 stride-2 LeakyReLU blocks + the 4x4
  * head of DCDiscriminator(img_size 64, n_feat 512) -- reference src/models/discriminator.py:57-85, ada/augment.py:284-301.
  *   x [B][C][64][64];  theta_host: HOST array, passed to the kernel by value (no copy on the stream) | theta_dev: device

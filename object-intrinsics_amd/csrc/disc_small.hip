@@ -2,7 +2,7 @@
 //
 // Replaces, for the 64 x 64 / n_feat 512 network of configs/train.yaml (reference src/models/discriminator.py:57-85 with
 // AugmentPipe.forward, src/third_party/ada/augment.py:284-301, in front), the nine dependent launches of the general path
-// (csrc/disc.hip: pad + up-FIR | resample + down-FIR | five split-K MFMA convolutions | copies) by FIVE:
+// (csrc/disc.hip: pad + up-FIR | resample + down-FIR | five split-K MFMA convolutions | copies) by FIVE (four when the canvas is built inside d_aug_conv1_kernel<true>, see there):
 //     ada_pad_up2_kernel (disc.hip)                         canvas
 //     d_aug_conv1_kernel       resample + down-FIR + conv 1 + LeakyReLU           (C -> 64, 64^2 -> 32^2)
 //     d_conv_small_kernel x 3  conv 2, conv 3, conv 4 (+ the 4 x 4 head)          (64 -> 128 -> 256 -> 512 -> out_dim)

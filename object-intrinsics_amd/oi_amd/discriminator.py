@@ -64,7 +64,7 @@ class DCDiscriminator(nn.Module):
         return x
 
     def _small_ok(self, x):
-        """The five-launch forward of csrc/disc_small.hip: no gradient, batch <= 4, the 64 x 64 / n_feat 512 network."""
+        """The four- / five-launch forward of csrc/disc_small.hip: no gradient, batch <= 4, the 64 x 64 / n_feat 512 network."""
         return (SMALL_PATH and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.shape[0] <= 4 and x.shape[1] <= 4
                 and tuple(x.shape[2:]) == (64, 64) and len(self.blocks) == 4 and self.blocks[0].weight.shape[0] == 64
                 and self.blocks[3].weight.shape[0] == 512 and self.out_dim <= 8)
@@ -131,7 +131,7 @@ class ADADiscriminator(DCDiscriminator):
         aug = self.aug
         if (self._small_ok(x) and type(aug).forward is AugmentPipe.forward and "forward" not in aug.__dict__
                 and aug.Hz_geom.shape[0] == 12):
-            # augmentation + network in five launches; the sampling matrix goes to the kernel by value (no upload)
+            # augmentation + network in four launches; the sampling matrix goes to the kernel by value (no upload)
             H, W = x.shape[2:]
             if aug_theta is not None:
                 return self._forward_small(x, f12=aug.Hz_geom, theta_dev=aug_theta, margins=aug.static_margins(H, W))

@@ -733,7 +733,7 @@ _DISC_TICKETS = {}
 
 
 def disc_fwd_small(x, weights, whead, bhead, f12=None, theta_np=None, theta_dev=None, margins=(0, 0, 0, 0), slope=0.2):
-    """DCDiscriminator(img_size 64, n_feat 512) forward at batch <= 4 in five launches (oi_disc_fwd_small): optional ADA
+    """DCDiscriminator(img_size 64, n_feat 512) forward at batch <= 4 in four / five launches (oi_disc_fwd_small): optional ADA
     geometry (theta_np: (B, 2, 3) numpy, passed by value | theta_dev: device tensor; margins (mx0, my0, mx1, my1) as
     AugmentPipe.margins_for returns them) + four conv blocks + head.  -> logits (B, out_dim)."""
     L = _l.load()
