@@ -187,7 +187,8 @@ def bench_training(args, gen, disc, device, world, barrier, distributed, sub_leg
     it_s = args.train_steps / dt
 
     if not sub_legs:
-        return {"it_per_s": it_s, "ms_per_it": 1e3 / it_s, "steps": args.train_steps}
+        return {"it_per_s": it_s, "ms_per_it": 1e3 / it_s, "steps": args.train_steps,
+                "finite": bool(all(torch.isfinite(torch.as_tensor(v)).all() for v in out.values()))}
 
     # the training render alone (forward + backward incl. the double-backward through the
     # normals: image, mask and eikonal terms all carry gradient) and one discriminator training step alone
@@ -214,6 +215,11 @@ def bench_training(args, gen, disc, device, world, barrier, distributed, sub_leg
 
     n_sub = max(3, min(10, args.train_steps))
     t_render = timed(render_fwd_bwd, n_sub)
+    if sub_legs == "render":   # (the bf16-mode leg: iteration rate + the training render alone)
+        return {"it_per_s": it_s, "ms_per_it": 1e3 / it_s, "steps": args.train_steps,
+                "rays_per_s": 3 * world * B * R * R * it_s,
+                "render_fwd_bwd": {"ms": 1e3 * t_render, "rays_per_s_per_gpu": B * R * R / t_render},
+                "finite": bool(all(torch.isfinite(torch.as_tensor(v)).all() for v in out.values()))}
     with torch.no_grad():
         fake = g_raw(bs=B, it=tr.it, data={})["box"]
     fake_d = {**fake["render_out"], "c2b": fake["prior_info"]["c2b"]}
@@ -425,8 +431,21 @@ def main():
                          "measured against the reference's F4 / F5 outputs and the fp32 oracle at the full C2 size: image 5e-3, "
                          "mask 6e-3, colour 2.5e-3 worst pixel (tests/test_gpu_modules.py BF16_*_TOL, tests/test_gpu_fullsize.py); "
                          "not the 1e-4 parity path"}
+            # configs[1] end to end: the SAME training iteration (G step with the bf16 forward + the bf16 backward sweep / weight
+            # gradient, D and mask-D steps) on a fresh generator, so that the headline training leg below starts from untouched
+            # weights; gradient parity of this mode: tests/test_gpu_backward.py (bf16 rows), tests/test_gpu_fullsize.py
+            if args.train_steps > 0 and not args.no_disc:
+                import copy
+                ab = copy.copy(args)
+                ab.train_steps = max(5, min(20, args.train_steps))
+                g_b, d_b = build_models(R, S, I, K, "bf16", device)
+                g_b.train()
+                bf16_mode["training"] = bench_training(ab, g_b, d_b, device, 1, torch.cuda.synchronize, False, sub_legs="render")
+                bf16_mode["training"]["what"] = ("Trainer.train_step with the generator in the bf16 operand mode: bf16 forward kernel, "
+                                                 "mlp_bwd_sweep_kernel<bf16> + mlp_wgrad_kernel backward; discriminators unchanged")
+                del g_b, d_b
         except Exception as ex:
-            bf16_mode = {"error": f"{type(ex).__name__}: {ex}"}
+            bf16_mode = {**(bf16_mode or {}), "error": f"{type(ex).__name__}: {ex}"}
         finally:
             timer_on[0] = False
             gen.renderer.pack.set_precision(args.precision)

@@ -213,8 +213,18 @@ def _oracle_mlp_grads(sdf_sd, col_sd, pts, w, cs, cg, cr):
 
 # tolerances: 3x the error measured in the native-fp32 mode (6.7e-6 worst over 59 tensors, tools/grad_margin.py; DESIGN.md
 # section 5); bf16x3 (bf16x3 forward, f16x3 backward) 3x its own 1.2e-5
+# bf16 (BASELINE configs[1]: one bf16 MFMA per product forward AND backward, unreduced v_sin / v_cos): the bar is 3x the worst
+# error measured on the MI355X (profiles/r5_gradient_margins.txt), relative to the largest entry of each tensor
+# measured: worst 4.4e-2 (layer-0 FiLM rows), median 1.8e-2 over 60 tensors, loss 1.4e-3 -- bf16 operands (2^-8) under FiLM
+# scales of ~30 through eight layers; the fp32-class modes sit at 5e-6
+BF16_MLP_BWD_TOL = 0.13
+BF16_MLP_BWD_MEDIAN_TOL = 0.05
+BF16_LOSS_TOL = 4.5e-3
+
+
 @pytest.mark.parametrize("n,B,precision,tol", [(96, 2, "f32", 2e-5), (300, 1, "f32", 2e-5), (64, 2, "bf16x3", 4e-5),
-                                               (160, 1, "bf16x6", 2e-5), (160, 1, "f16x3", 2e-5)])
+                                               (160, 1, "bf16x6", 2e-5), (160, 1, "f16x3", 2e-5),
+                                               (160, 1, "bf16", BF16_MLP_BWD_TOL), (96, 2, "bf16", BF16_MLP_BWD_TOL)])
 def test_mlp_backward_vs_oracle(sdf_sd, col_sd, n, B, precision, tol):
     """dL/d(every parameter, w) for L = <cs, sdf> + <cg, d sdf/dx> + <cr, rgb> (random cotangents)."""
     from oi_amd.fields import ShapeNetwork, ColorNetwork, FieldPack
@@ -234,7 +244,9 @@ def test_mlp_backward_vs_oracle(sdf_sd, col_sd, n, B, precision, tol):
     _, gamma, beta = pack.film(w=wh)
     sdf, grad, rgb, _ = sdf_mlp(pack, pts.cuda(), gamma, beta, B, True, True, False)
     loss = (sdf * cs.cuda()).sum() + (grad * cg.cuda()).sum() + (rgb * cr.cuda()).sum()
-    assert abs(float(loss) - loss_o) < 1e-3 * max(1.0, abs(loss_o))
+    if precision == "bf16":
+        record_margin("mlp_backward_vs_fp64_oracle[bf16]", "(loss)", abs(float(loss) - loss_o) / max(1.0, abs(loss_o)))
+    assert abs(float(loss) - loss_o) < (BF16_LOSS_TOL if precision == "bf16" else 1e-3) * max(1.0, abs(loss_o))
     named = [("sdf." + k, v) for k, v in sdf_net.named_parameters() if not k.startswith("style.")] + \
             [("col." + k, v) for k, v in col_net.named_parameters()] + [("w", wh)]
     gr = torch.autograd.grad(loss, [v for _, v in named])
@@ -244,6 +256,9 @@ def test_mlp_backward_vs_oracle(sdf_sd, col_sd, n, B, precision, tol):
         record_margin(f"mlp_backward_vs_fp64_oracle[{precision}]", name, worst[name])
     bad = {k: v for k, v in worst.items() if v > tol}
     assert not bad, bad
+    if precision == "bf16":
+        import statistics
+        assert statistics.median(worst.values()) < BF16_MLP_BWD_MEDIAN_TOL, statistics.median(worst.values())
 
 
 # 3x the error measured in the native-fp32 mode against the reference's own (fp32) gradients: 2.3e-5 (F6), 3.5e-5 (F9)
@@ -251,6 +266,14 @@ def test_mlp_backward_vs_oracle(sdf_sd, col_sd, n, B, precision, tol):
 F9_D_TOL = 3e-6  # discriminator weight gradients of the D / mask-D steps: measured 9.2e-7; round 2 accepted 2e-3
 F6_TOL = 7e-5
 F9_TOL = 1e-4
+# bf16 operand mode (BASELINE configs[1]) end to end: forward maps AND every gradient of the training losses against the
+# reference's own fp32 values.  Bars = ~3x the worst error measured on the MI355X (record_margin ->
+# profiles/r5_gradient_margins.txt); gradient errors are relative to the largest entry of the tensor (floor as in the fp32 rows).
+# measured: F6 image 9.8e-4 / mask 1.6e-3 / eikonal 1.6e-4 / loss (a sum over 64 rays x 7 channels) 1.6e-2, gradients 3.9e-2 worst,
+# 7.1e-3 median; F9 G-step losses 9.8e-4, gradients 4.2e-2 worst; D-step losses 6.0e-5, weight gradients 4.1e-4 (their only
+# bf16 input is the fake image)
+BF16_F6 = {"image": 3e-3, "mask": 5e-3, "eikonal": 5e-4, "loss": 5e-2, "grad": 0.12}
+BF16_F9 = {"g_loss": 3e-3, "g_grad": 0.13, "d_loss": 2e-4, "d_grad": 1.3e-3}
 
 
 def _f6_render(precision="f16x3"):
@@ -289,7 +312,7 @@ def _f6_render(precision="f16x3"):
     return g, to_map(c["image"]), to_map(c["shading"]).expand(1, 3, 8, 8), to_map(c["mask"]), c["reduce4"][0] / (c["reduce4"][1] + 1e-5), named
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("precision", ["f16x3", "f32", "bf16"])
 def test_scripted_train_step_golden_f9(precision):
     """F9: one training iteration assembled from the reference's own pieces (gan_pose_trainer.py:103-200 call pattern,
     configs/train.yaml loss weights): G-step loss + generator gradients through both discriminators, D / mask-D step
@@ -312,8 +335,11 @@ def test_scripted_train_step_golden_f9(precision):
     ld = gan(D(image, it=it)[:, :1], 1)
     lm = gan(M(mask, it=it), 1)
     lg = ld * 1.0 + lm * 0.1 + 10.0 * eik
+    bf = precision == "bf16"
     for name, a, b in (("disc", ld, g["g_loss_disc"]), ("mask", lm, g["g_loss_mask"]), ("total", lg, g["g_loss"])):
-        assert abs(float(a) - float(b)) < 1e-4 * max(1.0, abs(float(b))), (name, float(a), float(b))
+        if bf:
+            record_margin("f9_g_step_losses_vs_reference[bf16]", name, abs(float(a) - float(b)) / max(1.0, abs(float(b))))
+        assert abs(float(a) - float(b)) < (BF16_F9["g_loss"] if bf else 1e-4) * max(1.0, abs(float(b))), (name, float(a), float(b))
     grads = torch.autograd.grad(lg, [v for _, v in named], allow_unused=True, retain_graph=True)
     checked, bad = 0, {}
     for (name, _), gr in zip(named, grads):
@@ -323,7 +349,7 @@ def test_scripted_train_step_golden_f9(precision):
             continue
         err = maxdiff(gr.cpu(), g[key]) / max(1e-3, float(g[key].abs().max()))
         record_margin(f"f9_g_step_grads_vs_reference[{precision}]", name, err)
-        if err > F9_TOL:
+        if err > (BF16_F9["g_grad"] if bf else F9_TOL):
             bad[name] = err
         checked += 1
     assert checked > 60 and not bad, bad
@@ -343,16 +369,18 @@ def test_scripted_train_step_golden_f9(precision):
         loss = l_real + l_fake + l_reg * 10.0 + l_aux * linear_increase(1000, 1)(it)
         for nm, a in (("real", l_real), ("fake", l_fake), ("reg", l_reg), ("aux", l_aux), ("loss", loss)):
             b = float(g[f"{tag}_{nm}"])
-            assert abs(float(a) - b) < 2e-4 * max(1.0, abs(b)), (tag, nm, float(a), b)
+            if bf:   # (the fake batch is the bf16-mode render: its error is the image's)
+                record_margin("f9_d_step_losses_vs_reference[bf16]", f"{tag}.{nm}", abs(float(a) - b) / max(1.0, abs(b)))
+            assert abs(float(a) - b) < (BF16_F9["d_loss"] if bf else 2e-4) * max(1.0, abs(b)), (tag, nm, float(a), b)
         gw = torch.autograd.grad(loss, list(net.parameters()))
         for (k, _), gr in zip(net.named_parameters(), gw):
             ref = g[f"{tag}_g." + k]
             record_margin(f"f9_d_step_weight_grads_vs_reference[{precision}]", f"{tag}.{k}",
                           maxdiff(gr.cpu(), ref) / max(1e-3, float(ref.abs().max())))
-            assert maxdiff(gr.cpu(), ref) < F9_D_TOL * max(1e-3, float(ref.abs().max())), (tag, k, maxdiff(gr.cpu(), ref), float(ref.abs().max()))
+            assert maxdiff(gr.cpu(), ref) < (BF16_F9["d_grad"] if bf else F9_D_TOL) * max(1e-3, float(ref.abs().max())), (tag, k, maxdiff(gr.cpu(), ref), float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("precision", ["f16x3", "f32", "bf16"])
 def test_generator_grads_golden_f6(precision):
     """The reference's own parameter gradients for loss = sum(image) + 10*eikonal + sum(shading) + 0.5*sum(mask)
     (training mode: jitter on, cos_anneal 0.4) -- exercises MLP double-backward + compositing backward + light."""
@@ -388,10 +416,14 @@ def test_generator_grads_golden_f6(precision):
     to_map = lambda x: x.reshape(1, 8, 8, -1).permute(0, 3, 1, 2)
     image, shading, mask = to_map(c["image"]), to_map(c["shading"]).expand(1, 3, 8, 8), to_map(c["mask"])
     eik = c["reduce4"][0] / (c["reduce4"][1] + 1e-5)
-    assert maxdiff(image.cpu(), g["image"]) < 1e-4 and maxdiff(mask.cpu(), g["mask"]) < 1e-4
-    assert abs(float(eik) - float(g["eikonal"])) < 1e-4
+    bf = precision == "bf16"
     loss = image.sum() + 10.0 * eik + shading.sum() + 0.5 * mask.sum()
-    assert abs(float(loss) - float(g["loss"])) < 1e-3
+    fwd = {"image": maxdiff(image.cpu(), g["image"]), "mask": maxdiff(mask.cpu(), g["mask"]),
+           "eikonal": abs(float(eik) - float(g["eikonal"])), "loss": abs(float(loss) - float(g["loss"]))}
+    for k, e in fwd.items():
+        if bf:
+            record_margin("f6_forward_bf16_mode_vs_reference", k, e)
+        assert e < (BF16_F6[k] if bf else {"loss": 1e-3}.get(k, 1e-4)), (k, e)
     named = [("sdf_network." + k, v) for k, v in sdf.named_parameters()] + [("color_network." + k, v) for k, v in col.named_parameters()] + \
             [("deviation_network." + k, v) for k, v in dev.named_parameters()] + [("light." + k, v) for k, v in light.named_parameters()]
     grads = torch.autograd.grad(loss, [v for _, v in named], allow_unused=True)
@@ -404,7 +436,7 @@ def test_generator_grads_golden_f6(precision):
         ref = g[key]
         err = maxdiff(gr.cpu(), ref) / max(1.0, float(ref.abs().max()))
         record_margin(f"f6_generator_grads_vs_reference[{precision}]", name, err)
-        if err > F6_TOL:
+        if err > (BF16_F6["grad"] if bf else F6_TOL):
             bad[name] = err
         checked += 1
     assert checked > 60 and not bad, bad

@@ -153,10 +153,16 @@ def test_c5_mlp_only_microbench_size(sdf_sd, col_sd):
 # 6.4e-6 (training render, 58 tensors) -- tools/grad_margin.py; round 2 accepted 2e-3 / 3e-3
 C2_MLP_BWD_TOL = 2.5e-5
 C2_RENDER_BWD_TOL = 2e-5
+# bf16 operand mode (BASELINE configs[1]): ~3x the worst error measured on the MI355X (profiles/r5_gradient_margins.txt)
+# measured: MLP op 3.9e-2 worst / 1.3e-2 median over 60 tensors; training render 1.05e-1 worst / 4.5e-2 median over 59 (the
+# compositing turns sdf errors into weight errors at 1/s_val); losses 5.1e-4 / 2.9e-4
+C2_MLP_BWD_TOL_BF16 = 0.12
+C2_RENDER_BWD_TOL_BF16 = 0.32
+C2_LOSS_TOL_BF16 = 2e-3
 
 
-@pytest.mark.parametrize("n,precision", [(4096 * 128, "f16x3"), (4096 * 128, "f32"), (128 * 128 * 256, "f16x3")],
-                         ids=["C2-f16x3", "C2-f32", "C4-eight-chunks-f16x3"])
+@pytest.mark.parametrize("n,precision", [(4096 * 128, "f16x3"), (4096 * 128, "f32"), (128 * 128 * 256, "f16x3"), (4096 * 128, "bf16")],
+                         ids=["C2-f16x3", "C2-f32", "C4-eight-chunks-f16x3", "C2-bf16"])
 def test_c2_size_mlp_backward_vs_oracle(sdf_sd, col_sd, n, precision):
     """Backward of the MLP op at the full C2 launch size (524,288 points = 4,096 rays x 128 samples; the real grid of the
     sweep kernel, its scratch indexing, the split weight-gradient GEMM and every atomics-accumulated output): the
@@ -186,18 +192,22 @@ def test_c2_size_mlp_backward_vs_oracle(sdf_sd, col_sd, n, precision):
     _, gamma, beta = pack.film(w=wh)
     sdf, grad, rgb, _ = sdf_mlp(pack, pts.cuda(), gamma, beta, B, True, True, False)
     loss = (sdf * cs.cuda()).sum() + (grad * cg.cuda()).sum() + (rgb * cr.cuda()).sum()
-    assert abs(float(loss) - loss_o) < 1e-3 * max(1.0, abs(loss_o))
+    bf = precision == "bf16"
+    case = f"{'c2' if n < 1 << 20 else 'c4'}_size_mlp_backward_vs_fp64_oracle[{precision}]"
+    if bf:
+        record_margin(case, "(loss)", abs(float(loss) - loss_o) / max(1.0, abs(loss_o)))
+    assert abs(float(loss) - loss_o) < (C2_LOSS_TOL_BF16 if bf else 1e-3) * max(1.0, abs(loss_o))
     named = [("sdf." + k, v) for k, v in sdf_net.named_parameters() if not k.startswith("style.")] + \
             [("col." + k, v) for k, v in col_net.named_parameters()] + [("w", wh)]
     gr = torch.autograd.grad(loss, [v for _, v in named])
     errs = {name: rel_err(a, g_o[name]) for (name, _), a in zip(named, gr)}
     for name, e in errs.items():
-        record_margin(f"{'c2' if n < 1 << 20 else 'c4'}_size_mlp_backward_vs_fp64_oracle[{precision}]", name, e)
-    bad = {k: v for k, v in errs.items() if v > C2_MLP_BWD_TOL}
+        record_margin(case, name, e)
+    bad = {k: v for k, v in errs.items() if v > (C2_MLP_BWD_TOL_BF16 if bf else C2_MLP_BWD_TOL)}
     assert not bad, bad
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("precision", ["f16x3", "f32", "bf16"])
 def test_c2_size_render_backward_ray_subset_vs_oracle(sdf_sd, col_sd, precision):
     """Training render at C2 size (4,096 rays x 64+64 samples, gradient enabled): loss = <c, color_fine> + <c', weight_sum>
     with cotangents on a 128-ray subset.  Rays are independent, so the parameter gradients equal those of the subset
@@ -226,7 +236,10 @@ def test_c2_size_render_backward_ray_subset_vs_oracle(sdf_sd, col_sd, precision)
     ref = O.render_core(sd, csd, torch.tensor(0.3, dtype=torch.float64), ro[idx].double(), rd[idx].double(), z,
                         w.double(), S, 0.5)
     loss_o = (ref["color_fine"] * c_col[idx].double()).sum() + (ref["weight_sum"] * c_ws[idx].double()).sum()
-    assert abs(float(loss) - float(loss_o)) < 1e-3 * max(1.0, abs(float(loss_o)))
+    bf = precision == "bf16"
+    if bf:
+        record_margin("c2_size_render_backward_vs_fp64_oracle[bf16]", "(loss)", abs(float(loss) - float(loss_o)) / max(1.0, abs(float(loss_o))))
+    assert abs(float(loss) - float(loss_o)) < (C2_LOSS_TOL_BF16 if bf else 1e-3) * max(1.0, abs(float(loss_o)))
     leaves = [("sdf." + k, v) for k, v in sd.items()] + [("col." + k, v) for k, v in csd.items()]
     g_o = dict(zip([n_ for n_, _ in leaves], torch.autograd.grad(loss_o, [v for _, v in leaves], allow_unused=True)))
     bad, checked = {}, 0
@@ -236,6 +249,6 @@ def test_c2_size_render_backward_ray_subset_vs_oracle(sdf_sd, col_sd, precision)
             continue
         checked += 1
         record_margin(f"c2_size_render_backward_vs_fp64_oracle[{precision}]", name, rel_err(a, b))
-        if rel_err(a, b) > C2_RENDER_BWD_TOL:
+        if rel_err(a, b) > (C2_RENDER_BWD_TOL_BF16 if bf else C2_RENDER_BWD_TOL):
             bad[name] = rel_err(a, b)
     assert checked > 50 and not bad, bad
