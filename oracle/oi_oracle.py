@@ -541,6 +541,23 @@ def dc_discriminator(dsd, x):
     return out.reshape(x.shape[0], -1)
 
 
+def seeded_conv_weights(shapes, seed):
+    """Test input recipe (NOT reference arithmetic): one seeded uniform(-b, b) draw per tensor with b = sqrt(6 / (1.04 fan_in))
+    -- the variance-preserving bound for LeakyReLU(0.2) layers, so that the logits of the six-layer network of
+    discriminator.py:63-72 are O(1) and a forward tolerance means something (nn.Conv2d's default bound 1/sqrt(fan_in) shrinks
+    the signal 2.4x per layer: logits of 1e-3).  `shapes`: {name: shape} in state_dict order.  The 128 x 128 fixture (tests/golden/f14_discriminator_128.npz) stores check sums of these tensors
+    instead of 2 x 11.4 MB of weights; both the generating script and the test call this function."""
+    out = {}
+    for i, (k, shp) in enumerate(shapes.items()):
+        g = torch.Generator().manual_seed(int(seed) * 1000 + i)
+        fan_in = 1
+        for d in shp[1:]:
+            fan_in *= int(d)
+        b = math.sqrt(6.0 / (1.04 * max(1, fan_in)))
+        out[k] = (torch.rand(*shp, generator=g) * 2.0 - 1.0) * b
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # a20: losses
 # --------------------------------------------------------------------------------------

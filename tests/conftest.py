@@ -59,3 +59,46 @@ def pytest_sessionfinish(session, exitstatus):
         import json
         with open(out, "w") as fh:
             json.dump(MARGINS, fh, indent=1, sort_keys=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# F14 (tests/golden/f14_discriminator_128.npz, oracle/gen_golden_r5.py): the shipped 128 x 128 discriminators.  The fixture
+# stores the weight recipe's check sums and strided samples of the two large gradient tensors instead of 4 x 11.4 MB.
+# ------------------------------------------------------------------------------------------------------------------
+F14_GRAD_STRIDE = {"blocks.2.weight": 5, "blocks.3.weight": 17, "blocks.4.weight": 61}
+F14_NETS = {"v_": dict(view=True, in_dim=3, out_dim=7), "m_": dict(view=False, in_dim=1, out_dim=1)}
+
+
+def f14_weights(g, tag):
+    """The network's weights from the seeded recipe, verified against the fixture's check sums (a different torch whose
+    generator drew other numbers must fail HERE, not as a parity error)."""
+    import oi_oracle as O
+    kw = F14_NETS[tag]
+    chans = [kw["in_dim"], 32, 64, 128, 256, 512]
+    shapes = {f"blocks.{i}.weight": (chans[i + 1], chans[i], 4, 4) for i in range(5)}
+    shapes["conv_out.weight"] = (kw["out_dim"], 512, 4, 4)
+    wsd = O.seeded_conv_weights(shapes, int(g[tag + "seed"]))
+    for k, v in wsd.items():
+        ref = g[tag + "wsum." + k].double()
+        got = torch.stack([v.double().sum(), (v.double() ** 2).sum()])
+        assert float((got - ref).abs().max()) <= 1e-9 * max(1.0, float(ref.abs().max())), ("weight recipe check sum", tag, k)
+        assert torch.equal(v.flatten()[:: max(1, v.numel() // 64)][:64], g[tag + "wsample." + k]), ("weight recipe samples", tag, k)
+    return wsd
+
+
+def f14_grad_errors(g, t, named_grads):
+    """{name: relative error} of weight gradients against the fixture (whole tensors, or strided samples + exact sums)."""
+    errs = {}
+    for k, gr in named_grads:
+        gr = gr.detach().double().cpu()
+        st = F14_GRAD_STRIDE.get(k)
+        if st is None:
+            ref = g[t + "g." + k].double()
+            errs[k] = float((gr - ref).abs().max() / ref.abs().max())
+        else:
+            ref = g[t + "gs." + k].double()
+            errs[k] = float((gr.flatten()[::st] - ref).abs().max() / ref.abs().max())
+            sums = g[t + "gsum." + k].double()
+            errs[k + "(sum)"] = float(abs(gr.sum() - sums[0]) / gr.abs().sum())
+            errs[k + "(sum of squares)"] = float(abs((gr ** 2).sum() - sums[1]) / sums[1])
+    return errs

@@ -149,6 +149,32 @@ def test_f7_discriminator(tag):
     assert maxdiff(gx, g[tag + "gx"]) < 1e-6
 
 
+@pytest.mark.parametrize("tag,B", [("v_", 1), ("v_", 2), ("m_", 1), ("m_", 2)])
+def test_f14_shipped_discriminators_128(tag, B):
+    """The oracle against the reference's own 128 x 128 ADA discriminators (configs/train.yaml:78-102): augmentation at a
+    pinned percentile -> six convolutions -> logits, R1, d/dx and the loss's weight gradients (double backward through the
+    augmentation)."""
+    from conftest import f14_weights, f14_grad_errors
+    g = load_golden("f14_discriminator_128")
+    t = f"{tag}b{B}_"
+    dsd = {k: v.clone().requires_grad_(True) for k, v in f14_weights(g, tag).items()}
+    x = g[t + "x"].clone().requires_grad_(True)
+    p = g[t + "pct"]
+    G = O.ada_G_inv(B, 128, 128, ((p * 2 - 1) * 0.125).expand(B, 2), torch.exp2(torch.erfinv(p * 2 - 1) * 0.2).expand(B))
+    d = O.dc_discriminator(dsd, O.ada_geometric(x, G)[0])
+    assert maxdiff(d, g[t + "d"]) < 1e-5
+    d1 = d[:, :1]
+    reg = O.r1_penalty(d1, x)
+    assert abs(float(reg) - float(g[t + "reg"])) < 1e-5 * max(1.0, float(g[t + "reg"]))
+    loss = O.bce_logits_const(d1, 1) + 10.0 * reg
+    assert abs(float(loss) - float(g[t + "loss"])) < 1e-5 * max(1.0, float(g[t + "loss"]))
+    gw = torch.autograd.grad(loss, list(dsd.values()), retain_graph=True)
+    errs = f14_grad_errors(g, t, zip(dsd.keys(), gw))
+    assert max(errs.values()) < 1e-4, errs
+    (gx,) = torch.autograd.grad(d1.sum(), x)
+    assert maxdiff(gx, g[t + "gx"]) < 1e-5 * max(1.0, float(g[t + "gx"].abs().max()))
+
+
 def test_f8_augment():
     g = load_golden("f8_augment")
     assert maxdiff(O.hz_geom(), g["Hz_geom"]) < 1e-7
