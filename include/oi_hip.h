@@ -154,6 +154,29 @@ int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, con
                    oi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a6 stand-alone: the albedo head on CALLER-SUPPLIED features and normals.
+ * Replaces ColorNetwork.forward(points, normals, view_dirs, feature_vectors, z, w) (src/models/fields.py:89-101: `points`,
+ * `view_dirs` and `z` are ignored there) = FiLMSiren(131 -> 128) (stylesdf/volume_renderer.py:50-61) + rgb_linear + sigmoid,
+ * for a caller that keeps the reference's renderer.py:241-261.  (NeuSRenderer.render of this library never calls it: there
+ * the head is the tail of oi_sdf_mlp_fwd and its inputs stay in registers.)
+ *   feat [B*n][128], normals [B*n][3] (raw d sdf/dx); gamma / beta: row e at gamma + e * film_stride (128 floats each; pass
+ *   oi_film_params' [B][9][128] + 8 * 128 with film_stride = 9 * 128, or a dense [B][128] with 128);
+ *   wv [128][131], bv [128], wrgb [3][128], brgb [3] in the reference's state_dict layout  ->  rgb [B*n][3].
+ * Exact fp32 (v_mfma_f32_32x32x2_f32).
+ * Backward: g_rgb [B*n][3] -> d_feat [B*n][128], d_normals [B*n][3], d_gamma / d_beta (row e at + e * d_film_stride), d_wv,
+ * d_bv, d_wrgb, d_brgb -- all ASSIGNED; sums over the points are formed from per-workgroup partials in a fixed order (no
+ * atomics: bit-reproducible).  workspace: oi_color_head_bwd_workspace_bytes(B, n) bytes (~1 KB per point). */
+int oi_color_head_fwd(const float* feat, const float* normals, const float* gamma, const float* beta, long long film_stride,
+                      const float* wv, const float* bv, const float* wrgb, const float* brgb, float* rgb, int B,
+                      long long n_per_elem, oi_stream_t stream);
+size_t oi_color_head_bwd_workspace_bytes(int B, long long n_per_elem);
+int oi_color_head_bwd(const float* feat, const float* normals, const float* gamma, const float* beta, long long film_stride,
+                      const float* wv, const float* bv, const float* wrgb, const float* brgb, const float* g_rgb, float* d_feat,
+                      float* d_normals, float* d_gamma, float* d_beta, long long d_film_stride, float* d_wv, float* d_bv,
+                      float* d_wrgb, float* d_brgb, void* workspace, size_t workspace_bytes, int B, long long n_per_elem,
+                      oi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a13 + a14: crop rays.  Replaces Generator.gen_rays_at + build_rays + near_far_from_sphere
  * (src/models/generator.py:255-279, 317-333, 336-342).
  *   c2b [B][4][4] (camera->box), kinv [3][3] (row-major 3x3 of intrinsics_inv), offs [B][2]

@@ -101,6 +101,31 @@ def sdf_mlp(pack, pts, gamma, beta, B, want_grad, want_rgb, want_feat, scratch=N
     return sdf, grad, rgb, feat
 
 
+class ColorHeadFunction(torch.autograd.Function):
+    """ColorNetwork.forward on caller-supplied features (fields.py:89-101): oi_color_head_fwd / oi_color_head_bwd.  First
+    order: the head is a plain function of (features, normals, FiLM rows, weights) -- the second-order terms of a training loss
+    live in whatever produced `normals` (ShapeNetwork.gradient), not here."""
+
+    @staticmethod
+    def forward(ctx, feat, normals, gamma, beta, wv, bv, wrgb, brgb, B):
+        args = [ops._c(t) for t in (feat, normals, gamma, beta, wv, bv, wrgb, brgb)]
+        ctx.save_for_backward(*args)
+        ctx.B = B
+        return ops.color_head_fwd(*args, B)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_rgb):
+        return ops.color_head_bwd(*ctx.saved_tensors, ops._c(g_rgb), ctx.B) + (None,)
+
+
+def color_head(feat, normals, gamma, beta, wv, bv, wrgb, brgb, B):
+    if _needs_grad(feat, normals, gamma, beta, wv, bv, wrgb, brgb):
+        return ColorHeadFunction.apply(feat, normals, gamma, beta, wv, bv, wrgb, brgb, B)
+    with torch.no_grad():
+        return ops.color_head_fwd(*[ops._c(t) for t in (feat, normals, gamma, beta, wv, bv, wrgb, brgb)], B)
+
+
 # ------------------------------------------------------------------------------------------
 # a12/a15: compositing + shading maps
 # ------------------------------------------------------------------------------------------

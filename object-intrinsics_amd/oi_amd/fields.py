@@ -132,14 +132,27 @@ class ColorNetwork(nn.Module):
         self.style_dim, self.w_dim = style_dim, W
 
     def forward(self, points, normals, view_dirs, feature_vectors, z=None, w=None):
-        """The reference evaluates the albedo head on (feature_vectors, normals) handed over from the SDF network
-        (fields.py:89-101; `points`, `view_dirs`, `z` are ignored there).  Here the head is the tail of the fused MLP
-        launch -- features and d sdf/dx never leave the kernel -- so there is no stand-alone evaluation on caller-supplied
-        features: use `oi_amd.autograd.sdf_mlp(pack, points, gamma, beta, B, want_grad=True, want_rgb=True, ...)`
-        (what NeuSRenderer.render_full does) with a FieldPack over the (ShapeNetwork, ColorNetwork) pair."""
-        raise NotImplementedError(
-            "ColorNetwork.forward on caller-supplied features is not part of the HIP path: the albedo head runs fused "
-            "behind the SDF network (oi_amd.autograd.sdf_mlp(..., want_grad=True, want_rgb=True) / NeuSRenderer.render)")
+        """The reference's stand-alone evaluation (fields.py:89-101): rgb = sigmoid(rgb_linear(FiLM-sin(cat[feature_vectors,
+        normals]; w))) on CALLER-SUPPLIED features and normals; `points`, `view_dirs` and `z` are ignored there and here (only
+        points.shape[0] is used).  One HIP launch (csrc/color_head.hip, exact fp32 on the matrix cores) behind an autograd
+        Function whose backward reaches the features, the normals, w and every parameter of this module.  NeuSRenderer.render
+        does NOT come through here: in the render the head is the tail of the fused MLP launch and its inputs never leave the
+        kernel -- this entry is for a caller that keeps the reference's renderer.py:241-261."""
+        from .autograd import color_head, FilmParamsFunction, _needs_grad
+        if w is None:
+            raise ValueError("ColorNetwork.forward needs the style vector w (fields.py:91: bs = w.shape[0])")
+        n, B = feature_vectors.shape[0], w.shape[0]
+        if points.shape[0] != n or normals.shape[0] != n or n % B:
+            raise ValueError(f"ColorNetwork.forward: {n} feature rows, {points.shape[0]} points, {normals.shape[0]} normals, batch {B}")
+        vl = self.views_linears
+        heads = (vl.gamma.weight[None], vl.gamma.bias[None], vl.beta.weight[None], vl.beta.bias[None])   # NL = 1
+        if _needs_grad(w, *heads):
+            _, gamma, beta = FilmParamsFunction.apply(None, w, None, None, *heads)
+        else:
+            with torch.no_grad():
+                _, gamma, beta = ops.film_params(None, None, *[ops._c(t) for t in heads], w=w)
+        return color_head(feature_vectors.reshape(n, 128), normals.reshape(n, 3), gamma[:, 0], beta[:, 0], vl.weight, vl.bias,
+                          self.rgb_linear.weight, self.rgb_linear.bias, B)
 
 
 class SingleVarianceNetwork(nn.Module):

@@ -128,6 +128,35 @@ def _zeros_split(dev, *shapes):
 
 
 # ------------------------------------------------------------------------------------------
+# a6 stand-alone: the albedo head on caller-supplied features (csrc/color_head.hip)
+# ------------------------------------------------------------------------------------------
+
+def color_head_fwd(feat, normals, gamma, beta, wv, bv, wrgb, brgb, B):
+    """feat (n,128), normals (n,3), gamma / beta (B,128) -> rgb (n,3); n = B * points per element (element-major rows)."""
+    n = feat.shape[0]
+    assert n % B == 0 and feat.shape[1] == 128 and normals.shape == (n, 3) and gamma.shape == (B, 128) == beta.shape
+    rgb = _new(feat, n, 3)
+    _l.check(_l.load().oi_color_head_fwd(_p(feat), _p(normals), _p(gamma), _p(beta), 128, _p(wv), _p(bv), _p(wrgb), _p(brgb),
+                                         _p(rgb), B, n // B, _stream()), "oi_color_head_fwd")
+    return rgb
+
+
+def color_head_bwd(feat, normals, gamma, beta, wv, bv, wrgb, brgb, g_rgb, B):
+    """-> d_feat, d_normals, d_gamma, d_beta, d_wv, d_bv, d_wrgb, d_brgb (all assigned; fixed summation order)."""
+    L = _l.load()
+    n = feat.shape[0]
+    ws_bytes = int(L.oi_color_head_bwd_workspace_bytes(B, n // B))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=feat.device)
+    d_feat, d_normals = _new(feat, n, 128), _new(feat, n, 3)
+    d_gamma, d_beta = _new(feat, B, 128), _new(feat, B, 128)
+    d_wv, d_bv, d_wrgb, d_brgb = _new(feat, 128, 131), _new(feat, 128), _new(feat, 3, 128), _new(feat, 3)
+    _l.check(L.oi_color_head_bwd(_p(feat), _p(normals), _p(gamma), _p(beta), 128, _p(wv), _p(bv), _p(wrgb), _p(brgb), _p(g_rgb),
+                                 _p(d_feat), _p(d_normals), _p(d_gamma), _p(d_beta), 128, _p(d_wv), _p(d_bv), _p(d_wrgb),
+                                 _p(d_brgb), _p(ws), ws_bytes, B, n // B, _stream()), "oi_color_head_bwd")
+    return d_feat, d_normals, d_gamma, d_beta, d_wv, d_bv, d_wrgb, d_brgb
+
+
+# ------------------------------------------------------------------------------------------
 # MLP
 # ------------------------------------------------------------------------------------------
 

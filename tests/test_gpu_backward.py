@@ -340,6 +340,47 @@ def test_mlp_backward_vs_oracle(sdf_sd, col_sd, n, B, precision, tol):
         assert statistics.median(worst.values()) < BF16_MLP_BWD_MEDIAN_TOL, statistics.median(worst.values())
 
 
+# measured 1.5e-6 worst (d normals; every other tensor <= 6e-7): exact-fp32 MFMA products, fixed summation order
+COLOR_HEAD_BWD_TOL = 5e-6
+
+
+@pytest.mark.parametrize("npe,B", [(200, 2), (1, 1), (4100, 1)])
+def test_color_network_standalone_backward_vs_oracle(col_sd, npe, B):
+    """d L / d (feature_vectors, normals, w, every parameter) of ColorNetwork.forward (oi_color_head_bwd) for L = <c, rgb>
+    against fp64 autograd through the oracle (fields.py:89-101); bit-reproducible (no atomics)."""
+    from oi_amd.fields import ColorNetwork
+    gen = torch.Generator().manual_seed(npe + B)
+    n = B * npe
+    feat = torch.rand(n, 128, generator=gen) * 2 - 1
+    nrm = torch.randn(n, 3, generator=gen) * 3
+    w = torch.randn(B, 64, generator=gen)
+    c = torch.randn(n, 3, generator=gen)
+    csd = {k: v.double().clone().requires_grad_(True) for k, v in col_sd.items()}
+    fo, no, wo = (t.double().clone().requires_grad_(True) for t in (feat, nrm, w))
+    lo = (O.color_head(csd, fo, no, wo) * c.double()).sum()
+    g_o = dict(zip(["feat", "normals", "w"] + list(csd), torch.autograd.grad(lo, [fo, no, wo] + list(csd.values()))))
+    col = ColorNetwork(**NET_KW)
+    col.load_state_dict(col_sd)
+    col = col.cuda()
+    fh, nh, wh = (t.cuda().requires_grad_(True) for t in (feat, nrm, w))
+    params = dict(col.named_parameters())
+
+    def run():
+        rgb = col(torch.zeros(n, 3, device="cuda"), nh, None, fh, None, wh)
+        return torch.autograd.grad((rgb * c.cuda()).sum(), [fh, nh, wh] + list(params.values()))
+
+    g_h = dict(zip(["feat", "normals", "w"] + list(params), run()))
+    bad = {}
+    for k, a in g_h.items():
+        e = rel_err(a, g_o[k])
+        record_margin("color_head_standalone_backward_vs_fp64_oracle", k, e)
+        if e > COLOR_HEAD_BWD_TOL:
+            bad[k] = e
+    assert set(g_h) == set(g_o) and not bad, bad
+    for a, b in zip(g_h.values(), run()):
+        assert torch.equal(a, b)
+
+
 # 3x the error measured in the native-fp32 mode against the reference's own (fp32) gradients: 2.3e-5 (F6), 3.5e-5 (F9)
 # worst over 69 tensors (tools/grad_margin.py, DESIGN.md section 5); round 2 accepted 3e-3
 F9_D_TOL = 3e-6  # discriminator weight gradients of the D / mask-D steps: measured 9.2e-7; round 2 accepted 2e-3

@@ -82,6 +82,34 @@ def test_sdf_mlp_golden(ops, packed_all, col_sd, mode, tol_sdf, tol_grad, tol_rg
     assert maxdiff(sdf2, sdf) < {"f16x3": 5e-6, "bf16": tol_sdf}.get(mode, 1e-6)
 
 
+def test_color_network_forward_standalone_golden_f2(col_sd):
+    """ColorNetwork.forward(points, normals, view_dirs, feature_vectors, z, w) on the REFERENCE's own feature vectors and
+    normals (F2: fields.py:89-101 evaluated by the reference): the stand-alone entry oi_color_head_fwd."""
+    from oi_amd.fields import ColorNetwork
+    g2 = load_golden("f2_color")
+    col = ColorNetwork(D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64)
+    col.load_state_dict(col_sd)
+    col = col.cuda()
+    n = g2["feat"].shape[0]
+    pts = torch.zeros(n, 3, device="cuda")
+    with torch.no_grad():
+        rgb = col(pts, g2["grad"].cuda(), None, g2["feat"].cuda(), None, g2["w"].cuda())
+    assert rgb.shape == (n, 3) and maxdiff(rgb.cpu(), g2["rgb"]) < 2e-5, maxdiff(rgb.cpu(), g2["rgb"])
+    # ragged point counts (tile tails), three batch elements, against the oracle
+    for npe in (1, 37, 130, 1000):
+        gen = torch.Generator().manual_seed(npe)
+        B = 3
+        feat = torch.rand(B * npe, 128, generator=gen) * 2 - 1
+        nrm = torch.randn(B * npe, 3, generator=gen) * 3
+        w = torch.randn(B, 64, generator=gen)
+        ref = O.color_head(col_sd, feat, nrm, w)
+        with torch.no_grad():
+            out = col(torch.zeros(B * npe, 3, device="cuda"), nrm.cuda(), None, feat.cuda(), None, w.cuda())
+        assert maxdiff(out.cpu(), ref) < 2e-5, (npe, maxdiff(out.cpu(), ref))
+    with pytest.raises(ValueError):
+        col(pts, g2["grad"].cuda(), None, g2["feat"].cuda()[:-1], None, g2["w"].cuda())
+
+
 RAGGED_TOL = {"f32": (2e-5, 1e-4, 2e-5), "f16x3": (2e-5, 1e-4, 2e-5), "bf16": (3e-2, 1.5e-1, 3e-2)}
 
 
