@@ -152,6 +152,15 @@ int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, con
                    const float* g_rgb, float* d_small, float* d_wmat, float* d_gamma, float* d_beta,
                    void* scratch, size_t scratch_bytes, int B, long long n_per_elem, int prec, int fast_trig,
                    oi_stream_t stream);
+/* The same with an upstream gradient of the FEATURE output (feat of oi_sdf_mlp_fwd = the second to 129th column of
+ * ShapeNetwork.forward, fields.py:72): g_feat [B*n][128] joins abar_8 at the turn of the sweep.  For a caller that keeps the
+ * reference's renderer.py:241-261 (features read out, albedo head evaluated by oi_color_head_fwd): the head's d_feat comes back
+ * through here.  g_feat == NULL is oi_sdf_mlp_bwd. */
+int oi_sdf_mlp_bwd_feat(const float* pts, const void* packed, const float* gamma, const float* beta,
+                        const float* grad_fwd, const float* rgb_fwd, const float* feat_fwd, const float* g_sdf,
+                        const float* g_grad, const float* g_rgb, const float* g_feat, float* d_small, float* d_wmat,
+                        float* d_gamma, float* d_beta, void* scratch, size_t scratch_bytes, int B, long long n_per_elem,
+                        int prec, int fast_trig, oi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a6 stand-alone: the albedo head on CALLER-SUPPLIED features and normals.

@@ -398,13 +398,16 @@ __device__ unsigned long long oi_prof_bwd[16];
 // section markers in the assembly listing (comments only): tools/isa_mix.py --sections splits the instruction mix on them,
 // the up / down layer bodies are run-time loops and execute 7 times per tile
 #define OI_MARK(name) asm volatile("; OI_MARK " name)
-template <int PREC, bool FAST>
+// GFEAT: an upstream gradient of the FEATURE output a_8 (`g_feat`, [B n][128]) joins abar_8 at the turn -- a caller that keeps the
+// reference's renderer.py:241-261 reads the features out (ShapeNetwork.forward) and feeds them to ColorNetwork.forward, so their
+// gradient comes back from outside.  A separate instantiation: the fused path (GFEAT = false) compiles exactly as before.
+template <int PREC, bool FAST, bool GFEAT = false>
 __global__ void __launch_bounds__(BW_THREADS)
 mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ packed, const float* __restrict__ gamma,
                      const float* __restrict__ beta, const float* __restrict__ grad_fwd,
                      const float* __restrict__ rgb_fwd, const float* __restrict__ feat_fwd,
                      const float* __restrict__ g_sdf, const float* __restrict__ g_grad,
-                     const float* __restrict__ g_rgb, float* __restrict__ d_small, float* __restrict__ d_gamma,
+                     const float* __restrict__ g_rgb, const float* __restrict__ g_feat, float* __restrict__ d_small, float* __restrict__ d_gamma,
                      float* __restrict__ d_beta, char* __restrict__ scratch, float* __restrict__ op_max,
                      long long n_per_elem, long long n_stride, long long pt_off) {
   // this launch covers points [pt_off, pt_off + n_per_elem) of every batch element; an element holds n_stride points
@@ -622,6 +625,24 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       f32x4 v;
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = SC ? acc[g >> 2][4 * (g & 3) + k] * fT : acc[g >> 2][4 * (g & 3) + k];
+      if constexpr (GFEAT) {
+        const f32x4 gf = *reinterpret_cast<const f32x4*>(g_feat + pt * C + grp_f0(g) + 4 * h);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaf(gf[k], vmask, v[k]);
+      }
+#if OI_BWD_AC_REGS
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ac[4 * g + k] = v[k];
+#else
+      ws.store(S_AC, g, o.l16, v);
+#endif
+    }
+  } else if constexpr (GFEAT) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(g_feat + pt * C + grp_f0(g) + 4 * h);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] *= vmask;
 #if OI_BWD_AC_REGS
 #pragma unroll
       for (int k = 0; k < 4; ++k) ac[4 * g + k] = v[k];
@@ -822,7 +843,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           const f32x4 a8 = ws.value(phn[g & (PFT - 1)]);
 #endif
 #pragma unroll
-          for (int k = 0; k < 4; ++k) abx[k] = has_col ? fmaf(gs, gnx[k], a8[k]) : gs * gnx[k];  // abar_8
+          for (int k = 0; k < 4; ++k) abx[k] = (has_col || GFEAT) ? fmaf(gs, gnx[k], a8[k]) : gs * gnx[k];  // abar_8
         } else {
           gnx = f32x4{gb[4 * g], gb[4 * g + 1], gb[4 * g + 2], gb[4 * g + 3]};
           abx = f32x4{act[4 * g], act[4 * g + 1], act[4 * g + 2], act[4 * g + 3]};
@@ -1461,7 +1482,8 @@ mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__
 
 template <int PREC, bool FAST>
 int launch_bwd(const float* pts, const void* packed, const float* gamma, const float* beta, const float* grad_fwd,
-               const float* rgb_fwd, const float* feat_fwd, const float* g_sdf, const float* g_grad, const float* g_rgb, float* d_small,
+               const float* rgb_fwd, const float* feat_fwd, const float* g_sdf, const float* g_grad, const float* g_rgb,
+               const float* g_feat, float* d_small,
                float* d_wmat, float* d_gamma, float* d_beta, void* scratch, size_t scratch_bytes, int B, long long n,
                hipStream_t st) {
   // The scratch is a bound, not a function of the problem: the points of every batch element are processed in chunks of
@@ -1478,7 +1500,7 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
   if (tiles_fit > tiles_all) tiles_fit = tiles_all;
   tiles_fit = oi::cdiv(tiles_all, oi::cdiv(tiles_all, tiles_fit));  // equal chunks: no short last launch
   const int has_col = (rgb_fwd != nullptr && g_rgb != nullptr && feat_fwd != nullptr) ? 1 : 0;
-  auto k = mlp_bwd_sweep_kernel<PREC, FAST>;
+  auto k = g_feat ? mlp_bwd_sweep_kernel<PREC, FAST, true> : mlp_bwd_sweep_kernel<PREC, FAST, false>;
   // per launch: the attribute is per device, and a process may drive several
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL_BWD);
   for (long long t0 = 0; t0 < tiles_all; t0 += tiles_fit) {
@@ -1490,7 +1512,7 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
       if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_sdf_mlp_bwd: zero fill: %s", hipGetErrorString(e));
     }
     hipLaunchKernelGGL(k, grid, dim3(BW_THREADS), L_TOTAL_BWD, st, pts, reinterpret_cast<const char*>(packed), gamma, beta, grad_fwd,
-                       rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, d_gamma, d_beta, tiles, op_max, cn, n, off);
+                       rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, g_feat, d_small, d_gamma, d_beta, tiles, op_max, cn, n, off);
     int rc = oi::check_launch("oi_sdf_mlp_bwd(sweep)");
     if (rc != OI_OK) return rc;
     const long long wt_per_elem = (long long)grid.x * BW_NW, n_wt = (long long)B * wt_per_elem;
@@ -1550,8 +1572,9 @@ size_t oi_mlp_bwd_scratch_bytes_capped(int B, long long n_per_elem, size_t cap_b
 
 int oi_mlp_bwd_small_floats(void) { return DS_TOTAL; }
 
-int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, const float* beta, const float* grad_fwd,
-                   const float* rgb_fwd, const float* feat_fwd, const float* g_sdf, const float* g_grad, const float* g_rgb, float* d_small,
+int oi_sdf_mlp_bwd_feat(const float* pts, const void* packed, const float* gamma, const float* beta, const float* grad_fwd,
+                        const float* rgb_fwd, const float* feat_fwd, const float* g_sdf, const float* g_grad, const float* g_rgb,
+                        const float* g_feat, float* d_small,
                    float* d_wmat, float* d_gamma, float* d_beta, void* scratch, size_t scratch_bytes, int B,
                    long long n_per_elem, int prec, int fast_trig, oi_stream_t stream) {
   OI_REQUIRE(pts && packed && gamma && beta && d_small && d_wmat && d_gamma && d_beta && scratch,
@@ -1565,9 +1588,9 @@ int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, con
   hipStream_t st = oi::as_stream(stream);
 #define OI_BWD_CASE(P)                                                                                              \
   case P:                                                                                                           \
-    return fast_trig ? launch_bwd<P, true>(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, \
+    return fast_trig ? launch_bwd<P, true>(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, g_feat, d_small, \
                                            d_wmat, d_gamma, d_beta, scratch, scratch_bytes, B, n_per_elem, st)      \
-                     : launch_bwd<P, false>(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, d_small, \
+                     : launch_bwd<P, false>(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, g_feat, d_small, \
                                             d_wmat, d_gamma, d_beta, scratch, scratch_bytes, B, n_per_elem, st);
   switch (prec) {
     OI_BWD_CASE(OI_PREC_F32)
@@ -1577,6 +1600,14 @@ int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, con
       return oi::fail(OI_ERR_INVALID_ARG, "oi_sdf_mlp_bwd: bad precision %d", prec);
   }
 #undef OI_BWD_CASE
+}
+
+int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, const float* beta, const float* grad_fwd,
+                   const float* rgb_fwd, const float* feat_fwd, const float* g_sdf, const float* g_grad, const float* g_rgb, float* d_small,
+                   float* d_wmat, float* d_gamma, float* d_beta, void* scratch, size_t scratch_bytes, int B,
+                   long long n_per_elem, int prec, int fast_trig, oi_stream_t stream) {
+  return oi_sdf_mlp_bwd_feat(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, nullptr, d_small, d_wmat, d_gamma,
+                             d_beta, scratch, scratch_bytes, B, n_per_elem, prec, fast_trig, stream);
 }
 
 }  // extern "C"

@@ -30,18 +30,20 @@ class SdfMlpFunction(torch.autograd.Function):
         # the image of the weights the forward used (parameters may be stepped before backward is called)
         ctx.packed = packed if pack.prec_bwd == pack.prec else pack.packed(for_backward=True)
         ctx.save_for_backward(pts, gamma, beta, grad, rgb, feat)
-        if feat is not None:
+        if feat is not None and not want_feat:
             ctx.mark_non_differentiable(feat)
+        # a feature output the caller asked for is differentiable: its gradient (ColorNetwork.forward on the features read out,
+        # the reference's renderer.py:241-261) joins abar_8 in the sweep (oi_sdf_mlp_bwd_feat)
         return sdf, grad, rgb, (feat if want_feat else None)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_sdf, g_grad, g_rgb, _g_feat):
+    def backward(ctx, g_sdf, g_grad, g_rgb, g_feat):
         pts, gamma, beta, grad, rgb, feat = ctx.saved_tensors
         pack = ctx.pack
         d_small, d_wmat, d_gamma, d_beta = ops.sdf_mlp_bwd(pts, ctx.packed, gamma, beta, grad, rgb, feat, g_sdf, g_grad,
                                                            g_rgb if rgb is not None else None, ctx.B, pack.prec_bwd,
-                                                           pack.fast_trig)
+                                                           pack.fast_trig, g_feat=g_feat)
         s = d_small
         d_w0 = s[0:384].view(128, 3)
         d_b = s[384:1536].view(9, 128)

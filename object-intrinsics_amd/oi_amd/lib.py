@@ -69,6 +69,7 @@ _SIGS = {
     "oi_mlp_bwd_scratch_bytes_capped": (_sz, [_i, _ll, _sz]),
     "oi_mlp_bwd_small_floats": (_i, []),
     "oi_sdf_mlp_bwd": (_i, [_vp] * 15 + [_sz, _i, _ll, _i, _i, _vp]),
+    "oi_sdf_mlp_bwd_feat": (_i, [_vp] * 16 + [_sz, _i, _ll, _i, _i, _vp]),
     "oi_color_head_fwd": (_i, [_vp] * 4 + [_ll] + [_vp] * 5 + [_i, _ll, _vp]),
     "oi_color_head_bwd_workspace_bytes": (_sz, [_i, _ll]),
     "oi_color_head_bwd": (_i, [_vp] * 4 + [_ll] + [_vp] * 9 + [_ll] + [_vp] * 5 + [_sz, _i, _ll, _vp]),

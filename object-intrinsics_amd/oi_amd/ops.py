@@ -281,9 +281,10 @@ def bwd_scratch_cap_bytes():
 
 
 def sdf_mlp_bwd(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, B, prec, fast_trig=False,
-                scratch_cap=None):
+                scratch_cap=None, g_feat=None):
     """-> d_small (flat), d_wmat (8,128,128), d_gamma (B,9,128), d_beta (B,9,128).  Working memory is bounded by
-    `scratch_cap` bytes (default bwd_scratch_cap_bytes()); the library processes the points in chunks that fit."""
+    `scratch_cap` bytes (default bwd_scratch_cap_bytes()); the library processes the points in chunks that fit.
+    `g_feat` (n,128): upstream gradient of the feature output (oi_sdf_mlp_bwd_feat; None = the fused-path kernel)."""
     L = _l.load()
     pts = _c(pts)
     n = pts.shape[0] // B
@@ -293,9 +294,14 @@ def sdf_mlp_bwd(pts, packed, gamma, beta, grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_
     nbytes = L.oi_mlp_bwd_scratch_bytes_capped(B, n, bwd_scratch_cap_bytes() if scratch_cap is None else int(scratch_cap))
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     args = [_c(t) for t in (grad_fwd, rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb)]
-    _l.check(L.oi_sdf_mlp_bwd(_p(pts), _p(packed), _p(_c(gamma)), _p(_c(beta)), *[_p(a) for a in args], _p(d_small),
-                              _p(d_wmat), _p(d_gamma), _p(d_beta), _p(scratch), nbytes, B, n, prec, int(bool(fast_trig)),
-                              _stream()), "oi_sdf_mlp_bwd")
+    if g_feat is None:
+        _l.check(L.oi_sdf_mlp_bwd(_p(pts), _p(packed), _p(_c(gamma)), _p(_c(beta)), *[_p(a) for a in args], _p(d_small),
+                                  _p(d_wmat), _p(d_gamma), _p(d_beta), _p(scratch), nbytes, B, n, prec, int(bool(fast_trig)),
+                                  _stream()), "oi_sdf_mlp_bwd")
+    else:
+        _l.check(L.oi_sdf_mlp_bwd_feat(_p(pts), _p(packed), _p(_c(gamma)), _p(_c(beta)), *[_p(a) for a in args], _p(_c(g_feat)),
+                                       _p(d_small), _p(d_wmat), _p(d_gamma), _p(d_beta), _p(scratch), nbytes, B, n, prec,
+                                       int(bool(fast_trig)), _stream()), "oi_sdf_mlp_bwd_feat")
     return d_small, d_wmat, d_gamma, d_beta
 
 

@@ -381,6 +381,43 @@ def test_color_network_standalone_backward_vs_oracle(col_sd, npe, B):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n,B", [(150, 2), (700, 1)])
+def test_reference_style_field_chain_backward_vs_oracle(sdf_sd, col_sd, n, B):
+    """The call pattern of the reference's renderer.py:241-261 on the drop-in modules, un-fused:
+        out = sdf_network(pts, z, w); gradients = sdf_network.gradient(pts, z, w); rgb = color_network(pts, gradients, dirs, out[:, 1:], z, w)
+    The albedo head's gradient with respect to the FEATURES re-enters the SDF network's backward (oi_sdf_mlp_bwd_feat), its
+    gradient with respect to the normals the double backward of `gradient`.  Every parameter and w against fp64 autograd of
+    the same loss through the oracle (the loss of test_mlp_backward_vs_oracle: the fused path must agree with this one)."""
+    from oi_amd.fields import ShapeNetwork, ColorNetwork
+    g = torch.Generator().manual_seed(n)
+    pts = torch.rand(B * n, 3, generator=g) * 2.0 - 1.0
+    w = O.style_mlp(sdf_sd, torch.randn(B, 64, generator=g))
+    cs, cg, cr = torch.randn(B * n, generator=g), 0.1 * torch.randn(B * n, 3, generator=g), torch.randn(B * n, 3, generator=g)
+    loss_o, g_o = _oracle_mlp_grads(sdf_sd, col_sd, pts, w, cs, cg, cr)
+    sdf_net = ShapeNetwork(SDF_NPZ, **NET_KW).cuda()
+    col_net = ColorNetwork(**NET_KW)
+    col_net.load_state_dict(col_sd)
+    col_net = col_net.cuda()
+    wh = w.cuda().requires_grad_(True)
+    x = pts.cuda()
+    out = sdf_net(x, None, wh)
+    assert out.shape == (B * n, 129)
+    grads = sdf_net.gradient(x, None, wh)
+    rgb = col_net(x, grads, None, out[:, 1:], None, wh)
+    loss = (out[:, 0] * cs.cuda()).sum() + (grads * cg.cuda()).sum() + (rgb * cr.cuda()).sum()
+    assert abs(float(loss) - loss_o) < 1e-3 * max(1.0, abs(loss_o))
+    named = [("sdf." + k, v) for k, v in sdf_net.named_parameters() if not k.startswith("style.")] + \
+            [("col." + k, v) for k, v in col_net.named_parameters()] + [("w", wh)]
+    gr = torch.autograd.grad(loss, [v for _, v in named])
+    bad = {}
+    for (name, _), a in zip(named, gr):
+        e = rel_err(a, g_o[name])
+        record_margin("reference_style_field_chain_backward_vs_fp64_oracle", name, e)
+        if e > 2e-5:
+            bad[name] = e
+    assert not bad, bad
+
+
 # 3x the error measured in the native-fp32 mode against the reference's own (fp32) gradients: 2.3e-5 (F6), 3.5e-5 (F9)
 # worst over 69 tensors (tools/grad_margin.py, DESIGN.md section 5); round 2 accepted 3e-3
 F9_D_TOL = 3e-6  # discriminator weight gradients of the D / mask-D steps: measured 9.2e-7; round 2 accepted 2e-3
