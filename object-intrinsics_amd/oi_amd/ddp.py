@@ -1,6 +1,6 @@
 """Data parallelism for the path: one process per GPU, weights replicated, ONE
-all-reduce(sum)/world per network per backward on a flat fp32 gradient buffer, issued by RCCL over
-xGMI (torch.distributed backend "nccl" is RCCL on ROCm).
+all-reduce(mean) per network per backward on a flat fp32 gradient buffer, issued by RCCL over xGMI (torch.distributed
+backend "nccl" is RCCL on ROCm; ReduceOp.AVG: the division happens inside the collective, no scale launch behind it).
 
 Replaces torch.nn.parallel.DistributedDataParallel as used by the reference (scripts/train.py:50-56,
 157-158; tu/ddp.py) with the minimum the workload needs:
@@ -37,6 +37,7 @@ class FlatGradDDP(nn.Module):
         self._dist = dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self._dist else 1
         self.exchange_enabled = True
+        self._avg = self._dist and dist.get_backend(process_group) == "nccl"   # RCCL averages inside the reduction
         params = [p for p in module.parameters()]
         self._params = params
         n = sum(p.numel() for p in params)
@@ -89,18 +90,24 @@ class FlatGradDDP(nn.Module):
         if not self._dist or not self.exchange_enabled:
             return
         if self._stream is None:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-            if self.world > 1:
-                self.flat_grad.mul_(1.0 / self.world)
+            self._all_reduce_mean()
             return
         cur = torch.cuda.current_stream(self.flat_grad.device)
         self._stream.wait_stream(cur)                       # the backward's kernels first
         with torch.cuda.stream(self._stream):
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-            if self.world > 1:
-                self.flat_grad.mul_(1.0 / self.world)
+            self._all_reduce_mean()
             self._event = torch.cuda.Event()
             self._event.record(self._stream)
+
+    def _all_reduce_mean(self):
+        """Mean over the ranks of the flat gradient buffer: ONE collective.  RCCL divides inside the reduction
+        (ReduceOp.AVG); gloo (the CPU tests, the one-GPU rehearsals) has no AVG and takes SUM + one scale launch."""
+        if self._avg:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.AVG, group=self.pg)
+            return
+        dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+        if self.world > 1:
+            self.flat_grad.mul_(1.0 / self.world)
 
     def sync(self):
         """Issue the collective now unless this round's end-of-backward callback already did (a round starts at

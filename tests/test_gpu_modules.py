@@ -243,6 +243,18 @@ def test_generator_golden_f5(precision):
         assert abs(float(blob["stats"][k]) - float(g["stat_" + k])) < 1e-4, k
     for k in ("light/ambient", "light/diffuse", "light/specular", "material/shininess"):
         assert abs(float(blob["stats"][k]) - float(g["stat_" + k.replace("/", "_")])) < 1e-5, k
+    # STATED DEVIATION, pinned: the reference returns these four (and nothing else of `stats`) as Python floats through
+    # .item() -- four host syncs per forward (generator.py:219-222); here every stat is a detached 0-dim DEVICE tensor, like
+    # the reference's own loss entries of the same dict (gan_pose_trainer.py:126-139 mixes both), and float(x) at logging
+    # time is the caller's sync.  Same values, same keys; with a gradient recorded they still carry no graph.
+    gen.train()
+    blob_t = gen(bs=2, it=None, data={"z": g["z"].cuda(), "b2w": g["b2w"].cuda()})["box"]
+    for st in (blob["stats"], blob_t["stats"]):
+        for k in ("light/ambient", "light/diffuse", "light/specular", "material/shininess", "s_val", "cdf", "weight_max", "weight_sum"):
+            v = st[k]
+            assert isinstance(v, torch.Tensor) and v.is_cuda and v.dim() == 0 and not v.requires_grad, (k, type(v))
+            assert isinstance(float(v), float) and f"{float(v):.4f}"
+    gen.eval()
 
 
 @pytest.mark.parametrize("bs,train", [(1, True), (2, True), (2, False)])

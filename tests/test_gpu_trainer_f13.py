@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, sub_sd
+from conftest import load_golden, sub_sd, F13_VARIANCE_GRAD_SENSITIVITY
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -118,12 +118,12 @@ def test_trainer_two_iterations_match_the_reference_trainer_class_f13(graph_d_st
             norms = [torch.linalg.norm(p.grad) for p in child.parameters() if p.grad is not None]
             if key in g and float(g[key]) >= 0 and norms:
                 got, ref = float(torch.stack(norms).mean()), float(g[key])
-                # deviation_network = ONE scalar (d loss / d variance: a sum over every sample of every ray of terms of both
-                # signs, scaled by inv_s ~ 20).  It moves by 0.5 % when near / far change in their LAST BIT: measured in round 4
-                # with the ray set-up arithmetic compiled with and without floating-point contraction (0.08583 vs 0.08628 in
-                # iteration 1, the reference's value 0.08583; importance samples switch bins) -- a property of the quantity,
-                # so its bar is 1e-2; every other gradient norm stays at 2e-3.
-                tol = 1e-2 if name == "deviation_network" else 2e-3
+                # deviation_network = ONE scalar (d loss / d variance).  In iteration 1 it is BIMODAL under last-bit changes of
+                # near / far: the oracle, which reproduces the reference's 0.0858335 to 3e-7, reports 0.08627 (+0.51 %) for 2 of 12
+                # seeded +-1 ulp perturbations (one importance sample of one render switches bins; measured by
+                # tests/test_oracle_golden.py::test_f13_two_iterations_on_the_oracle_and_last_bit_sensitivity) -- the HIP path sits
+                # on that second mode (0.08628).  Bar = 3x the measured jump; every other gradient norm stays at 2e-3.
+                tol = 3 * F13_VARIANCE_GRAD_SENSITIVITY if name == "deviation_network" else 2e-3
                 assert abs(got - ref) < tol * max(ref, 1e-3), (key, got, ref)
                 worst[key] = abs(got - ref) / max(ref, 1e-3)
         for tag, net in (("g", gen), ("d", D), ("m", M)):

@@ -1,11 +1,14 @@
 """Pins the oracle (oracle/oi_oracle.py) against golden vectors produced by the reference itself
 (oracle/gen_golden.py, fixtures F1-F8 of SURVEY.md section 8c).  CPU only."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 import oi_oracle as O
-from conftest import load_golden, maxdiff, sub_sd
+from conftest import ROOT, load_golden, maxdiff, sub_sd, F13_VARIANCE_GRAD_SENSITIVITY
 
 TOL = 2e-5
 
@@ -279,6 +282,39 @@ def test_k4_end_to_end_flip_fraction_fp32_vs_fp64(sdf_sd, col_sd):
     # measured 11.7 %: fp32 round-off alone moves the samples of more rays than the 3 % the GPU test tolerates between
     # two fp32-class implementations -- the allowance is not hiding an implementation difference
     assert 0.03 <= float(flipped) <= 0.25
+
+
+def test_f13_two_iterations_on_the_oracle_and_last_bit_sensitivity():
+    """(1) The oracle, driven through two whole training iterations (G / D / mask-D steps with torch.optim), reproduces every
+    scalar the reference's own Trainer.train_step returned (F13) -- losses, R1, pose term, per-module gradient norms, after the
+    first AND the second iteration -- to 2e-6.  (2) MEASURED SENSITIVITY behind the bar of tests/test_gpu_trainer_f13.py:
+    near / far moved by +-1 ulp per ray (12 seeded draws).  Iteration 0 does not care (4e-5); iteration 1's d loss / d variance
+    is BIMODAL -- 0.08583 (the reference's value) or 0.08627 (+0.51 %), depending on whether one importance sample of one
+    render switched bins -- which is the 0.08628 the HIP path reports.  The GPU bar for that scalar is 3x this measurement."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import f13_oracle
+    g = load_golden("f13_trainer")
+    st = f13_oracle.run(g, check_calls=True)
+    checked = 0
+    for k, v in st.items():
+        if k.endswith("discriminator/loss"):
+            continue   # (the reference reports real + fake there; the restatement's `loss` is the optimised sum)
+        ref = float(g[k])
+        assert abs(v - ref) < 2e-6 * max(1e-3, abs(ref)) + 1e-9, (k, v, ref)
+        checked += 1
+    assert checked >= 28
+    base0, base1 = st["it0.grad_stats/deviation_network"], st["it1.grad_stats/deviation_network"]
+    dev0, dev1 = [], []
+    for seed in range(12):
+        s2 = f13_oracle.run(g, perturb_seed=seed)
+        dev0.append(abs(s2["it0.grad_stats/deviation_network"] - base0) / base0)
+        dev1.append(abs(s2["it1.grad_stats/deviation_network"] - base1) / base1)
+        for name in ("sdf_network", "color_network", "light"):   # every OTHER gradient norm stays inside its 2e-3 bar
+            k = f"it1.grad_stats/{name}"
+            assert abs(s2[k] - st[k]) < 7e-4 * st[k], (seed, k, s2[k], st[k])
+    assert max(dev0) < 2e-4, dev0
+    assert 3e-3 < max(dev1) < F13_VARIANCE_GRAD_SENSITIVITY * 1.2, dev1     # the jump exists, and is what the GPU bar assumes
+    assert sum(d > 3e-3 for d in dev1) >= 1 and sum(d < 3e-4 for d in dev1) >= 6, dev1   # two modes
 
 
 def test_f12_reference_checkpoint_loads_into_dropin_modules():
