@@ -497,8 +497,14 @@ def main():
             train = {"error": f"{type(ex).__name__}: {ex}"}
         dog.cancel()
 
+    rank_devices = None
+    if distributed:   # (rank, LOCAL_RANK, device it would take un-overridden, device it runs on): one small object gather
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, [rank, local_rank, local_rank, dev_index])
     if rank == 0:
         line = build_line(args, value, dt, world, timer, float(dd) if d_img_s else None, train, distributed, bf16_mode, spread)
+        if rank_devices is not None:
+            line["rank_devices"] = {"columns": ["rank", "local_rank", "cuda_index_by_local_rank", "cuda_index_used"], "rows": rank_devices}
         if world == 1 and not args.no_extras and not args.no_disc:
             try:
                 line["extras"] = extras(args, gen, device)

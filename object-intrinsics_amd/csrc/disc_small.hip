@@ -539,6 +539,7 @@ int oi_disc_fwd_small(const float* x, const float* theta_host, const float* thet
                      nullptr, 0, nullptr, nullptr, nullptr);
   rc = oi::check_launch("oi_disc_fwd_small(conv3)");
   if (rc != OI_OK) return rc;
+  static_assert(512 / 2 <= oi::LA_GROUP * (oi::LA_WORDS - 1), "conv4 + head: the arrival counters cover the grid");
   hipLaunchKernelGGL((d_conv_small_kernel<256, 8, 4, 2, true>), dim3(512 / 2, 1), dim3(256), 0, st, a3, w4, a1, B, 512, slope, whead, bhead,
                      out_dim, partials, ticket, logits);
   return oi::check_launch("oi_disc_fwd_small(conv4 + head)");

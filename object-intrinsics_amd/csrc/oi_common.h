@@ -153,6 +153,11 @@ constexpr int LA_WORDS = 1 + 4096;   // callers allocate this many words (up to 
 __device__ __forceinline__ bool last_arriver(unsigned* ticket, unsigned block, unsigned nblocks) {
   const unsigned ngroups = (nblocks + LA_GROUP - 1) / LA_GROUP, g = block / LA_GROUP;
   const unsigned gsize = g + 1 == ngroups ? nblocks - g * LA_GROUP : LA_GROUP;
+  // Relaxed agent-scope atomics on purpose.  The hand-off is the guide's "write-through payload + drained flag" form
+  // (MI355X_MICROARCH.md, valid forms: `sc1` payload stores -> asm s_waitcnt vmcnt(0) -> agent-scope atomic; the reader uses
+  // agent-scope loads): visibility comes from the write-through stores being ACKNOWLEDGED before the arrival, not from a fence.
+  // acq_rel orderings here lower to buffer_wbl2 + buffer_inv per arrival (1.7-3.5 us each on this part, price list row
+  // "fence") -- more than the 4.5 us launch the last-arriver form replaces.  Both launchers check the grid against the ticket.
   if (__hip_atomic_fetch_add(ticket + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gsize - 1) return false;
   __hip_atomic_store(ticket + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ngroups - 1) return false;

@@ -779,7 +779,18 @@ int oi_upsample_mid(const float* rays_o, const float* rays_d, const float* z, co
   OI_REQUIRE(Sc <= MAX_SC && n_new <= MAX_SC, "oi_upsample_mid: at most %d samples per ray", MAX_SC);
   const size_t sh = (size_t)RAYS_PER_BLOCK * (3 * Sc + n_new + Sc + n_new) * sizeof(float);  // + the merged list
   auto k = upsample_kernel;
-  if (sh > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  if (sh > 65536) {
+    // more than the default dynamic-LDS limit: opt in, and if this device cannot give the merged list its own rows (the
+    // attribute call fails, or the footprint exceeds the CU's 160 KiB), take the two launches this one replaces
+    // (bit-identical by construction: tests/test_gpu_kernels.py)
+    if (sh > 160 * 1024 ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) {
+      (void)hipGetLastError();
+      const int rc = oi_upsample(rays_o, rays_d, z, sdf, N, Sc, n_new, inv_s, z_new, pts_new, z_merged, stream);
+      if (rc != OI_OK) return rc;
+      return oi_midpoints(rays_o, rays_d, z_merged, N, Sc + n_new, last_dist, dists, mid_z, pts_mid, stream);
+    }
+  }
   hipLaunchKernelGGL(k, dim3(oi::cdiv(N, RAYS_PER_BLOCK)), dim3(256), sh, oi::as_stream(stream), rays_o, rays_d, z, sdf, N, Sc,
                      n_new, inv_s, z_new, pts_new, z_merged, last_dist, dists, mid_z, pts_mid);
   return oi::check_launch("oi_upsample_mid");
@@ -804,7 +815,10 @@ int oi_composite_fwd(const oi_composite_params* p, oi_stream_t stream) {
   OI_REQUIRE(p->N > 0 && p->T > 0 && p->B > 0 && p->N % p->B == 0, "oi_composite_fwd: N=%lld T=%d B=%d", p->N, p->T,
              p->B);
   OI_REQUIRE(p->stats16 == nullptr || (p->stats_ticket != nullptr && p->block_partials != nullptr),
-             "oi_composite_fwd: stats16 needs stats_ticket (one zero-initialised word) and block_partials");
+             "oi_composite_fwd: stats16 needs stats_ticket (OI_TICKET_WORDS zero-initialised words) and block_partials");
+  // the two-level arrival counters cover LA_GROUP * (OI_TICKET_WORDS - 1) workgroups
+  OI_REQUIRE(p->stats16 == nullptr || oi::cdiv(p->N, RAYS_PER_BLOCK) <= (long long)oi::LA_GROUP * (OI_TICKET_WORDS - 1),
+             "oi_composite_fwd: stats16 supports at most %lld rays per launch", (long long)oi::LA_GROUP * (OI_TICKET_WORDS - 1) * RAYS_PER_BLOCK);
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(oi::cdiv(p->N, RAYS_PER_BLOCK)), dim3(256), 0, oi::as_stream(stream),
                      *p);
   return oi::check_launch("oi_composite_fwd");

@@ -64,10 +64,26 @@ class DCDiscriminator(nn.Module):
         return x
 
     def _small_ok(self, x):
-        """The four- / five-launch forward of csrc/disc_small.hip: no gradient, batch <= 4, the 64 x 64 / n_feat 512 network."""
-        return (SMALL_PATH and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.shape[0] <= 4 and x.shape[1] <= 4
+        """The four- / five-launch forward of csrc/disc_small.hip: no gradient, batch <= 4, the 64 x 64 / n_feat 512 network, fp32
+        contiguous weights with the input's channel count (the kernels index them by shape), Callers that would
+        create a library plan also ask `_plan_ok()`: a plan's arrival counters are zeroed when the plan is created, and a fill
+        recorded into someone else's stream capture never runs for the eager calls that follow (advisor, round 4) -- under capture
+        the general chain is taken instead; the plain entry with a device-resident matrix (`theta_dev`, what captured graphs use)
+        refuses a FIRST call inside a capture (ops.disc_fwd_small)."""
+        if not (SMALL_PATH and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.shape[0] <= 4 and x.shape[1] <= 4
                 and tuple(x.shape[2:]) == (64, 64) and len(self.blocks) == 4 and self.blocks[0].weight.shape[0] == 64
-                and self.blocks[3].weight.shape[0] == 512 and self.out_dim <= 8)
+                and self.blocks[3].weight.shape[0] == 512 and self.out_dim <= 8):
+            return False
+        ws = [l.weight for l in self.blocks] + [self.conv_out.weight] + ([] if self.conv_out.bias is None else [self.conv_out.bias])
+        if not (x.shape[1] == self.in_dim == self.blocks[0].weight.shape[1]
+                and all(w.dtype == torch.float32 and w.is_contiguous() for w in ws)):
+            return False
+        return True
+
+    @staticmethod
+    def _plan_ok():
+        """Library plans (ops.DiscGraph) are created lazily: never inside somebody's stream capture (see _small_ok)."""
+        return not torch.cuda.is_current_stream_capturing()
 
     def _forward_small(self, x, f12=None, theta_np=None, theta_dev=None, margins=None):
         """theta_dev (captured graphs): the plain entry.  Otherwise a plan held by the library (ops.DiscGraph, launch by launch):
@@ -93,7 +109,7 @@ class DCDiscriminator(nn.Module):
     def forward(self, x, **kwargs):
         batch_size = x.shape[0]
         assert x.shape[1] == self.in_dim, x.shape
-        if self._small_ok(x):
+        if self._small_ok(x) and self._plan_ok():
             return self._forward_small(x)
         if not torch.is_grad_enabled():
             return self._forward_nograd(x.float()).reshape(batch_size, self.out_dim)
@@ -135,6 +151,8 @@ class ADADiscriminator(DCDiscriminator):
             H, W = x.shape[2:]
             if aug_theta is not None:
                 return self._forward_small(x, f12=aug.Hz_geom, theta_dev=aug_theta, margins=aug.static_margins(H, W))
+            if not self._plan_ok():
+                return super().forward(self.aug(x), **kwargs)
             G_inv = aug.sample_G_inv(x, None)
             if G_inv is None:
                 return self._forward_small(x)

@@ -249,10 +249,16 @@ class FieldPack:
 
     def hold(self, on):
         """Between hold(True) and hold(False) the caller guarantees that no parameter changes (one Generator.forward): the
-        (data_ptr, _version) walk over ~65 parameters -- 20 us of host time, three times per render -- runs once."""
+        (data_ptr, _version) walk over ~65 parameters -- 20 us of host time, three times per render -- runs once.  A depth
+        counter, not a flag: a nested forward that shares the pack (a render inside a render's callback) must not release the
+        outer hold early, and the outermost release is what re-arms the version walk."""
+        depth = getattr(self, "_held", 0)
         if on:
-            self._refresh_key()
-        self._held = bool(on)
+            if depth == 0:
+                self._refresh_key()
+            self._held = depth + 1
+        else:
+            self._held = max(0, depth - 1)
 
     def _refresh_key(self):
         sd, csd = self._sds()

@@ -780,6 +780,11 @@ def disc_fwd_small(x, weights, whead, bhead, f12=None, theta_np=None, theta_dev=
     key = (x.device, _stream().value or 0)
     ticket = _DISC_TICKETS.get(key)
     if ticket is None:
+        if torch.cuda.is_current_stream_capturing():
+            # the zero fill would become a node of the caller's graph (and the memory part of its private pool): eager calls on
+            # this stream would then reuse counters that were never cleared.  Warm the entry point up before capturing.
+            raise _l.OiHipError("oi_disc_fwd_small: first call on this stream is inside a stream capture; call it once eagerly "
+                                "(warm-up) before capturing")
         ticket = _DISC_TICKETS[key] = torch.zeros(4097, dtype=torch.int32, device=x.device)   # OI_TICKET_WORDS
     out_dim = whead.shape[0]
     logits = _new(x, B, out_dim)
@@ -808,6 +813,9 @@ class DiscGraph:
     def __init__(self, shape, device, weights, whead, bhead, f12=None, margins=None, slope=0.2, launch=None):
         L = _l.load()
         B, C, H, W = shape
+        if torch.cuda.is_current_stream_capturing():
+            raise _l.OiHipError("ops.DiscGraph: created inside a stream capture (its arrival counters are zeroed at creation: the "
+                                "fill must run, not be recorded); create the plan before capturing")
         self.shape, self.aug = (B, C, H, W), margins is not None
         launch = launch or os.environ.get("OI_DISC_LAUNCH", "eager")
         assert launch in ("eager", "graph"), launch
