@@ -248,7 +248,7 @@ def test_generator_golden_f5(precision):
     # the reference's own loss entries of the same dict (gan_pose_trainer.py:126-139 mixes both), and float(x) at logging
     # time is the caller's sync.  Same values, same keys; with a gradient recorded they still carry no graph.
     gen.train()
-    blob_t = gen(bs=2, it=None, data={"z": g["z"].cuda(), "b2w": g["b2w"].cuda()})["box"]
+    blob_t = gen(bs=2, it=None, data={})["box"]   # (training mode samples its own poses, as the reference's does: generator.py:178)
     for st in (blob["stats"], blob_t["stats"]):
         for k in ("light/ambient", "light/diffuse", "light/specular", "material/shininess", "s_val", "cdf", "weight_max", "weight_sum"):
             v = st[k]
