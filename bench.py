@@ -600,9 +600,10 @@ def extras(args, gen, device):
                                                       "executed_mfma_frac_of_peak": 3 * bsz * d_flops / ms / 1e9 / 2500.0},
                                          "weight_read_hbm": {"achieved_GB_per_s": d_wbytes / ms / 1e6, "peak": 8000.0,
                                                              "frac": d_wbytes / ms / 1e6 / 8000.0}}}
-    out["discriminator"] = {"what": "ADADiscriminatorView forward (ADA xint + scale, 5 conv4x4 s2 + head), 64^2; convolutions: fp32 MFMA "
-                                    "per-wave gather below 512 output pixels per layer, LDS-tiled f16x3 (22-bit operands, fp32 "
-                                    "accumulate, fixed summation order) above; wall time per forward incl. host launches; bound: "
+    out["discriminator"] = {"what": "ADADiscriminatorView forward (ADA xint + scale, 5 conv4x4 s2 + head), 64^2; batch <= 4: csrc/disc_small.hip "
+                                    "(four launches, fp32 VALU, weight-stream bound); batch >= 16: csrc/disc_large.hip (NHWC fp16 limb planes, "
+                                    "packed weight images, f16x3 = 22-bit operands / fp32 accumulate on the matrix cores, fixed-order "
+                                    "split-K); wall time per forward incl. host launches; bound: "
                                     "weight read at B = 1; at B = 64 both yardsticks: the fp32-MFMA peak (what an fp32 convolution could reach) and the fp16-MFMA "
                                     "peak of the unit the tiled kernel actually runs on", **sweep}
     del disc

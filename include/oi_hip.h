@@ -624,6 +624,24 @@ int oi_multi_lerp(const oi_mt_chunk* table, int n_chunks, float beta, oi_stream_
  * hold one nn.Parameter per layer, fields.py:49-77, and torch.stack would be one launch per stacked array). */
 int oi_multi_copy(const oi_mt_chunk* table, int n_chunks, oi_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * a16 at batch >= 16 without gradient (round 5): DCDiscriminator.forward (src/models/discriminator.py:57-85) as GEMMs whose
+ * operands are prepared once -- activations as NHWC fp16 limb planes (hi + lo = 22 bits) written by the producing layer, weights
+ * as fp16 limb images in MFMA fragment order (packed per parameter version) -- three fp16 MFMAs per product, fp32 accumulation,
+ * split-K partial planes added in a fixed order (no atomics: bit-reproducible).  csrc/disc_large.hip.
+ *   chans [n_blocks + 1]: in_dim (<= 4), then the output channels of every 4x4 stride-2 block; covered when chans[1] % 8 == 0,
+ *   every later block has Cin % 64 == 0 and Cout % 128 == 0, and H / 2^n_blocks == 4 (the 64 x 64 / n_feat 512 network of
+ *   configs/train.yaml at 64 x 64: {3 | 1, 64, 128, 256, 512}).  oi_disc_large_packed_bytes / _workspace_bytes return 0 and the
+ *   other two OI_ERR_UNSUPPORTED for anything else (the caller keeps the general chain).
+ *   w_blocks: HOST array of n_blocks device pointers ([Cout][Cin][4][4] each, the reference's layout); w_head [out_dim][C][4][4].
+ *   x [B][chans[0]][H][H] (after the augmentation), w1 = w_blocks[0] (read as it is), bhead [out_dim] or NULL -> logits [B][out_dim]. */
+size_t oi_disc_large_packed_bytes(const int* chans, int n_blocks, int out_dim);
+int oi_disc_large_pack(const float* const* w_blocks, const float* w_head, const int* chans, int n_blocks, int out_dim, void* packed,
+                       oi_stream_t stream);
+size_t oi_disc_large_workspace_bytes(const int* chans, int n_blocks, int out_dim, int B, int H);
+int oi_disc_fwd_large(const float* x, const float* w1, const void* packed, const float* bhead, void* workspace, size_t workspace_bytes,
+                      float* logits, const int* chans, int n_blocks, int out_dim, int B, int H, float slope, oi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

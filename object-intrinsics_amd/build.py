@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "oi_amd")
 LIB = os.path.join(OUT_DIR, "liboi_hip.so")
 STAMP = os.path.join(OUT_DIR, ".liboi_hip.stamp")
-SOURCES = ["mlp.hip", "mlp_fwd3.hip", "mlp_fwd3b.hip", "color_head.hip", "render.hip", "disc.hip", "disc_small.hip", "mlp_bwd.hip", "render_bwd.hip", "disc_bwd.hip", "optim.hip", "loss.hip"]
+SOURCES = ["mlp.hip", "mlp_fwd3.hip", "mlp_fwd3b.hip", "color_head.hip", "render.hip", "disc.hip", "disc_small.hip", "disc_large.hip", "mlp_bwd.hip", "render_bwd.hip", "disc_bwd.hip", "optim.hip", "loss.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"] + os.environ.get("OI_FLAGS", "").split()
 # per-file extra flags.  mlp_fwd3.hip pins 256 parked values to the AGPR half of the register file; hipcc's default
 # (AGPR-form MFMA accumulators) would need 32 more AGPRs than exist, the VGPR form keeps the accumulators with the VALU.

@@ -14,6 +14,9 @@ from .config import build_from_config
 import weakref
 
 _SMALL_PLANS = weakref.WeakKeyDictionary()
+_LARGE_PACKS = weakref.WeakKeyDictionary()
+LARGE_PATH = True   # batch >= 16 no-grad forwards take csrc/disc_large.hip when the network is covered (False: the general chain)
+LARGE_MIN_BATCH = 16
 SMALL_PATH = True   # batch <= 4 no-grad forwards of the 64 x 64 network take csrc/disc_small.hip (False: the general chain)
 
 
@@ -44,6 +47,10 @@ class DCDiscriminator(nn.Module):
         split-K layer) and every block hands over its pre-activation sums -- the LeakyReLU is applied by the next
         layer while it loads them, so the split-K layers need no activation pass: 6 launches instead of 13."""
         from . import ops
+        if LARGE_PATH and x.shape[0] >= LARGE_MIN_BATCH and x.is_cuda:
+            out = self._forward_large(x)
+            if out is not None:
+                return out
         layers = [(l.weight, None, 2, 1, 0.2) for l in self.blocks] + [(self.conv_out.weight, self.conv_out.bias, 1, 0, 1.0)]
         shapes, shp = [], tuple(x.shape)
         for w, _, stride, pad, _ in layers:
@@ -62,6 +69,17 @@ class DCDiscriminator(nn.Module):
             x_slope = slope  # this block's activation, deferred to the next layer's loads
             off += n
         return x
+
+    def _forward_large(self, x):
+        """Batch >= 16: activations as NHWC fp16 limb planes, weights packed once per parameter version (ops.DiscLargePack), K split
+        with a fixed-order reduction -- csrc/disc_large.hip.  None when the network / shape is not covered."""
+        from . import ops
+        ws = [l.weight for l in self.blocks] + [self.conv_out.weight]
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        ent = _LARGE_PACKS.get(self)
+        if ent is None or ent[0] != key:
+            ent = _LARGE_PACKS[self] = (key, ops.DiscLargePack(ws[:-1], ws[-1]))
+        return ops.disc_fwd_large(x, ent[1], ws[0], self.conv_out.bias)
 
     def _small_ok(self, x):
         """The four- / five-launch forward of csrc/disc_small.hip: no gradient, batch <= 4, the 64 x 64 / n_feat 512 network, fp32

@@ -102,6 +102,10 @@ _SIGS = {
     "oi_ada_pad_up2": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "oi_disc_fwd_small_workspace_floats": (_sz, [_i] * 6),
     "oi_disc_fwd_small": (_i, [_vp] * 4 + [_i] * 4 + [_vp] * 9 + [_i] * 6 + [_f, _vp]),
+    "oi_disc_large_packed_bytes": (_sz, [_vp, _i, _i]),
+    "oi_disc_large_pack": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "oi_disc_large_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "oi_disc_fwd_large": (_i, [_vp] * 5 + [_sz, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "oi_disc_graph_create": (_i, [_vp, _i, _vp] + [_i] * 4 + [_vp] * 9 + [_i] * 6 + [_f]),
     "oi_disc_graph_launch": (_i, [_vp, _vp, _vp, _vp]),
     "oi_disc_graph_launch_eager": (_i, [_vp, _vp, _vp, _vp, _vp]),

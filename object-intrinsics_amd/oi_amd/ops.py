@@ -800,6 +800,53 @@ def disc_fwd_small(x, weights, whead, bhead, f12=None, theta_np=None, theta_dev=
     return logits
 
 
+class DiscLargePack:
+    """Packed weights of the batch >= 16 no-grad discriminator forward (oi_disc_large_*, csrc/disc_large.hip).  `ok` is False when
+    the network is not covered (the caller keeps the general chain)."""
+
+    def __init__(self, weights, whead):
+        L = _l.load()
+        self.chans = [int(weights[0].shape[1])] + [int(w.shape[0]) for w in weights]
+        self.nb, self.out_dim = len(weights), int(whead.shape[0])
+        self.c_chans = (ctypes.c_int * len(self.chans))(*self.chans)
+        n = int(L.oi_disc_large_packed_bytes(self.c_chans, self.nb, self.out_dim))
+        self.ok = n > 0 and all(w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda for w in list(weights) + [whead])
+        if not self.ok:
+            return
+        self.packed = torch.empty(n, dtype=torch.uint8, device=weights[0].device)
+        ptrs = (ctypes.c_void_p * self.nb)(*[w.data_ptr() for w in weights])
+        _l.check(L.oi_disc_large_pack(ptrs, _p(whead), self.c_chans, self.nb, self.out_dim, _p(self.packed), _stream()),
+                 "oi_disc_large_pack")
+        self._ws = {}
+
+    def workspace(self, B, H, device):
+        key = (B, H, _stream().value or 0)
+        ws = self._ws.get(key)
+        if ws is None:
+            n = int(_l.load().oi_disc_large_workspace_bytes(self.c_chans, self.nb, self.out_dim, B, H))
+            if n == 0:
+                return None
+            if len(self._ws) >= 4:
+                self._ws.clear()
+            ws = self._ws[key] = torch.empty(n, dtype=torch.uint8, device=device)
+        return ws
+
+
+def disc_fwd_large(x, pack, w1, bhead, slope=0.2):
+    """-> logits (B, out_dim), or None when the (shape, network) pair is not covered."""
+    x = _c(x)
+    B, C, H, W = x.shape
+    if not pack.ok or H != W or C != pack.chans[0]:
+        return None
+    ws = pack.workspace(B, H, x.device)
+    if ws is None:
+        return None
+    logits = _new(x, B, pack.out_dim)
+    _l.check(_l.load().oi_disc_fwd_large(_p(x), _p(w1), _p(pack.packed), _p(_c(bhead)), _p(ws), ws.numel(), _p(logits), pack.c_chans,
+                                         pack.nb, pack.out_dim, B, H, float(slope), _stream()), "oi_disc_fwd_large")
+    return logits
+
+
 class DiscGraph:
     """oi_disc_graph_*: the batch <= 4 discriminator forward as a plan owned by the library -- every argument but the image pointer
     and the sampling matrices is fixed at creation; a call passes those two and costs one short ctypes call.  `launch`:

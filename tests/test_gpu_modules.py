@@ -902,3 +902,59 @@ def test_small_batch_discriminator_forward_vs_oracle_and_general_path(monkeypatc
             by_value = D._forward_small(x0.cuda(), f12=D.aug.Hz_geom, theta_np=th_np, margins=m)
             from_mem = D._forward_small(x0.cuda(), f12=D.aug.Hz_geom, theta_dev=torch.from_numpy(th_np).cuda(), margins=m)
         assert torch.equal(by_value, from_mem), (i, sc, maxdiff(by_value, from_mem))
+
+
+@pytest.mark.parametrize("B,in_dim,out_dim,view", [(16, 3, 7, True), (64, 3, 7, True), (24, 1, 1, False)])
+def test_large_batch_discriminator_forward_vs_oracle(B, in_dim, out_dim, view):
+    """Batch >= 16 without gradient (csrc/disc_large.hip: NHWC fp16 limb planes, packed weight images, fixed-order split-K) for the
+    64 x 64 / n_feat 512 network: (a) the fp64 oracle on a subset of the images, with and without ADA at a pinned percentile;
+    (b) the general chain it replaces; (c) bit-reproducible; (d) follows a weight update (the pack is keyed by parameter
+    versions); (e) a network the kernels do not cover keeps the general chain."""
+    import oi_amd.discriminator as DM
+    from oi_amd.config import build_from_config
+    torch.manual_seed(B)
+    aug = {"__target__": "src.third_party.ada.augment.AugmentPipe", "kwargs": {"scale": 1, "xint": 1}}
+    common = dict(aug=aug, aug_p=1, in_dim=in_dim, out_dim=out_dim, n_feat=512, img_size=64, last_bias=False)
+    cfg = ({"__target__": "src.models.discriminator.ADADiscriminatorView", "kwargs": dict(out_dim_position=6, out_dim_latent=0, **common)}
+           if view else {"__target__": "src.models.discriminator.ADADiscriminator", "kwargs": common})
+    D = build_from_config(cfg).cuda().eval()
+    with torch.no_grad():   # variance-preserving weights: O(1) logits (the default initialisation gives 1e-3)
+        for p_ in D.parameters():
+            fan_in = p_[0].numel()
+            p_.copy_((torch.rand_like(p_) * 2 - 1) * (6.0 / (1.04 * fan_in)) ** 0.5)
+    x = torch.rand(B, in_dim, 64, 64, device="cuda")
+    dsd = {k: v.detach().double().cpu() for k, v in D.state_dict().items() if "aug." not in k}
+    sub = [0, B // 2, B - 1]
+    with torch.no_grad():
+        # ---- no augmentation: DCDiscriminator.forward
+        plain = DM.DCDiscriminator.forward(D, x)
+        ref = O.dc_discriminator(dsd, x[sub].double().cpu())
+        assert float(ref.abs().max()) > 0.05
+        assert maxdiff(plain[sub].cpu(), ref) < 2e-5, maxdiff(plain[sub].cpu(), ref)
+        DM.LARGE_PATH = False
+        try:
+            general = DM.DCDiscriminator.forward(D, x)
+        finally:
+            DM.LARGE_PATH = True
+        assert maxdiff(plain, general) < 2e-5 and not torch.equal(plain, general)   # (another summation order: really another path)
+        assert torch.equal(plain, DM.DCDiscriminator.forward(D, x))
+        # ---- with ADA at a pinned percentile
+        pct = 0.7
+        orig = D.aug.forward
+        D.aug.forward = lambda im: orig(im, debug_percentile=pct)
+        d = D(x)
+        p = torch.tensor(pct)
+        G = O.ada_G_inv(3, 64, 64, ((p * 2 - 1) * 0.125).expand(3, 2), torch.exp2(torch.erfinv(p * 2 - 1) * 0.2).expand(3)).double()
+        refa = O.dc_discriminator(dsd, O.ada_geometric(x[sub].double().cpu(), G)[0])
+        assert maxdiff(d[sub].cpu(), refa) < 2e-5, maxdiff(d[sub].cpu(), refa)
+        del D.aug.forward
+        # ---- a weight update is picked up
+        D.blocks[2].weight.mul_(0.5)
+        dsd2 = {k: v.detach().double().cpu() for k, v in D.state_dict().items() if "aug." not in k}
+        assert maxdiff(DM.DCDiscriminator.forward(D, x)[sub].cpu(), O.dc_discriminator(dsd2, x[sub].double().cpu())) < 2e-5
+        # ---- not covered (n_feat 64: 8 -> 16 -> 32 -> 64 channels): the general chain answers
+        D2 = build_from_config({"__target__": "src.models.discriminator.ADADiscriminator",
+                                "kwargs": dict(common, n_feat=64, in_dim=in_dim, out_dim=1)}).cuda().eval()
+        d2 = DM.DCDiscriminator.forward(D2, x)
+        dsd3 = {k: v.detach().double().cpu() for k, v in D2.state_dict().items() if "aug." not in k}
+        assert maxdiff(d2[sub].cpu(), O.dc_discriminator(dsd3, x[sub].double().cpu())) < 2e-5
