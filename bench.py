@@ -651,7 +651,7 @@ def csrc_digest():
     return mod._digest()
 
 
-TRAFFIC_FILE = "r4_traffic.json"
+TRAFFIC_FILE = "r5_traffic.json"
 
 
 def measured_traffic(args, precision=None):

@@ -197,10 +197,23 @@ __device__ unsigned long long oi_prof3b[1024][16];  // replicated by workgroup: 
 // wait until at most KEEP of this wave's vector-memory operations are outstanding (they retire in issue order: everything
 // older -- the image this layer reads -- has landed), then rendezvous: image resident for every wave, the slot of the
 // layer before free
+// OI_B3_BARE_BARRIER (round 5): __syncthreads() carries workgroup-scope fences, and for those hipcc drains EVERY outstanding
+// vector-memory operation in front of the s_barrier (`s_waitcnt vmcnt(0) lgkmcnt(0)` right behind the counted wait below: read off
+// the ISA) -- the two younger images included, i.e. the ring never had more than the image it was waiting for in flight.  A bare
+// s_barrier behind the counted wait keeps them in flight; LDS visibility of the awaited image follows from the wait itself plus
+// the barrier (MI355X_MICROARCH.md: "nothing orders a ds_read behind a pending LDS-DMA except the issuing wave's covering vmcnt
+// (plus a barrier, for other waves' reads)").
+#ifndef OI_B3_BARE_BARRIER
+#define OI_B3_BARE_BARRIER 1
+#endif
 template <int KEEP>
 __device__ __forceinline__ void ring_sync_b() {
+#if OI_B3_BARE_BARRIER
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
   __syncthreads();
+#endif
 }
 
 template <bool FAST>

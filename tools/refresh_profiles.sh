@@ -1,11 +1,11 @@
 #!/bin/bash
 # Runs ON the GPU box (gpurun): regenerates every file profiles/ holds for the default (f16x3) mode into gpurun_out/.
 #   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'
-# then copy gpurun_out/r4_* into profiles/.  Counter passes are separate runs (--pmc never combined with other traces).
+# then copy gpurun_out/r5_* into profiles/.  Counter passes are separate runs (--pmc never combined with other traces).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
-T=${OI_PROFILE_TAG:-r4}
+T=${OI_PROFILE_TAG:-r5}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bf16 --no-extras --min-seconds 0.2"
@@ -43,6 +43,26 @@ python $R/tools/prof_summary.py /tmp/p_bks $O/${T}_kernel_stats_bf16.txt > /dev/
 python $R/tools/dbg/timeline.py /tmp/p_bks $O/${T}_timeline_step_bf16.txt prep_render_kernel > /dev/null
 rm -rf /tmp/p_bsq; rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/p_bsq -- $BENCH --precision bf16 --steps 5 --warmup 2 --train-steps 0 > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/p_bsq $O/${T}_pmc_sq_bf16.txt > /dev/null
+# bf16 mode END TO END (BASELINE configs[1]): the training iteration with the generator in the bf16 operand mode -- kernel stats
+# and the PMC traffic of its backward (mlp_bwd_sweep_kernel<2, ...> + mlp_wgrad_kernel)
+TRAINB="python $R/bench.py --precision bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-bf16 --no-extras --min-seconds 0.01"
+rm -rf /tmp/p_tb; rocprofv3 --kernel-trace --output-format csv -d /tmp/p_tb -- $TRAINB --train-steps 20 > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/p_tb $O/${T}_kernel_stats_train_bf16.txt > /dev/null
+for c in "FETCH_SIZE:fetch" "WRITE_SIZE:write"; do
+  ctr=${c%%:*}; tag=${c##*:}
+  rm -rf /tmp/p_tb$tag; rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/p_tb$tag -- $TRAINB --train-steps 4 > /dev/null 2>&1
+  python $R/tools/prof_summary.py /tmp/p_tb$tag $O/${T}_pmc_${tag}_train_bf16.txt > /dev/null
+done
+python $R/tools/traffic_json.py $O/${T}_pmc_fetch_train_bf16.txt $O/${T}_pmc_write_train_bf16.txt "mlp_bwd_sweep_kernel<2" "bf16-train-sweep:1x64x64:64+64" $O/${T}_traffic.json
+python $R/tools/traffic_json.py $O/${T}_pmc_fetch_train_bf16.txt $O/${T}_pmc_write_train_bf16.txt "mlp_wgrad_kernel" "bf16-train-wgrad:1x64x64:64+64" $O/${T}_traffic.json
+python $R/tools/traffic_json.py $O/${T}_pmc_fetch_f16x3.txt $O/${T}_pmc_write_f16x3.txt "mlp_bwd_sweep_kernel<4" "f16x3-train-sweep:1x64x64:64+64" $O/${T}_traffic.json
+python $R/tools/traffic_json.py $O/${T}_pmc_fetch_f16x3.txt $O/${T}_pmc_write_f16x3.txt "mlp_wgrad_f16_kernel" "f16x3-train-wgrad:1x64x64:64+64" $O/${T}_traffic.json
+# the batch-64 discriminator forward (csrc/disc_large.hip): one step's timeline + kernel stats
+rm -rf /tmp/p_d64; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_d64 -- python $R/tools/dbg/prof_disc64.py > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/p_d64 $O/${T}_kernel_stats_disc_b64.txt > /dev/null
+python $R/tools/dbg/timeline.py /tmp/p_d64 $O/${T}_timeline_disc_b64.txt ada_pad_up2_kernel > /dev/null
+# the stand-alone albedo head (oi_color_head_fwd / _bwd) at the C2 point count
+python $R/tools/dbg/time_color_head.py > $O/${T}_color_head.txt 2>/dev/null
 # the same dominant kernel at the C4 per-GPU size (128^2 rays, 128 + 128 samples, 4 up-sampling steps: eight times the points)
 C4="--res 128 --samples 128 --importance 128 --up-steps 4"
 for c in "FETCH_SIZE:fetch" "WRITE_SIZE:write"; do
