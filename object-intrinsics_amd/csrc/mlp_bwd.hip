@@ -1196,10 +1196,26 @@ __device__ __forceinline__ float frag16(const float* sl, int f, int p0, f16x8& h
   return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));  // used for the bias gradient (sum over points)
 }
 
+// the same 8 points as ONE bf16 fragment (bf16 operand mode: a single MFMA per product, no scale -- bf16 has fp32's range)
+__device__ __forceinline__ float frag_bf16(const float* sl, int f, int p0, f16x8& out) {
+  float v[8];
+  bf16x8 b;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    v[q] = sl[slot_index4(f, p0 + q)];
+    b[q] = (__bf16)v[q];
+  }
+  out = __builtin_bit_cast(f16x8, b);
+  return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+}
+
 // the scratch operands are read exactly once by this kernel: non-temporal loads (streaming-read ceiling of the box
 // 5.8 TB/s ordinary, 6.5-7.0 non-temporal: tools/dbg/hbm_read.hip)
 #ifndef OI_WGRAD_NT
 #define OI_WGRAD_NT 1
+#endif
+#ifndef OI_WGRAD_BF16
+#define OI_WGRAD_BF16 1   // bf16 operand mode: the two-tiles-in-flight GEMM with bf16 operands (0: the generic fp32-MFMA GEMM)
 #endif
 #ifndef OI_WG_TARGET
 #define OI_WG_TARGET 2048  // workgroups of the weight-gradient GEMM (8 matrices x chunks)
@@ -1228,7 +1244,10 @@ typedef f16x8 (*SbPtr)[4][2][64];  // [hi|lo][column tile][k-step][lane]
 // compile-time split: with `m` tested at run time hipcc turned the per-element selects of the hot loop into branches.
 // MODE 0: a layer matrix m = 1..6;  1 (COL): the colour head;  2 (FIRST): m = 0, whose Y operands come from layer 0 -- not
 // parked, formed here from the point and dL/dgrad (l0tab)
-template <int MODE, bool FAST>
+// BF (round 5): the bf16 operand mode's GEMM -- operands rounded to bf16 as they are staged, one v_mfma_f32_32x32x16_bf16 per
+// product, no operand scales.  (Until round 5 that mode fell through to the generic fp32-MFMA GEMM: 3.2 ms per backward against
+// 1.45 ms for this body, the largest kernel of a bf16-mode training iteration.)
+template <int MODE, bool FAST, bool BF = false>
 __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, const float* l0tab, const int m, const char* __restrict__ scratch,
                                                const float* __restrict__ op_max, const char* __restrict__ packed,
                                                size_t plain_offset, const float* __restrict__ gamma,
@@ -1249,8 +1268,8 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
   // tile in flight): the pair whose products are larger gets the optimal operand scales
   // (max |X|, max |Y| -> [2^13, 2^14)), the other pair's Y scale is lowered so that both products carry the same factor.
   // Nothing can overflow, and the smaller pair is resolved to 2^-22 of the larger one's terms -- the sum they form.
-  float scx[2], scy[2], inv[2], inv_scx[2];
-  {
+  float scx[2] = {1.f, 1.f}, scy[2] = {1.f, 1.f}, inv[2] = {1.f, 1.f}, inv_scx[2] = {1.f, 1.f};
+  if constexpr (!BF) {
     // maximum over the replicas: lane r of every wave reads replica r (the table is 8 KiB and L2-resident)
     const float* rep = op_max + lane * OM_STRIDE;
     const float mx0 = oi::wave_max(rep[COL ? OM_UV : OM_V + m]);
@@ -1328,13 +1347,20 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       f16x8 bh, bl;
-      frag16(sy, fo, 16 * ks + 8 * h, bh, bl);
-      sb[0][wave][ks][lane] = bh;
-      sb[1][wave][ks][lane] = bl;
+      if constexpr (BF) {
+        frag_bf16(sy, fo, 16 * ks + 8 * h, bh);
+        sb[0][wave][ks][lane] = bh;
+      } else {
+        frag16(sy, fo, 16 * ks + 8 * h, bh, bl);
+        sb[0][wave][ks][lane] = bh;
+        sb[1][wave][ks][lane] = bl;
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const float xs = frag16(sx, fo, 16 * ks + 8 * h, ah[ks], al[ks]);
+      float xs;
+      if constexpr (BF) xs = frag_bf16(sx, fo, 16 * ks + 8 * h, ah[ks]);
+      else xs = frag16(sx, fo, 16 * ks + 8 * h, ah[ks], al[ks]);
       if (last_pair) sub += xs;  // the last pair's X is ubar_l / uvbar
     }
   };
@@ -1343,10 +1369,15 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const f16x8 bh = sb[0][t][ks][lane], bl = sb[1][t][ks][lane];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, acc[t], 0, 0, 0);
+        if constexpr (BF) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[ks]),
+                                                           __builtin_bit_cast(bf16x8, sb[0][t][ks][lane]), acc[t], 0, 0, 0);
+        } else {
+          const f16x8 bh = sb[0][t][ks][lane], bl = sb[1][t][ks][lane];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh, acc[t], 0, 0, 0);
+        }
       }
     }
   };
@@ -1453,7 +1484,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
                          d_small + DS_B + lrow * C, tid);
 }
 
-template <bool FAST>
+template <bool FAST, bool BF = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))  // VGPRs + AGPRs <= 256: two workgroups per CU
 mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__ op_max, const char* __restrict__ packed,
                      size_t plain_offset, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -1467,15 +1498,15 @@ mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__
   // a compile-time split per kind of matrix: with `m` tested at run time hipcc turned per-element selects into branches
   if (m == 7) {
     if (has_col)
-      wgrad_f16_body<1, FAST>(sx, sy, sb, l0tab, 7, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
+      wgrad_f16_body<1, FAST, BF>(sx, sy, sb, l0tab, 7, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
                               d_small, wt_per_elem, tiles_per_chunk);
   } else if (m == 0) {
     l0tab_fill(l0tab, reinterpret_cast<const float*>(packed), gamma, beta, blockIdx.z, threadIdx.x);
     __syncthreads();
-    wgrad_f16_body<2, FAST>(sx, sy, sb, l0tab, 0, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
+    wgrad_f16_body<2, FAST, BF>(sx, sy, sb, l0tab, 0, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
                             d_small, wt_per_elem, tiles_per_chunk);
   } else {
-    wgrad_f16_body<0, FAST>(sx, sy, sb, l0tab, m, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
+    wgrad_f16_body<0, FAST, BF>(sx, sy, sb, l0tab, m, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
                             d_small, wt_per_elem, tiles_per_chunk);
   }
 }
@@ -1522,6 +1553,9 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
     const char* pk = reinterpret_cast<const char*>(packed);
     if constexpr (PREC == OI_PREC_F16X3) {
       hipLaunchKernelGGL(mlp_wgrad_f16_kernel<FAST>, g2, block, 0, st, tiles, op_max, pk, plain_off(PREC), gamma, beta,
+                         d_wmat, d_gamma, d_beta, d_small, wt_per_elem, chunk, has_col);
+    } else if constexpr (PREC == OI_PREC_BF16 && OI_WGRAD_BF16) {
+      hipLaunchKernelGGL((mlp_wgrad_f16_kernel<FAST, true>), g2, block, 0, st, tiles, op_max, pk, plain_off(PREC), gamma, beta,
                          d_wmat, d_gamma, d_beta, d_small, wt_per_elem, chunk, has_col);
     } else {
       hipLaunchKernelGGL(mlp_wgrad_kernel<FAST>, g2, block, 0, st, tiles, pk, plain_off(PREC), gamma, beta, d_wmat, d_gamma,
