@@ -442,7 +442,8 @@ def main():
                 g_b.train()
                 bf16_mode["training"] = bench_training(ab, g_b, d_b, device, 1, torch.cuda.synchronize, False, sub_legs="render")
                 bf16_mode["training"]["what"] = ("Trainer.train_step with the generator in the bf16 operand mode: bf16 forward kernel, "
-                                                 "mlp_bwd_sweep_kernel<bf16> + mlp_wgrad_kernel backward; discriminators unchanged")
+                                                 "mlp_bwd_sweep_kernel<bf16> (16-bit scratch slots: bf16 values, unorm16 phases) + "
+                                                 "mlp_wgrad_f16_kernel<bf16 operands> backward; discriminators unchanged")
                 del g_b, d_b
         except Exception as ex:
             bf16_mode = {**(bf16_mode or {}), "error": f"{type(ex).__name__}: {ex}"}

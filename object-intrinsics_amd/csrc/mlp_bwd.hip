@@ -126,6 +126,9 @@ constexpr int L_TOTAL_BWD = L_FILM2 + 1536;
 #ifndef OI_BWD_PACK24
 #define OI_BWD_PACK24 0
 #endif
+#ifndef OI_WGRAD_BF16
+#define OI_WGRAD_BF16 1   // bf16 operand mode: the two-tiles-in-flight GEMM with bf16 operands (0: the generic fp32-MFMA GEMM)
+#endif
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ u32x3 pack24f(f32x4 v) {
   // (element copies first: __builtin_bit_cast applied to a vector-element lvalue read element 0 four times -- hipcc 7.2)
@@ -155,10 +158,41 @@ __device__ __forceinline__ f32x4 unpack24q(u32x3 d) {
   return f32x4{(float)q0 * S, (float)q1 * S, (float)q2 * S, (float)q3 * S};
 }
 
-template <bool PACK>
+// Round 5, the bf16 operand mode only (OI_BWD_PACK16, default on): 16-bit slots -- values as bf16 (v_cvt_pk_bf16_f32: fp32's
+// range, 8 bits, what the mode's MFMA operands carry anyway), phases REDUCED to [0, 1) and stored as unorm16
+// (v_cvt_pknorm_u16_f32: 1.5e-5 revolutions).  Half the bytes of a backward in the mode BASELINE's configs[1] names; four values
+// = two dwords, 2 instructions to pack, 4 to unpack.
+#ifndef OI_BWD_PACK16
+#define OI_BWD_PACK16 1
+#endif
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 pack16f(f32x4 v) {
+  const bf16x2 a = {(__bf16)v[0], (__bf16)v[1]}, b = {(__bf16)v[2], (__bf16)v[3]};
+  return u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+}
+__device__ __forceinline__ f32x4 unpack16f(u32x2 d) {
+  return f32x4{__builtin_bit_cast(float, d[0] << 16), __builtin_bit_cast(float, d[0] & 0xffff0000u),
+               __builtin_bit_cast(float, d[1] << 16), __builtin_bit_cast(float, d[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ u32x2 pack16q(f32x4 r) {  // any phase in revolutions: reduced here
+  const float r0 = __builtin_amdgcn_fractf(r[0]), r1 = __builtin_amdgcn_fractf(r[1]);
+  const float r2 = __builtin_amdgcn_fractf(r[2]), r3 = __builtin_amdgcn_fractf(r[3]);
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  const u16x2 a = __builtin_amdgcn_cvt_pknorm_u16(r0, r1), b = __builtin_amdgcn_cvt_pknorm_u16(r2, r3);
+  return u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+}
+__device__ __forceinline__ f32x4 unpack16q(u32x2 d) {
+  constexpr float S = 1.0f / 65535.f;
+  return f32x4{(float)(d[0] & 0xffffu) * S, (float)(d[0] >> 16) * S, (float)(d[1] & 0xffffu) * S, (float)(d[1] >> 16) * S};
+}
+
+// PACK: 0 = fp32 slots (16 bytes per lane and group), 1 = 24-bit (12), 2 = 16-bit (8)
+template <int PACK>
 struct WaveScratchT {
   __amdgpu_buffer_rsrc_t rs;
-  int l12;  // 12 * lane (PACK)
+  int l12;  // 12 * lane (PACK 1) / 8 * lane (PACK 2)
+  static constexpr int GROUP = PACK == 0 ? 1024 : (PACK == 1 ? 768 : 512);   // bytes of one group of a slot
   // (stores: the wave-uniform offset is folded into voffset, soffset = 0: the >64-bit store hazard of oi::buffer_store_b128)
   template <int AUX = OI_BWD_ST_LOCAL>
   __device__ __forceinline__ void store(int slot, int g, int l16, f32x4 v) const {
@@ -168,27 +202,30 @@ struct WaveScratchT {
       if ((OI_BWD_Q24_SET >> fam) & 1) v = unpack24f(pack24f(v));
     }
 #endif
-    if constexpr (PACK) __builtin_amdgcn_raw_buffer_store_b96(pack24f(v), rs, l12 + (slot * 16384 + g * 768), 0, AUX);
+    if constexpr (PACK == 1) __builtin_amdgcn_raw_buffer_store_b96(pack24f(v), rs, l12 + (slot * 16384 + g * 768), 0, AUX);
+    else if constexpr (PACK == 2) __builtin_amdgcn_raw_buffer_store_b64(pack16f(v), rs, l12 + (slot * 16384 + g * 512), 0, AUX);
     else oi::buffer_store_b128<AUX>(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024);
   }
   template <int AUX = OI_BWD_ST_LOCAL>
   __device__ __forceinline__ void store_phase(int slot, int g, int l16, f32x4 v) const {
-    if constexpr (PACK) __builtin_amdgcn_raw_buffer_store_b96(pack24q(v), rs, l12 + (slot * 16384 + g * 768), 0, AUX);
+    if constexpr (PACK == 1) __builtin_amdgcn_raw_buffer_store_b96(pack24q(v), rs, l12 + (slot * 16384 + g * 768), 0, AUX);
+    else if constexpr (PACK == 2) __builtin_amdgcn_raw_buffer_store_b64(pack16q(v), rs, l12 + (slot * 16384 + g * 512), 0, AUX);
     else oi::buffer_store_b128<AUX>(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024);
   }
-  // A parked fragment as it arrives (3 or 4 dwords); unpacked where it is USED -- the ring of the down sweep requests
+  // A parked fragment as it arrives (2, 3 or 4 dwords); unpacked where it is USED -- the ring of the down sweep requests
   // fragments a layer ahead, and an unpack next to the load would wait for it on the spot
-  using Frag = std::conditional_t<PACK, u32x3, f32x4>;
+  using Frag = std::conditional_t<PACK == 1, u32x3, std::conditional_t<PACK == 2, u32x2, f32x4>>;
   template <int AUX = OI_BWD_LD_LAST>
   __device__ __forceinline__ Frag load(int slot, int g, int l16) const {
-    if constexpr (PACK) return __builtin_amdgcn_raw_buffer_load_b96(rs, l12, slot * 16384 + g * 768, AUX);
+    if constexpr (PACK == 1) return __builtin_amdgcn_raw_buffer_load_b96(rs, l12, slot * 16384 + g * 768, AUX);
+    else if constexpr (PACK == 2) return __builtin_amdgcn_raw_buffer_load_b64(rs, l12, slot * 16384 + g * 512, AUX);
     else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, l16, slot * 16384 + g * 1024, AUX));
   }
   static __device__ __forceinline__ f32x4 value(const Frag& f) {
-    if constexpr (PACK) return unpack24f(f); else return f;
+    if constexpr (PACK == 1) return unpack24f(f); else if constexpr (PACK == 2) return unpack16f(f); else return f;
   }
   static __device__ __forceinline__ f32x4 phase(const Frag& f) {
-    if constexpr (PACK) return unpack24q(f); else return f;
+    if constexpr (PACK == 1) return unpack24q(f); else if constexpr (PACK == 2) return unpack16q(f); else return f;
   }
 };
 
@@ -435,9 +472,10 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   const __amdgpu_buffer_rsrc_t img_rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(mats), 0, NMAT * layer_bytes(PREC), 0x00020000);
 
-  constexpr bool PK = OI_BWD_PACK24 && PREC == OI_PREC_F16X3 && !FAST;  // (fast trig parks unreduced phases: not fixed point)
+  // (24-bit: accurate trig only -- fast trig parks unreduced phases; the 16-bit format reduces them as it packs)
+  constexpr int PK = (OI_BWD_PACK16 && OI_WGRAD_BF16 && PREC == OI_PREC_BF16) ? 2 : ((OI_BWD_PACK24 && PREC == OI_PREC_F16X3 && !FAST) ? 1 : 0);
   WaveScratchT<PK> ws;
-  ws.l12 = 12 * lane;
+  ws.l12 = (PK == 2 ? 8 : 12) * lane;
   asm volatile("" : "+v"(ws.l12));
   {
     const long long wt = ((long long)e * gridDim.x + blockIdx.x) * BW_NW + wave;
@@ -1214,9 +1252,6 @@ __device__ __forceinline__ float frag_bf16(const float* sl, int f, int p0, f16x8
 #ifndef OI_WGRAD_NT
 #define OI_WGRAD_NT 1
 #endif
-#ifndef OI_WGRAD_BF16
-#define OI_WGRAD_BF16 1   // bf16 operand mode: the two-tiles-in-flight GEMM with bf16 operands (0: the generic fp32-MFMA GEMM)
-#endif
 #ifndef OI_WG_TARGET
 #define OI_WG_TARGET 2048  // workgroups of the weight-gradient GEMM (8 matrices x chunks)
 #endif
@@ -1306,7 +1341,8 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
   // the top of the tile and waited: a full memory round trip exposed per tile and workgroup, 4.4 TB/s).
   //   both Y operands of a layer matrix come from the SAME parked phase (reduced, in revolutions): one read, one sin / cos
   //   pair 0: Y = gbar_l = (gamma vbar)_{l-1} cos(phi_{l-1})      pair 1: Y = a_l = sin(phi_{l-1})
-  constexpr bool PK = OI_BWD_PACK24 && !FAST;  // the sweep parked 24-bit values (see WaveScratchT): 60 staging registers
+  // what the sweep parked (see WaveScratchT): 24-bit values -> 60 staging registers, 16-bit (bf16 mode) -> 40
+  constexpr int PK = BF ? (OI_BWD_PACK16 ? 2 : 0) : ((OI_BWD_PACK24 && !FAST) ? 1 : 0);
   using WS = WaveScratchT<PK>;
   using Frag = typename WS::Frag;
   struct Stage {  // the five slots of one wave tile as they arrive: 80 registers (48 for the colour head); 60 (36) packed
@@ -1316,12 +1352,13 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
   Stage stA, stB;
   // through a buffer descriptor over the wave tile (512 KiB): the tile base and the slot offsets travel in SGPRs, the lane
   // offset in ONE VGPR -- with flat pointers hipcc kept 20 address pairs live across the loop and spilled
-  const int t16 = tid * (PK ? 12 : 16);
+  const int t16 = tid * (PK == 1 ? 12 : (PK == 2 ? 8 : 16));
   auto request = [&](long long wt, Stage& st) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(scratch) + wt * (long long)(NSLOT_BWD * 16384), 0, NSLOT_BWD * 16384, 0x00020000);
     auto ld = [&](int slot, int it) -> Frag {   // granule q = it 256 + tid of the slot: group q / 64, lane q % 64
-      if constexpr (PK) return __builtin_amdgcn_raw_buffer_load_b96(rs, t16, slot * 16384 + it * 3072, OI_WGRAD_NT ? 2 : 0);
+      if constexpr (PK == 1) return __builtin_amdgcn_raw_buffer_load_b96(rs, t16, slot * 16384 + it * 3072, OI_WGRAD_NT ? 2 : 0);
+      else if constexpr (PK == 2) return __builtin_amdgcn_raw_buffer_load_b64(rs, t16, slot * 16384 + it * 2048, OI_WGRAD_NT ? 2 : 0);
       else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, t16, slot * 16384 + it * 4096,
                                                                                   OI_WGRAD_NT ? 2 : 0));
     };
