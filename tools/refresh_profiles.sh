@@ -54,7 +54,7 @@ for c in "FETCH_SIZE:fetch" "WRITE_SIZE:write"; do
   python $R/tools/prof_summary.py /tmp/p_tb$tag $O/${T}_pmc_${tag}_train_bf16.txt > /dev/null
 done
 python $R/tools/traffic_json.py $O/${T}_pmc_fetch_train_bf16.txt $O/${T}_pmc_write_train_bf16.txt "mlp_bwd_sweep_kernel<2" "bf16-train-sweep:1x64x64:64+64" $O/${T}_traffic.json
-python $R/tools/traffic_json.py $O/${T}_pmc_fetch_train_bf16.txt $O/${T}_pmc_write_train_bf16.txt "mlp_wgrad_kernel" "bf16-train-wgrad:1x64x64:64+64" $O/${T}_traffic.json
+python $R/tools/traffic_json.py $O/${T}_pmc_fetch_train_bf16.txt $O/${T}_pmc_write_train_bf16.txt "mlp_wgrad_f16_kernel<true, true" "bf16-train-wgrad:1x64x64:64+64" $O/${T}_traffic.json
 python $R/tools/traffic_json.py $O/${T}_pmc_fetch_f16x3.txt $O/${T}_pmc_write_f16x3.txt "mlp_bwd_sweep_kernel<4" "f16x3-train-sweep:1x64x64:64+64" $O/${T}_traffic.json
 python $R/tools/traffic_json.py $O/${T}_pmc_fetch_f16x3.txt $O/${T}_pmc_write_f16x3.txt "mlp_wgrad_f16_kernel" "f16x3-train-wgrad:1x64x64:64+64" $O/${T}_traffic.json
 # the batch-64 discriminator forward (csrc/disc_large.hip): one step's timeline + kernel stats
