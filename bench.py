@@ -421,8 +421,9 @@ def main():
             tr_b, tr_src = measured_traffic(args, "bf16")
             bf16_mode = {"value": B * R * R * n_b / dtb, "unit": "rays/s", "ms_per_step": dtb / n_b * 1e3, "steps": n_b,
                          "kernel_ms": kms, "kernel_ms_samples": kms_n,
-                         "roofline": {"bound": "mfma", "kernel": "sdf_mlp_full3b_kernel (register-resident, one bf16 MFMA per product, cosines parked as "
-                                      "fp16 pairs in AGPRs: no scratch stream)", "achieved": ach, "peak": PEAK_TFLOPS["bf16"],
+                         "roofline": {"bound": "mfma", "kernel": "film_images_b_kernel + sdf_mlp_full3p_kernel (per-element bf16 images diag(gamma) W built per call, "
+                                      "then the register-resident kernel: one bf16 MFMA per product, accumulator = phase, cosines parked as "
+                                      "fp16 pairs in AGPRs, no scratch stream; kernel_ms covers BOTH launches)", "achieved": ach, "peak": PEAK_TFLOPS["bf16"],
                                       "unit": "TFLOP/s", "frac": (ach / PEAK_TFLOPS["bf16"]) if ach else None,
                                       "traffic": tr_b, "traffic_source": tr_src,
                                       "hbm": ({"achieved": tr_b / (kms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",

@@ -110,8 +110,10 @@ int oi_mlp_pack_status(const void* packed, oi_stream_t stream);
  *   rgb [B*n][3] = colour head on [feat, grad].  feat [B*n][128] optional (NULL to skip).
  *   scratch: oi_mlp_scratch_bytes_prec(B, n, prec) bytes, needed when grad != NULL.  OI_PREC_F16X3 (the default mode)
  *   runs the register-resident kernel (csrc/mlp_fwd3.hip): the phases the reverse sweep needs stay in the register
- *   file and only the 128 features per point cross HBM (512 B/point); the other modes park gamma*cos(phase) of every
- *   layer (4.6 KB/point).  oi_mlp_scratch_bytes(B, n) is an upper bound over all modes.
+ *   file and only the 128 features per point cross HBM (512 B/point); OI_PREC_BF16 (csrc/mlp_fwd3b.hip) keeps nothing per
+ *   point in memory -- its scratch holds the 15 per-element images diag(gamma_l) W_l rounded to bf16 (480 KiB per batch
+ *   element, built by a first launch of the same call); the other modes park gamma*cos(phase) of every layer (4.6 KB/point).
+ *   oi_mlp_scratch_bytes(B, n) is an upper bound over all modes.
  */
 size_t oi_mlp_scratch_bytes(int B, long long n_per_elem);
 size_t oi_mlp_scratch_bytes_prec(int B, long long n_per_elem, int prec);

@@ -20,7 +20,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 # per-file extra flags.  mlp_fwd3.hip pins 256 parked values to the AGPR half of the register file; hipcc's default
 # (AGPR-form MFMA accumulators) would need 32 more AGPRs than exist, the VGPR form keeps the accumulators with the VALU.
 EXTRA = {"mlp_fwd3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-         "mlp_fwd3b.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],  # (224 AGPRs hold the parked cosines)
+         # (224 AGPRs hold the parked cosines; without the SLP vectoriser hipcc selects v_fma_mix_f32 for acc * fp16 half)
+         "mlp_fwd3b.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"],
          # backward sweep + weight-gradient GEMM: same choice -- no private-memory scratch left (76 spilled dwords before),
          # sweep -1.5 %, weight-gradient GEMM -5 % on the same box
          "mlp_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}

@@ -940,7 +940,7 @@ size_t oi_mlp_scratch_bytes(int B, long long n_per_elem) {  // upper bound over 
 size_t oi_mlp_scratch_bytes_prec(int B, long long n_per_elem, int prec) {
   static const bool use_v2 = [] { const char* v = getenv("OI_FWD_V2"); return v && v[0] == '1'; }();
   if (prec == OI_PREC_F16X3 && !use_v2) return oimlp::full3_scratch_bytes(B, n_per_elem);  // 512 B/point
-  if (prec == OI_PREC_BF16 && !use_v2) return 256;  // mlp_fwd3b.hip needs none (the pointer must still be valid)
+  if (prec == OI_PREC_BF16 && !use_v2) return oimlp::full3_bf16_scratch_bytes(B);  // mlp_fwd3b.hip: 15 per-element images
   return oi_mlp_scratch_bytes(B, n_per_elem);                                               // 4.6 KB/point
 }
 
@@ -958,7 +958,7 @@ int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, con
     return oimlp::launch_full3_f16x3(pts, packed, gamma, beta, sdf, grad, rgb, feat, scratch, B, n_per_elem, fast_trig, st);
   // BF16 with the gradient: the register-resident kernel of mlp_fwd3b.hip (no scratch stream)
   if (prec == OI_PREC_BF16 && grad != nullptr && !use_v2)
-    return oimlp::launch_full3_bf16(pts, packed, gamma, beta, sdf, grad, rgb, feat, B, n_per_elem, fast_trig, st);
+    return oimlp::launch_full3_bf16(pts, packed, gamma, beta, sdf, grad, rgb, feat, scratch, B, n_per_elem, fast_trig, st);
 #define OI_MLP_CASE(P)                                                                                        \
   case P:                                                                                                     \
     return fast_trig ? launch_mlp<P, true>(pts, packed, gamma, beta, sdf, grad, rgb, feat, scratch, B, n_per_elem, st) \

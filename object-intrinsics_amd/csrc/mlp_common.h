@@ -590,7 +590,9 @@ int launch_full3_f16x3(const float* pts, const void* packed, const float* gamma,
                        hipStream_t st);
 
 // mlp_fwd3b.hip: register-resident BF16 forward with gradient (+ albedo); no scratch
+// (scratch: full3_bf16_scratch_bytes(B) = 15 per-element bf16 images of 32 KiB per batch element, built per call)
+size_t full3_bf16_scratch_bytes(int B);
 int launch_full3_bf16(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf, float* grad,
-                      float* rgb, float* feat, int B, long long n, int fast_trig, hipStream_t st);
+                      float* rgb, float* feat, void* scratch, int B, long long n, int fast_trig, hipStream_t st);
 
 }  // namespace oimlp

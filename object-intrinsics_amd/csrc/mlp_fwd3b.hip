@@ -117,10 +117,19 @@ struct NoPost {
   __device__ __forceinline__ void operator()(int, f32x16&) const {}
 };
 // POST(t, acc[t]) runs right after block t's eight MFMAs (the albedo head adds its three gradient columns there: one more MFMA)
-template <class TAIL, class EPI, class POST = NoPost>
+// INIT (per-element images, sdf_mlp_full3p_kernel): the accumulators start from the FiLM offset row instead of zero, so that the
+// finished accumulator IS the phase.  acc[0] must hold init(0) on entry; init(t + 1) is loaded straight into acc[t + 1] half a
+// block ahead (its previous contents died with the previous layer's epilogue of that block, or with this layer's TAIL).
+struct NoInit {
+  __device__ __forceinline__ f32x16 operator()(int) const { return f32x16{}; }
+};
+template <class T> struct is_no_init_b { static constexpr bool value = false; };
+template <> struct is_no_init_b<NoInit> { static constexpr bool value = true; };
+template <class TAIL, class EPI, class POST = NoPost, class INIT = NoInit>
 __device__ __forceinline__ void stream_layer_b(const char* lds, int wl, const Limb& bh, f32x16 (&acc)[4], TAIL&& tail,
-                                               EPI&& epi, POST&& post = POST()) {
+                                               EPI&& epi, POST&& post = POST(), INIT&& init = INIT()) {
   constexpr bool HAS_TAIL = !is_no_tail_b<std::remove_cv_t<std::remove_reference_t<TAIL>>>::value;
+  constexpr bool HAS_INIT = !is_no_init_b<std::remove_cv_t<std::remove_reference_t<INIT>>>::value;
   constexpr int AD = OI_B3_ADIST;
   f32x4 a[AD + 1];
 #pragma unroll
@@ -150,7 +159,8 @@ __device__ __forceinline__ void stream_layer_b(const char* lds, int wl, const Li
       const bf16x8 w = __builtin_bit_cast(bf16x8, a[(OI_B3_ABL == 2 ? cur % AD : cur) % (AD + 1)]);
       const u32x4 ub = {bh[s][0], bh[s][1], bh[s][2], bh[s][3]};
       const bf16x8 v = __builtin_bit_cast(bf16x8, ub);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, v, s == 0 ? zero : acc[t], 0, 0, 0);
+      if (HAS_INIT && s == 4 && t < 3) acc[t + 1] = init(t + 1);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, v, (s == 0 && !HAS_INIT) ? zero : acc[t], 0, 0, 0);
       // OI_B3_WINSTEPS k-steps per scheduling window: with 2, two epilogue pairs (independent chains) share a window and fill
       // each other's wait states (accvgpr read -> use, v_fma_mix -> v_cvt_pk: an s_nop each when a pair is alone)
       if (OI_B3_WINSTEPS == 1 || (s % OI_B3_WINSTEPS) == OI_B3_WINSTEPS - 1) {
@@ -763,6 +773,476 @@ sdf_mlp_full3b_kernel(const float* __restrict__ pts, const char* __restrict__ pa
 #undef ROW_SIG
 }
 
+
+// =====================================================================================================================
+// Per-element images (round 5, second half): sdf_mlp_full3p_kernel
+//
+// phi_l / 2pi = (gamma_l / 2pi) (W_l a + b_l) + beta_l / 2pi depends on gamma_l and W_l only through diag(gamma_l) W_l, and so does
+// the reverse sweep: g_l = W_l^T (gamma_l * cos(phi_l) * g_{l+1}) = (diag(gamma_l) W_l)^T (cos(phi_l) * g_{l+1}).  One launch per
+// MLP call (film_images_b_kernel: 15 x 32 KiB per batch element, built from the plain fp32 copy of the weights behind the
+// packed images) rounds diag(gamma_l / 2pi) W_l and (diag(gamma_l) W_l)^T to bf16 ONCE -- the same 2^-9 per operand the mode
+// carries, applied to gamma W instead of W.  In the kernel
+//   * the accumulators of a forward product start from the row B2_l = (gamma_l b_l + beta_l) / 2pi (four ds_read_b128 per
+//     output block, straight into the accumulator registers) instead of an inline zero: the finished accumulator IS the phase
+//     in revolutions.  A forward epilogue pair is 2 sin + 2 cos + 2 packs + the AGPR write: no FMA, no FiLM row reads;
+//   * a reverse epilogue pair is the AGPR read + 2 v_fma_mix (accumulator x parked fp16 cosine) + the pack: no gamma row, no
+//     multiply (the mixes are C: see mul_pair_c).
+// Image order in the per-element buffer = ring position: 0..6 forward layers 1..7, 7..13 transposed layers 7..1, 14 albedo head.
+// =====================================================================================================================
+constexpr int NIMG_P = 15;
+constexpr int P_FILM = 0;                          // [9][128] B2_l
+constexpr int P_FILM_ROW = C * 4;
+constexpr int P_TABS = P_FILM + 9 * P_FILM_ROW;    // 4608: the header tables, TAB0 rows x gamma_0 / 2pi, TABV rows x gamma_v / 2pi
+constexpr int P_WBUF = P_TABS + H_TABS_END * 4;    // 10880
+constexpr int P_SIMG = P_WBUF + B3_NSLOT * LBB;    // 141,952
+constexpr int P_LDS = P_SIMG + 2 * SIMG_BYTES;     // 146,048
+
+// one 16-byte A fragment (8 bf16) per thread: fragment u = lane + 64 (s + 8 t) of image `pos` of batch element e
+__global__ void __launch_bounds__(256) film_images_b_kernel(const char* __restrict__ packed, const float* __restrict__ gamma,
+                                                            char* __restrict__ out) {
+  const int pos = blockIdx.y, e = blockIdx.z;
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  const int lane = u & 63, s_ = (u >> 6) & 7, t = u >> 9;
+  const int hh = lane >> 5, row = 32 * t + (lane & 31);
+  const float* plain = reinterpret_cast<const float*>(packed + plain_off(OI_PREC_BF16));
+  const float* gm = gamma + (size_t)e * 9 * C;
+  constexpr float INV_2PI = 0.15915494309189533577f;
+  float v[8];
+  if (pos < 7 || pos == 14) {  // diag(gamma_l / 2pi) W_l: element [row][k]
+    const int m = pos < 7 ? pos : 7, l = pos < 7 ? pos + 1 : 8;
+    const float sc = gm[l * C + row] * INV_2PI;
+    const float* src = plain + ((size_t)m * C + row) * C;
+#pragma unroll
+    for (int ip = 0; ip < 8; ++ip) v[ip] = sc * src[feat_of(8 * s_ + ip, hh)];
+  } else {                     // (diag(gamma_l) W_l)^T: element [row][k] = gamma_l[k] W_l[k][row]
+    const int l = 14 - pos, m = l - 1;
+#pragma unroll
+    for (int ip = 0; ip < 8; ++ip) {
+      const int k = feat_of(8 * s_ + ip, hh);
+      v[ip] = gm[l * C + k] * plain[((size_t)m * C + k) * C + row];
+    }
+  }
+  const u32x4 d = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+  *reinterpret_cast<u32x4*>(out + ((size_t)e * NIMG_P + pos) * LBB + (size_t)u * 16) = d;
+}
+
+// x * (fp16 half of the parked pair), written in C: with -fno-slp-vectorize (build.py, this file) hipcc selects v_fma_mix_f32
+// itself (with the SLP vectoriser on it packs the pair into 2 x v_cvt_f32_f16 + v_pk_fma_f32) AND pads the MFMA-result hazard
+// of the accumulator operand (11 wait states behind an 8-pass MFMA); an inline-asm reader gets no padding.
+__device__ __forceinline__ void mul_pair_c(float x0, float x1, unsigned c, float& v0, float& v1) {
+  const f16x2 hc = __builtin_bit_cast(f16x2, c);
+  v0 = __builtin_fmaf((float)hc[0], x0, 0.0f);
+  v1 = __builtin_fmaf((float)hc[1], x1, 0.0f);
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(64 * B3_WAVES) __attribute__((amdgpu_waves_per_eu(1, 1)))
+sdf_mlp_full3p_kernel(const float* __restrict__ pts, const char* __restrict__ packed, const char* __restrict__ fimg,
+                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ sdf_out,
+                      float* __restrict__ grad_out, float* __restrict__ rgb_out, float* __restrict__ feat_out,
+                      long long n_per_elem) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+#ifdef OI_B3_PROF
+  const unsigned long long t_entry = __builtin_readcyclecounter();
+  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, j = lane & 31;
+  const int e = blockIdx.y;
+  const float* hdr = reinterpret_cast<const float*>(packed);
+
+  LaneOff o;
+  o.h16 = 16 * h;
+  o.h64 = 64 * h;
+  o.l16 = 16 * lane;
+  o.l16hi = 0;
+  asm volatile("" : "+v"(o.h16), "+v"(o.h64), "+v"(o.l16));
+
+  auto point_of = [&](bool& valid) {
+    int jj = lane & 31;
+    asm volatile("" : "+v"(jj));
+    const long long local = (long long)blockIdx.x * B3_TILE + wave * WAVE_PTS + jj;
+    valid = local < n_per_elem;
+    return (long long)e * n_per_elem + (valid ? local : n_per_elem - 1);
+  };
+
+  __amdgpu_buffer_rsrc_t feat_rs;
+  int feat_off;
+  {
+    const long long base_pt = (long long)e * n_per_elem + (long long)blockIdx.x * B3_TILE + wave * WAVE_PTS;
+    const long long left = n_per_elem - ((long long)blockIdx.x * B3_TILE + wave * WAVE_PTS);
+    const int npts = feat_out == nullptr ? 0 : (left >= WAVE_PTS ? WAVE_PTS : (left > 0 ? (int)left : 0));
+    feat_rs = __builtin_amdgcn_make_buffer_rsrc(feat_out + base_pt * C, 0, npts * C * 4, 0x00020000);
+    feat_off = j * C * 4 + 16 * h;
+  }
+
+  const __amdgpu_buffer_rsrc_t img_rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(fimg + (size_t)e * NIMG_P * LBB), 0, NIMG_P * LBB, 0x00020000);
+  auto prefetch = [&](int pos) {
+#pragma unroll
+    for (int q = 0; q < LBB / 4096 / B3_WAVES; ++q) {
+      const int c = (wave * (LBB / 4096 / B3_WAVES) + q) * 4096;
+      auto* dst = (__attribute__((address_space(3))) void*)(lds + P_WBUF + (pos & (B3_NSLOT - 1)) * LBB + c);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, pos * LBB + c, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, pos * LBB + c, 1024, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, pos * LBB + c, 2048, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, pos * LBB + c, 3072, 0);
+    }
+  };
+  constexpr int DMA_PER_IMAGE = LBB / 1024 / B3_WAVES;
+  auto lay = [&](int pos) {
+    int b = o.l16 + P_WBUF + (pos & (B3_NSLOT - 1)) * LBB;
+    asm volatile("" : "+v"(b));
+    return b;
+  };
+  auto film_base = [&](int l) { return o.h16 + P_FILM + l * P_FILM_ROW; };
+
+  float px, py, pz;
+  {
+    bool valid;
+    const long long pt = point_of(valid);
+    px = pts[pt * 3 + 0], py = pts[pt * 3 + 1], pz = pts[pt * 3 + 2];
+  }
+  constexpr float INV_2PI = 0.15915494309189533577f;
+  {  // header tables (the three-column tables of layer 0 and of the head carry their layer's gamma / 2pi per row) + B2 rows
+    float* tabs = reinterpret_cast<float*>(lds + P_TABS);
+    const float* gm = gamma + (size_t)e * 9 * C;
+    for (int i = tid; i < H_TABS_END; i += 64 * B3_WAVES) {
+      float v = hdr[i];
+      if (i < H_SIG) v *= gm[i >> 2] * INV_2PI;
+      else if (i >= H_TABV && i < H_RGB) v *= gm[8 * C + ((i - H_TABV) >> 2)] * INV_2PI;
+      tabs[i] = v;
+    }
+    float* film = reinterpret_cast<float*>(lds + P_FILM);
+    for (int i = tid; i < 9 * C; i += 64 * B3_WAVES)
+      film[i] = fmaf(gm[i], hdr[H_BIAS + i], beta[(size_t)e * 9 * C + i]) * INV_2PI;
+  }
+  {  // the two 3-row A images: image 0 = rows of (diag(gamma_0) W_0)^T (d sdf/dx), image 1 = Wrgb
+    const int img = tid >> 7, s_ = (tid >> 4) & 7, hh = (tid >> 3) & 1, i = tid & 7;
+    const int c = i < 3 ? i : i - 3;
+    unsigned d[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[2];
+#pragma unroll
+      for (int e_ = 0; e_ < 2; ++e_) {
+        const int f = feat_of(8 * s_ + 2 * q + e_, hh);
+        const float w = i < 6 ? (img == 0 ? hdr[H_TAB0 + 4 * f + c] * gamma[(size_t)e * 9 * C + f] : hdr[H_RGB + c * C + f]) : 0.f;
+        const float whi = (float)(__bf16)w;
+        v[e_] = i < 3 ? whi : w - whi;
+      }
+      d[q] = pk_bf16(v[0], v[1]);
+    }
+    *reinterpret_cast<u32x4*>(lds + P_SIMG + img * SIMG_BYTES + ((s_ * 2 + hh) * 8 + i) * 16) = u32x4{d[0], d[1], d[2], d[3]};
+  }
+  prefetch(0);
+  prefetch(1);
+  prefetch(2);
+  __syncthreads();  // tables visible
+
+#ifdef OI_B3_PROF
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = __builtin_readcyclecounter();
+  const unsigned long long tstart = tprev;
+  pacc[4] = tstart - t_entry;  // prologue
+#endif
+  f32x16 acc[4];
+  Limb AH, BH, CH;
+  BankB P0, P1, P2, P3, P4, P5, P6;
+  f32x4 sg[4];  // w_sigma rows of layer 7's epilogue, requested two groups ahead
+  f32x4 fv;
+  float sdf_part = 0.f;
+
+  auto reduce = [&](float phi) { return FAST ? phi : __builtin_amdgcn_fractf(phi); };
+  auto ld = [&](int imm, int base) { return lds_f4(lds, imm, base); };
+  // the B2 rows of output block t of the layer whose rows sit at lane base FB, in accumulator order
+  auto initrows = [&](int fb, int t) {
+    f32x16 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 b = ld(grp_f0(4 * t + i) * 4, fb);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[4 * i + k] = b[k];
+    }
+    return a;
+  };
+#define INIT_P(FB) [&](int t_) { return initrows(FB, t_); }
+
+  auto frag3_b = [&](float vx, float vy, float vz) {
+    const float hx = (float)(__bf16)vx, hy = (float)(__bf16)vy, hz = (float)(__bf16)vz;
+    const unsigned d0 = pk_bf16(hx, hy);
+    const unsigned d1 = h == 0 ? pk_bf16(hz, vx - hx) : pk_bf16(hz, 0.f);
+    const unsigned d2 = h == 0 ? pk_bf16(vy - hy, vz - hz) : 0u;
+    return __builtin_bit_cast(bf16x8, u32x4{d0, d1, d2, 0u});
+  };
+  auto frag3_a = [&](int tab, int t) {
+    const f32x4 w = lds_f4(lds, tab + t * 32 * 16, 16 * (lane & 31));
+    const float hx = (float)(__bf16)w[0], hy = (float)(__bf16)w[1], hz = (float)(__bf16)w[2];
+    const float ax = h == 0 ? hx : w[0] - hx, ay = h == 0 ? hy : w[1] - hy, az = h == 0 ? hz : w[2] - hz;
+    const unsigned d0 = pk_bf16(ax, ay);
+    const unsigned d1 = h == 0 ? pk_bf16(az, hx) : pk_bf16(az, 0.f);
+    const unsigned d2 = h == 0 ? pk_bf16(hy, hz) : 0u;
+    return __builtin_bit_cast(bf16x8, u32x4{d0, d1, d2, 0u});
+  };
+  auto simg = [&](int img, int s_) {
+    return __builtin_bit_cast(bf16x8, lds_f4(lds, P_SIMG + img * SIMG_BYTES + s_ * 256, 128 * h + 16 * (lane & 7)));
+  };
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto rows3 = [&](const f32x16& a, float& r0, float& r1, float& r2) {
+    const float u0 = __shfl_xor(a[0], 32, 64), u1 = __shfl_xor(a[1], 32, 64);
+    r0 = a[0] + a[3];
+    r1 = a[1] + u0;
+    r2 = a[2] + u1;
+  };
+
+  // forward epilogue pair (tb, rp): the accumulator is the phase; sin -> next limb set NH, cos -> BANK
+#define OI_FWD_EPI_P(NH, BANK)                                                                             \
+  [&](int tb, int rp) {                                                                                    \
+    const int g = tb * 4 + (rp >> 1), k = 2 * (rp & 1);                                                    \
+    const float r0 = reduce(acc[tb][2 * rp]), r1 = reduce(acc[tb][2 * rp + 1]);                           \
+    NH[2 * tb + (rp >> 2)][rp & 3] = pk_bf16(__builtin_amdgcn_sinf(r0), __builtin_amdgcn_sinf(r1));        \
+    BANK[g][k >> 1] = to_acc_u(pk_f16(__builtin_amdgcn_cosf(r0), __builtin_amdgcn_cosf(r1)));              \
+  }
+  // reverse epilogue pair of the transposed product of layer l: V'_{l-1} = g_l * cos(phi_{l-1}) -> limb set NH
+#define OI_REV_EPI_P(BANK, NH)                                                                             \
+  [&](int tb, int rp) {                                                                                    \
+    const int g = tb * 4 + (rp >> 1), k = 2 * (rp & 1);                                                    \
+    const unsigned c2 = from_acc_u(BANK[g][k >> 1]);                                                       \
+    float v0, v1;                                                                                          \
+    mul_pair_c(acc[tb][2 * rp], acc[tb][2 * rp + 1], c2, v0, v1);                                          \
+    NH[2 * tb + (rp >> 2)][rp & 3] = pk_bf16(v0, v1);                                                      \
+  }
+
+  const int F0 = film_base(0), F1 = film_base(1), F2 = film_base(2), F3 = film_base(3), F4 = film_base(4),
+            F5 = film_base(5), F6 = film_base(6), F7 = film_base(7), F8 = film_base(8);
+
+  // ================= forward, layers 0..7 =================
+  {  // layer 0 (K = 3): one MFMA per output block on top of the B2 row, then the ordinary forward epilogue
+    const bf16x8 bp = frag3_b(px, py, pz);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag3_a(P_TABS + H_TAB0 * 4, t), bp, initrows(F0, t), 0, 0, 0);
+    auto e0 = OI_FWD_EPI_P(AH, P0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int rp = 0; rp < 8; ++rp) {
+        e0(t, rp);
+        if (rp & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  B3_T(0);
+  acc[0] = initrows(F1, 0);
+  ring_sync_b<2 * DMA_PER_IMAGE>();  // image 0 resident (1 and 2 may still be in flight)
+  B3_T(2);
+  prefetch(3);
+  auto e1 = OI_FWD_EPI_P(BH, P1);
+  stream_layer_b(lds, lay(0), AH, acc, NoTailB(), e1, NoPost(), INIT_P(F1));
+  B3_T(1);
+  acc[0] = initrows(F2, 0);
+  ring_sync_b<2 * DMA_PER_IMAGE>();
+  B3_T(2);
+  prefetch(4);
+  auto e2 = OI_FWD_EPI_P(AH, P2);
+  stream_layer_b(lds, lay(1), BH, acc, e1, e2, NoPost(), INIT_P(F2));
+  B3_T(1);
+  acc[0] = initrows(F3, 0);
+  ring_sync_b<2 * DMA_PER_IMAGE>();
+  B3_T(2);
+  prefetch(5);
+  auto e3 = OI_FWD_EPI_P(BH, P3);
+  stream_layer_b(lds, lay(2), AH, acc, e2, e3, NoPost(), INIT_P(F3));
+  B3_T(1);
+  acc[0] = initrows(F4, 0);
+  ring_sync_b<2 * DMA_PER_IMAGE>();
+  B3_T(2);
+  prefetch(6);
+  auto e4 = OI_FWD_EPI_P(AH, P4);
+  stream_layer_b(lds, lay(3), BH, acc, e3, e4, NoPost(), INIT_P(F4));
+  B3_T(1);
+  acc[0] = initrows(F5, 0);
+  ring_sync_b<2 * DMA_PER_IMAGE>();
+  B3_T(2);
+  prefetch(7);
+  auto e5 = OI_FWD_EPI_P(BH, P5);
+  stream_layer_b(lds, lay(4), AH, acc, e4, e5, NoPost(), INIT_P(F5));
+  B3_T(1);
+  acc[0] = initrows(F6, 0);
+  ring_sync_b<2 * DMA_PER_IMAGE>();
+  B3_T(2);
+  prefetch(8);
+  auto e6 = OI_FWD_EPI_P(AH, P6);
+  stream_layer_b(lds, lay(5), BH, acc, e5, e6, NoPost(), INIT_P(F6));
+  B3_T(1);
+  acc[0] = initrows(F7, 0);
+  auto req_sig = [&](int g_) { sg[g_ & 3] = ld(P_TABS + (H_SIG + grp_f0(g_)) * 4, o.h16); };
+  req_sig(0);
+  req_sig(1);
+  ring_sync_b<2 * DMA_PER_IMAGE>();
+  B3_T(2);
+  prefetch(9);
+  // layer 7: features a8 = sin(phi7) -> limb set CH (+ feat_out), sdf = a8 . wsig + bsig on the fly, and the reverse sweep's
+  // first operand V'7 = wsig * cos(phi7) is formed in place (cos(phi7) is never parked; gamma_7 sits in the transposed image)
+  auto e7 = [&](int tb, int rp) {
+    const int g = tb * 4 + (rp >> 1), k = 2 * (rp & 1);
+    const f32x4& ws = sg[g & 3];
+    if (k == 0 && g + 2 < 16) req_sig(g + 2);
+    float sn[2], v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float r = reduce(acc[tb][2 * rp + i]);
+      sn[i] = __builtin_amdgcn_sinf(r);
+      fv[k + i] = sn[i];
+      sdf_part = fmaf(sn[i], ws[k + i], sdf_part);
+      v[i] = ws[k + i] * __builtin_amdgcn_cosf(r);
+    }
+    CH[2 * tb + (rp >> 2)][rp & 3] = pk_bf16(sn[0], sn[1]);
+    BH[2 * tb + (rp >> 2)][rp & 3] = pk_bf16(v[0], v[1]);
+    if (k == 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, fv), feat_rs, feat_off + grp_f0(g) * 4, 0, 0);
+  };
+  stream_layer_b(lds, lay(6), AH, acc, e6, e7, NoPost(), INIT_P(F7));
+  B3_T(1);
+  ring_sync_b<2 * DMA_PER_IMAGE>();
+  B3_T(2);
+  prefetch(10);
+
+  // ================= reverse, layers 7..1 =================
+  auto r7 = OI_REV_EPI_P(P6, AH);   // V'6 = g7 * cos(phi6)
+  stream_layer_b(lds, lay(7), BH, acc, e7, r7);
+  B3_T(1);
+  {
+    sdf_part += __shfl_xor(sdf_part, 32, 64);  // complete since e7's last pair (inside the layer above)
+    const float sdf_v = sdf_part + *reinterpret_cast<const float*>(lds + P_TABS + (H_SIG + C) * 4);
+    bool valid;
+    const long long pt = point_of(valid);
+    if (valid && h == 0) sdf_out[pt] = sdf_v;
+  }
+  ring_sync_b<2 * DMA_PER_IMAGE>();
+  B3_T(2);
+  prefetch(11);
+  auto r6 = OI_REV_EPI_P(P5, BH);
+  stream_layer_b(lds, lay(8), AH, acc, r7, r6);
+  B3_T(1);
+  ring_sync_b<2 * DMA_PER_IMAGE>();
+  B3_T(2);
+  prefetch(12);
+  auto r5 = OI_REV_EPI_P(P4, AH);
+  stream_layer_b(lds, lay(9), BH, acc, r6, r5);
+  B3_T(1);
+  ring_sync_b<2 * DMA_PER_IMAGE>();
+  B3_T(2);
+  prefetch(13);
+  auto r4 = OI_REV_EPI_P(P3, BH);
+  stream_layer_b(lds, lay(10), AH, acc, r5, r4);
+  B3_T(1);
+  ring_sync_b<2 * DMA_PER_IMAGE>();
+  B3_T(2);
+  prefetch(14);
+  auto r3 = OI_REV_EPI_P(P2, AH);
+  stream_layer_b(lds, lay(11), BH, acc, r4, r3);
+  B3_T(1);
+  ring_sync_b<2 * DMA_PER_IMAGE>();  // image 12 resident; 13 and 14 in flight, nothing more to request
+  B3_T(2);
+  auto r2 = OI_REV_EPI_P(P1, BH);   // V'1 = g2 * cos(phi1)
+  stream_layer_b(lds, lay(12), AH, acc, r3, r2);
+  B3_T(1);
+  ring_sync_b<DMA_PER_IMAGE>();      // image 13 resident
+  B3_T(2);
+  // transposed layer 1: V'0 = g1 * cos(phi0) as limbs; then d sdf/dx = (diag(gamma_0) W0)^T V'0 (K = 128 -> 3 rows) as eight
+  // MFMAs against the small image
+  auto r1 = OI_REV_EPI_P(P0, AH);
+  stream_layer_b(lds, lay(13), BH, acc, r2, r1);
+  B3_T(1);
+  run_tail_b(r1);
+  B3_T(3);
+  float gx, gy, gz;
+  {
+    f32x16 a0 = zero16;
+#pragma unroll
+    for (int s_ = 0; s_ < 8; ++s_) {
+      const u32x4 ub = {AH[s_][0], AH[s_][1], AH[s_][2], AH[s_][3]};
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(simg(0, s_), __builtin_bit_cast(bf16x8, ub), a0, 0, 0, 0);
+    }
+    rows3(a0, gx, gy, gz);
+    gx = __shfl(gx, lane & 31, 64);  // both halves of the point need the gradient (the albedo head's B fragment)
+    gy = __shfl(gy, lane & 31, 64);
+    gz = __shfl(gz, lane & 31, 64);
+  }
+  bool valid;
+  const long long pt = point_of(valid);
+  if (valid && h == 0) {
+    grad_out[pt * 3 + 0] = gx;
+    grad_out[pt * 3 + 1] = gy;
+    grad_out[pt * 3 + 2] = gz;
+  }
+
+  {
+    // ---- albedo head: sigmoid(Wrgb sin(gv * (Wv [feat, grad] + bv) + bv') + brgb)   (fields.py:89-101)
+    acc[0] = initrows(F8, 0);
+    ring_sync_b<0>();  // image 14 resident
+  B3_T(2);
+    float r0 = 0.f, r1c = 0.f, r2c = 0.f;
+    // the head's three gradient columns (rows of TABV x gamma_v / 2pi) are a ninth MFMA of every output block; its activations
+    // sin(phi_v) go on as bf16 limbs (AH: free) and rgb = Wrgb sin(phi_v) is eight MFMAs against the second small image
+    const bf16x8 bg3 = frag3_b(gx, gy, gz);
+    auto post = [&](int t, f32x16& a) { a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag3_a(P_TABS + H_TABV * 4, t), bg3, a, 0, 0, 0); };
+    auto ec = [&](int tb, int rp) {
+      const float s0 = __builtin_amdgcn_sinf(reduce(acc[tb][2 * rp]));
+      const float s1 = __builtin_amdgcn_sinf(reduce(acc[tb][2 * rp + 1]));
+      AH[2 * tb + (rp >> 2)][rp & 3] = pk_bf16(s0, s1);
+    };
+    stream_layer_b(lds, lay(14), CH, acc, NoTailB(), ec, post, INIT_P(F8));
+  B3_T(1);
+    run_tail_b(ec);
+  B3_T(3);
+    {
+      f32x16 a0 = zero16;
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_) {
+        const u32x4 ub = {AH[s_][0], AH[s_][1], AH[s_][2], AH[s_][3]};
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(simg(1, s_), __builtin_bit_cast(bf16x8, ub), a0, 0, 0, 0);
+      }
+      rows3(a0, r0, r1c, r2c);
+    }
+    if (valid && h == 0 && rgb_out != nullptr) {
+      const float* brgb = reinterpret_cast<const float*>(lds + P_TABS + (H_RGB + 3 * C) * 4);
+      rgb_out[pt * 3 + 0] = oi::sigmoidf_(r0 + brgb[0]);
+      rgb_out[pt * 3 + 1] = oi::sigmoidf_(r1c + brgb[1]);
+      rgb_out[pt * 3 + 2] = oi::sigmoidf_(r2c + brgb[2]);
+    }
+  }
+#ifdef OI_B3_PROF
+  B3_T(5);
+  if (lane == 0) {
+    unsigned long long* pr = oi_prof3b[(blockIdx.x * 4 + wave) & 1023];
+    for (int i = 0; i < 6; ++i) atomicAdd(&pr[i], pacc[i]);
+    atomicAdd(&pr[6], __builtin_readcyclecounter() - tstart);
+    atomicAdd(&pr[7], 1ull);
+    atomicAdd(&pr[8], __builtin_readcyclecounter() - t_entry);  // with [9]: the shader clock in the kernel
+    atomicAdd(&pr[9], __builtin_amdgcn_s_memrealtime() - rt_entry);
+  }
+#endif
+#undef OI_FWD_EPI_P
+#undef OI_REV_EPI_P
+#undef INIT_P
+}
+
+size_t full3p_scratch(int B) { return (size_t)B * NIMG_P * LBB; }
+
+template <bool FAST>
+int launch_full3p(const float* pts, const char* pk, const float* gamma, const float* beta, float* sdf, float* grad,
+                  float* rgb, float* feat, void* scratch, int B, long long n, hipStream_t st) {
+  char* fimg = reinterpret_cast<char*>(scratch);
+  hipLaunchKernelGGL(film_images_b_kernel, dim3(C * C / 8 / 256, NIMG_P, B), dim3(256), 0, st, pk, gamma, fimg);
+  dim3 grid(oi::cdiv(n, B3_TILE), B), block(64 * B3_WAVES);
+  auto k = sdf_mlp_full3p_kernel<FAST>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+  hipLaunchKernelGGL(k, grid, block, P_LDS, st, pts, pk, fimg, gamma, beta, sdf, grad, rgb, feat, n);
+  return oi::check_launch("oi_sdf_mlp_fwd(full3p)");
+}
+
 template <bool FAST>
 int launch_full3b(const float* pts, const char* pk, const float* gamma, const float* beta, float* sdf, float* grad,
                   float* rgb, float* feat, int B, long long n, hipStream_t st) {
@@ -777,9 +1257,16 @@ int launch_full3b(const float* pts, const char* pk, const float* gamma, const fl
 
 namespace oimlp {
 
+size_t full3_bf16_scratch_bytes(int B) { return full3p_scratch(B); }
+
+// OI_BF16_PRESCALE=0 (environment, read once) keeps the round-4 kernel with shared images + FiLM rows: the same-box A/B switch
 int launch_full3_bf16(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf, float* grad,
-                      float* rgb, float* feat, int B, long long n, int fast_trig, hipStream_t st) {
+                      float* rgb, float* feat, void* scratch, int B, long long n, int fast_trig, hipStream_t st) {
   const char* pk = reinterpret_cast<const char*>(packed);
+  static const bool prescale = [] { const char* v = getenv("OI_BF16_PRESCALE"); return !(v && v[0] == '0'); }();
+  if (prescale)
+    return fast_trig ? launch_full3p<true>(pts, pk, gamma, beta, sdf, grad, rgb, feat, scratch, B, n, st)
+                     : launch_full3p<false>(pts, pk, gamma, beta, sdf, grad, rgb, feat, scratch, B, n, st);
   return fast_trig ? launch_full3b<true>(pts, pk, gamma, beta, sdf, grad, rgb, feat, B, n, st)
                    : launch_full3b<false>(pts, pk, gamma, beta, sdf, grad, rgb, feat, B, n, st);
 }

@@ -8,6 +8,7 @@ src=$1; shift
 mkdir -p $R/build/ab
 extra=""
 { [ "$src" = "mlp_fwd3.hip" ] || [ "$src" = "mlp_fwd3b.hip" ] || [ "$src" = "mlp_bwd.hip" ]; } && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
+[ "$src" = "mlp_fwd3b.hip" ] && extra="$extra -fno-slp-vectorize"
 others=$(ls $R/build/*.o | grep -v "/${src%.hip}.o")
 while [ $# -gt 0 ]; do
   name=$1; flags=$2; shift 2

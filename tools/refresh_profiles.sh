@@ -31,13 +31,13 @@ python $R/tools/train_launches.py /tmp/p_t10 10 /tmp/p_t30 30 > $O/${T}_timeline
 rm -rf /tmp/p_dist; OI_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29555 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_dist -- $TRAIN --train-steps 10 > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/p_dist $O/${T}_kernel_stats_train_rccl_1rank.txt > /dev/null
 python $R/tools/traffic_json.py $O/${T}_pmc_fetch_f16x3.txt $O/${T}_pmc_write_f16x3.txt sdf_mlp_full3_kernel "f16x3:1x64x64:64+64" $O/${T}_traffic.json
-# the bf16 mode's dominant kernel (sdf_mlp_full3b_kernel<true>: register-resident, fast trig) + its kernel stats / timeline
+# the bf16 mode's dominant kernel (sdf_mlp_full3p_kernel<true>: register-resident, per-element images, fast trig) + its kernel stats / timeline
 for c in "FETCH_SIZE:fetch" "WRITE_SIZE:write"; do
   ctr=${c%%:*}; tag=${c##*:}
   rm -rf /tmp/p_b$tag; rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/p_b$tag -- $BENCH --precision bf16 --steps 5 --warmup 2 --train-steps 0 > /dev/null 2>&1
   python $R/tools/prof_summary.py /tmp/p_b$tag $O/${T}_pmc_${tag}_bf16.txt > /dev/null
 done
-python $R/tools/traffic_json.py $O/${T}_pmc_fetch_bf16.txt $O/${T}_pmc_write_bf16.txt "sdf_mlp_full3b_kernel" "bf16:1x64x64:64+64" $O/${T}_traffic.json
+python $R/tools/traffic_json.py $O/${T}_pmc_fetch_bf16.txt $O/${T}_pmc_write_bf16.txt "sdf_mlp_full3p_kernel" "bf16:1x64x64:64+64" $O/${T}_traffic.json
 rm -rf /tmp/p_bks; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bks -- $BENCH --precision bf16 --train-steps 0 > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/p_bks $O/${T}_kernel_stats_bf16.txt > /dev/null
 python $R/tools/dbg/timeline.py /tmp/p_bks $O/${T}_timeline_step_bf16.txt prep_render_kernel > /dev/null
