@@ -790,16 +790,22 @@ sdf_mlp_full3b_kernel(const float* __restrict__ pts, const char* __restrict__ pa
 // Image order in the per-element buffer = ring position: 0..6 forward layers 1..7, 7..13 transposed layers 7..1, 14 albedo head.
 // =====================================================================================================================
 constexpr int NIMG_P = 15;
+// The per-element tables arrive as ONE blob the builder writes behind the 15 images (P_BLOB bytes, LDS layout = blob layout): a
+// tile's prologue is 15 LDS-DMA copies of 1 KiB instead of ~40 dependent global loads, 15 KB of ds_writes and the small-image
+// arithmetic per workgroup (4,096 workgroups per C2 launch did that work again and again).
 constexpr int P_FILM = 0;                          // [9][128] B2_l
 constexpr int P_FILM_ROW = C * 4;
 constexpr int P_TABS = P_FILM + 9 * P_FILM_ROW;    // 4608: the header tables, TAB0 rows x gamma_0 / 2pi, TABV rows x gamma_v / 2pi
-constexpr int P_WBUF = P_TABS + H_TABS_END * 4;    // 10880
-constexpr int P_SIMG = P_WBUF + B3_NSLOT * LBB;    // 141,952
-constexpr int P_LDS = P_SIMG + 2 * SIMG_BYTES;     // 146,048
+constexpr int P_SIMG = P_TABS + H_TABS_END * 4;    // 10880: the two 3-row A images
+constexpr int P_BLOB = 15360;                      // 10880 + 4096 = 14976, padded to 15 KiB
+constexpr int P_WBUF = P_BLOB;
+constexpr int P_LDS = P_WBUF + B3_NSLOT * LBB;     // 146,432
+constexpr size_t P_ELEM_BYTES = (size_t)NIMG_P * LBB + P_BLOB;   // scratch per batch element
+static_assert(P_SIMG + 2 * SIMG_BYTES <= P_BLOB, "blob layout");
 
 // one 16-byte A fragment (8 bf16) per thread: fragment u = lane + 64 (s + 8 t) of image `pos` of batch element e
 __global__ void __launch_bounds__(256) film_images_b_kernel(const char* __restrict__ packed, const float* __restrict__ gamma,
-                                                            char* __restrict__ out) {
+                                                            const float* __restrict__ beta, char* __restrict__ out) {
   const int pos = blockIdx.y, e = blockIdx.z;
   const int u = blockIdx.x * 256 + threadIdx.x;
   const int lane = u & 63, s_ = (u >> 6) & 7, t = u >> 9;
@@ -807,6 +813,37 @@ __global__ void __launch_bounds__(256) film_images_b_kernel(const char* __restri
   const float* plain = reinterpret_cast<const float*>(packed + plain_off(OI_PREC_BF16));
   const float* gm = gamma + (size_t)e * 9 * C;
   constexpr float INV_2PI = 0.15915494309189533577f;
+  if (pos == NIMG_P) {  // the table blob (P_BLOB bytes behind the images), two dwords per thread
+    const float* hdr = reinterpret_cast<const float*>(packed);
+    unsigned* blob = reinterpret_cast<unsigned*>(out + (size_t)e * P_ELEM_BYTES + (size_t)NIMG_P * LBB);
+    for (int i = u; i < P_BLOB / 4; i += C * C / 8) {
+      unsigned w = 0u;
+      if (i < 9 * C) {                                  // B2_l = (gamma_l b_l + beta_l) / 2pi
+        w = __builtin_bit_cast(unsigned, fmaf(gm[i], hdr[H_BIAS + i], beta[(size_t)e * 9 * C + i]) * INV_2PI);
+      } else if (i < 9 * C + H_TABS_END) {              // header tables; the three-column tables carry gamma / 2pi per row
+        const int k = i - 9 * C;
+        float v = hdr[k];
+        if (k < H_SIG) v *= gm[k >> 2] * INV_2PI;
+        else if (k >= H_TABV && k < H_RGB) v *= gm[8 * C + ((k - H_TABV) >> 2)] * INV_2PI;
+        w = __builtin_bit_cast(unsigned, v);
+      } else if (i < P_SIMG / 4 + 2 * SIMG_BYTES / 4) {  // small images: [img][k-step 8][half 2][row 8][dword 4]
+        const int k = i - P_SIMG / 4;
+        const int q = k & 3, r = (k >> 2) & 7, h2 = (k >> 5) & 1, ks = (k >> 6) & 7, img = k >> 9;
+        const int c = r < 3 ? r : r - 3;
+        float v2[2];
+#pragma unroll
+        for (int e_ = 0; e_ < 2; ++e_) {
+          const int f = feat_of(8 * ks + 2 * q + e_, h2);
+          const float wv = r < 6 ? (img == 0 ? hdr[H_TAB0 + 4 * f + c] * gm[f] : hdr[H_RGB + c * C + f]) : 0.f;
+          const float whi = (float)(__bf16)wv;
+          v2[e_] = r < 3 ? whi : wv - whi;
+        }
+        w = pk_bf16(v2[0], v2[1]);
+      }
+      blob[i] = w;
+    }
+    return;
+  }
   float v[8];
   if (pos < 7 || pos == 14) {  // diag(gamma_l / 2pi) W_l: element [row][k]
     const int m = pos < 7 ? pos : 7, l = pos < 7 ? pos + 1 : 8;
@@ -823,7 +860,7 @@ __global__ void __launch_bounds__(256) film_images_b_kernel(const char* __restri
     }
   }
   const u32x4 d = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
-  *reinterpret_cast<u32x4*>(out + ((size_t)e * NIMG_P + pos) * LBB + (size_t)u * 16) = d;
+  *reinterpret_cast<u32x4*>(out + (size_t)e * P_ELEM_BYTES + (size_t)pos * LBB + (size_t)u * 16) = d;
 }
 
 // x * (fp16 half of the parked pair), written in C: with -fno-slp-vectorize (build.py, this file) hipcc selects v_fma_mix_f32
@@ -850,7 +887,7 @@ sdf_mlp_full3p_kernel(const float* __restrict__ pts, const char* __restrict__ pa
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, j = lane & 31;
   const int e = blockIdx.y;
-  const float* hdr = reinterpret_cast<const float*>(packed);
+  (void)packed;  // (everything per element comes from the builder's blob)
 
   LaneOff o;
   o.h16 = 16 * h;
@@ -878,7 +915,7 @@ sdf_mlp_full3p_kernel(const float* __restrict__ pts, const char* __restrict__ pa
   }
 
   const __amdgpu_buffer_rsrc_t img_rs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(fimg + (size_t)e * NIMG_P * LBB), 0, NIMG_P * LBB, 0x00020000);
+      const_cast<char*>(fimg + (size_t)e * P_ELEM_BYTES), 0, (int)P_ELEM_BYTES, 0x00020000);
   auto prefetch = [&](int pos) {
 #pragma unroll
     for (int q = 0; q < LBB / 4096 / B3_WAVES; ++q) {
@@ -904,42 +941,18 @@ sdf_mlp_full3p_kernel(const float* __restrict__ pts, const char* __restrict__ pa
     const long long pt = point_of(valid);
     px = pts[pt * 3 + 0], py = pts[pt * 3 + 1], pz = pts[pt * 3 + 2];
   }
-  constexpr float INV_2PI = 0.15915494309189533577f;
-  {  // header tables (the three-column tables of layer 0 and of the head carry their layer's gamma / 2pi per row) + B2 rows
-    float* tabs = reinterpret_cast<float*>(lds + P_TABS);
-    const float* gm = gamma + (size_t)e * 9 * C;
-    for (int i = tid; i < H_TABS_END; i += 64 * B3_WAVES) {
-      float v = hdr[i];
-      if (i < H_SIG) v *= gm[i >> 2] * INV_2PI;
-      else if (i >= H_TABV && i < H_RGB) v *= gm[8 * C + ((i - H_TABV) >> 2)] * INV_2PI;
-      tabs[i] = v;
-    }
-    float* film = reinterpret_cast<float*>(lds + P_FILM);
-    for (int i = tid; i < 9 * C; i += 64 * B3_WAVES)
-      film[i] = fmaf(gm[i], hdr[H_BIAS + i], beta[(size_t)e * 9 * C + i]) * INV_2PI;
-  }
-  {  // the two 3-row A images: image 0 = rows of (diag(gamma_0) W_0)^T (d sdf/dx), image 1 = Wrgb
-    const int img = tid >> 7, s_ = (tid >> 4) & 7, hh = (tid >> 3) & 1, i = tid & 7;
-    const int c = i < 3 ? i : i - 3;
-    unsigned d[4];
+  // the per-element table blob -> LDS [0, P_BLOB): 15 copies of 1 KiB, wave w takes chunks w, w + 4, ...
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float v[2];
-#pragma unroll
-      for (int e_ = 0; e_ < 2; ++e_) {
-        const int f = feat_of(8 * s_ + 2 * q + e_, hh);
-        const float w = i < 6 ? (img == 0 ? hdr[H_TAB0 + 4 * f + c] * gamma[(size_t)e * 9 * C + f] : hdr[H_RGB + c * C + f]) : 0.f;
-        const float whi = (float)(__bf16)w;
-        v[e_] = i < 3 ? whi : w - whi;
-      }
-      d[q] = pk_bf16(v[0], v[1]);
-    }
-    *reinterpret_cast<u32x4*>(lds + P_SIMG + img * SIMG_BYTES + ((s_ * 2 + hh) * 8 + i) * 16) = u32x4{d[0], d[1], d[2], d[3]};
+  for (int q = 0; q < 4; ++q) {
+    const int c = q * 4 + wave;
+    if (c < P_BLOB / 1024)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, (__attribute__((address_space(3))) void*)(lds + c * 1024), 16, o.l16,
+                                               NIMG_P * LBB + c * 1024, 0, 0);
   }
   prefetch(0);
   prefetch(1);
   prefetch(2);
-  __syncthreads();  // tables visible
+  ring_sync_b<3 * DMA_PER_IMAGE>();  // point + tables landed (the three images may still be in flight), visible to every wave
 
 #ifdef OI_B3_PROF
   unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1229,13 +1242,13 @@ sdf_mlp_full3p_kernel(const float* __restrict__ pts, const char* __restrict__ pa
 #undef INIT_P
 }
 
-size_t full3p_scratch(int B) { return (size_t)B * NIMG_P * LBB; }
+size_t full3p_scratch(int B) { return (size_t)B * P_ELEM_BYTES; }
 
 template <bool FAST>
 int launch_full3p(const float* pts, const char* pk, const float* gamma, const float* beta, float* sdf, float* grad,
                   float* rgb, float* feat, void* scratch, int B, long long n, hipStream_t st) {
   char* fimg = reinterpret_cast<char*>(scratch);
-  hipLaunchKernelGGL(film_images_b_kernel, dim3(C * C / 8 / 256, NIMG_P, B), dim3(256), 0, st, pk, gamma, fimg);
+  hipLaunchKernelGGL(film_images_b_kernel, dim3(C * C / 8 / 256, NIMG_P + 1, B), dim3(256), 0, st, pk, gamma, beta, fimg);
   dim3 grid(oi::cdiv(n, B3_TILE), B), block(64 * B3_WAVES);
   auto k = sdf_mlp_full3p_kernel<FAST>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
