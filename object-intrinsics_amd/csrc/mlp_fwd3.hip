@@ -32,8 +32,17 @@ constexpr int F3_FILM = 0;
 constexpr int F3_FILM_ROW = 3 * C * 4;                      // bytes per FiLM layer
 constexpr int F3_TABS = F3_FILM + 10 * F3_FILM_ROW;         // 15360
 constexpr int F3_GMAX = F3_TABS + H_TABS_END * 4;           // [16] max |G_l| per FiLM layer (9: max |G7 w_sigma|)
-constexpr int F3_WBUF = F3_GMAX + 64;                       // 21696
-constexpr int F3_LDS = F3_WBUF + 2 * 65536;                 // 152,768 of the CU's 163,840 bytes
+// OI_F3_BLOB (round 5): everything in front of the image ring depends on the batch element only, so ONE launch per call
+// (film_blob_f3_kernel, a block per element) writes it as a 22 KiB blob and a tile's prologue is 22 LDS-DMA copies of 1 KiB
+// instead of ~25 dependent global loads per thread, 21 KB of ds_writes, the row maxima and two barriers -- 4,096 workgroups of
+// a C2 launch repeated that work, 8.7k of a tile's 136k cycles with nothing to hide behind (one workgroup per CU).
+#ifndef OI_F3_BLOB
+#define OI_F3_BLOB 1
+#endif
+constexpr int F3_BLOB = 22528;
+constexpr int F3_WBUF = OI_F3_BLOB ? F3_BLOB : F3_GMAX + 64;  // 22,528 (21,696 without the blob)
+constexpr int F3_LDS = F3_WBUF + 2 * 65536;                 // 153,600 of the CU's 163,840 bytes
+static_assert(F3_GMAX + 64 <= F3_BLOB, "blob layout");
 
 // One parked 128-vector of this lane's point: [group g][k]  <->  act[4 g + k].  The values are pinned to the ACCUMULATOR
 // half of the register file through the "a" constraint: left to itself hipcc's allocator treats them as ordinary
@@ -295,7 +304,7 @@ __global__ void __launch_bounds__(64 * F3_WAVES) __attribute__((amdgpu_waves_per
 sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ packed, const float* __restrict__ gamma,
                      const float* __restrict__ beta, float* __restrict__ sdf_out, float* __restrict__ grad_out,
                      float* __restrict__ rgb_out, float* __restrict__ feat_out, char* __restrict__ scratch,
-                     long long n_per_elem) {
+                     const char* __restrict__ blob, long long n_per_elem) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int LB = 65536;
 #ifdef OI_F3_PROF
@@ -391,6 +400,29 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   // lane base of FiLM layer l's rows: [A | B | G] x 128 floats (see the staging loop)
   auto film_base = [&](int l) { return o.h16 + F3_FILM + l * F3_FILM_ROW; };
 
+#if OI_F3_BLOB
+  float px, py, pz;
+  {
+    bool valid;
+    const long long pt = point_of(valid);
+    px = pts[pt * 3 + 0], py = pts[pt * 3 + 1], pz = pts[pt * 3 + 2];
+  }
+  {  // the element's blob (tables, FiLM rows in revolutions, row maxima: see film_blob_f3_kernel) -> LDS [0, F3_BLOB)
+    const __amdgpu_buffer_rsrc_t blob_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(blob + (size_t)e * F3_BLOB), 0, F3_BLOB, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < (F3_BLOB / 1024 + F3_WAVES - 1) / F3_WAVES; ++q) {
+      const int c = q * F3_WAVES + wave;
+      if (c < F3_BLOB / 1024)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(blob_rs, (__attribute__((address_space(3))) void*)(lds + c * 1024), 16, o.l16,
+                                                 c * 1024, 0, 0);
+    }
+  }
+  prefetch(0);
+  // point + blob landed (everything older than image 0's 16 copies per wave: the counter retires in issue order), and visible
+  // to every wave; image 0 stays in flight
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(LB / 1024 / F3_WAVES) : "memory");
+#else
   prefetch(0);
   {  // small tables + the FiLM rows of all 9 layers, once.  The phase is formed in REVOLUTIONS so that the range reduction
      // is  r = phi - rint(phi)  (exact):  phi / 2pi = A * acc + B  with  A = gamma * 2^-k_image / 2pi  (2^-k: the power-of-
@@ -430,6 +462,7 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   }
   __syncthreads();
 
+#endif
 #ifdef OI_F3_PROF
   unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = __builtin_readcyclecounter();
@@ -877,13 +910,56 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #undef ROW_SIG
 }
 
+// The per-element blob of sdf_mlp_full3_kernel: LDS bytes [0, F3_BLOB) as the kernel's own staging loop formed them (the
+// phase in REVOLUTIONS: phi / 2pi = A * acc + B with A = gamma * 2^-k_image / 2pi, B = (gamma * bias + beta) / 2pi; G = gamma *
+// 2^-k_image; row 9 = G7 * w_sigma; the header tables; max |G_l| per layer and of row 9).  One block per batch element.
+__global__ void __launch_bounds__(256) film_blob_f3_kernel(const char* __restrict__ packed, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, char* __restrict__ blob) {
+  __shared__ float gl[10 * C];
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* hdr = reinterpret_cast<const float*>(packed);
+  float* out = reinterpret_cast<float*>(blob + (size_t)e * F3_BLOB);
+  float* tabs = out + F3_TABS / 4;
+  for (int i = tid; i < H_TABS_END; i += 256) tabs[i] = hdr[i];
+  float* film = out + F3_FILM / 4;
+  constexpr float INV_2PI = 0.15915494309189533577f;
+  for (int i = tid; i < 9 * C; i += 256) {
+    const int l = i / C, f = i % C;
+    const float gm = gamma[((size_t)e * 9 + l) * C + f];
+    const float wsc = l == 0 ? 1.f : hdr[H_WSCALE + (l < NL_SDF ? l - 1 : 14)];
+    const float G = gm * wsc;
+    film[l * (F3_FILM_ROW / 4) + f] = G * INV_2PI;
+    film[l * (F3_FILM_ROW / 4) + C + f] = fmaf(gm, hdr[H_BIAS + l * C + f], beta[((size_t)e * 9 + l) * C + f]) * INV_2PI;
+    film[l * (F3_FILM_ROW / 4) + 2 * C + f] = G;
+    gl[l * C + f] = G;
+    if (l == 7) {
+      film[9 * (F3_FILM_ROW / 4) + f] = G * hdr[H_SIG + f];
+      gl[9 * C + f] = G * hdr[H_SIG + f];
+    }
+  }
+  __syncthreads();
+  for (int l = wave; l < 10; l += 4) {
+    const float m = oi::wave_max(fmaxf(fabsf(gl[l * C + lane]), fabsf(gl[l * C + 64 + lane])));
+    if (lane == 0) out[F3_GMAX / 4 + l] = m;
+  }
+}
+
+size_t full3_slot_bytes(int B, long long n_per_elem) {
+  const long long wgs = (long long)B * oi::cdiv(n_per_elem, F3_TILE);
+  return (size_t)(wgs > F3_WG_SLOTS ? F3_CU_SLOTS : wgs) * F3_WAVES * 16384;
+}
+
 template <bool FAST>
 int launch_full3(const float* pts, const char* pk, const float* gamma, const float* beta, float* sdf, float* grad,
                  float* rgb, float* feat, char* scratch, int B, long long n, hipStream_t st) {
   dim3 grid(oi::cdiv(n, F3_TILE), B), block(64 * F3_WAVES);
   auto k = sdf_mlp_full3_kernel<FAST>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS);
-  hipLaunchKernelGGL(k, grid, block, F3_LDS, st, pts, pk, gamma, beta, sdf, grad, rgb, feat, scratch, n);
+  char* blob = scratch + full3_slot_bytes(B, n);   // behind the feature slots
+#if OI_F3_BLOB
+  hipLaunchKernelGGL(film_blob_f3_kernel, dim3(B), dim3(256), 0, st, pk, gamma, beta, blob);
+#endif
+  hipLaunchKernelGGL(k, grid, block, F3_LDS, st, pts, pk, gamma, beta, sdf, grad, rgb, feat, scratch, blob, n);
   return oi::check_launch("oi_sdf_mlp_fwd(full3)");
 }
 
@@ -891,9 +967,8 @@ int launch_full3(const float* pts, const char* pk, const float* gamma, const flo
 
 namespace oimlp {
 
-size_t full3_scratch_bytes(int B, long long n_per_elem) {
-  const long long wgs = (long long)B * oi::cdiv(n_per_elem, F3_TILE);
-  return (size_t)(wgs > F3_WG_SLOTS ? F3_CU_SLOTS : wgs) * F3_WAVES * 16384;
+size_t full3_scratch_bytes(int B, long long n_per_elem) {   // feature slots + the per-element blobs
+  return full3_slot_bytes(B, n_per_elem) + (size_t)B * F3_BLOB;
 }
 
 int launch_full3_f16x3(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf,
