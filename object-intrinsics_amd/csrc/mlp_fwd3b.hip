@@ -17,6 +17,13 @@
 //  * 32 KiB images: a FOUR-slot LDS ring, three images in flight (a layer lasts ~0.6 us, an LDS-DMA round trip ~1 us).
 //  * Every layer product is formed output block by output block; the FiLM / sin / cos (or cos-multiply) work of block
 //    t-1 is issued between block t's MFMAs.  The first MFMA of a block takes an inline-constant zero accumulator.
+//
+// Two kernels share the machinery above:
+//   sdf_mlp_full3p_kernel (round 5, the default)   per-element images diag(gamma) W built once per call by film_images_b_kernel
+//                                                   (the accumulator IS the phase: no FiLM arithmetic in the epilogues) and a
+//                                                   per-element table blob fetched by LDS-DMA -- see the section further down;
+//   sdf_mlp_full3b_kernel (round 4)                 shared bf16(W) images + FiLM rows staged per tile; kept behind the run-time
+//                                                   switch OI_BF16_PRESCALE=0 as the same-box A/B reference of the former.
 #include <type_traits>
 
 #include "mlp_common.h"
