@@ -24,6 +24,7 @@
 //                                                   per-element table blob fetched by LDS-DMA -- see the section further down;
 //   sdf_mlp_full3b_kernel (round 4)                 shared bf16(W) images + FiLM rows staged per tile; kept behind the run-time
 //                                                   switch OI_BF16_PRESCALE=0 as the same-box A/B reference of the former.
+#include <algorithm>
 #include <type_traits>
 
 #include "mlp_common.h"
@@ -895,6 +896,12 @@ sdf_mlp_full3p_kernel(const float* __restrict__ pts, const char* __restrict__ pa
   const int h = lane >> 5, j = lane & 31;
   const int e = blockIdx.y;
   (void)packed;  // (everything per element comes from the builder's blob)
+  // PERSISTENT workgroups (OI_B3P_PERSIST, launch_full3p): a workgroup walks tiles blockIdx.x, + gridDim.x, ... of its batch
+  // element.  The table blob is fetched once, and the image ring keeps turning across tiles: the last three layers of a tile
+  // request images 0..2 of the next one (ring position 15 k + p of tile k: `rb` = 15 k mod 4 shifts the slots).
+  const int ntiles = (int)((n_per_elem + B3_TILE - 1) / B3_TILE);
+  int tile = blockIdx.x;
+  int rb = 0;
 
   LaneOff o;
   o.h16 = 16 * h;
@@ -906,37 +913,39 @@ sdf_mlp_full3p_kernel(const float* __restrict__ pts, const char* __restrict__ pa
   auto point_of = [&](bool& valid) {
     int jj = lane & 31;
     asm volatile("" : "+v"(jj));
-    const long long local = (long long)blockIdx.x * B3_TILE + wave * WAVE_PTS + jj;
+    const long long local = (long long)tile * B3_TILE + wave * WAVE_PTS + jj;
     valid = local < n_per_elem;
     return (long long)e * n_per_elem + (valid ? local : n_per_elem - 1);
   };
 
   __amdgpu_buffer_rsrc_t feat_rs;
-  int feat_off;
-  {
-    const long long base_pt = (long long)e * n_per_elem + (long long)blockIdx.x * B3_TILE + wave * WAVE_PTS;
-    const long long left = n_per_elem - ((long long)blockIdx.x * B3_TILE + wave * WAVE_PTS);
+  const int feat_off = j * C * 4 + 16 * h;
+  auto set_feat_rs = [&]() {
+    const long long base_pt = (long long)e * n_per_elem + (long long)tile * B3_TILE + wave * WAVE_PTS;
+    const long long left = n_per_elem - ((long long)tile * B3_TILE + wave * WAVE_PTS);
     const int npts = feat_out == nullptr ? 0 : (left >= WAVE_PTS ? WAVE_PTS : (left > 0 ? (int)left : 0));
     feat_rs = __builtin_amdgcn_make_buffer_rsrc(feat_out + base_pt * C, 0, npts * C * 4, 0x00020000);
-    feat_off = j * C * 4 + 16 * h;
-  }
+  };
 
   const __amdgpu_buffer_rsrc_t img_rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(fimg + (size_t)e * P_ELEM_BYTES), 0, (int)P_ELEM_BYTES, 0x00020000);
+  // image (pos mod 15) of this or the next tile -> ring slot (pos + rb) & 3
   auto prefetch = [&](int pos) {
+    const int img = pos < NIMG_P ? pos : pos - NIMG_P;
+    const int slot = (pos + rb) & (B3_NSLOT - 1);
 #pragma unroll
     for (int q = 0; q < LBB / 4096 / B3_WAVES; ++q) {
       const int c = (wave * (LBB / 4096 / B3_WAVES) + q) * 4096;
-      auto* dst = (__attribute__((address_space(3))) void*)(lds + P_WBUF + (pos & (B3_NSLOT - 1)) * LBB + c);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, pos * LBB + c, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, pos * LBB + c, 1024, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, pos * LBB + c, 2048, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, pos * LBB + c, 3072, 0);
+      auto* dst = (__attribute__((address_space(3))) void*)(lds + P_WBUF + slot * LBB + c);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, img * LBB + c, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, img * LBB + c, 1024, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, img * LBB + c, 2048, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rs, dst, 16, o.l16, img * LBB + c, 3072, 0);
     }
   };
   constexpr int DMA_PER_IMAGE = LBB / 1024 / B3_WAVES;
   auto lay = [&](int pos) {
-    int b = o.l16 + P_WBUF + (pos & (B3_NSLOT - 1)) * LBB;
+    int b = o.l16 + P_WBUF + ((pos + rb) & (B3_NSLOT - 1)) * LBB;
     asm volatile("" : "+v"(b));
     return b;
   };
@@ -960,6 +969,7 @@ sdf_mlp_full3p_kernel(const float* __restrict__ pts, const char* __restrict__ pa
   prefetch(1);
   prefetch(2);
   ring_sync_b<3 * DMA_PER_IMAGE>();  // point + tables landed (the three images may still be in flight), visible to every wave
+  int tiles_done = 0;
 
 #ifdef OI_B3_PROF
   unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1037,6 +1047,20 @@ sdf_mlp_full3p_kernel(const float* __restrict__ pts, const char* __restrict__ pa
   const int F0 = film_base(0), F1 = film_base(1), F2 = film_base(2), F3 = film_base(3), F4 = film_base(4),
             F5 = film_base(5), F6 = film_base(6), F7 = film_base(7), F8 = film_base(8);
 
+  for (;;) {  // ---- one tile per trip
+  set_feat_rs();
+  sdf_part = 0.f;
+  // the next tile's point is requested now and used a tile later (a clamped re-read of this one on the last trip)
+  float nx, ny, nz;
+  const int ntile = tile + (int)gridDim.x;
+  {
+    const int keep = tile;
+    if (ntile < ntiles) tile = ntile;
+    bool v_;
+    const long long pn = point_of(v_);
+    nx = pts[pn * 3 + 0], ny = pts[pn * 3 + 1], nz = pts[pn * 3 + 2];
+    tile = keep;
+  }
   // ================= forward, layers 0..7 =================
   {  // layer 0 (K = 3): one MFMA per output block on top of the B2 row, then the ordinary forward epilogue
     const bf16x8 bp = frag3_b(px, py, pz);
@@ -1163,13 +1187,15 @@ sdf_mlp_full3p_kernel(const float* __restrict__ pts, const char* __restrict__ pa
   auto r3 = OI_REV_EPI_P(P2, AH);
   stream_layer_b(lds, lay(11), BH, acc, r4, r3);
   B3_T(1);
-  ring_sync_b<2 * DMA_PER_IMAGE>();  // image 12 resident; 13 and 14 in flight, nothing more to request
+  ring_sync_b<2 * DMA_PER_IMAGE>();  // image 12 resident; 13 and 14 in flight
   B3_T(2);
+  prefetch(15);                      // the next tile's image 0 (requested again, unused, on a workgroup's last trip)
   auto r2 = OI_REV_EPI_P(P1, BH);   // V'1 = g2 * cos(phi1)
   stream_layer_b(lds, lay(12), AH, acc, r3, r2);
   B3_T(1);
-  ring_sync_b<DMA_PER_IMAGE>();      // image 13 resident
+  ring_sync_b<2 * DMA_PER_IMAGE>();  // image 13 resident
   B3_T(2);
+  prefetch(16);
   // transposed layer 1: V'0 = g1 * cos(phi0) as limbs; then d sdf/dx = (diag(gamma_0) W0)^T V'0 (K = 128 -> 3 rows) as eight
   // MFMAs against the small image
   auto r1 = OI_REV_EPI_P(P0, AH);
@@ -1201,8 +1227,9 @@ sdf_mlp_full3p_kernel(const float* __restrict__ pts, const char* __restrict__ pa
   {
     // ---- albedo head: sigmoid(Wrgb sin(gv * (Wv [feat, grad] + bv) + bv') + brgb)   (fields.py:89-101)
     acc[0] = initrows(F8, 0);
-    ring_sync_b<0>();  // image 14 resident
+    ring_sync_b<2 * DMA_PER_IMAGE>();  // image 14 resident (the next tile's images 0 and 1 and this tile's gradient stores are younger)
   B3_T(2);
+    prefetch(17);
     float r0 = 0.f, r1c = 0.f, r2c = 0.f;
     // the head's three gradient columns (rows of TABV x gamma_v / 2pi) are a ninth MFMA of every output block; its activations
     // sin(phi_v) go on as bf16 limbs (AH: free) and rgb = Wrgb sin(phi_v) is eight MFMAs against the second small image
@@ -1233,13 +1260,20 @@ sdf_mlp_full3p_kernel(const float* __restrict__ pts, const char* __restrict__ pa
       rgb_out[pt * 3 + 2] = oi::sigmoidf_(r2c + brgb[2]);
     }
   }
+  ++tiles_done;
+  if (ntile >= ntiles) break;
+  tile = ntile;
+  rb = (rb + NIMG_P) & (B3_NSLOT - 1);
+  px = nx, py = ny, pz = nz;
+  }  // tiles
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the three images requested for a tile that does not exist
 #ifdef OI_B3_PROF
   B3_T(5);
   if (lane == 0) {
     unsigned long long* pr = oi_prof3b[(blockIdx.x * 4 + wave) & 1023];
     for (int i = 0; i < 6; ++i) atomicAdd(&pr[i], pacc[i]);
     atomicAdd(&pr[6], __builtin_readcyclecounter() - tstart);
-    atomicAdd(&pr[7], 1ull);
+    atomicAdd(&pr[7], (unsigned long long)tiles_done);
     atomicAdd(&pr[8], __builtin_readcyclecounter() - t_entry);  // with [9]: the shader clock in the kernel
     atomicAdd(&pr[9], __builtin_amdgcn_s_memrealtime() - rt_entry);
   }
@@ -1256,7 +1290,19 @@ int launch_full3p(const float* pts, const char* pk, const float* gamma, const fl
                   float* rgb, float* feat, void* scratch, int B, long long n, hipStream_t st) {
   char* fimg = reinterpret_cast<char*>(scratch);
   hipLaunchKernelGGL(film_images_b_kernel, dim3(C * C / 8 / 256, NIMG_P + 1, B), dim3(256), 0, st, pk, gamma, beta, fimg);
-  dim3 grid(oi::cdiv(n, B3_TILE), B), block(64 * B3_WAVES);
+  // persistent workgroups: as many as the device runs at once (one per CU: the LDS), each walks its share of the tiles;
+  // OI_B3P_PERSIST=0 (environment): one workgroup per tile, the same kernel (A/B switch)
+  static const int per_dev = [] {
+    const char* v = getenv("OI_B3P_PERSIST");
+    if (v && v[0] == '0') return 0;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+  }();
+  const int tiles = oi::cdiv(n, B3_TILE);
+  const int gx = per_dev > 0 ? std::min(tiles, std::max(1, per_dev / B)) : tiles;
+  dim3 grid(gx, B), block(64 * B3_WAVES);
   auto k = sdf_mlp_full3p_kernel<FAST>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
   hipLaunchKernelGGL(k, grid, block, P_LDS, st, pts, pk, fimg, gamma, beta, sdf, grad, rgb, feat, n);
