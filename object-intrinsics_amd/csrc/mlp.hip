@@ -22,6 +22,8 @@
 //    sin/cos are always fp32.
 #include <cstdlib>
 
+#include <algorithm>
+
 #include "mlp_common.h"
 
 namespace {
@@ -540,9 +542,20 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   };
 
   constexpr int NW = NWV, NT = 64 * NW;
-  const long long local = (long long)blockIdx.x * (NW * WAVE_PTS) + wave * WAVE_PTS + j;
-  const bool valid = local < n_per_elem;
-  const long long pt = (long long)e * n_per_elem + (valid ? local : n_per_elem - 1);
+  // PERSISTENT workgroups for the sdf-only passes (round 5; launch_mlp_variant sizes the grid): a workgroup walks tiles
+  // blockIdx.x, + gridDim.x, ... of its batch element -- tables and FiLM rows are staged once instead of once per tile, the
+  // last layer of a tile requests image 0 of the next one (7 images on a two-slot ring: `rb` swaps the slots per tile).
+  constexpr bool PERSIST = !FULL && RING2;
+  const int ntiles = (int)((n_per_elem + NW * WAVE_PTS - 1) / (NW * WAVE_PTS));
+  int tile = blockIdx.x, rb = 0;
+  bool valid;
+  long long pt;
+  auto set_point = [&](int t_) {
+    const long long local = (long long)t_ * (NW * WAVE_PTS) + wave * WAVE_PTS + j;
+    valid = local < n_per_elem;
+    pt = (long long)e * n_per_elem + (valid ? local : n_per_elem - 1);
+  };
+  set_point(tile);
 
   constexpr bool HALF_SCR = PREC == OI_PREC_BF16;
   constexpr int SLOT_B = HALF_SCR ? 8192 : 16384;
@@ -570,7 +583,7 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       film[l * 256 + C + f] = fmaf(gm, hdr[H_BIAS + l * C + f], beta[((size_t)e * 9 + l) * C + f]) * TO_REV;
     }
   }
-  const float px = pts[pt * 3 + 0], py = pts[pt * 3 + 1], pz = pts[pt * 3 + 2];
+  float px = pts[pt * 3 + 0], py = pts[pt * 3 + 1], pz = pts[pt * 3 + 2];
   __syncthreads();  // tables visible (image 0 still in flight)
 
   float act[64];
@@ -580,6 +593,14 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   unsigned long long tprev = __builtin_readcyclecounter();
   const unsigned long long tstart = tprev;
 #endif
+  for (;;) {  // ---- one tile per trip (exactly one unless PERSIST)
+  const int ntile = tile + (int)gridDim.x;
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  if constexpr (PERSIST) {  // the next tile's point, used a tile later (a clamped re-read of this one on the last trip)
+    set_point(ntile < ntiles ? ntile : tile);
+    nx = pts[pt * 3 + 0], ny = pts[pt * 3 + 1], nz = pts[pt * 3 + 2];
+    set_point(tile);
+  }
 
   // ---- layer 0 (K = 3) on the VALU, overlapping the first image's DMA
   {
@@ -594,9 +615,9 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
   for (int l = 1; l < NL_SDF; ++l) {
     const int i = l - 1;
     // next image: forward layer l+1, or the first transposed image (layer 7) / nothing for the sdf-only variant
-    const int next = (l < NL_SDF - 1) ? l : (FULL ? 13 : -1);  // image index, -1: none
-    if (next >= 0) stage_early(next, (i + 1) & 1);
-    const LayOff y = lay_off<PREC>(o, RING2 ? (i & 1) : 0, l);
+    const int next = (l < NL_SDF - 1) ? l : (FULL ? 13 : (PERSIST ? 0 : -1));  // image index, -1: none; PERSIST: the next tile's first
+    if (next >= 0) stage_early(next, ((i + 1) & 1) ^ rb);
+    const LayOff y = lay_off<PREC>(o, RING2 ? ((i & 1) ^ rb) : 0, l);
 #if OI_PIPE_FWD
     if constexpr (PREC == OI_PREC_F16X3 && RING2) {
       layer_fwd_pipelined<FAST, FULL, REV>(lds, o, y, acc, act, ws, l);
@@ -640,6 +661,13 @@ sdf_mlp_kernel(const float* __restrict__ pts, const char* __restrict__ packed, c
       *reinterpret_cast<f32x4*>(feat_out + pt * C + grp_f0(g) + 4 * h) = v;
     }
   }
+
+  if (!PERSIST || ntile >= ntiles) break;
+  tile = ntile;
+  rb ^= 1;
+  set_point(tile);
+  px = nx, py = ny, pz = nz;
+  }  // tiles
 
   if constexpr (FULL) {
     // park the features (slot 8) and start the reverse sweep with g8 = wsig
@@ -792,7 +820,19 @@ int launch_mlp_variant(const float* pts, const char* pk, const float* gamma, con
                        float* rgb, float* feat, char* scratch, int B, long long n, hipStream_t st) {
   constexpr int NWV = v2_waves(PREC, FULL);
   constexpr int LDS_BYTES = v2_lds_total(PREC, FULL);
-  dim3 grid(oi::cdiv(n, NWV * WAVE_PTS), B), block(64 * NWV);
+  // the sdf-only passes run persistent workgroups (one per CU: the LDS): as many as the device has CUs (/ B), each walks its
+  // share of the tiles; OI_V2_PERSIST=0 (environment): one workgroup per tile, the same kernel (A/B switch)
+  static const int per_dev = [] {
+    const char* v = getenv("OI_V2_PERSIST");
+    if (v && v[0] == '0') return 0;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+  }();
+  const int tiles = oi::cdiv(n, NWV * WAVE_PTS);
+  const bool persist = !FULL && v2_two_slots(PREC, FULL) && per_dev > 0;
+  dim3 grid(persist ? std::min(tiles, std::max(1, per_dev / B)) : tiles, B), block(64 * NWV);
   auto k = sdf_mlp_kernel<PREC, FAST, FULL>;
   // per launch: the attribute is per device, and a process may drive several
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
