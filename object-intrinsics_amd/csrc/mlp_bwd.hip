@@ -187,6 +187,43 @@ __device__ __forceinline__ f32x4 unpack16q(u32x2 d) {
   return f32x4{(float)(d[0] & 0xffffu) * S, (float)(d[0] >> 16) * S, (float)(d[1] & 0xffffu) * S, (float)(d[1] >> 16) * S};
 }
 
+// Round 5 (second half), f16x3 mode: the two slot families only the weight-gradient GEMM reads (S_V, S_U: 14 of the 29 slots a
+// sweep writes, 14 of the 28 the GEMM reads) as 24-bit FIXED point relative to a per-lane power-of-two scale (OI_BWD_XQ24).
+//   y = x * s + 1.5 with |x| s < 1/4 puts a value into ONE binade: its 23 mantissa bits are fixed point (2^-23 of 4 max|x|:
+//   2^-21 of the lane's largest value, the resolution of the GEMM's own fp16 hi + lo split), rounded to nearest by the FMA.
+//   The low three bytes of y are kept; four values = three dwords [a0 a1 a2 d0] [b0 b1 b2 d1] [c0 c1 c2 d2]: 4 FMA + 3 v_perm to
+//   pack (the round-4 float24 format: 4 adds + 3 v_perm), 3 v_and_or + 3 to unpack, and the de-scaling rides on the multiply by
+//   the launch-wide scale the GEMM applies anyway (x * scx = y * k - 1.5 k, k = scx / s).  The lane's 1 / s sits behind the 16
+//   groups of the slot (byte 12,288 + 4 lane).  The lane maximum exists before the first store because the down sweep stores
+//   v / phibar AFTER its epilogue (OI_BWD_STORES_LAST): one v_max3 per two values, then reused for the launch-wide maxima.
+#ifndef OI_BWD_XQ24
+#define OI_BWD_XQ24 1
+#endif
+constexpr int XQ_SCALE_OFF = 16 * 768;  // byte offset of the per-lane inverse scales inside a slot
+__device__ __forceinline__ u32x3 pack_q24(f32x4 v, float s) {
+  const float y0 = fmaf(v[0], s, 1.5f), y1 = fmaf(v[1], s, 1.5f), y2 = fmaf(v[2], s, 1.5f), y3 = fmaf(v[3], s, 1.5f);
+  const unsigned a = __builtin_bit_cast(unsigned, y0), b = __builtin_bit_cast(unsigned, y1);
+  const unsigned c = __builtin_bit_cast(unsigned, y2), d = __builtin_bit_cast(unsigned, y3);
+  return u32x3{__builtin_amdgcn_perm(d, a, 0x04020100u), __builtin_amdgcn_perm(d, b, 0x05020100u),
+               __builtin_amdgcn_perm(d, c, 0x06020100u)};
+}
+// -> the four y in [1.25, 1.75] (the caller applies x = (y - 1.5) / s together with its own scale)
+__device__ __forceinline__ f32x4 unpack_q24(u32x3 q) {
+  const unsigned a = (q[0] & 0x00ffffffu) | 0x3f000000u, b = (q[1] & 0x00ffffffu) | 0x3f000000u;
+  const unsigned c = (q[2] & 0x00ffffffu) | 0x3f000000u;
+  const unsigned t = __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0703u);            // [q0.3 q1.3 0 0]
+  const unsigned d = __builtin_amdgcn_perm(q[2], t, 0x0c070100u) | 0x3f000000u;  // [q0.3 q1.3 q2.3 3f]
+  return f32x4{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b), __builtin_bit_cast(float, c),
+               __builtin_bit_cast(float, d)};
+}
+// s with max|x| * s < 1/4 (mx < 2^(E - 126) for the biased exponent E of mx) and its inverse, both exact powers of two
+__device__ __forceinline__ void q24_scale(float mx, float& s, float& inv_s) {
+  int E = (__builtin_bit_cast(int, mx) >> 23) & 0xff;
+  E = E > 250 ? 250 : E;
+  s = __builtin_bit_cast(float, (251 - E) << 23);
+  inv_s = __builtin_bit_cast(float, (E + 3) << 23);
+}
+
 // PACK: 0 = fp32 slots (16 bytes per lane and group), 1 = 24-bit (12), 2 = 16-bit (8)
 template <int PACK>
 struct WaveScratchT {
@@ -475,6 +512,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   // (24-bit: accurate trig only -- fast trig parks unreduced phases; the 16-bit format reduces them as it packs)
   constexpr int PK = (OI_BWD_PACK16 && OI_WGRAD_BF16 && PREC == OI_PREC_BF16) ? 2 : ((OI_BWD_PACK24 && PREC == OI_PREC_F16X3 && !FAST) ? 1 : 0);
   WaveScratchT<PK> ws;
+  constexpr bool XQ = OI_BWD_XQ24 && PK == 0 && PREC == OI_PREC_F16X3 && OI_BWD_STORES_LAST;  // S_V / S_U as 24-bit fixed point
   ws.l12 = (PK == 2 ? 8 : 12) * lane;
   asm volatile("" : "+v"(ws.l12));
   {
@@ -950,15 +988,36 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       }
     }
     if (l >= 1) store_flm(fr, (l - 1) & 1);  // FiLM slot of layer l + 1: free since this layer's barrier
+    [[maybe_unused]] float mxq_v = 0.f, mxq_u = 0.f;  // lane maxima of the parked vectors (XQ: taken at the stores, reused below)
 #if OI_BWD_STORES_LAST
     // v_l / ubar_l leave AFTER the next layer's phi / vbar have been requested: the vector memory pipe is one in-order
     // queue per wave, and a load issued behind two 1 KiB stores waited for their data to drain first (phase profile: the
     // reloads cost 100k of 470k ticks per tile, 67k of them gone when the stores are removed)
     if constexpr (!L0 && !(OI_BWD_ABL & 1)) {
+      if constexpr (XQ) {
+        auto store_q = [&](int slot, const float (&v)[64], float& mx) {
+          mx = 0.f;
+#pragma unroll
+          for (int k = 0; k < 64; k += 2) mx = fmaxf(mx, fmaxf(fabsf(v[k]), fabsf(v[k + 1])));
+          float sq, inv_sq;
+          q24_scale(mx, sq, inv_sq);
+          const int l12 = 12 * lane;
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            const u32x3 q = pack_q24(f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}, sq);
+            __builtin_amdgcn_raw_buffer_store_b96(q, ws.rs, l12 + (slot * 16384 + g * 768), 0, OI_BWD_ST_WGRAD);
+          }
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, inv_sq), ws.rs,
+                                                4 * lane + (slot * 16384 + XQ_SCALE_OFF), 0, OI_BWD_ST_WGRAD);
+        };
+        store_q(S_V + l - 1, gb, mxq_v);
+        store_q(S_U + l - 1, act, mxq_u);
+      } else {
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         ws.template store<OI_BWD_ST_WGRAD>(S_V + l - 1, g, o.l16, f32x4{gb[4 * g], gb[4 * g + 1], gb[4 * g + 2], gb[4 * g + 3]});
         ws.template store<OI_BWD_ST_WGRAD>(S_U + l - 1, g, o.l16, f32x4{act[4 * g], act[4 * g + 1], act[4 * g + 2], act[4 * g + 3]});
+      }
       }
     }
 #endif
@@ -966,14 +1025,14 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     if constexpr (!L0) {
       // the point vectors hold v_l / gamma_l and phibar_l (what was parked); the products want v_l and ubar_l = gamma_l phibar_l.
       // The launch-wide maxima the weight-gradient GEMM scales its operands with are those of the PARKED vectors.
-      auto times_gamma = [&](float (&v)[64], int om_slot) {
-        float mx = 0.f;
+      auto times_gamma = [&](float (&v)[64], int om_slot, [[maybe_unused]] float mx_known) {
+        float mx = (XQ && !(OI_BWD_ABL & 1)) ? mx_known : 0.f;
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
           const f32x4 gm = lds_f4(lds, L_FILM + grp_f0(g) * 4, ol.h16);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            if constexpr (SC) mx = fmaxf(mx, fabsf(v[4 * g + k]));
+            if constexpr (SC && !(XQ && !(OI_BWD_ABL & 1))) mx = fmaxf(mx, fabsf(v[4 * g + k]));
             v[4 * g + k] *= gm[k];
             asm volatile("" : "+v"(v[4 * g + k]));  // (pins the group: see the epilogue above)
           }
@@ -982,7 +1041,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         if constexpr (SC) publish_max(op_max, om_slot, mx);  // (at once: nothing scalar stays live across the next product)
       };
       const float inv_t = SC ? hdr[H_WSCALE + 7 + l - 1] : 1.f;
-      times_gamma(gb, OM_V + l - 1);
+      times_gamma(gb, OM_V + l - 1, mxq_v);
       acc_zero(acc);
       BW_T(9);
       const float f1 = gemm2<PREC, true>(lds, ol, gb, acc, inv_t);   // g_l = W_l^T v_l
@@ -990,7 +1049,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gb[16 * t + r] = SC ? acc[t][r] * f1 : acc[t][r];
-      times_gamma(act, OM_U + l - 1);
+      times_gamma(act, OM_U + l - 1, mxq_u);
       acc_zero(acc);
       const float f2 = gemm2<PREC, true>(lds, ol, act, acc, inv_t);  // abar_l = W_l^T ubar_l
 #pragma unroll
@@ -1345,9 +1404,14 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
   constexpr int PK = BF ? (OI_BWD_PACK16 ? 2 : 0) : ((OI_BWD_PACK24 && !FAST) ? 1 : 0);
   using WS = WaveScratchT<PK>;
   using Frag = typename WS::Frag;
+  // X slots of the layer matrices (S_V, S_U) as 24-bit fixed point + a per-lane scale (see OI_BWD_XQ24; the sweep's condition)
+  constexpr bool XQ = OI_BWD_XQ24 && PK == 0 && !BF && !COL && OI_BWD_STORES_LAST;
+  using XFrag = std::conditional_t<XQ, u32x3, Frag>;
   struct Stage {  // the five slots of one wave tile as they arrive: 80 registers (48 for the colour head); 60 (36) packed
-    Frag xall[2][4], ph4[4], vb4[4];
+    XFrag xall[2][4];
+    Frag ph4[4], vb4[4];
     f32x4 pt[2];  // FIRST: the point and dL/dgrad of this thread's lane (raw fp32)
+    float xinv[2];  // XQ: 1 / s of this thread's lane of the two X slots
   };
   Stage stA, stB;
   // through a buffer descriptor over the wave tile (512 KiB): the tile base and the slot offsets travel in SGPRs, the lane
@@ -1362,14 +1426,24 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
       else return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, t16, slot * 16384 + it * 4096,
                                                                                   OI_WGRAD_NT ? 2 : 0));
     };
+    auto ldx = [&](int slot, int it) -> XFrag {
+      if constexpr (XQ) return __builtin_amdgcn_raw_buffer_load_b96(rs, tid * 12, slot * 16384 + it * 3072, OI_WGRAD_NT ? 2 : 0);
+      else return ld(slot, it);
+    };
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       if constexpr (!FIRST) st.ph4[it] = ld(S_PHI + m, it);
-      st.xall[0][it] = ld(COL ? S_UV : S_V + m, it);
+      st.xall[0][it] = ldx(COL ? S_UV : S_V + m, it);
       if constexpr (!COL) {
         if constexpr (!FIRST) st.vb4[it] = ld(S_VB + m, it);  // gamma_{l-1} vbar_{l-1}
-        st.xall[1][it] = ld(S_U + m, it);
+        st.xall[1][it] = ldx(S_U + m, it);
       }
+    }
+    if constexpr (XQ) {
+      st.xinv[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * (tid & 63), (S_V + m) * 16384 + XQ_SCALE_OFF,
+                                                                                  OI_WGRAD_NT ? 2 : 0));
+      st.xinv[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * (tid & 63), (S_U + m) * 16384 + XQ_SCALE_OFF,
+                                                                                  OI_WGRAD_NT ? 2 : 0));
     }
     if constexpr (FIRST) {  // this thread's point (lane j = point j): (x y z .), (Gx Gy Gz .)
 #pragma unroll
@@ -1423,6 +1497,16 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
   unsigned long long wprev = __builtin_readcyclecounter();
   const unsigned long long wstart = wprev;
 #endif
+  // X fragment `it` of pair pr, times the launch-wide scale scx[pr]
+  auto xval = [&](const Stage& st, int pr, int it) -> f32x4 {
+    if constexpr (XQ) {
+      const float k = st.xinv[pr] * scx[pr], c = -1.5f * k;   // x scx = (y - 1.5) / s scx
+      const f32x4 y = unpack_q24(st.xall[pr][it]);
+      return f32x4{fmaf(y[0], k, c), fmaf(y[1], k, c), fmaf(y[2], k, c), fmaf(y[3], k, c)};
+    } else {
+      return WS::value(st.xall[pr][it]) * scx[pr];
+    }
+  };
   // one wave tile out of staging set `st`; the set is dead once pair 1 is staged, and the tile TWO ahead is requested into it
   auto tile = [&](long long wt, Stage& st) {
 #if OI_WG_ABL & 1  // timing ablation: the loads alone (streaming rate of this access pattern)
@@ -1432,8 +1516,8 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
       for (int it = 0; it < 4; ++it)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          z += (FIRST ? st.pt[it & 1][k] : WS::phase(st.ph4[it])[k]) + WS::value(st.xall[0][it])[k] +
-               (COL ? 0.f : (FIRST ? 0.f : WS::value(st.vb4[it])[k]) + WS::value(st.xall[1][it])[k]);
+          z += (FIRST ? st.pt[it & 1][k] : WS::phase(st.ph4[it])[k]) + xval(st, 0, it)[k] +
+               (COL ? 0.f : (FIRST ? 0.f : WS::value(st.vb4[it])[k]) + xval(st, 1, it)[k]);
       sub += z;
       __builtin_amdgcn_sched_barrier(0);
       if (wt + 2 < t_end) request(wt + 2, st);
@@ -1463,7 +1547,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
     for (int it = 0; it < 4; ++it) {
       const int q = it * 256 + tid;
       const int dq = q + (q >> 5);  // + 4 floats per 32-point block
-      reinterpret_cast<f32x4*>(sx)[dq] = WS::value(st.xall[0][it]) * scx[0];
+      reinterpret_cast<f32x4*>(sx)[dq] = xval(st, 0, it);
       reinterpret_cast<f32x4*>(sy)[dq] = y0[it];
     }
     WG_T(2);
@@ -1477,7 +1561,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
       for (int it = 0; it < 4; ++it) {
         const int q = it * 256 + tid;
         const int dq = q + (q >> 5);
-        reinterpret_cast<f32x4*>(sx)[dq] = WS::value(st.xall[1][it]) * scx[1];
+        reinterpret_cast<f32x4*>(sx)[dq] = xval(st, 1, it);
         f32x4 y1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) y1[k] = __builtin_amdgcn_sinf(ph4[it][k]) * scy[1];
