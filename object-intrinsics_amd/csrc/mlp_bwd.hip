@@ -207,14 +207,28 @@ __device__ __forceinline__ u32x3 pack_q24(f32x4 v, float s) {
   return u32x3{__builtin_amdgcn_perm(d, a, 0x04020100u), __builtin_amdgcn_perm(d, b, 0x05020100u),
                __builtin_amdgcn_perm(d, c, 0x06020100u)};
 }
-// -> the four y in [1.25, 1.75] (the caller applies x = (y - 1.5) / s together with its own scale)
+// -> the four y in [1.25, 1.75] (the caller applies x = (y - 1.5) / s together with its own scale).  The exponent's lowest bit is
+// OR-ed in with the upper ones (0x3f800000, not 0x3f000000): a PHASE within 2^-24 of 1 rounds to y = 2.0, whose low 24 bits are
+// zero -- it then decodes to 1.0 = phase 0, the same angle (with 0x3f000000 it decoded to 0.5: half a revolution off, ~30 values
+// per 524,288-point backward, 1e-2 in the weight gradients they hit)
 __device__ __forceinline__ f32x4 unpack_q24(u32x3 q) {
-  const unsigned a = (q[0] & 0x00ffffffu) | 0x3f000000u, b = (q[1] & 0x00ffffffu) | 0x3f000000u;
-  const unsigned c = (q[2] & 0x00ffffffu) | 0x3f000000u;
+  const unsigned a = (q[0] & 0x00ffffffu) | 0x3f800000u, b = (q[1] & 0x00ffffffu) | 0x3f800000u;
+  const unsigned c = (q[2] & 0x00ffffffu) | 0x3f800000u;
   const unsigned t = __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0703u);            // [q0.3 q1.3 0 0]
-  const unsigned d = __builtin_amdgcn_perm(q[2], t, 0x0c070100u) | 0x3f000000u;  // [q0.3 q1.3 q2.3 3f]
+  const unsigned d = __builtin_amdgcn_perm(q[2], t, 0x0c070100u) | 0x3f800000u;  // [q0.3 q1.3 q2.3 3f]
   return f32x4{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b), __builtin_bit_cast(float, c),
                __builtin_bit_cast(float, d)};
+}
+// OI_BWD_PHQ24: the phase slots the same way without a scale -- the parked phase is already reduced to [0, 1) revolutions, so
+// y = r + 1 is its 23-bit fixed-point form (2^-23 revolutions: 7.5e-7 rad), and v_sin / v_cos take y AS IT IS (the period is 1).
+#ifndef OI_BWD_PHQ24
+#define OI_BWD_PHQ24 1
+#endif
+__device__ __forceinline__ u32x3 pack_q24_phase(f32x4 r) {
+  const unsigned a = __builtin_bit_cast(unsigned, r[0] + 1.0f), b = __builtin_bit_cast(unsigned, r[1] + 1.0f);
+  const unsigned c = __builtin_bit_cast(unsigned, r[2] + 1.0f), d = __builtin_bit_cast(unsigned, r[3] + 1.0f);
+  return u32x3{__builtin_amdgcn_perm(d, a, 0x04020100u), __builtin_amdgcn_perm(d, b, 0x05020100u),
+               __builtin_amdgcn_perm(d, c, 0x06020100u)};
 }
 // s with max|x| * s < 1/4 (mx < 2^(E - 126) for the biased exponent E of mx) and its inverse, both exact powers of two
 __device__ __forceinline__ void q24_scale(float mx, float& s, float& inv_s) {
@@ -225,7 +239,7 @@ __device__ __forceinline__ void q24_scale(float mx, float& s, float& inv_s) {
 }
 
 // PACK: 0 = fp32 slots (16 bytes per lane and group), 1 = 24-bit (12), 2 = 16-bit (8)
-template <int PACK>
+template <int PACK, bool PHQ = false>
 struct WaveScratchT {
   __amdgpu_buffer_rsrc_t rs;
   int l12;  // 12 * lane (PACK 1) / 8 * lane (PACK 2)
@@ -245,7 +259,8 @@ struct WaveScratchT {
   }
   template <int AUX = OI_BWD_ST_LOCAL>
   __device__ __forceinline__ void store_phase(int slot, int g, int l16, f32x4 v) const {
-    if constexpr (PACK == 1) __builtin_amdgcn_raw_buffer_store_b96(pack24q(v), rs, l12 + (slot * 16384 + g * 768), 0, AUX);
+    if constexpr (PHQ) __builtin_amdgcn_raw_buffer_store_b96(pack_q24_phase(v), rs, l12 + (slot * 16384 + g * 768), 0, AUX);
+    else if constexpr (PACK == 1) __builtin_amdgcn_raw_buffer_store_b96(pack24q(v), rs, l12 + (slot * 16384 + g * 768), 0, AUX);
     else if constexpr (PACK == 2) __builtin_amdgcn_raw_buffer_store_b64(pack16q(v), rs, l12 + (slot * 16384 + g * 512), 0, AUX);
     else oi::buffer_store_b128<AUX>(__builtin_bit_cast(u32x4, v), rs, l16, slot * 16384 + g * 1024);
   }
@@ -263,6 +278,16 @@ struct WaveScratchT {
   }
   static __device__ __forceinline__ f32x4 phase(const Frag& f) {
     if constexpr (PACK == 1) return unpack24q(f); else if constexpr (PACK == 2) return unpack16q(f); else return f;
+  }
+  // phase slots under PHQ: three dwords per four values, whatever the other slots are
+  using PFrag = std::conditional_t<PHQ, u32x3, Frag>;
+  template <int AUX = OI_BWD_LD_LAST>
+  __device__ __forceinline__ PFrag load_phase(int slot, int g, int l16) const {
+    if constexpr (PHQ) return __builtin_amdgcn_raw_buffer_load_b96(rs, l12, slot * 16384 + g * 768, AUX);
+    else return load<AUX>(slot, g, l16);
+  }
+  static __device__ __forceinline__ f32x4 phase_of(const PFrag& f) {   // (PHQ: phase + 1, which is what the trig wants anyway)
+    if constexpr (PHQ) return unpack_q24(f); else return phase(f);
   }
 };
 
@@ -511,7 +536,8 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 
   // (24-bit: accurate trig only -- fast trig parks unreduced phases; the 16-bit format reduces them as it packs)
   constexpr int PK = (OI_BWD_PACK16 && OI_WGRAD_BF16 && PREC == OI_PREC_BF16) ? 2 : ((OI_BWD_PACK24 && PREC == OI_PREC_F16X3 && !FAST) ? 1 : 0);
-  WaveScratchT<PK> ws;
+  constexpr bool PHQ = OI_BWD_PHQ24 && PK == 0 && PREC == OI_PREC_F16X3 && !FAST;   // phase slots as 24-bit fixed point
+  WaveScratchT<PK, PHQ> ws;
   constexpr bool XQ = OI_BWD_XQ24 && PK == 0 && PREC == OI_PREC_F16X3 && OI_BWD_STORES_LAST;  // S_V / S_U as 24-bit fixed point
   ws.l12 = (PK == 2 ? 8 : 12) * lane;
   asm volatile("" : "+v"(ws.l12));
@@ -849,13 +875,15 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   // (a ring of PF groups: with 512 registers a whole layer, PF = 16, is in flight across the two products)
   constexpr int PF = PREC == OI_PREC_F32 ? OI_BWD_PF_F32 : OI_BWD_PF, CARRY = OI_BWD_CARRY;
   static_assert(PF >= 1 && PF <= 16 && (PF & (PF - 1)) == 0 && CARRY >= 1 && CARRY <= PF, "OI_BWD_PF / OI_BWD_CARRY");
-  using Frag = typename WaveScratchT<PK>::Frag;
-  Frag phn[PF], vbn[PF];
+  using Frag = typename WaveScratchT<PK, PHQ>::Frag;
+  using PFrag = typename WaveScratchT<PK, PHQ>::PFrag;
+  PFrag phn[PF];
+  Frag vbn[PF];   // (the top layer, whose phi_7 / vbar_7 travel in the point vectors, uses vbn for the colour head's slot S_AC)
   f32x4 abl_sink;  // (OI_BWD_ABL & 8)
   constexpr int PFT = PF < 4 ? PF : 4;  // ring depth of the top layer (its point vectors carry phi_7 / vbar_7 as well)
 #if !OI_BWD_AC_REGS
 #pragma unroll
-  for (int g = 0; g < PFT; ++g) phn[g] = ws.load(S_AC, g, o.l16);  // (no colour head: never written, never used)
+  for (int g = 0; g < PFT; ++g) vbn[g] = ws.load(S_AC, g, o.l16);  // (no colour head: never written, never used)
 #endif
   BW_T(6);
   // layer 0 is peeled (its extra d W0 rows and missing products are compile-time): no branch inside the unrolled epilogue
@@ -873,7 +901,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     if constexpr (!L0 && !TOP && CARRY < PF && !(OI_BWD_ABL & 2)) {  // groups 0 .. CARRY-1 travelled under the products; fill the ring
 #pragma unroll
       for (int g = CARRY; g < PF; ++g) {
-        phn[g] = ws.load(S_PHI + l, g, o.l16);
+        phn[g] = ws.load_phase(S_PHI + l, g, o.l16);
         vbn[g] = ws.load(S_VB + l, g, o.l16);
       }
     }
@@ -907,7 +935,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           ph = f32x4{act[4 * g], act[4 * g + 1], act[4 * g + 2], act[4 * g + 3]};
           vb = f32x4{gb[4 * g], gb[4 * g + 1], gb[4 * g + 2], gb[4 * g + 3]};
         } else {
-          ph = ws.phase(phn[g & (PF - 1)]);
+          ph = ws.phase_of(phn[g & (PF - 1)]);
           vb = ws.value(vbn[g & (PF - 1)]);
         }
         f32x4 gnx, abx;  // g_{l+1}, abar_{l+1}
@@ -916,7 +944,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #if OI_BWD_AC_REGS
           const f32x4 a8 = {ac[4 * g], ac[4 * g + 1], ac[4 * g + 2], ac[4 * g + 3]};
 #else
-          const f32x4 a8 = ws.value(phn[g & (PFT - 1)]);
+          const f32x4 a8 = ws.value(vbn[g & (PFT - 1)]);
 #endif
 #pragma unroll
           for (int k = 0; k < 4; ++k) abx[k] = (has_col || GFEAT) ? fmaf(gs, gnx[k], a8[k]) : gs * gnx[k];  // abar_8
@@ -953,16 +981,16 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           // ring slot g & (PF - 1) next holds group g + PF of this layer, or group g + PF - 16 of the layer below
           if constexpr (TOP) {
 #if !OI_BWD_AC_REGS
-            if (g + PFT < 16) phn[g & (PFT - 1)] = ws.load(S_AC, g + PFT, o.l16);
+            if (g + PFT < 16) vbn[g & (PFT - 1)] = ws.load(S_AC, g + PFT, o.l16);
 #endif
           } else if (!L0 && g + PF < 16) {
-            phn[g & (PF - 1)] = ws.load(S_PHI + l, g + PF, o.l16);
+            phn[g & (PF - 1)] = ws.load_phase(S_PHI + l, g + PF, o.l16);
             vbn[g & (PF - 1)] = ws.load(S_VB + l, g + PF, o.l16);
           } else if constexpr (!L0) {
             // (layer 1 requests CARRY groups of the un-parked layer 0 as well: nobody reads them, and a run-time test of `l`
             // here splits the unrolled epilogue into blocks the register allocator handles badly -- 220 spilled registers)
             if (g + PF - 16 < CARRY) {
-              phn[g & (PF - 1)] = ws.load(S_PHI + l - 1, g + PF - 16, o.l16);
+              phn[g & (PF - 1)] = ws.load_phase(S_PHI + l - 1, g + PF - 16, o.l16);
               vbn[g & (PF - 1)] = ws.load(S_VB + l - 1, g + PF - 16, o.l16);
             }
           }
@@ -1060,7 +1088,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     if constexpr (TOP && !(OI_BWD_ABL & 2)) {  // (the top layer's products run at the register limit: its successor's first
 #pragma unroll                                 // groups are requested after them, not under them)
       for (int q = 0; q < CARRY; ++q) {
-        phn[q] = ws.load(S_PHI + l - 1, q, o.l16);
+        phn[q] = ws.load_phase(S_PHI + l - 1, q, o.l16);
         vbn[q] = ws.load(S_VB + l - 1, q, o.l16);
       }
     }
@@ -1402,14 +1430,17 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
   //   pair 0: Y = gbar_l = (gamma vbar)_{l-1} cos(phi_{l-1})      pair 1: Y = a_l = sin(phi_{l-1})
   // what the sweep parked (see WaveScratchT): 24-bit values -> 60 staging registers, 16-bit (bf16 mode) -> 40
   constexpr int PK = BF ? (OI_BWD_PACK16 ? 2 : 0) : ((OI_BWD_PACK24 && !FAST) ? 1 : 0);
-  using WS = WaveScratchT<PK>;
+  constexpr bool PHQ = OI_BWD_PHQ24 && PK == 0 && !BF && !FAST;   // (the sweep's condition)
+  using WS = WaveScratchT<PK, PHQ>;
   using Frag = typename WS::Frag;
+  using PFrag = typename WS::PFrag;
   // X slots of the layer matrices (S_V, S_U) as 24-bit fixed point + a per-lane scale (see OI_BWD_XQ24; the sweep's condition)
   constexpr bool XQ = OI_BWD_XQ24 && PK == 0 && !BF && !COL && OI_BWD_STORES_LAST;
   using XFrag = std::conditional_t<XQ, u32x3, Frag>;
   struct Stage {  // the five slots of one wave tile as they arrive: 80 registers (48 for the colour head); 60 (36) packed
     XFrag xall[2][4];
-    Frag ph4[4], vb4[4];
+    PFrag ph4[4];
+    Frag vb4[4];
     f32x4 pt[2];  // FIRST: the point and dL/dgrad of this thread's lane (raw fp32)
     float xinv[2];  // XQ: 1 / s of this thread's lane of the two X slots
   };
@@ -1432,7 +1463,10 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
     };
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      if constexpr (!FIRST) st.ph4[it] = ld(S_PHI + m, it);
+      if constexpr (!FIRST) {
+        if constexpr (PHQ) st.ph4[it] = __builtin_amdgcn_raw_buffer_load_b96(rs, tid * 12, (S_PHI + m) * 16384 + it * 3072, OI_WGRAD_NT ? 2 : 0);
+        else st.ph4[it] = ld(S_PHI + m, it);
+      }
       st.xall[0][it] = ldx(COL ? S_UV : S_V + m, it);
       if constexpr (!COL) {
         if constexpr (!FIRST) st.vb4[it] = ld(S_VB + m, it);  // gamma_{l-1} vbar_{l-1}
@@ -1516,7 +1550,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
       for (int it = 0; it < 4; ++it)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          z += (FIRST ? st.pt[it & 1][k] : WS::phase(st.ph4[it])[k]) + xval(st, 0, it)[k] +
+          z += (FIRST ? st.pt[it & 1][k] : WS::phase_of(st.ph4[it])[k]) + xval(st, 0, it)[k] +
                (COL ? 0.f : (FIRST ? 0.f : WS::value(st.vb4[it])[k]) + xval(st, 1, it)[k]);
       sub += z;
       __builtin_amdgcn_sched_barrier(0);
@@ -1533,7 +1567,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
       if constexpr (FIRST) {
         l0_phase_vb<FAST>(l0tab, st.pt[0], st.pt[1], grp_f0(4 * it + wave) + 4 * h, ph4[it], vb4);
       } else {
-        ph4[it] = WS::phase(st.ph4[it]);
+        ph4[it] = WS::phase_of(st.ph4[it]);
         if constexpr (!COL) vb4 = WS::value(st.vb4[it]);
       }
 #pragma unroll
