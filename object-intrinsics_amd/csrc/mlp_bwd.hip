@@ -230,6 +230,11 @@ __device__ __forceinline__ u32x3 pack_q24_phase(f32x4 r) {
   return u32x3{__builtin_amdgcn_perm(d, a, 0x04020100u), __builtin_amdgcn_perm(d, b, 0x05020100u),
                __builtin_amdgcn_perm(d, c, 0x06020100u)};
 }
+// OI_BWD_VBQ24: the gamma vbar slots (S_VB: written by the up sweep, read by the down sweep and by the GEMM) in the X-slot format;
+// the up sweep finishes the vector in its point registers, takes the lane maximum, then packs and stores
+#ifndef OI_BWD_VBQ24
+#define OI_BWD_VBQ24 1
+#endif
 // s with max|x| * s < 1/4 (mx < 2^(E - 126) for the biased exponent E of mx) and its inverse, both exact powers of two
 __device__ __forceinline__ void q24_scale(float mx, float& s, float& inv_s) {
   int E = (__builtin_bit_cast(int, mx) >> 23) & 0xff;
@@ -539,6 +544,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   constexpr bool PHQ = OI_BWD_PHQ24 && PK == 0 && PREC == OI_PREC_F16X3 && !FAST;   // phase slots as 24-bit fixed point
   WaveScratchT<PK, PHQ> ws;
   constexpr bool XQ = OI_BWD_XQ24 && PK == 0 && PREC == OI_PREC_F16X3 && OI_BWD_STORES_LAST;  // S_V / S_U as 24-bit fixed point
+  constexpr bool VBQ = OI_BWD_VBQ24 && PK == 0 && PREC == OI_PREC_F16X3;                      // S_VB likewise
   ws.l12 = (PK == 2 ? 8 : 12) * lane;
   asm volatile("" : "+v"(ws.l12));
   {
@@ -820,7 +826,22 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         v[k] = SC ? acc[g >> 2][4 * (g & 3) + k] * (fA * gm[k]) : acc[g >> 2][4 * (g & 3) + k] * gm[k];
         gb[4 * g + k] = v[k];
       }
-      if (!LAST && !(OI_BWD_ABL & 4)) ws.store(S_VB + l, g, o.l16, v);
+      if constexpr (!VBQ)
+        if (!LAST && !(OI_BWD_ABL & 4)) ws.store(S_VB + l, g, o.l16, v);
+    }
+    if constexpr (VBQ && !LAST && !(OI_BWD_ABL & 4)) {  // the vector is complete in gb: lane maximum, then pack and store
+      float mx = 0.f;
+#pragma unroll
+      for (int k = 0; k < 64; k += 2) mx = fmaxf(mx, fmaxf(fabsf(gb[k]), fabsf(gb[k + 1])));
+      float sq, inv_sq;
+      q24_scale(mx, sq, inv_sq);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const u32x3 q = pack_q24(f32x4{gb[4 * g], gb[4 * g + 1], gb[4 * g + 2], gb[4 * g + 3]}, sq);
+        __builtin_amdgcn_raw_buffer_store_b96(q, ws.rs, ws.l12 + ((S_VB + l) * 16384 + g * 768), 0, OI_BWD_ST_LOCAL);
+      }
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, inv_sq), ws.rs,
+                                            4 * lane + ((S_VB + l) * 16384 + XQ_SCALE_OFF), 0, OI_BWD_ST_LOCAL);
     }
     if constexpr (!LAST) store_flm(fr, (l + 1) & 1);  // FiLM slot of layer l - 1: free since this layer's barrier
     // phi_l / 2pi = G (W_img a_l) + B2 (image scale and bias folded into the staged rows) -> a_{l+1};
@@ -877,13 +898,25 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   static_assert(PF >= 1 && PF <= 16 && (PF & (PF - 1)) == 0 && CARRY >= 1 && CARRY <= PF, "OI_BWD_PF / OI_BWD_CARRY");
   using Frag = typename WaveScratchT<PK, PHQ>::Frag;
   using PFrag = typename WaveScratchT<PK, PHQ>::PFrag;
+  using VFrag = std::conditional_t<VBQ, u32x3, Frag>;
   PFrag phn[PF];
-  Frag vbn[PF];   // (the top layer, whose phi_7 / vbar_7 travel in the point vectors, uses vbn for the colour head's slot S_AC)
+  VFrag vbn[PF];
+  Frag acn[PF < 4 ? PF : 4];   // the colour head's slot S_AC, top layer only (the two rings above are idle there)
+  [[maybe_unused]] float vbinv_next = 1.f;   // VBQ: 1 / s of this lane's gamma vbar of the layer about to be swept
+  auto load_vb = [&](int slot, int g) -> VFrag {
+    if constexpr (VBQ) return __builtin_amdgcn_raw_buffer_load_b96(ws.rs, ws.l12, slot * 16384 + g * 768, OI_BWD_LD_LAST);
+    else return ws.load(slot, g, o.l16);
+  };
+  auto load_vb_scale = [&](int slot) {
+    if constexpr (VBQ)
+      vbinv_next = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ws.rs, 4 * lane, slot * 16384 + XQ_SCALE_OFF,
+                                                                                  OI_BWD_LD_LAST));
+  };
   f32x4 abl_sink;  // (OI_BWD_ABL & 8)
   constexpr int PFT = PF < 4 ? PF : 4;  // ring depth of the top layer (its point vectors carry phi_7 / vbar_7 as well)
 #if !OI_BWD_AC_REGS
 #pragma unroll
-  for (int g = 0; g < PFT; ++g) vbn[g] = ws.load(S_AC, g, o.l16);  // (no colour head: never written, never used)
+  for (int g = 0; g < PFT; ++g) acn[g] = ws.load(S_AC, g, o.l16);  // (no colour head: never written, never used)
 #endif
   BW_T(6);
   // layer 0 is peeled (its extra d W0 rows and missing products are compile-time): no branch inside the unrolled epilogue
@@ -898,11 +931,12 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       __syncthreads();
     }
     const FilmRegs fr = load_flm(l >= 1 ? l - 1 : 0);  // ahead of the image DMA (see film_load)
+    [[maybe_unused]] const float vbinv = vbinv_next;   // (requested with this layer's first ring groups, a layer ago)
     if constexpr (!L0 && !TOP && CARRY < PF && !(OI_BWD_ABL & 2)) {  // groups 0 .. CARRY-1 travelled under the products; fill the ring
 #pragma unroll
       for (int g = CARRY; g < PF; ++g) {
         phn[g] = ws.load_phase(S_PHI + l, g, o.l16);
-        vbn[g] = ws.load(S_VB + l, g, o.l16);
+        vbn[g] = load_vb(S_VB + l, g);
       }
     }
     if (l >= 2) stage_img(7 + l - 2, (l - 1) & 1);
@@ -936,7 +970,13 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           vb = f32x4{gb[4 * g], gb[4 * g + 1], gb[4 * g + 2], gb[4 * g + 3]};
         } else {
           ph = ws.phase_of(phn[g & (PF - 1)]);
-          vb = ws.value(vbn[g & (PF - 1)]);
+          if constexpr (VBQ) {
+            const f32x4 yv = unpack_q24(vbn[g & (PF - 1)]);
+            const float cq = -1.5f * vbinv;
+            vb = f32x4{fmaf(yv[0], vbinv, cq), fmaf(yv[1], vbinv, cq), fmaf(yv[2], vbinv, cq), fmaf(yv[3], vbinv, cq)};
+          } else {
+            vb = ws.value(vbn[g & (PF - 1)]);
+          }
         }
         f32x4 gnx, abx;  // g_{l+1}, abar_{l+1}
         if constexpr (TOP) {
@@ -944,7 +984,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #if OI_BWD_AC_REGS
           const f32x4 a8 = {ac[4 * g], ac[4 * g + 1], ac[4 * g + 2], ac[4 * g + 3]};
 #else
-          const f32x4 a8 = ws.value(vbn[g & (PFT - 1)]);
+          const f32x4 a8 = ws.value(acn[g & (PFT - 1)]);
 #endif
 #pragma unroll
           for (int k = 0; k < 4; ++k) abx[k] = (has_col || GFEAT) ? fmaf(gs, gnx[k], a8[k]) : gs * gnx[k];  // abar_8
@@ -981,17 +1021,18 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
           // ring slot g & (PF - 1) next holds group g + PF of this layer, or group g + PF - 16 of the layer below
           if constexpr (TOP) {
 #if !OI_BWD_AC_REGS
-            if (g + PFT < 16) vbn[g & (PFT - 1)] = ws.load(S_AC, g + PFT, o.l16);
+            if (g + PFT < 16) acn[g & (PFT - 1)] = ws.load(S_AC, g + PFT, o.l16);
 #endif
           } else if (!L0 && g + PF < 16) {
             phn[g & (PF - 1)] = ws.load_phase(S_PHI + l, g + PF, o.l16);
-            vbn[g & (PF - 1)] = ws.load(S_VB + l, g + PF, o.l16);
+            vbn[g & (PF - 1)] = load_vb(S_VB + l, g + PF);
           } else if constexpr (!L0) {
             // (layer 1 requests CARRY groups of the un-parked layer 0 as well: nobody reads them, and a run-time test of `l`
             // here splits the unrolled epilogue into blocks the register allocator handles badly -- 220 spilled registers)
             if (g + PF - 16 < CARRY) {
               phn[g & (PF - 1)] = ws.load_phase(S_PHI + l - 1, g + PF - 16, o.l16);
-              vbn[g & (PF - 1)] = ws.load(S_VB + l - 1, g + PF - 16, o.l16);
+              vbn[g & (PF - 1)] = load_vb(S_VB + l - 1, g + PF - 16);
+              if (g + PF - 16 == 0) load_vb_scale(S_VB + l - 1);
             }
           }
         }
@@ -1089,8 +1130,9 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #pragma unroll                                 // groups are requested after them, not under them)
       for (int q = 0; q < CARRY; ++q) {
         phn[q] = ws.load_phase(S_PHI + l - 1, q, o.l16);
-        vbn[q] = ws.load(S_VB + l - 1, q, o.l16);
+        vbn[q] = load_vb(S_VB + l - 1, q);
       }
+      load_vb_scale(S_VB + l - 1);
     }
     BW_T(10);
     if constexpr (L0) {
@@ -1437,10 +1479,13 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
   // X slots of the layer matrices (S_V, S_U) as 24-bit fixed point + a per-lane scale (see OI_BWD_XQ24; the sweep's condition)
   constexpr bool XQ = OI_BWD_XQ24 && PK == 0 && !BF && !COL && OI_BWD_STORES_LAST;
   using XFrag = std::conditional_t<XQ, u32x3, Frag>;
+  constexpr bool VBQ = OI_BWD_VBQ24 && PK == 0 && !BF;   // (the sweep's condition)
+  using VFrag = std::conditional_t<VBQ, u32x3, Frag>;
   struct Stage {  // the five slots of one wave tile as they arrive: 80 registers (48 for the colour head); 60 (36) packed
     XFrag xall[2][4];
     PFrag ph4[4];
-    Frag vb4[4];
+    VFrag vb4[4];
+    float vbinv;    // VBQ: 1 / s of this thread's lane of the gamma vbar slot
     f32x4 pt[2];  // FIRST: the point and dL/dgrad of this thread's lane (raw fp32)
     float xinv[2];  // XQ: 1 / s of this thread's lane of the two X slots
   };
@@ -1469,10 +1514,16 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
       }
       st.xall[0][it] = ldx(COL ? S_UV : S_V + m, it);
       if constexpr (!COL) {
-        if constexpr (!FIRST) st.vb4[it] = ld(S_VB + m, it);  // gamma_{l-1} vbar_{l-1}
+        if constexpr (!FIRST) {   // gamma_{l-1} vbar_{l-1}
+          if constexpr (VBQ) st.vb4[it] = __builtin_amdgcn_raw_buffer_load_b96(rs, tid * 12, (S_VB + m) * 16384 + it * 3072, OI_WGRAD_NT ? 2 : 0);
+          else st.vb4[it] = ld(S_VB + m, it);
+        }
         st.xall[1][it] = ldx(S_U + m, it);
       }
     }
+    if constexpr (VBQ && !FIRST && !COL)
+      st.vbinv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * (tid & 63), (S_VB + m) * 16384 + XQ_SCALE_OFF,
+                                                                                OI_WGRAD_NT ? 2 : 0));
     if constexpr (XQ) {
       st.xinv[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * (tid & 63), (S_V + m) * 16384 + XQ_SCALE_OFF,
                                                                                   OI_WGRAD_NT ? 2 : 0));
@@ -1551,7 +1602,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           z += (FIRST ? st.pt[it & 1][k] : WS::phase_of(st.ph4[it])[k]) + xval(st, 0, it)[k] +
-               (COL ? 0.f : (FIRST ? 0.f : WS::value(st.vb4[it])[k]) + xval(st, 1, it)[k]);
+               (COL ? 0.f : (FIRST ? 0.f : (float)st.vb4[it][k & 1]) + xval(st, 1, it)[k]);
       sub += z;
       __builtin_amdgcn_sched_barrier(0);
       if (wt + 2 < t_end) request(wt + 2, st);
@@ -1568,11 +1619,15 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
         l0_phase_vb<FAST>(l0tab, st.pt[0], st.pt[1], grp_f0(4 * it + wave) + 4 * h, ph4[it], vb4);
       } else {
         ph4[it] = WS::phase_of(st.ph4[it]);
-        if constexpr (!COL) vb4 = WS::value(st.vb4[it]);
+        if constexpr (!COL) {
+          if constexpr (VBQ) vb4 = unpack_q24(st.vb4[it]); else vb4 = WS::value(st.vb4[it]);
+        }
       }
+      // (VBQ: vb4 holds y = vbar s + 1.5; the de-scaling joins the multiply by the launch-wide scale)
+      const float kv = (VBQ && !FIRST && !COL) ? st.vbinv * scy[0] : scy[0], cv = (VBQ && !FIRST && !COL) ? -1.5f * kv : 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k)  // colour head (one pair): Y = a_8 = sin
-        y0[it][k] = COL ? __builtin_amdgcn_sinf(ph4[it][k]) * scy[0] : vb4[k] * scy[0] * __builtin_amdgcn_cosf(ph4[it][k]);
+        y0[it][k] = COL ? __builtin_amdgcn_sinf(ph4[it][k]) * scy[0] : fmaf(vb4[k], kv, cv) * __builtin_amdgcn_cosf(ph4[it][k]);
     }
     WG_T(0);
     __syncthreads();  // (1) the previous tile's readers of sx / sy / sb are done
