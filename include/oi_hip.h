@@ -149,6 +149,12 @@ int oi_selftest_cu_slots(int* busy, int* clashes, int* used, int n_workgroups, i
  * mode).  x, s, c: n floats. */
 int oi_selftest_sincos(const float* x, float* s, float* c, long long n, int fast, oi_stream_t stream);
 
+/* Test hook: the 24-bit fixed-point slot format of the f16x3 backward (csrc/mlp_bwd.hip: pack_q24 / unpack_q24), one round trip
+ * on the device.  x, y: n floats, n a multiple of 64; every run of 64 values is one lane's vector (shares one power-of-two scale).
+ * mode 0: values -- y = what a consumer reconstructs; mode 1: phases in [0, 1) revolutions -- y = the decoded phase + 1 (what the
+ * trig instructions are handed: the period is 1). */
+int oi_selftest_q24(const float* x, float* y, long long n, int mode, oi_stream_t stream);
+
 int oi_sdf_mlp_bwd(const float* pts, const void* packed, const float* gamma, const float* beta,
                    const float* grad_fwd, const float* rgb_fwd, const float* feat_fwd, const float* g_sdf, const float* g_grad,
                    const float* g_rgb, float* d_small, float* d_wmat, float* d_gamma, float* d_beta,

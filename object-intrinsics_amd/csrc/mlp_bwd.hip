@@ -243,6 +243,30 @@ __device__ __forceinline__ void q24_scale(float mx, float& s, float& inv_s) {
   inv_s = __builtin_bit_cast(float, (E + 3) << 23);
 }
 
+// oi_selftest_q24: thread t owns values [64 t, 64 t + 64) -- one lane's vector
+__global__ void selftest_q24_kernel(const float* __restrict__ x, float* __restrict__ y, long long nvec, int mode) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nvec) return;
+  const float* xi = x + t * 64;
+  float* yo = y + t * 64;
+  if (mode == 1) {
+    for (int g = 0; g < 16; ++g) {
+      const f32x4 d = unpack_q24(pack_q24_phase(f32x4{xi[4 * g], xi[4 * g + 1], xi[4 * g + 2], xi[4 * g + 3]}));
+      for (int k = 0; k < 4; ++k) yo[4 * g + k] = d[k];
+    }
+    return;
+  }
+  float mx = 0.f;
+  for (int k = 0; k < 64; ++k) mx = fmaxf(mx, fabsf(xi[k]));
+  float sq, inv_sq;
+  q24_scale(mx, sq, inv_sq);
+  const float c = -1.5f * inv_sq;
+  for (int g = 0; g < 16; ++g) {
+    const f32x4 d = unpack_q24(pack_q24(f32x4{xi[4 * g], xi[4 * g + 1], xi[4 * g + 2], xi[4 * g + 3]}, sq));
+    for (int k = 0; k < 4; ++k) yo[4 * g + k] = fmaf(d[k], inv_sq, c);
+  }
+}
+
 // PACK: 0 = fp32 slots (16 bytes per lane and group), 1 = 24-bit (12), 2 = 16-bit (8)
 template <int PACK, bool PHQ = false>
 struct WaveScratchT {
@@ -1800,6 +1824,14 @@ extern "C" int oi_prof_bwd_read(unsigned long long* out, int reset) {
 #endif
 
 extern "C" {
+
+int oi_selftest_q24(const float* x, float* y, long long n, int mode, oi_stream_t stream) {
+  OI_REQUIRE(x && y && n > 0 && n % 64 == 0 && (mode == 0 || mode == 1), "oi_selftest_q24: bad argument");
+  const long long nvec = n / 64;
+  hipLaunchKernelGGL(selftest_q24_kernel, dim3(oi::cdiv(nvec, 256)), dim3(256), 0, oi::as_stream(stream), x, y, nvec, mode);
+  return oi::check_launch("oi_selftest_q24");
+}
+
 
 size_t oi_mlp_bwd_scratch_bytes(int B, long long n_per_elem) {
   const long long tiles = (n_per_elem + BW_TILE - 1) / BW_TILE;

@@ -64,6 +64,7 @@ _SIGS = {
     "oi_mlp_scratch_bytes_prec": (_sz, [_i, _ll, _i]),
     "oi_sdf_mlp_fwd": (_i, [_vp] * 9 + [_i, _ll, _i, _i, _vp]),
     "oi_selftest_sincos": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
+    "oi_selftest_q24": (_i, [_vp, _vp, _ll, _i, _vp]),
     "oi_selftest_cu_slots": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "oi_mlp_bwd_scratch_bytes": (_sz, [_i, _ll]),
     "oi_mlp_bwd_scratch_bytes_capped": (_sz, [_i, _ll, _sz]),

@@ -142,6 +142,45 @@ def test_sdf_mlp_ragged_tiles(ops, packed_all, sdf_sd, col_sd, n, mode):
     assert maxdiff(sdf2.cpu(), sdf_o.squeeze(-1)) < t_sdf
 
 
+def test_q24_slot_format_round_trip():
+    """The 24-bit fixed-point slots of the f16x3 backward (csrc/mlp_bwd.hip pack_q24 / unpack_q24, through oi_selftest_q24).
+    Values: a lane's 64 entries share one power-of-two scale chosen from their maximum -- the reconstruction error is at most
+    2^-21 of that maximum (the resolution of the weight-gradient GEMM's fp16 hi + lo split) whatever the entries' own size, zeros
+    and lane maxima included.  Phases: 2^-23 revolutions, and a phase within 2^-24 of 1 -- which rounds to the top of the binade --
+    must come back as the SAME ANGLE (1.0 = 0 revolutions), not half a revolution off (the bug the C2-size gradient test caught)."""
+    import ctypes
+    from oi_amd import lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(5)
+    # 512 lanes: magnitudes over 30 decades between lanes, 6 decades inside a lane, exact zeros, a lane of zeros, a lane of 1 value
+    mag = 10.0 ** (torch.rand(512, 1, generator=g) * 30 - 20)
+    x = torch.randn(512, 64, generator=g) * mag * 10.0 ** (-6 * torch.rand(512, 64, generator=g))
+    x[::7, 3] = 0.0
+    x[5] = 0.0
+    x[6] = 0.0
+    x[6, 17] = -3.25e-9
+    x[9, 0] = x[9].abs().max() * 1.999999   # an entry at the very top of the lane's binade
+    x = x.float().cuda().contiguous()
+    y = torch.empty_like(x)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert L.oi_selftest_q24(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()), x.numel(), 0, ctypes.c_void_p(stream)) == 0
+    mx = x.abs().amax(dim=1, keepdim=True)
+    err = (y.double() - x.double()).abs()
+    assert bool((err <= mx.double() * 2.0 ** -21 + 1e-45).all()), float((err / mx.clamp_min(1e-30)).max())
+    assert bool((y[5] == 0).all())
+    # phases: a dense sample, the ends of the interval and the values that round to y = 2.0
+    r = torch.rand(64 * 256, generator=g)
+    r[:8] = torch.tensor([0.0, 1.0 - 2.0 ** -24, 1.0 - 2.0 ** -25, 1.0 - 2.0 ** -23, 0.5, 0.25, 2.0 ** -30, 0.75])
+    r = r.float().clamp(max=float(torch.nextafter(torch.tensor(1.0), torch.tensor(0.0)))).cuda().contiguous()
+    d = torch.empty_like(r)
+    assert L.oi_selftest_q24(ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(d.data_ptr()), r.numel(), 1, ctypes.c_void_p(stream)) == 0
+    assert bool(((d >= 1.0) & (d <= 2.0)).all())
+    ang = 2 * math.pi * r.double()
+    dec = 2 * math.pi * (d.double() - 1.0)
+    assert float((torch.sin(dec) - torch.sin(ang)).abs().max()) < 1e-6
+    assert float((torch.cos(dec) - torch.cos(ang)).abs().max()) < 1e-6
+
+
 def test_gen_rays(ops):
     g = load_golden("f5_generator")
     R, SR = int(g["resolution"]), int(g["scene_resolution"])
