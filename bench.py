@@ -710,7 +710,9 @@ def build_line(args, value, dt, world, timer, d_img_s, train, distributed, bf16_
             "training": train,
             "bf16_mode": bf16_mode,
             "roofline": {"bound": "mfma",
-                         "kernel": ("sdf_mlp_full3_kernel (register-resident: sdf + d sdf/dx + albedo at the fine samples)"
+                         "kernel": ("sdf_mlp_full3_kernel (register-resident: sdf + d sdf/dx + albedo at the fine samples; kernel_ms "
+                                    "also covers the call's first launch, film_blob_f3_kernel: ~6 us of per-element tables, so frac is "
+                                    "conservative by ~0.7 %)"
                                     if args.precision == "f16x3" else "sdf_mlp_kernel<full> (sdf + d sdf/dx + albedo at the fine samples)"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None,
