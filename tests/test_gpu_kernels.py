@@ -142,6 +142,28 @@ def test_sdf_mlp_ragged_tiles(ops, packed_all, sdf_sd, col_sd, n, mode):
     assert maxdiff(sdf2.cpu(), sdf_o.squeeze(-1)) < t_sdf
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "bf16"])
+def test_persistent_workgroups_bit_identical(mode, tmp_path):
+    """The persistent-workgroup launches (a workgroup walks several tiles: the bf16 full kernel, the sdf-only passes of every
+    mode) against one workgroup per tile of the SAME kernels (OI_B3P_PERSIST=0 / OI_V2_PERSIST=0, read once per process: two
+    subprocesses): a seeded forward of 2 x 100,003 points -- 782 tiles of 128 (391 of 256) per element on at most 128 workgroups,
+    ragged last tile -- must agree bit for bit in sdf, gradient, albedo and features."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for v in ("1", "0"):
+        out = str(tmp_path / f"fwd_{mode}_{v}.pt")
+        env = dict(os.environ, OI_B3P_PERSIST=v, OI_V2_PERSIST=v)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg", "fwd_dump.py"), out, mode], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:]
+        outs.append(torch.load(out))
+    a, b = outs
+    assert set(a) == set(b) and len(a) >= 5
+    for k in a:
+        assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), k
+
+
 def test_q24_slot_format_round_trip():
     """The 24-bit fixed-point slots of the f16x3 backward (csrc/mlp_bwd.hip pack_q24 / unpack_q24, through oi_selftest_q24).
     Values: a lane's 64 entries share one power-of-two scale chosen from their maximum -- the reconstruction error is at most
