@@ -111,9 +111,11 @@ int oi_mlp_pack_status(const void* packed, oi_stream_t stream);
  *   scratch: oi_mlp_scratch_bytes_prec(B, n, prec) bytes, needed when grad != NULL.  OI_PREC_F16X3 (the default mode)
  *   runs the register-resident kernel (csrc/mlp_fwd3.hip): the phases the reverse sweep needs stay in the register
  *   file and only the 128 features per point cross HBM (512 B/point); OI_PREC_BF16 (csrc/mlp_fwd3b.hip) keeps nothing per
- *   point in memory -- its scratch holds the 15 per-element images diag(gamma_l) W_l rounded to bf16 (480 KiB per batch
- *   element, built by a first launch of the same call); the other modes park gamma*cos(phase) of every layer (4.6 KB/point).
- *   oi_mlp_scratch_bytes(B, n) is an upper bound over all modes.
+ *   point in memory -- its scratch holds the 15 per-element images diag(gamma_l) W_l rounded to bf16 plus a 15 KiB table blob
+ *   (15 * 32 KiB + 15 KiB = 495 KiB per batch element, built by a first launch of the same call); the other modes park
+ *   gamma*cos(phase) of every layer (4.6 KB/point).  oi_mlp_scratch_bytes(B, n) is an upper bound over all modes.
+ *   The call takes no scratch_bytes: the caller MUST size `scratch` with oi_mlp_scratch_bytes_prec for the same (B, n, prec) --
+ *   the minimum differs per mode (OI_PREC_BF16: B * 495 KiB whatever n is) and an undersized buffer is written past its end.
  */
 size_t oi_mlp_scratch_bytes(int B, long long n_per_elem);
 size_t oi_mlp_scratch_bytes_prec(int B, long long n_per_elem, int prec);
@@ -637,12 +639,13 @@ int oi_multi_copy(const oi_mt_chunk* table, int n_chunks, oi_stream_t stream);
  * operands are prepared once -- activations as NHWC fp16 limb planes (hi + lo = 22 bits) written by the producing layer, weights
  * as fp16 limb images in MFMA fragment order (packed per parameter version) -- three fp16 MFMAs per product, fp32 accumulation,
  * split-K partial planes added in a fixed order (no atomics: bit-reproducible).  csrc/disc_large.hip.
- *   chans [n_blocks + 1]: in_dim (<= 4), then the output channels of every 4x4 stride-2 block; covered when chans[1] % 8 == 0,
- *   every later block has Cin % 64 == 0 and Cout % 128 == 0, and H / 2^n_blocks == 4 (the 64 x 64 / n_feat 512 network of
+ *   chans [n_blocks + 1]: in_dim (<= 4), then the output channels of every 4x4 stride-2 block; covered when chans[1] % 32 == 0
+ *   and chans[1] <= 128, every later block has Cin % 64 == 0 and Cout % 128 == 0, and H / 2^n_blocks == 4 (the 64 x 64 / n_feat 512 network of
  *   configs/train.yaml at 64 x 64: {3 | 1, 64, 128, 256, 512}).  oi_disc_large_packed_bytes / _workspace_bytes return 0 and the
  *   other two OI_ERR_UNSUPPORTED for anything else (the caller keeps the general chain).
  *   w_blocks: HOST array of n_blocks device pointers ([Cout][Cin][4][4] each, the reference's layout); w_head [out_dim][C][4][4].
- *   x [B][chans[0]][H][H] (after the augmentation), w1 = w_blocks[0] (read as it is), bhead [out_dim] or NULL -> logits [B][out_dim]. */
+ *   x [B][chans[0]][H][H] (after the augmentation), bhead [out_dim] or NULL -> logits [B][out_dim].  w1 is IGNORED (kept in the
+ *   signature for ABI stability: layer 1 is read from the packed image like every other layer; pass w_blocks[0] or NULL). */
 size_t oi_disc_large_packed_bytes(const int* chans, int n_blocks, int out_dim);
 int oi_disc_large_pack(const float* const* w_blocks, const float* w_head, const int* chans, int n_blocks, int out_dim, void* packed,
                        oi_stream_t stream);

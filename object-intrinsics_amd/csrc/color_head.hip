@@ -223,13 +223,16 @@ __global__ void __launch_bounds__(256) color_head_wgrad_kernel(
       q.a1[s] = ok ? v1 : 0.f;
       q.a2[s] = ok ? v2 : 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q.b[s][j] = feat[row * C + 32 * j + pl];
+      for (int j = 0; j < 4; ++j) {   // (B zeroed on tail steps too: 0 * inf from the clamped row must not reach the sums)
+        const float vb = feat[row * C + 32 * j + pl];
+        q.b[s][j] = ok ? vb : 0.f;
+      }
       // column block 4: normals (3) | 1 | dpre (3) | 0 ...
       float v4 = 0.f;
       if (pl < 3) v4 = normals[row * 3 + pl];
       else if (pl == 3) v4 = 1.f;
       else if (pl < 7) v4 = dpre_s[row * 4 + pl - 4];
-      q.b[s][4] = v4;
+      q.b[s][4] = ok ? v4 : 0.f;
     }
   };
   auto mma = [&](const Batch& q) {

@@ -47,7 +47,10 @@ class DCDiscriminator(nn.Module):
         split-K layer) and every block hands over its pre-activation sums -- the LeakyReLU is applied by the next
         layer while it loads them, so the split-K layers need no activation pass: 6 launches instead of 13."""
         from . import ops
-        if LARGE_PATH and x.shape[0] >= LARGE_MIN_BATCH and x.is_cuda:
+        # (never under somebody's stream capture: the packed weights and the workspace are eager allocations keyed on the
+        #  parameter versions -- a replay after an optimiser step would read the stale pack, and the next eager call frees it
+        #  under the graph (advisor, round 5).  The general chain below reads the live parameters.)
+        if LARGE_PATH and x.shape[0] >= LARGE_MIN_BATCH and x.is_cuda and not torch.cuda.is_current_stream_capturing():
             out = self._forward_large(x)
             if out is not None:
                 return out

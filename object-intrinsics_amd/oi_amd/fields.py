@@ -185,6 +185,19 @@ class FieldPack:
         self._packs = {}
         self._stacks = None
 
+    def __deepcopy__(self, memo):
+        """A copy taken while a forward is in flight (an EMA snapshot from a callback) must not inherit the hold depth: nothing
+        would ever release it, and the copy's version walk would be skipped for good (advisor, round 5).  Caches are not copied
+        either -- they are keyed on the ORIGINAL parameters' addresses."""
+        import copy
+        twin = FieldPack.__new__(FieldPack)
+        memo[id(self)] = twin
+        twin.sdf_network = copy.deepcopy(self.sdf_network, memo)
+        twin.color_network = copy.deepcopy(self.color_network, memo)
+        twin.prec, twin.fast_trig = self.prec, self.fast_trig
+        twin._key, twin._packs, twin._stacks = None, {}, None
+        return twin
+
     def set_precision(self, precision, fast_trig=None):
         self.prec = _l.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
         self.fast_trig = (self.prec == _l.OI_PREC_BF16) if fast_trig is None else bool(fast_trig)

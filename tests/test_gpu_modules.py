@@ -958,3 +958,50 @@ def test_large_batch_discriminator_forward_vs_oracle(B, in_dim, out_dim, view):
         d2 = DM.DCDiscriminator.forward(D2, x)
         dsd3 = {k: v.detach().double().cpu() for k, v in D2.state_dict().items() if "aug." not in k}
         assert maxdiff(d2[sub].cpu(), O.dc_discriminator(dsd3, x[sub].double().cpu())) < 2e-5
+
+
+def test_graphed_large_batch_discriminator_follows_weight_updates():
+    """GraphedDForward at batch 16 (a captured hipGraph, not the library plan): the captured forward must read the LIVE
+    parameters -- csrc/disc_large.hip's packed weight images are eager allocations keyed on parameter versions and are therefore
+    never recorded into a capture (advisor, round 5: a replay after an optimiser step read the stale pack, and the next eager
+    forward freed it under the graph).  Replay, change a weight in place, replay, run an eager batch-16 forward (which rebuilds the
+    pack), replay again: each replay equals the eager answer for the weights of that moment."""
+    import oi_amd.discriminator as DM
+    from oi_amd.config import build_from_config
+    from oi_amd.graphed import GraphedDForward
+    torch.manual_seed(11)
+    aug = {"__target__": "src.third_party.ada.augment.AugmentPipe", "kwargs": {}}   # (no geometric branch: the chain alone)
+    D = build_from_config({"__target__": "src.models.discriminator.ADADiscriminator",
+                           "kwargs": dict(aug=aug, aug_p=1, in_dim=3, out_dim=1, n_feat=512, img_size=64, last_bias=False)}).cuda().eval()
+    with torch.no_grad():
+        for p_ in D.parameters():
+            p_.copy_((torch.rand_like(p_) * 2 - 1) * (6.0 / (1.04 * p_[0].numel())) ** 0.5)
+    x = torch.rand(16, 3, 64, 64, device="cuda")
+    gd = GraphedDForward(D)
+
+    def eager_general():
+        DM.LARGE_PATH = False
+        try:
+            with torch.no_grad():
+                return DM.DCDiscriminator.forward(D, x).clone()
+        finally:
+            DM.LARGE_PATH = True
+
+    got0 = gd(x).clone()
+    assert gd._lib is None and gd.graph is not None
+    assert torch.equal(got0, eager_general())          # the capture holds the general chain: same launches, same bits
+    with torch.no_grad():
+        D.blocks[1].weight.mul_(0.5)
+        D.conv_out.weight.add_(0.01)
+    want1 = eager_general()
+    assert maxdiff(want1, got0) > 1e-3                  # (the update matters)
+    got1 = gd(x).clone()
+    assert torch.equal(got1, want1), maxdiff(got1, want1)
+    with torch.no_grad():
+        large = DM.DCDiscriminator.forward(D, x)        # eager: rebuilds the pack, frees the previous one
+        assert maxdiff(large, want1) < 2e-5
+        D.blocks[3].weight.mul_(1.25)
+        DM.DCDiscriminator.forward(D, x)
+    got2 = gd(x).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got2, eager_general())

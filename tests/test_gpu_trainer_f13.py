@@ -122,10 +122,12 @@ def test_trainer_two_iterations_match_the_reference_trainer_class_f13(graph_d_st
                 # near / far: the oracle, which reproduces the reference's 0.0858335 to 3e-7, reports 0.08627 (+0.51 %) for 2 of 12
                 # seeded +-1 ulp perturbations (one importance sample of one render switches bins; measured by
                 # tests/test_oracle_golden.py::test_f13_two_iterations_on_the_oracle_and_last_bit_sensitivity) -- the HIP path sits
-                # on that second mode (0.08628).  Bar = 3x the measured jump; every other gradient norm stays at 2e-3.
-                tol = 3 * F13_VARIANCE_GRAD_SENSITIVITY if name == "deviation_network" else 2e-3
-                assert abs(got - ref) < tol * max(ref, 1e-3), (key, got, ref)
-                worst[key] = abs(got - ref) / max(ref, 1e-3)
+                # on that second mode (0.08628).  Not a wider bar: the value must sit on ONE of the two measured modes (the
+                # reference's, or the reference's x (1 + the measured jump)) at the 2e-3 of every other gradient norm.
+                modes = (ref, ref * (1 + F13_VARIANCE_GRAD_SENSITIVITY)) if name == "deviation_network" else (ref,)
+                err = min(abs(got - m) for m in modes)
+                assert err < 2e-3 * max(ref, 1e-3), (key, got, ref, modes)
+                worst[key] = err / max(ref, 1e-3)
         for tag, net in (("g", gen), ("d", D), ("m", M)):
             flat = torch.cat([p.detach().double().reshape(-1) for p in net.parameters()]).cpu()
             for nm, val in (("sum", flat.sum()), ("abs", flat.abs().sum())):

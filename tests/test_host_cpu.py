@@ -147,3 +147,26 @@ def small_generator_cfg(R, S, I, K):
                anneal_end=50000,
                pose_prior=net("src.utils.pose_sampler.Plane", cam_loc=[0, -1, 0], rot_degree_range_scale=360,
                               rot_roll_degree_range_scale=20, xy_range_scale=[6, 3.5]))
+
+
+def test_field_pack_deepcopy_does_not_inherit_the_hold_depth():
+    """FieldPack.hold is a depth counter: a deep copy taken while a forward is in flight (an EMA snapshot from a callback) starts
+    released and with empty caches, or its parameter-version walk would be skipped for good (advisor, round 5)."""
+    import copy
+    from oi_amd.fields import ShapeNetwork, ColorNetwork, FieldPack
+    kw = dict(D=8, W=128, input_ch=3, input_ch_views=3, style_dim=64)
+    pack = FieldPack(ShapeNetwork(None, **kw), ColorNetwork(**kw))
+    pack.hold(True)
+    key0 = pack._key
+    assert pack._held == 1 and key0 is not None
+    twin = copy.deepcopy(pack)
+    assert getattr(twin, "_held", 0) == 0 and twin._key is None and twin._packs == {}
+    assert twin.sdf_network is not pack.sdf_network and twin.prec == pack.prec
+    twin._refresh_key()
+    with torch.no_grad():
+        twin.sdf_network.sigma_linear.weight.add_(1.0)
+    k1 = twin._key
+    twin._refresh_key()
+    assert twin._key != k1            # the copy's version walk is live
+    pack.hold(False)
+    assert pack._held == 0
