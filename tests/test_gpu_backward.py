@@ -293,12 +293,13 @@ def _oracle_mlp_grads(sdf_sd, col_sd, pts, w, cs, cg, cr):
 # tolerances: 3x the error measured in the native-fp32 mode (6.7e-6 worst over 59 tensors, tools/grad_margin.py; DESIGN.md
 # section 5); bf16x3 (bf16x3 forward, f16x3 backward) 3x its own 1.2e-5
 # bf16 (BASELINE configs[1]: one bf16 MFMA per product forward AND backward, unreduced v_sin / v_cos): the bar is 3x the worst
-# error measured on the MI355X (profiles/r5_gradient_margins.txt), relative to the largest entry of each tensor
-# measured: worst 4.4e-2 (layer-0 FiLM rows), median 1.8e-2 over 60 tensors, loss 1.4e-3 -- bf16 operands (2^-8) under FiLM
+# error measured on the MI355X AT THE FINAL KERNELS (profiles/r6_gradient_margins.txt, row mlp_backward_vs_fp64_oracle[bf16]),
+# relative to the largest entry of each tensor
+# measured: worst 4.11e-2 (layer-0 FiLM rows), median 1.82e-2 over 60 tensors, loss 4.4e-4 -- bf16 operands (2^-8) under FiLM
 # scales of ~30 through eight layers; the fp32-class modes sit at 5e-6
-BF16_MLP_BWD_TOL = 0.13
+BF16_MLP_BWD_TOL = 0.12
 BF16_MLP_BWD_MEDIAN_TOL = 0.05
-BF16_LOSS_TOL = 4.5e-3
+BF16_LOSS_TOL = 1.3e-3
 
 
 @pytest.mark.parametrize("n,B,precision,tol", [(96, 2, "f32", 2e-5), (300, 1, "f32", 2e-5), (64, 2, "bf16x3", 4e-5),
@@ -425,12 +426,13 @@ F6_TOL = 7e-5
 F9_TOL = 1e-4
 # bf16 operand mode (BASELINE configs[1]) end to end: forward maps AND every gradient of the training losses against the
 # reference's own fp32 values.  Bars = ~3x the worst error measured on the MI355X (record_margin ->
-# profiles/r5_gradient_margins.txt); gradient errors are relative to the largest entry of the tensor (floor as in the fp32 rows).
-# measured: F6 image 9.8e-4 / mask 1.6e-3 / eikonal 1.6e-4 / loss (a sum over 64 rays x 7 channels) 1.6e-2, gradients 3.9e-2 worst,
-# 7.1e-3 median; F9 G-step losses 9.8e-4, gradients 4.2e-2 worst; D-step losses 6.0e-5, weight gradients 4.1e-4 (their only
-# bf16 input is the fake image)
-BF16_F6 = {"image": 3e-3, "mask": 5e-3, "eikonal": 5e-4, "loss": 5e-2, "grad": 0.12}
-BF16_F9 = {"g_loss": 3e-3, "g_grad": 0.13, "d_loss": 2e-4, "d_grad": 1.3e-3}
+# profiles/r6_gradient_margins.txt, re-measured at the final kernels); gradient errors are relative to the largest entry of the
+# tensor (floor as in the fp32 rows).
+# measured: F6 image 1.0e-3 / mask 1.53e-3 / eikonal 1.34e-4 / loss (a sum over 64 rays x 7 channels) 1.2e-2, gradients 3.41e-2
+# worst, 7.6e-3 median; F9 G-step losses 8.8e-4, gradients 4.8e-2 worst; D-step losses 7.7e-5, weight gradients 3.95e-4 (their
+# only bf16 input is the fake image)
+BF16_F6 = {"image": 3e-3, "mask": 4.6e-3, "eikonal": 4e-4, "loss": 3.6e-2, "grad": 0.10}
+BF16_F9 = {"g_loss": 2.7e-3, "g_grad": 0.13, "d_loss": 2e-4, "d_grad": 1.2e-3}
 
 
 def _f6_render(precision="f16x3"):
@@ -702,45 +704,129 @@ def test_style_mlp_under_autograd_runs_on_hip_kernels(sdf_sd):
             assert maxdiff(p.grad.cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max())), name
 
 
-def test_training_trajectory_f16x3_tracks_native_fp32():
-    """Six full training iterations (G / D / mask-D steps, fused optimisers) from identical seeds in the default
-    f16x3 operand mode and in native fp32 MFMA: every logged loss agrees to 1e-4 while the dynamics are still
-    deterministic enough to compare (GAN training is chaotic: by iteration ~20 two fp32 runs differ as much)."""
+TRAJ_KEYS = ("generator/loss", "generator/eikonal", "discriminator/loss", "discriminator/reg", "mask_discriminator/loss")
+
+
+def _trajectory(prec, iters=6, R=16):
+    """`iters` full training iterations (G / D / mask-D steps, fused optimisers) at R x R, 8 + 8 samples, from fixed seeds with the
+    generator in operand mode `prec`: the logged losses, one row per iteration (TRAJ_KEYS)."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_gpu_modules import build_generator
     from oi_amd.config import build_from_config
     from oi_amd.optim import FusedAdam, FusedRMSprop
     from oi_amd.trainer import Trainer
-    R = 16
-    keys = ("generator/loss", "generator/eikonal", "discriminator/loss", "discriminator/reg", "mask_discriminator/loss")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    gen = build_generator(R, 8, 8, 1, prec)
+    mk = lambda cin, cout, cls, extra: build_from_config({"__target__": "src.models.discriminator." + cls, "kwargs": dict(
+        aug={"__target__": "src.third_party.ada.augment.AugmentPipe", "kwargs": {"scale": 1, "xint": 1}}, aug_p=1,
+        img_size=R, in_dim=cin, last_bias=False, n_feat=64, out_dim=cout, **extra)}).cuda()
+    disc = mk(3, 7, "ADADiscriminatorView", dict(out_dim_latent=0, out_dim_position=6))
+    mdisc = mk(1, 1, "ADADiscriminator", {})
+    tr = Trainer({"generator": gen, "discriminator": disc, "mask_discriminator": mdisc,
+                  "opt_generator": FusedAdam(gen.parameters(), lr=2e-5, betas=(0.0, 0.9)),
+                  "opt_discriminator": FusedRMSprop(disc.parameters(), lr=1e-4),
+                  "opt_mask_discriminator": FusedRMSprop(mdisc.parameters(), lr=1e-4)})
+    g = torch.Generator().manual_seed(1)
+    rows = []
+    for it in range(iters):
+        data = {"image": torch.rand(1, 3, R, R, generator=g).cuda(), "mask": (torch.rand(1, 1, R, R, generator=g) > 0.5).float().cuda()}
+        torch.manual_seed(100 + it)
+        np.random.seed(100 + it)
+        o = tr.train_step(data)
+        rows.append([float(o[k].detach()) if torch.is_tensor(o[k]) else float(o[k]) for k in TRAJ_KEYS])
+    return np.array(rows)
 
-    def run(prec):
-        torch.manual_seed(0)
-        np.random.seed(0)
-        gen = build_generator(R, 8, 8, 1, prec)
-        mk = lambda cin, cout, cls, extra: build_from_config({"__target__": "src.models.discriminator." + cls, "kwargs": dict(
-            aug={"__target__": "src.third_party.ada.augment.AugmentPipe", "kwargs": {"scale": 1, "xint": 1}}, aug_p=1,
-            img_size=R, in_dim=cin, last_bias=False, n_feat=64, out_dim=cout, **extra)}).cuda()
-        disc = mk(3, 7, "ADADiscriminatorView", dict(out_dim_latent=0, out_dim_position=6))
-        mdisc = mk(1, 1, "ADADiscriminator", {})
-        tr = Trainer({"generator": gen, "discriminator": disc, "mask_discriminator": mdisc,
-                      "opt_generator": FusedAdam(gen.parameters(), lr=2e-5, betas=(0.0, 0.9)),
-                      "opt_discriminator": FusedRMSprop(disc.parameters(), lr=1e-4),
-                      "opt_mask_discriminator": FusedRMSprop(mdisc.parameters(), lr=1e-4)})
-        g = torch.Generator().manual_seed(1)
-        rows = []
-        for it in range(6):
-            data = {"image": torch.rand(1, 3, R, R, generator=g).cuda(), "mask": (torch.rand(1, 1, R, R, generator=g) > 0.5).float().cuda()}
-            torch.manual_seed(100 + it)
-            np.random.seed(100 + it)
-            o = tr.train_step(data)
-            rows.append([float(o[k].detach()) if torch.is_tensor(o[k]) else float(o[k]) for k in keys])
-        return np.array(rows)
 
-    a, b = run("f32"), run("f16x3")
+def test_training_trajectory_f16x3_tracks_native_fp32():
+    """Six full training iterations (G / D / mask-D steps, fused optimisers) from identical seeds in the default
+    f16x3 operand mode and in native fp32 MFMA: every logged loss agrees to 1e-4 while the dynamics are still
+    deterministic enough to compare (GAN training is chaotic: by iteration ~20 two fp32 runs differ as much)."""
+    a, b = _trajectory("f32"), _trajectory("f16x3")
     assert np.isfinite(a).all() and np.isfinite(b).all()
     assert np.abs(a - b).max() < 1e-4, np.abs(a - b).max(axis=1)
+
+
+# bf16 operand mode (BASELINE configs[1]) over the same six iterations: per logged loss, <= 3x the worst |bf16 - f32| / max(1, |f32|)
+# measured on the MI355X (profiles/r6_gradient_margins.txt, rows training_trajectory_bf16_vs_f32)
+# measured: 2.45e-4, 6.54e-4, 2.45e-4, 5.8e-5, 1.68e-4
+BF16_TRAJ_TOL = {"generator/loss": 7.5e-4, "generator/eikonal": 2e-3, "discriminator/loss": 7.5e-4, "discriminator/reg": 2e-4,
+                 "mask_discriminator/loss": 5e-4}
+
+
+def test_training_trajectory_bf16_tracks_native_fp32():
+    """The same six iterations with the generator in the bf16 operand mode against native fp32: every logged loss of every
+    iteration inside a MEASURED bar (BF16_TRAJ_TOL).  Together with test_generator_fit_converges_bf16_like_fp32 this is the
+    evidence that the mode BASELINE's configs[1] names trains, not only renders (review, round 5: `bf16_mode.training` was a
+    speed figure with 1-5 % per-tensor gradient errors and no training-level check).  Reference behaviour replaced: autograd
+    through src/models/fields.py:104-122 and stylesdf/volume_renderer.py:50-61 in fp32."""
+    a, b = _trajectory("f32"), _trajectory("bf16")
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    rel = np.abs(a - b) / np.maximum(1.0, np.abs(a))
+    for j, k in enumerate(TRAJ_KEYS):
+        record_margin("training_trajectory_bf16_vs_f32", k, float(rel[:, j].max()))
+        assert rel[:, j].max() < BF16_TRAJ_TOL[k], (k, rel[:, j])
+
+
+def _generator_fit(prec, steps=200, R=16):
+    """`steps` Adam steps of the GENERATOR ALONE on a fixed objective that needs no discriminator (and therefore no chaos
+    argument): silhouette MSE against a target mask one pixel smaller all round than the initial sphere's + 0.1 * eikonal, from sphere_init.  The
+    generator draws its own poses / latents / jitter as in training (two elements); both RNGs are re-seeded with the SAME seed
+    before every forward, so every step sees the same rays and the objective is a fixed function of the weights.  Returns the
+    loss of every step."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_modules import build_generator
+    from oi_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    np.random.seed(0)
+    gen = build_generator(R, 16, 16, 1, prec).train()
+    bs = 2
+
+    def forward():
+        torch.manual_seed(4242)
+        np.random.seed(4242)
+        return gen(bs=bs, it=0, data={})["box"]
+
+    gen.renderer.pack.set_precision("f32")   # (the target is the same for every mode)
+    m0 = forward()["render_out"]["mask"].detach()
+    gen.renderer.pack.set_precision(prec)
+    # the silhouette to fit: the initial one (28 % of a 16 x 16 crop) eroded by one pixel on every side
+    target = (torch.nn.functional.avg_pool2d(m0, 3, stride=1, padding=1) > 0.98).float()
+    assert 0.03 < float(target.mean()) < float(m0.mean()) - 0.03, (float(target.mean()), float(m0.mean()))
+    opt = FusedAdam(gen.parameters(), lr=1e-4, betas=(0.0, 0.9))
+    losses = []
+    for it in range(steps):
+        opt.zero_grad(set_to_none=False)
+        box = forward()
+        loss = ((box["render_out"]["mask"] - target) ** 2).mean() + 0.1 * box["loss"]["eikonal"]
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+    return torch.stack(losses).cpu().numpy()
+
+
+# measured on the MI355X (profiles/r6_gradient_margins.txt, rows generator_fit_200_adam_steps): final / first loss 0.049 (f32),
+# 0.062 (bf16); bf16 final / f32 final 1.26; the first step's losses agree to 1.2e-5
+FIT_DROP = 0.15         # both modes: mean loss of the last 10 steps < FIT_DROP x the first step's (3 x the measured 0.05)
+FIT_BF16_VS_F32 = 1.8   # bf16's final loss within this factor of fp32's, either way (measured 1.26)
+
+
+def test_generator_fit_converges_bf16_like_fp32():
+    """200 Adam steps of the generator alone on a fixed silhouette + eikonal objective from sphere_init (`_generator_fit`) in
+    native fp32 and in the bf16 operand mode: both reduce the loss by the stated factor and end within the stated factor of
+    each other.  bf16's per-tensor gradient errors (1-5 %, section 5 of DESIGN.md) are unbiased enough for Adam to converge to
+    the same place; if this ever fails, bench.py's `bf16_mode.training` must stop being quoted."""
+    a, b = _generator_fit("f32"), _generator_fit("bf16")
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    fa, fb = float(a[-10:].mean()), float(b[-10:].mean())
+    record_margin("generator_fit_200_adam_steps", "f32 final / first", fa / float(a[0]))
+    record_margin("generator_fit_200_adam_steps", "bf16 final / first", fb / float(b[0]))
+    record_margin("generator_fit_200_adam_steps", "bf16 final / f32 final", fb / fa)
+    record_margin("generator_fit_200_adam_steps", "first step |bf16 - f32| / f32", abs(float(b[0]) - float(a[0])) / float(a[0]))
+    assert fa < FIT_DROP * float(a[0]) and fb < FIT_DROP * float(b[0]), (a[0], fa, b[0], fb)
+    assert 1 / FIT_BF16_VS_F32 < fb / fa < FIT_BF16_VS_F32, (fa, fb)
 
 
 @pytest.mark.parametrize("bs", [1, 2])

@@ -153,16 +153,14 @@ def test_c5_mlp_only_microbench_size(sdf_sd, col_sd):
 # 6.4e-6 (training render, 58 tensors) -- tools/grad_margin.py; round 2 accepted 2e-3 / 3e-3
 C2_MLP_BWD_TOL = 2.5e-5
 C2_RENDER_BWD_TOL = 2e-5
-# bf16 operand mode (BASELINE configs[1]): ~3x the worst error measured on the MI355X (profiles/r5_gradient_margins.txt)
-# measured: MLP op 3.9e-2 worst / 1.3e-2 median over 60 tensors; training render 1.05e-1 worst / 4.5e-2 median over 59 (the
-# compositing turns sdf errors into weight errors at 1/s_val); losses 5.1e-4 / 2.9e-4 with the round-4 forward kernel.
-# The loss of the render test is ONE scalar (512 randomly weighted colour / weight-sum terms of 128 rays): with the per-element
-# images of sdf_mlp_full3p_kernel (bf16(gamma W) instead of gamma * bf16(W): the same 2^-9 per operand, other rounding draws) the
-# same-box A/B measured 3.2e-3 where the round-4 kernel (OI_BF16_PRESCALE=0) has 5.1e-4, while every map- and tensor-level
-# margin of the mode moved by less than its own spread (profiles/r5_gradient_margins.txt lists both) -- the earlier 2e-3 was
-# 3 x a lucky draw; 1e-2 = 3 x the larger one.
-C2_MLP_BWD_TOL_BF16 = 0.12
-C2_RENDER_BWD_TOL_BF16 = 0.32
+# bf16 operand mode (BASELINE configs[1]): <= 3x the worst error measured on the MI355X at the FINAL kernels
+# (profiles/r6_gradient_margins.txt, rows c2_size_*[bf16]; re-measured in round 6 -- the round-5 bars 0.12 / 0.32 dated from the
+# round-4 forward kernel and sat 20x above the committed measurement of the render row):
+#   MLP op 3.83e-2 worst / 1.36e-2 median over 60 tensors, loss 8.1e-5;
+#   training render 1.56e-2 worst / 6.4e-3 median over 59, loss 3.2e-3 (ONE scalar: 512 randomly weighted colour / weight-sum
+#   terms of 128 rays; the compositing turns sdf errors into weight errors at 1/s_val).
+C2_MLP_BWD_TOL_BF16 = 0.115
+C2_RENDER_BWD_TOL_BF16 = 0.047
 C2_LOSS_TOL_BF16 = 1e-2
 
 
