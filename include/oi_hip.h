@@ -569,6 +569,17 @@ int oi_disc_graph_launch(oi_disc_graph* g, const float* x, const float* theta_ho
 /* the same launches issued one by one (no graph replay) from the object's stored arguments; `logits`: where this call's
  * [B][out_dim] result goes (NULL: the buffer given at creation) */
 int oi_disc_graph_launch_eager(oi_disc_graph* g, const float* x, const float* theta_host, float* logits, oi_stream_t stream);
+/* AugmentPipe's parameter draws (src/third_party/ada/augment.py:213-230: integer translation `xint`, isotropic `scale`) and the
+ * sampling matrix (augment.py:285-297) formed INSIDE the library from one 64-bit seed per forward (splitmix64 counter stream; per
+ * image: t_x, t_y, the translation gate, the scale's normal, the scale gate).  p_xint = xint * p, p_scale = scale * p (the gates'
+ * probabilities).  theta_host [B][2][3] (HOST memory); ts_host [B][3] = (t_x, t_y, s) as drawn, or NULL.  No HIP call.
+ * oi_disc_graph_launch_ada = these draws at the plan's static margins + oi_disc_graph_launch_eager (eager != 0; `logits` as there)
+ * or oi_disc_graph_launch (eager == 0; logits must be NULL): the reference's own call, ADADiscriminator.forward
+ * (src/models/discriminator.py:98-100), without numpy or Python arithmetic on the way. */
+int oi_ada_theta_xint_scale(unsigned long long seed, int B, int H, int W, int mx0, int mx1, int my0, int my1, float p_xint,
+                            float xint_max, float p_scale, float scale_std, float* theta_host, float* ts_host);
+int oi_disc_graph_launch_ada(oi_disc_graph* g, const float* x, unsigned long long seed, float p_xint, float xint_max, float p_scale,
+                             float scale_std, float* logits, int eager, oi_stream_t stream);
 void oi_disc_graph_destroy(oi_disc_graph* g);
 
 /* The whole geometric augmentation of AugmentPipe.forward (src/third_party/ada/augment.py:284-301) for a given sampling

@@ -693,6 +693,82 @@ int oi_disc_graph_launch_eager(oi_disc_graph* g, const float* x, const float* th
                            g->H, g->W, g->n_feat, g->out_dim, g->slope, stream);
 }
 
+// ---- AugmentPipe's parameter draws for the shipped configuration (xint + scale), inside the library --------------------------
+// One 64-bit seed per forward (the caller takes it from ITS random stream: one draw per call instead of four numpy calls and
+// ~60 numpy scalar operations, which cost more host time than the four launches of the forward) is expanded by a counter-based
+// generator (splitmix64) into the draws of src/third_party/ada/augment.py:213-230 -- per image, in this order: t_x, t_y ~ U[0, 1),
+// the xint gate ~ U[0, 1), the scale's N(0, 1) (Box-Muller on two further uniforms), the scale gate ~ U[0, 1) -- with the
+// reference's fp32 arithmetic: t = (u * 2 - 1) * xint_max if gate < xint * p else 0;  s = exp2(n * scale_std) if gate < scale * p
+// else 1;  G_inv = T(-round(t_x W), -round(t_y H)) . S(1 / s, 1 / s) (round half to even, as torch.round).  The sampling matrix
+// theta = [S(2 / Wp, 2 / Hp) T(-.5, -.5) S(2, 2) T((mx0 - mx1) / 2, (my0 - my1) / 2)] G_inv [S(.5, .5) T(.5, .5) S(Wo / 2, Ho / 2)]
+// (augment.py:285-297; Wp, Hp = the padded x2 canvas, Wo, Ho = 2 (W + 6), 2 (H + 6)) is formed in double and rounded once.
+namespace {
+struct SplitMix64 {
+  unsigned long long s;
+  unsigned long long next() {
+    unsigned long long z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  float uniform() { return (float)(next() >> 40) * (1.0f / 16777216.0f); }   // 24 bits: [0, 1), exactly representable
+  double uniform53() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+void mat3_mul(const double a[9], const double b[9], double out[9]) {
+  double t[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  for (int i = 0; i < 9; ++i) out[i] = t[i];
+}
+
+void ada_theta_draw(unsigned long long seed, int B, int H, int W, int mx0, int mx1, int my0, int my1, float p_xint, float xint_max,
+                    float p_scale, float scale_std, float* theta, float* ts) {
+  SplitMix64 rng{seed};
+  const double Wp = 2.0 * (W + mx0 + mx1), Hp = 2.0 * (H + my0 + my1), Wo = 2.0 * (W + DA_PAD), Ho = 2.0 * (H + DA_PAD);
+  const double S1[9] = {2 / Wp, 0, 0, 0, 2 / Hp, 0, 0, 0, 1}, T1[9] = {1, 0, -0.5, 0, 1, -0.5, 0, 0, 1}, S2[9] = {2, 0, 0, 0, 2, 0, 0, 0, 1};
+  const double Tm[9] = {1, 0, (mx0 - mx1) / 2.0, 0, 1, (my0 - my1) / 2.0, 0, 0, 1};
+  const double S3[9] = {0.5, 0, 0, 0, 0.5, 0, 0, 0, 1}, T2[9] = {1, 0, 0.5, 0, 1, 0.5, 0, 0, 1}, S4[9] = {Wo / 2, 0, 0, 0, Ho / 2, 0, 0, 0, 1};
+  double L[9], R[9];
+  mat3_mul(S1, T1, L); mat3_mul(L, S2, L); mat3_mul(L, Tm, L);
+  mat3_mul(S3, T2, R); mat3_mul(R, S4, R);
+  for (int b = 0; b < B; ++b) {
+    const float u_tx = rng.uniform(), u_ty = rng.uniform(), g_t = rng.uniform();
+    const double u1 = rng.uniform53(), u2 = rng.uniform53();
+    const float g_s = rng.uniform();
+    const float n = (float)(sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586476925 * u2));
+    const bool t_on = g_t < p_xint, s_on = g_s < p_scale;
+    const float tx = t_on ? (u_tx * 2.0f - 1.0f) * xint_max : 0.0f, ty = t_on ? (u_ty * 2.0f - 1.0f) * xint_max : 0.0f;
+    const float sc = s_on ? exp2f(n * scale_std) : 1.0f;
+    const float inv = 1.0f / sc;
+    const double G[9] = {inv, 0, -(double)nearbyintf(tx * (float)W), 0, inv, -(double)nearbyintf(ty * (float)H), 0, 0, 1};
+    double M[9];
+    mat3_mul(L, G, M); mat3_mul(M, R, M);
+    for (int i = 0; i < 6; ++i) theta[b * 6 + i] = (float)M[i];
+    if (ts != nullptr) ts[b * 3] = tx, ts[b * 3 + 1] = ty, ts[b * 3 + 2] = sc;
+  }
+}
+}  // namespace
+
+int oi_ada_theta_xint_scale(unsigned long long seed, int B, int H, int W, int mx0, int mx1, int my0, int my1, float p_xint,
+                            float xint_max, float p_scale, float scale_std, float* theta_host, float* ts_host) {
+  OI_REQUIRE(theta_host != nullptr && B >= 1 && H >= 1 && W >= 1, "oi_ada_theta_xint_scale: bad argument");
+  OI_REQUIRE(mx0 >= 0 && mx1 >= 0 && my0 >= 0 && my1 >= 0, "oi_ada_theta_xint_scale: negative margin");
+  ada_theta_draw(seed, B, H, W, mx0, mx1, my0, my1, p_xint, xint_max, p_scale, scale_std, theta_host, ts_host);
+  return OI_OK;
+}
+
+int oi_disc_graph_launch_ada(oi_disc_graph* g, const float* x, unsigned long long seed, float p_xint, float xint_max, float p_scale,
+                             float scale_std, float* logits, int eager, oi_stream_t stream) {
+  OI_REQUIRE(g != nullptr && x != nullptr, "oi_disc_graph_launch_ada: null pointer");
+  OI_REQUIRE(g->aug != 0, "oi_disc_graph_launch_ada: the object was created without augmentation");
+  float theta[DS_MAX_B * 6];
+  ada_theta_draw(seed, g->B, g->H, g->W, g->mx0, g->mx1, g->my0, g->my1, p_xint, xint_max, p_scale, scale_std, theta, nullptr);
+  if (eager) return oi_disc_graph_launch_eager(g, x, theta, logits, stream);
+  OI_REQUIRE(logits == nullptr, "oi_disc_graph_launch_ada: a graph replay writes the buffer the object was created with");
+  return oi_disc_graph_launch(g, x, theta, stream);
+}
+
 void oi_disc_graph_destroy(oi_disc_graph* g) {
   if (g == nullptr) return;
   graph_variant_free(g->v[0]);

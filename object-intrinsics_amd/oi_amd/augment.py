@@ -83,6 +83,36 @@ class AugmentPipe(torch.nn.Module):
             self._p_cache = (key, float(self.p))
         return self._p_cache[1]
 
+    def fast_draw_ok(self):
+        """True when a forward's parameters may be drawn inside the library from one seed (ops.DiscGraph.call_ada): the shipped
+        configuration (xint + scale only), this class's own `forward` / `sample_G_inv` (tests and the F13 replay pin
+        `debug_percentile` by overriding them on the instance), the 12-tap filter."""
+        d = self.__dict__
+        return (self._only_xint_scale and "forward" not in d and "sample_G_inv" not in d and type(self).forward is AugmentPipe.forward
+                and type(self).sample_G_inv is AugmentPipe.sample_G_inv and self.Hz_geom.shape[0] == 12)
+
+    def fast_params(self):
+        """(xint * p, xint_max, scale * p, scale_std): the gate probabilities and strengths oi_ada_theta_xint_scale takes."""
+        key = (self.p.data_ptr(), self.p._version)
+        hit = self.__dict__.get("_fast_params")
+        if hit is None or hit[0] != key:
+            p = self._p_host()
+            hit = self.__dict__["_fast_params"] = (key, (self.xint * p, self.xint_max, self.scale * p, self.scale_std))
+        return hit[1]
+
+    @staticmethod
+    def draw_seed():
+        """One 64-bit seed per forward from numpy's GLOBAL stream (so `np.random.seed` still pins a forward's augmentation; the
+        library expands it into the per-image draws).  53 random bits from one `np.random.random()` -- a Python float, 0.3 us."""
+        return int(np.random.random() * 9007199254740992.0)
+
+    def theta_fast(self, B, H, W, seed=None, with_draws=False):
+        """The sampling matrices a library-drawn forward uses for `seed` (default: the next draw_seed()), at the static margins."""
+        from . import ops
+        if seed is None:
+            seed = self.draw_seed()
+        return ops.ada_theta_xint_scale(seed, B, H, W, self.static_margins(H, W), *self.fast_params(), with_draws=with_draws)
+
     def sample_G_inv(self, images, debug_percentile=None):
         """augment.py:191-268 for the geometric branches.  Returns a (B,3,3) float32 numpy array or None."""
         B, _, H, W = images.shape

@@ -17,6 +17,7 @@ _SMALL_PLANS = weakref.WeakKeyDictionary()
 _LARGE_PACKS = weakref.WeakKeyDictionary()
 LARGE_PATH = True   # batch >= 16 no-grad forwards take csrc/disc_large.hip when the network is covered (False: the general chain)
 LARGE_MIN_BATCH = 16
+FAST_ADA = True     # ADADiscriminator.forward, shipped augmentation, batch <= 4: parameters drawn inside the library (False: numpy)
 SMALL_PATH = True   # batch <= 4 no-grad forwards of the 64 x 64 network take csrc/disc_small.hip (False: the general chain)
 
 
@@ -114,18 +115,25 @@ class DCDiscriminator(nn.Module):
         if theta_dev is not None:
             return ops.disc_fwd_small(x.float(), [l.weight for l in self.blocks], self.conv_out.weight, self.conv_out.bias, f12=f12,
                                       theta_dev=theta_dev, margins=margins)
+        aug_on = theta_np is not None
+        return self._small_plan(x, f12 if aug_on else None, margins if aug_on else None)(x.float(), theta_np, fresh=True)
+
+    def _small_plan(self, x, f12, margins):
+        """The library plan (ops.DiscGraph, launched launch by launch) for this image shape / stream / weight addresses; with the
+        augmentation at static `margins` when they are given."""
+        from . import ops
         ws = [l.weight for l in self.blocks] + [self.conv_out.weight] + ([] if self.conv_out.bias is None else [self.conv_out.bias])
-        key = (tuple(x.shape), x.device.index, ops._stream().value or 0, None if theta_np is None else tuple(int(v) for v in margins),
+        key = (tuple(x.shape), x.device.index, ops._stream().value or 0, None if margins is None else tuple(int(v) for v in margins),
                tuple(w.data_ptr() for w in ws))
         plans = _SMALL_PLANS.setdefault(self, {})   # (not in __dict__: the plans hold library handles; copy.deepcopy(module) must work)
         plan = plans.get(key)
         if plan is None:
             if len(plans) >= 8:
                 plans.clear()   # (weights moved, many shapes: start over rather than grow)
+                _FAST_ADA.pop(self, None)
             plan = plans[key] = ops.DiscGraph(tuple(x.shape), x.device, [l.weight for l in self.blocks], self.conv_out.weight,
-                                              self.conv_out.bias, f12=f12 if theta_np is not None else None,
-                                              margins=margins if theta_np is not None else None, launch="eager")
-        return plan(x.float(), theta_np, fresh=True)
+                                              self.conv_out.bias, f12=f12, margins=margins, launch="eager")
+        return plan
 
     def forward(self, x, **kwargs):
         batch_size = x.shape[0]
@@ -152,6 +160,39 @@ class DCDiscriminator(nn.Module):
         return out.reshape(batch_size, self.out_dim)
 
 
+class _FastSmallAda:
+    """What ADADiscriminator.forward needs to answer a no-grad batch <= 4 call of the shipped configuration with ONE library call
+    (ops.DiscGraph.call_ada: draws, sampling matrices, the four launches): the plan and the guards under which it stays valid --
+    shape / dtype / layout of the image, the stream, the addresses of the weights (the plan holds raw pointers; in-place
+    optimiser updates keep them), nobody capturing, the augmentation pipe un-patched.  Any guard failing -> None -> the general
+    path decides again (and may build a new one).  Review, round 5: the module's own forward ran at 38 % of the plan's rate --
+    numpy draws (20 us), matrix algebra (4 us), array marshalling (5 us) and ~15 us of per-call checks for 16 us of launches."""
+
+    __slots__ = ("shape", "device", "stream", "ws", "ptrs", "plan", "aug")
+
+    def __init__(self, disc, x, plan):
+        from . import ops
+        self.shape, self.device, self.stream = x.shape, x.device, ops._stream().value
+        self.ws = [l.weight for l in disc.blocks] + [disc.conv_out.weight] + ([] if disc.conv_out.bias is None else [disc.conv_out.bias])
+        self.ptrs = [w.data_ptr() for w in self.ws]
+        self.plan, self.aug = plan, disc.aug
+
+    def __call__(self, x):
+        if (x.shape != self.shape or x.dtype is not torch.float32 or x.device != self.device or not x.is_contiguous()
+                or [w.data_ptr() for w in self.ws] != self.ptrs):
+            return None
+        d = self.aug.__dict__
+        if "sample_G_inv" in d or "forward" in d or torch.cuda.is_current_stream_capturing():
+            return None
+        from . import ops
+        if ops._stream().value != self.stream:
+            return None
+        return self.plan.call_ada(x, self.aug.draw_seed(), *self.aug.fast_params(), fresh=True)
+
+
+_FAST_ADA = weakref.WeakKeyDictionary()
+
+
 class ADADiscriminator(DCDiscriminator):
     def __init__(self, aug, aug_p, **kwargs):
         super().__init__(**kwargs)
@@ -166,6 +207,12 @@ class ADADiscriminator(DCDiscriminator):
         """`aug_theta`: precomputed sampling grid for the shape-static augmentation (see AugmentPipe.forward)."""
         from .augment import AugmentPipe
         aug = self.aug
+        if aug_theta is None and not torch.is_grad_enabled():
+            fast = _FAST_ADA.get(self)
+            if fast is not None:
+                out = fast(x)
+                if out is not None:
+                    return out
         if (self._small_ok(x) and type(aug).forward is AugmentPipe.forward and "forward" not in aug.__dict__
                 and aug.Hz_geom.shape[0] == 12):
             # augmentation + network in four launches; the sampling matrix goes to the kernel by value (no upload)
@@ -174,6 +221,13 @@ class ADADiscriminator(DCDiscriminator):
                 return self._forward_small(x, f12=aug.Hz_geom, theta_dev=aug_theta, margins=aug.static_margins(H, W))
             if not self._plan_ok():
                 return super().forward(self.aug(x), **kwargs)
+            if FAST_ADA and aug.fast_draw_ok():
+                # the shipped configuration: parameters drawn inside the library from one seed of numpy's stream
+                x = x.float().contiguous()
+                margins = aug.static_margins(H, W)
+                plan = self._small_plan(x, aug.Hz_geom, margins)
+                fast = _FAST_ADA[self] = _FastSmallAda(self, x, plan)
+                return fast(x)
             G_inv = aug.sample_G_inv(x, None)
             if G_inv is None:
                 return self._forward_small(x)

@@ -379,6 +379,9 @@ class GraphedDForward:
         if self.graph is None or tuple(x.shape) != tuple(self.x.shape):
             self.capture(x)
         if self._lib is not None:
+            aug = getattr(self.disc, "aug", None)
+            if self._geom and aug.fast_draw_ok():   # the shipped configuration: one seed from numpy's stream, draws in the library
+                return self._lib.call_ada(x.float().contiguous(), aug.draw_seed(), *aug.fast_params())
             return self._lib(x.float(), self._thetas(tuple(x.shape)) if self._geom else None)
         self._upload(x)
         self.graph.replay()

@@ -110,6 +110,8 @@ _SIGS = {
     "oi_disc_graph_create": (_i, [_vp, _i, _vp] + [_i] * 4 + [_vp] * 9 + [_i] * 6 + [_f]),
     "oi_disc_graph_launch": (_i, [_vp, _vp, _vp, _vp]),
     "oi_disc_graph_launch_eager": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "oi_ada_theta_xint_scale": (_i, [ctypes.c_ulonglong] + [_i] * 7 + [_f] * 4 + [_vp, _vp]),
+    "oi_disc_graph_launch_ada": (_i, [_vp, _vp, ctypes.c_ulonglong, _f, _f, _f, _f, _vp, _i, _vp]),
     "oi_disc_graph_destroy": (None, [_vp]),
     "oi_outputs_prezeroed_stream": (_i, [_vp, _i]),
     "oi_light_dir_fwd": (_i, [_vp, _vp, _vp, _i, _vp]),

@@ -898,6 +898,22 @@ class DiscGraph:
         _l.check(L.oi_disc_graph_launch(self.handle, _p(x), th, _stream()), "oi_disc_graph_launch")
         return self.logits
 
+    def call_ada(self, x, seed, p_xint, xint_max, p_scale, scale_std, fresh=False):
+        """The forward with AugmentPipe's xint + scale draws made INSIDE the library from one 64-bit seed
+        (oi_disc_graph_launch_ada): no numpy, no matrix algebra and no array marshalling on the way.  `x` must already be a
+        contiguous fp32 CUDA tensor of the plan's shape (the caller's guard)."""
+        L = _l.load()
+        if self.eager:
+            out = torch.empty_like(self.logits) if fresh else self.logits
+            rc = L.oi_disc_graph_launch_ada(self.handle, x.data_ptr(), seed, p_xint, xint_max, p_scale, scale_std, out.data_ptr(), 1,
+                                            _stream())
+        else:
+            out = self.logits
+            rc = L.oi_disc_graph_launch_ada(self.handle, x.data_ptr(), seed, p_xint, xint_max, p_scale, scale_std, None, 0, _stream())
+        if rc != 0:
+            _l.check(rc, "oi_disc_graph_launch_ada")
+        return out
+
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
         if h:
@@ -905,6 +921,18 @@ class DiscGraph:
                 _l.load().oi_disc_graph_destroy(h)
             except Exception:
                 pass
+
+
+def ada_theta_xint_scale(seed, B, H, W, margins, p_xint, xint_max, p_scale, scale_std, with_draws=False):
+    """(B, 2, 3) float32 numpy: the sampling matrices the library forms from `seed` (oi_ada_theta_xint_scale; host only, no HIP
+    call) -- what DiscGraph.call_ada uses for the same seed.  with_draws: also (B, 3) = (t_x, t_y, s) as drawn."""
+    th = np.empty((B, 2, 3), np.float32)
+    ts = np.empty((B, 3), np.float32) if with_draws else None
+    mx0, my0, mx1, my1 = (int(v) for v in margins)
+    _l.check(_l.load().oi_ada_theta_xint_scale(int(seed), B, H, W, mx0, mx1, my0, my1, p_xint, xint_max, p_scale, scale_std,
+                                               th.ctypes.data_as(_vp), None if ts is None else ts.ctypes.data_as(_vp)),
+             "oi_ada_theta_xint_scale")
+    return (th, ts) if with_draws else th
 
 
 def ada_geom_fwd(x, theta, f12, margins):

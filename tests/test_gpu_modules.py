@@ -736,7 +736,7 @@ def test_library_graph_discriminator_forward_bit_identical(B, with_aug, launch, 
         np.random.seed(200 + i)
         with torch.no_grad():
             if with_aug:
-                th = disc.aug.theta_for(disc.aug.sample_G_inv(x, None), disc.aug.static_margins(64, 64), 64, 64)
+                th = disc.aug.theta_fast(B, 64, 64)   # (one seed from numpy's stream -> the library's draws: what gd(x) does)
                 want = disc._forward_small(x, f12=disc.aug.Hz_geom, theta_np=th, margins=disc.aug.static_margins(64, 64)).clone()
             else:
                 want = disc(x).clone()
@@ -1005,3 +1005,64 @@ def test_graphed_large_batch_discriminator_follows_weight_updates():
     got2 = gd(x).clone()
     torch.cuda.synchronize()
     assert torch.equal(got2, eager_general())
+
+
+@pytest.mark.parametrize("B,in_dim,out_dim,view", [(1, 3, 7, True), (4, 1, 1, False)])
+def test_ada_discriminator_eager_forward_draws_in_the_library(B, in_dim, out_dim, view, monkeypatch):
+    """The reference's own call -- ADADiscriminator.forward (src/models/discriminator.py:98-100) without gradient, batch <= 4, the
+    shipped xint + scale augmentation -- is ONE library call from the second call on (oi_disc_graph_launch_ada: draws, matrices,
+    four launches).  (a) bit-identical to the explicit route (the same seed's matrices from oi_ada_theta_xint_scale handed to
+    oi_disc_fwd_small) and seeded by numpy's stream; (b) against the fp64 oracle with the augmentation the library drew;
+    (c) follows an in-place weight update; (d) a pinned debug_percentile (instance override) or FAST_ADA = False takes the numpy
+    route; (e) the module still deep-copies, and the copy draws the same augmentation from the same numpy state."""
+    import copy
+    import oi_amd.discriminator as DM
+    D = _ada_disc(in_dim, out_dim).cuda().eval()   # (ADADiscriminatorView adds constructor arguments only: same forward)
+    with torch.no_grad():
+        for p_ in D.parameters():
+            p_.copy_((torch.rand_like(p_) * 2 - 1) * (6.0 / (1.04 * p_[0].numel())) ** 0.5)
+    H = W = 64
+    m = D.aug.static_margins(H, W)
+    g = torch.Generator().manual_seed(21)
+    dsd = {k: v.detach().double().cpu() for k, v in D.state_dict().items() if "aug." not in k}
+    for i in range(3):
+        x = torch.rand(B, in_dim, H, W, generator=g).cuda()
+        np.random.seed(300 + i)
+        with torch.no_grad():
+            got = D(x, it=0).clone()
+        assert (DM._FAST_ADA.get(D) is not None) and got.shape == (B, out_dim)
+        np.random.seed(300 + i)
+        th, ts = D.aug.theta_fast(B, H, W, with_draws=True)
+        with torch.no_grad():
+            want = D._forward_small(x, f12=D.aug.Hz_geom, theta_np=th, margins=m)
+        assert torch.equal(got, want), (i, maxdiff(got, want))
+        # the oracle on the augmentation the library drew: G_inv = T(-round(t W)) S(1 / s)  (augment.py:213-230)
+        t64, s64 = torch.from_numpy(ts[:, :2].astype(np.float64)), torch.from_numpy(ts[:, 2].astype(np.float64))
+        G = O.ada_G_inv(B, H, W, t64, s64, dtype=torch.float64)
+        ref = O.dc_discriminator(dsd, O.ada_geometric(x.double().cpu(), G)[0])
+        assert maxdiff(got.cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max())), (i, maxdiff(got.cpu(), ref))
+    # (c) in-place update: same plan, live weights
+    with torch.no_grad():
+        D.blocks[2].weight.mul_(0.5)
+        np.random.seed(7); a = D(x).clone()
+        np.random.seed(7); th = D.aug.theta_fast(B, H, W)
+        assert torch.equal(a, D._forward_small(x, f12=D.aug.Hz_geom, theta_np=th, margins=m))
+        # (e) deep copy
+        twin = copy.deepcopy(D)
+        np.random.seed(7); b = twin(x).clone()
+        assert torch.equal(a, b)
+        # (d) the numpy route: switched off, or debug_percentile pinned by an instance override
+        monkeypatch.setattr(DM, "FAST_ADA", False)
+        DM._FAST_ADA.pop(D, None)
+        np.random.seed(8); c = D(x).clone()
+        np.random.seed(8)
+        th_np = D.aug.theta_for(D.aug.sample_G_inv(x, None), m, H, W)
+        assert DM._FAST_ADA.get(D) is None and torch.equal(c, D._forward_small(x, f12=D.aug.Hz_geom, theta_np=th_np, margins=m))
+        monkeypatch.setattr(DM, "FAST_ADA", True)
+        D(x)
+        assert DM._FAST_ADA.get(D) is not None
+        orig = D.aug.sample_G_inv
+        D.aug.sample_G_inv = lambda im, _pct=None: orig(im, 0.7)
+        d = D(x).clone()
+        th_p = D.aug.theta_for(orig(x, 0.7), m, H, W)
+        assert torch.equal(d, D._forward_small(x, f12=D.aug.Hz_geom, theta_np=th_p, margins=m))

@@ -170,3 +170,53 @@ def test_field_pack_deepcopy_does_not_inherit_the_hold_depth():
     assert twin._key != k1            # the copy's version walk is live
     pack.hold(False)
     assert pack._held == 0
+
+
+def test_library_ada_draws_match_the_reference_distribution_and_matrix():
+    """oi_ada_theta_xint_scale (host-only entry of the library; no GPU): the per-image draws it expands from one seed against
+    what src/third_party/ada/augment.py:213-230 prescribes -- t ~ U(-xint_max, xint_max) per axis w.p. xint * p (else 0),
+    s = 2^(N(0, 1) * scale_std) w.p. scale * p (else 1), independent gates -- by mean / variance / gate frequency over 2^16
+    images, and the sampling matrix it forms against AugmentPipe.theta_for on the SAME draws (1 ulp), symmetric and
+    asymmetric margins.  Same seed -> same draws; different seeds differ."""
+    from oi_amd.augment import AugmentPipe
+    from oi_amd import ops
+    f32 = np.float32
+    aug = AugmentPipe(xint=1, scale=1)
+    n = 1 << 16
+    np.random.seed(3)
+    th, ts = aug.theta_fast(n, 64, 64, with_draws=True)
+    t, s = ts[:, :2].astype(np.float64), ts[:, 2].astype(np.float64)
+    # p = 1: every gate open.  U(-1/8, 1/8): mean 0, variance (1/4)^2 / 12; 5 sigma of the sample mean / variance
+    var_t = 0.25 ** 2 / 12
+    assert np.abs(t).max() < 0.125 and abs(t.mean()) < 5 * np.sqrt(var_t / (2 * n))
+    assert abs(t.var() - var_t) < 5 * var_t * np.sqrt(0.8 / (2 * n))          # (kurtosis of a uniform: var of var = 0.8 s^4 / n)
+    assert abs(np.corrcoef(t[:, 0], t[:, 1])[0, 1]) < 5 / np.sqrt(n)           # the two axes are independent draws
+    ls = np.log2(s)
+    assert abs(ls.mean()) < 5 * 0.2 / np.sqrt(n) and abs(ls.std() - 0.2) < 5 * 0.2 / np.sqrt(2 * n)
+    assert abs(((ls / 0.2) ** 4).mean() - 3.0) < 0.15 and abs(((ls / 0.2) ** 3).mean()) < 0.06   # a normal: kurtosis 3, no skew
+    assert abs(np.corrcoef(t[:, 0], ls)[0, 1]) < 5 / np.sqrt(n)
+    # the matrix: augment.py:285-297 on the same draws
+    for margins, H, W in ((aug.static_margins(64, 64), 64, 64), ((5, 9, 2, 11), 64, 48)):
+        th2, ts2 = ops.ada_theta_xint_scale(77, 512, H, W, margins, *aug.fast_params(), with_draws=True)
+        G = np.zeros((512, 3, 3), f32)
+        G[:, 0, 0] = G[:, 1, 1] = f32(1) / ts2[:, 2]
+        G[:, 0, 2], G[:, 1, 2], G[:, 2, 2] = -np.round(ts2[:, 0] * f32(W)), -np.round(ts2[:, 1] * f32(H)), 1
+        ref = aug.theta_for(G, margins, H, W)
+        assert np.abs(ref - th2).max() <= 1.2e-7 * max(1.0, np.abs(ref).max())
+    # gates at p = 0.3: frequencies, independence of the two gates, closed gates give exactly t = 0 / s = 1
+    aug.p.fill_(0.3)
+    _, ts = aug.theta_fast(n, 64, 64, seed=12345, with_draws=True)
+    on_t, on_s = ts[:, 0] != 0, ts[:, 2] != 1
+    sd = np.sqrt(0.3 * 0.7 / n)
+    assert abs(on_t.mean() - 0.3) < 5 * sd and abs(on_s.mean() - 0.3) < 5 * sd and abs((on_t & on_s).mean() - 0.09) < 5 * sd
+    assert np.all(ts[~on_t][:, 1] == 0) and np.all(ts[~on_s][:, 2] == 1)     # ONE gate for both axes of the translation
+    # determinism / seeding
+    a = aug.theta_fast(4, 64, 64, seed=9)
+    assert np.array_equal(a, aug.theta_fast(4, 64, 64, seed=9)) and not np.array_equal(a, aug.theta_fast(4, 64, 64, seed=10))
+    np.random.seed(1); b = aug.theta_fast(4, 64, 64)
+    np.random.seed(1); c = aug.theta_fast(4, 64, 64)
+    assert np.array_equal(b, c)
+    # an overridden sample_G_inv / forward (how tests pin debug_percentile) switches the library draws off
+    assert aug.fast_draw_ok()
+    aug.sample_G_inv = lambda *a, **k: None
+    assert not aug.fast_draw_ok()
