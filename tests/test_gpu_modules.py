@@ -987,24 +987,26 @@ def test_graphed_large_batch_discriminator_follows_weight_updates():
         finally:
             DM.LARGE_PATH = True
 
+    TOL = 2e-5   # (the bar of test_large_batch_discriminator_forward_vs_oracle; the weight updates below move the logits by > 1e-3)
     got0 = gd(x).clone()
     assert gd._lib is None and gd.graph is not None
-    assert torch.equal(got0, eager_general())          # the capture holds the general chain: same launches, same bits
+    assert maxdiff(got0, eager_general()) < TOL        # the capture holds the general chain (split-K atomics: not bit-stable)
     with torch.no_grad():
         D.blocks[1].weight.mul_(0.5)
         D.conv_out.weight.add_(0.01)
     want1 = eager_general()
     assert maxdiff(want1, got0) > 1e-3                  # (the update matters)
     got1 = gd(x).clone()
-    assert torch.equal(got1, want1), maxdiff(got1, want1)
+    assert maxdiff(got1, want1) < TOL, maxdiff(got1, want1)
     with torch.no_grad():
         large = DM.DCDiscriminator.forward(D, x)        # eager: rebuilds the pack, frees the previous one
         assert maxdiff(large, want1) < 2e-5
         D.blocks[3].weight.mul_(1.25)
         DM.DCDiscriminator.forward(D, x)
     got2 = gd(x).clone()
+    assert maxdiff(got2, got1) > 1e-3
     torch.cuda.synchronize()
-    assert torch.equal(got2, eager_general())
+    assert maxdiff(got2, eager_general()) < TOL
 
 
 @pytest.mark.parametrize("B,in_dim,out_dim,view", [(1, 3, 7, True), (4, 1, 1, False)])
