@@ -15,7 +15,15 @@ import torch
 
 from .losses import GANLoss, PositionLoss, gan_losses, grad_wrt_input, linear_increase, ones_scalar, weighted_sum
 
+import os
+
 MODULE_KEYS = ("generator", "discriminator", "mask_discriminator")
+# OI_TRAIN_OVERLAP=1: the graphed discriminator step on a second stream, overlapped with the render that follows it.  Built and
+# measured in round 6 (tools/dbg/run_overlap_ab.sh, run_overlap_tl.sh), NOT the default: 9.19-9.27 ms per iteration either way.
+# The timeline says why: the render's MLP launches own every compute unit (one workgroup per CU: the whole register file and
+# 150 KB of LDS), a freed CU goes to their next workgroup first, and each of the step's ~75 dependent launches then takes 25-90 us
+# instead of 5-10 -- the step stretches from 0.42 to 1.5 ms, exactly the render it hides behind (high stream priority: the same).
+OVERLAP_D_STEP = os.environ.get("OI_TRAIN_OVERLAP", "0") == "1"
 DATA_KEYS = {"generator": ["image"], "discriminator": ["image"], "mask_discriminator": ["mask"]}
 
 
@@ -202,10 +210,38 @@ class Trainer:
         x_real = _cat([real[k] for k in DATA_KEYS[key]]).detach()
         x_fake = _cat([fake[k] for k in DATA_KEYS[key]]).detach()
         has_aux = _unwrap(disc).out_dim > 1
-        out = gd(x_real, x_fake, fake["c2b"].detach() if has_aux else None,
-                 self.loss_weight["aux_pose"](self.it) if has_aux else 0.0)
-        ret = {f"{key}/loss": out["loss"], f"{key}/reg": out["reg"], f"{key}/fake": out["fake"], f"{key}/real": out["real"],
-               f"{key}/aux_pose": out["aux_pose"] if has_aux else 0}
+        c2b = fake["c2b"].detach() if has_aux else None
+        aux_w = self.loss_weight["aux_pose"](self.it) if has_aux else 0.0
+        named = lambda out: {f"{key}/loss": out["loss"], f"{key}/reg": out["reg"], f"{key}/fake": out["fake"],
+                             f"{key}/real": out["real"], f"{key}/aux_pose": out["aux_pose"] if has_aux else 0}
+        if defer_step and OVERLAP_D_STEP and x_real.is_cuda:
+            # The step (a replayed chain of ~75 launches of a few microseconds that wait for each other: 0.42 ms during which the
+            # chip is almost idle), its gradient exchange and its optimiser step go to a SECOND stream; the caller enqueues the
+            # next no-grad render -- which reads generator state only -- on the main stream meanwhile and joins in finish().
+            # Same arithmetic, same host-side draw order; the images the step reads are kept alive for the side stream.
+            main = torch.cuda.current_stream()
+            if getattr(self, "_side_stream", None) is None:
+                # high priority: the step's launches are tiny and wait for each other; a freed compute unit should go to them
+                # before the next workgroup of the render that fills the chip (OI_TRAIN_OVERLAP_PRIO=0: default priority)
+                prio = -1 if os.environ.get("OI_TRAIN_OVERLAP_PRIO", "1") != "0" else 0
+                self._side_stream = torch.cuda.Stream(device=x_real.device, priority=prio)
+            side = self._side_stream
+            side.wait_stream(main)
+            for t in (x_real, x_fake, c2b):
+                if t is not None:
+                    t.record_stream(side)
+            with torch.cuda.stream(side):
+                out = gd(x_real, x_fake, c2b, aux_w)
+                _sync(disc)
+                opt.step()
+            out["loss"].record_stream(main)   # (the five scalars are views of one clone made on the side stream)
+
+            def join():
+                main.wait_stream(side)
+
+            return named(out), join
+        out = gd(x_real, x_fake, c2b, aux_w)
+        ret = named(out)
 
         def finish():
             _sync(disc)

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Outputs of one seeded full forward (sdf, d sdf/dx, albedo, features) and one sdf-only forward of the library selected by
-OI_LIB, saved for a bit-for-bit comparison between library variants:  fwd_dump.py out.pt  |  fwd_dump.py --cmp a.pt b.pt"""
+OI_LIB, saved for a bit-for-bit comparison between library variants:  fwd_dump.py out.pt [mode]  |  fwd_dump.py --cmp a.pt b.pt
+Test infrastructure: tests/test_gpu_kernels.py::test_persistent_workgroups_bit_identical runs it in two subprocesses (the
+launch mode is read once per process); tools/dbg/run_fwd_ab.sh and run_v2_persist_ab.sh use it for same-box A/Bs."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/helpers/ -> repo root
 for p in (ROOT, ROOT + "/object-intrinsics_amd", ROOT + "/tests"):
     sys.path.insert(0, p)
 import torch

@@ -154,7 +154,7 @@ def test_persistent_workgroups_bit_identical(mode, tmp_path):
     for v in ("1", "0"):
         out = str(tmp_path / f"fwd_{mode}_{v}.pt")
         env = dict(os.environ, OI_B3P_PERSIST=v, OI_V2_PERSIST=v)
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg", "fwd_dump.py"), out, mode], env=env,
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "fwd_dump.py"), out, mode], env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
         assert r.returncode == 0, r.stdout[-2000:]
         outs.append(torch.load(out))

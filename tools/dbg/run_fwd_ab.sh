@@ -9,8 +9,8 @@ for v in "$@"; do
   echo == $v
   export OI_LIB=$R/object-intrinsics_amd/build/ab/liboi_$v.so
   timeout 300 python $R/tools/bench_c5.py --modes ${MODES:-f16x3,f16x3:fast} 2>&1 < /dev/null | grep '"mode"'
-  timeout 300 python $R/tools/dbg/fwd_dump.py $R/gpurun_out/fwd_$v.pt 2>&1 | tail -1
-  if [ -z "$first" ]; then first=$v; else python $R/tools/dbg/fwd_dump.py --cmp $R/gpurun_out/fwd_$first.pt $R/gpurun_out/fwd_$v.pt; fi
+  timeout 300 python $R/tests/helpers/fwd_dump.py $R/gpurun_out/fwd_$v.pt 2>&1 | tail -1
+  if [ -z "$first" ]; then first=$v; else python $R/tests/helpers/fwd_dump.py --cmp $R/gpurun_out/fwd_$first.pt $R/gpurun_out/fwd_$v.pt; fi
 done
 rm -f $R/gpurun_out/fwd_*.pt
 true

@@ -4,9 +4,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
 (timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_modules.py tests/test_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -3) > $O/v2p_tests.log
 : > $O/v2p.log
 for m in f16x3 bf16 f32; do
-OI_V2_PERSIST=0 python tools/dbg/fwd_dump.py $O/fwd_p0.pt $m > /dev/null 2>&1
-OI_V2_PERSIST=1 python tools/dbg/fwd_dump.py $O/fwd_p1.pt $m > /dev/null 2>&1
-echo "-- $m" >> $O/v2p.log; python tools/dbg/fwd_dump.py --cmp $O/fwd_p0.pt $O/fwd_p1.pt | grep sdf0 >> $O/v2p.log 2>&1
+OI_V2_PERSIST=0 python tests/helpers/fwd_dump.py $O/fwd_p0.pt $m > /dev/null 2>&1
+OI_V2_PERSIST=1 python tests/helpers/fwd_dump.py $O/fwd_p1.pt $m > /dev/null 2>&1
+echo "-- $m" >> $O/v2p.log; python tests/helpers/fwd_dump.py --cmp $O/fwd_p0.pt $O/fwd_p1.pt | grep sdf0 >> $O/v2p.log 2>&1
 done
 rm -f $O/fwd_p0.pt $O/fwd_p1.pt
 for v in 1 0 1 0; do
