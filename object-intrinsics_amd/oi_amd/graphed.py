@@ -277,10 +277,19 @@ class GraphedDStep:
         return self
 
     def __call__(self, x_real, x_fake, c2b=None, aux_w=0.0):
+        self.prepare(x_real, x_fake, c2b, aux_w)
+        return self.run()
+
+    def prepare(self, x_real, x_fake, c2b=None, aux_w=0.0):
+        """First half of a call: (re)capture if the shapes changed, draw the augmentation parameters on the host (numpy, the eager
+        order: this is where the step consumes the random stream) and stage the inputs -- one launch on the current stream."""
         sig = (tuple(x_real.shape), tuple(x_fake.shape), None if c2b is None else tuple(c2b.shape))
         if self.graph is None or sig != self._sig:
             self.capture(x_real, x_fake, c2b, aux_w)
         self._upload(x_real, x_fake, c2b, aux_w)
+
+    def run(self):
+        """Second half: replay on the current stream (after `prepare` on the same stream, or on one that waits for it)."""
         if os.environ.get("OI_GRAPH_D_EAGER") == "1":   # debugging aid: the same shape-static step, launch by launch
             vec = self._step()
         else:

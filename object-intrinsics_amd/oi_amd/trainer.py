@@ -18,12 +18,21 @@ from .losses import GANLoss, PositionLoss, gan_losses, grad_wrt_input, linear_in
 import os
 
 MODULE_KEYS = ("generator", "discriminator", "mask_discriminator")
-# OI_TRAIN_OVERLAP=1: the graphed discriminator step on a second stream, overlapped with the render that follows it.  Built and
-# measured in round 6 (tools/dbg/run_overlap_ab.sh, run_overlap_tl.sh), NOT the default: 9.19-9.27 ms per iteration either way.
-# The timeline says why: the render's MLP launches own every compute unit (one workgroup per CU: the whole register file and
-# 150 KB of LDS), a freed CU goes to their next workgroup first, and each of the step's ~75 dependent launches then takes 25-90 us
-# instead of 5-10 -- the step stretches from 0.42 to 1.5 ms, exactly the render it hides behind (high stream priority: the same).
-OVERLAP_D_STEP = os.environ.get("OI_TRAIN_OVERLAP", "0") == "1"
+# Where the two graphed discriminator steps run (each a replayed chain of ~75 launches of a few microseconds that wait for each
+# other: 0.42 ms during which the chip is almost idle):
+#   OI_TRAIN_D_STEPS=concurrent (default): both no-grad renders first (they read generator state only), then the discriminator's
+#     step on a second stream NEXT TO the mask discriminator's on the main one -- two latency-bound chains side by side.  Same-box
+#     A/B at C2 (tools/dbg/run_overlap_ab.sh): 9.20 -> 9.00 ms per iteration.
+#   OI_TRAIN_D_STEPS=overlap: the discriminator's step on a second stream under the SECOND RENDER.  Built and measured in round 6
+#     (tools/dbg/run_overlap_ab.sh, profiles/r6_overlap_timeline.txt): no gain, 9.19-9.27 ms per iteration either way -- the
+#     render's MLP launches own every compute unit (one workgroup per CU: the whole register file, 150 KB of LDS), a freed CU goes
+#     to their next workgroup first, and each of the step's dependent launches then takes 25-90 us instead of 5-10: the step
+#     stretches from 0.42 to 1.5 ms, exactly the render it hides behind (a high-priority stream: the same).
+#   OI_TRAIN_D_STEPS=serial: one stream, the reference's order (render, step, render, step).
+# Same arithmetic and the same order of host-side draws in all three (the steps draw nothing from torch's generator).
+D_STEPS_MODE = os.environ.get("OI_TRAIN_D_STEPS", "concurrent")
+CONCURRENT_MAX_PIXELS = 2 * 64 * 64
+assert D_STEPS_MODE in ("concurrent", "overlap", "serial"), D_STEPS_MODE
 DATA_KEYS = {"generator": ["image"], "discriminator": ["image"], "mask_discriminator": ["mask"]}
 
 
@@ -118,8 +127,24 @@ class Trainer:
         # discriminator's backward and its `sync(); opt.step()` so that, under FlatGradDDP, the 11 MB gradient exchange on
         # the communication stream overlaps it.  Same arithmetic and same RNG draw order as the reference's sequence
         # (gan_pose_trainer.py:84-90): the render only reads generator state.
+        # (side by side only while the steps are chains of launches too small to fill the chip -- up to 64 x 64 x 2 pixels per
+        #  batch; at the shipped 128 x 128 crop the same A/B measured 7.32 -> 7.51 ms per iteration: those steps are throughput-bound)
+        small = data["image"].shape[0] * data["image"].shape[-2] * data["image"].shape[-1] <= CONCURRENT_MAX_PIXELS
+        if self._graphed is not None and D_STEPS_MODE == "concurrent" and small and data["image"].is_cuda:
+            # inputs of the discriminator's step staged (and its augmentation drawn: the host's draw order stays render, step,
+            # render, step) on the second stream; the second render on the main one; then the two replays side by side
+            start_d = self.train_step_discriminator("discriminator", data, {**blob["render_out"], "c2b": blob["prior_info"]["c2b"]},
+                                                    defer_step=True, side="staged")
+            with torch.no_grad():
+                blob2 = self.generator(bs=bs, it=self.it, data={}, return_raw=False)["box"]
+            ret_d, join = start_d()
+            ret_m = self.train_step_discriminator("mask_discriminator", data, blob2["render_out"])
+            join()
+            out.update(ret_d)
+            out.update(ret_m)
+            return out
         ret_d, finish_d = self.train_step_discriminator("discriminator", data, {**blob["render_out"], "c2b": blob["prior_info"]["c2b"]},
-                                                        defer_step=True)
+                                                        defer_step=True, side=D_STEPS_MODE == "overlap")
         with torch.no_grad():
             blob = self.generator(bs=bs, it=self.it, data={}, return_raw=False)["box"]
         finish_d()
@@ -170,12 +195,14 @@ class Trainer:
         loss.backward(ones_scalar(loss))  # (a cached 1.0: autograd's default is a fill launch per call)
         return ret
 
-    def train_step_discriminator(self, key, real, fake, defer_step=False):
+    def train_step_discriminator(self, key, real, fake, defer_step=False, side=False):
+        """side (graphed steps only): enqueue the step, its gradient exchange and its optimiser step on the trainer's second
+        stream; the returned callable joins the main stream to it."""
         for k in MODULE_KEYS:
             self._toggle(k, self.modules[k], k == key)
         disc, opt = self.modules[key], self.modules[f"opt_{key}"]
         if self._graphed is not None:
-            return self._graphed_d_step(key, disc, opt, real, fake, defer_step)
+            return self._graphed_d_step(key, disc, opt, real, fake, defer_step, side)
         _zero_grad(disc, opt)
         x_real = _cat([real[k] for k in DATA_KEYS[key]]).detach().clone().requires_grad_()
         d_real = disc(x_real, it=self.it)
@@ -201,7 +228,7 @@ class Trainer:
         finish()
         return ret
 
-    def _graphed_d_step(self, key, disc, opt, real, fake, defer_step):
+    def _graphed_d_step(self, key, disc, opt, real, fake, defer_step, side=False):
         from .graphed import GraphedDStep
         gd = self._graphed.get(key)
         if gd is None:
@@ -214,32 +241,36 @@ class Trainer:
         aux_w = self.loss_weight["aux_pose"](self.it) if has_aux else 0.0
         named = lambda out: {f"{key}/loss": out["loss"], f"{key}/reg": out["reg"], f"{key}/fake": out["fake"],
                              f"{key}/real": out["real"], f"{key}/aux_pose": out["aux_pose"] if has_aux else 0}
-        if defer_step and OVERLAP_D_STEP and x_real.is_cuda:
-            # The step (a replayed chain of ~75 launches of a few microseconds that wait for each other: 0.42 ms during which the
-            # chip is almost idle), its gradient exchange and its optimiser step go to a SECOND stream; the caller enqueues the
-            # next no-grad render -- which reads generator state only -- on the main stream meanwhile and joins in finish().
-            # Same arithmetic, same host-side draw order; the images the step reads are kept alive for the side stream.
+        if defer_step and side and x_real.is_cuda:
+            # the step, its gradient exchange and its optimiser step on the SECOND stream; the images it reads are kept alive for
+            # that stream; the caller joins through the returned callable
             main = torch.cuda.current_stream()
             if getattr(self, "_side_stream", None) is None:
-                # high priority: the step's launches are tiny and wait for each other; a freed compute unit should go to them
-                # before the next workgroup of the render that fills the chip (OI_TRAIN_OVERLAP_PRIO=0: default priority)
-                prio = -1 if os.environ.get("OI_TRAIN_OVERLAP_PRIO", "1") != "0" else 0
-                self._side_stream = torch.cuda.Stream(device=x_real.device, priority=prio)
-            side = self._side_stream
+                self._side_stream = torch.cuda.Stream(device=x_real.device)
+            side_mode, side = side, self._side_stream
             side.wait_stream(main)
             for t in (x_real, x_fake, c2b):
                 if t is not None:
                     t.record_stream(side)
+
+            def replay():
+                with torch.cuda.stream(side):
+                    out = gd.run()
+                    _sync(disc)
+                    opt.step()
+                out["loss"].record_stream(main)   # (the five scalars are views of one clone made on the side stream)
+                return named(out), lambda: main.wait_stream(side)
+
             with torch.cuda.stream(side):
-                out = gd(x_real, x_fake, c2b, aux_w)
-                _sync(disc)
-                opt.step()
-            out["loss"].record_stream(main)   # (the five scalars are views of one clone made on the side stream)
+                gd.prepare(x_real, x_fake, c2b, aux_w)
+            if side_mode == "staged":   # the caller enqueues more on the main stream first; the replay waits for that too
 
-            def join():
-                main.wait_stream(side)
+                def start():
+                    side.wait_stream(main)
+                    return replay()
 
-            return named(out), join
+                return start
+            return replay()
         out = gd(x_real, x_fake, c2b, aux_w)
         ret = named(out)
 

@@ -1,23 +1,15 @@
 #!/bin/bash
-# same-box A/B of the side-stream discriminator step (OI_TRAIN_OVERLAP, OI_TRAIN_OVERLAP_PRIO)
+# same-box A/B of where the two graphed discriminator steps run (OI_TRAIN_D_STEPS: serial | overlap | concurrent), C2 and the
+# shipped configuration
 cd ${GRAFT_REPO_ROOT:-.}
 T="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bf16 --no-extras --min-seconds 0.01 --train-steps 40"
 for r in 1 2; do
-  for v in "0 0" "1 0" "1 1"; do
-    set -- $v
-    OI_TRAIN_OVERLAP=$1 OI_TRAIN_OVERLAP_PRIO=$2 $T 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); t=d['training']; print('overlap=$1 prio=$2', 'ms_per_it', round(t['ms_per_it'],3), 'd_step', round(t['d_step']['ms'],3), 'render_fwd_bwd', round(t['render_fwd_bwd']['ms'],3))"
+  for v in serial overlap concurrent; do
+    OI_TRAIN_D_STEPS=$v $T 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); t=d['training']; print('d_steps=$v', 'ms_per_it', round(t['ms_per_it'],3), 'd_step', round(t['d_step']['ms'],3), 'render_fwd_bwd', round(t['render_fwd_bwd']['ms'],3))"
   done
 done
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/p_ov; OI_TRAIN_OVERLAP=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_ov -- $T --train-steps 6 > /dev/null 2>&1
-f=$(ls /tmp/p_ov/*/*kernel_trace.csv 2>/dev/null | head -1)
-python - "$f" <<'PY'
-import csv,sys
-rows=list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r:int(r['Start_Timestamp']))
-# overlap statistics: for the last 400 kernels, print start, dur, name, stream/queue
-t0=int(rows[-420]['Start_Timestamp'])
-for r in rows[-420:-200]:
-    print(f"{(int(r['Start_Timestamp'])-t0)/1e3:9.1f} {(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:8.1f} q{r.get('Queue_Id','?')} {r['Kernel_Name'][:60]}")
-PY
+for v in serial concurrent; do
+  OI_TRAIN_D_STEPS=$v python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bf16 --min-seconds 0.01 --train-steps 5 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); t=d['extras']['training_shipped_config']; print('d_steps=$v shipped config', 'ms_per_it', round(t['ms_per_it'],3), 'it_per_s', round(t['it_per_s'],1))"
+done
