@@ -1427,6 +1427,33 @@ __device__ unsigned long long oi_prof_bwd[16];
 #else
 #define WG_T(i)
 #endif
+// OI_WG_TR (round 6, default on): the operands cross LDS as fp16 (bf16) limb planes [32 points][128 features] and come back as MFMA
+// fragments through gfx950's transposing read.  The slots hold "point on the lane, four features per granule"; an MFMA operand is
+// "feature on the lane, eight points per register group" -- a 32 x 128 transposition per operand and wave tile.  Until round 5:
+// fp32 copies in LDS, eight ds_read_b32 per fragment, the fp16 split AFTER the read, the column fragments converted by one wave
+// each and shared through a second LDS buffer -- 120 LDS instructions and five barriers per wave tile; the phase profile
+// (profiles/r6_wgrad_phase_profile.txt) had the matrix cores busy for 13 % of a tile.  Now the split happens on the granule the
+// thread holds anyway, the 8-byte piece (point p, features 4 c .. 4 c + 3) is written once per limb, and ds_read_b64_tr_b16
+// (each lane of a 16-lane group supplies the address of ONE piece; the group receives the 4 x 16 block transposed: lane t gets
+// column t, rows 0..3 -- tools/dbg/tr_probe2.hip) delivers four points of the lane's feature: two reads = one operand limb.  Both
+// pairs of a tile are staged at once: 32 ds_write_b64 + 80 transposing reads and TWO barriers per wave tile.
+//   piece (p, c) of a plane lives at byte 8 (32 p + (c ^ g(p))),  g(p) = 8 (p & 1) ^ 17 ((p >> 1) & 1) ^ 2 ((p >> 3) & 1):
+//   the 32 pieces a half wave reads (4 points x 8 feature quads) fall on 32 distinct 8-byte bank pairs (conflict-free reads), the
+//   16 a store group writes on 8 (2-way: 8 LDS cycles against the 6 the store's register transfer takes anyway).
+#ifndef OI_WG_TR
+#define OI_WG_TR 1
+#endif
+constexpr int TR_PLANE = 8192;   // bytes of one limb plane: 32 points x 32 pieces of 8 bytes
+constexpr int TR_PLANES = 8;     // X0h X0l Y0h Y0l X1h X1l Y1h Y1l  (bf16 operands: the four hi planes)
+typedef __fp16 trh4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ int tr_g(int p) { return ((p & 1) ? 8 : 0) ^ ((p & 2) ? 17 : 0) ^ ((p & 8) ? 2 : 0); }
+// one operand limb (8 consecutive points of the lane's feature) = two transposing reads, 4 points apart (1 KiB)
+__device__ __forceinline__ f16x8 tr_frag(const char* planes, int addr, int imm) {
+  const trh4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trh4*)(planes + addr + imm));
+  const trh4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trh4*)(planes + addr + imm + 1024));
+  const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+  return __builtin_bit_cast(f16x8, u32x4{ua[0], ua[1], ub[0], ub[1]});
+}
 typedef f16x8 (*SbPtr)[4][2][64];  // [hi|lo][column tile][k-step][lane]
 // COL: the colour-head matrix (m = 7, one pair: X = uvbar, Y = a_8 = sin phi_7); otherwise a layer matrix (two pairs).  A
 // compile-time split: with `m` tested at run time hipcc turned the per-element selects of the hot loop into branches.
@@ -1436,7 +1463,7 @@ typedef f16x8 (*SbPtr)[4][2][64];  // [hi|lo][column tile][k-step][lane]
 // product, no operand scales.  (Until round 5 that mode fell through to the generic fp32-MFMA GEMM: 3.2 ms per backward against
 // 1.45 ms for this body, the largest kernel of a bf16-mode training iteration.)
 template <int MODE, bool FAST, bool BF = false>
-__device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, const float* l0tab, const int m, const char* __restrict__ scratch,
+__device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, char* planes, const float* l0tab, const int m, const char* __restrict__ scratch,
                                                const float* __restrict__ op_max, const char* __restrict__ packed,
                                                size_t plain_offset, const float* __restrict__ gamma,
                                                float* __restrict__ d_wmat, float* __restrict__ d_gamma,
@@ -1696,11 +1723,110 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
       WG_T(7);
     }
   };
+  // ---- OI_WG_TR: fp16 limb planes + transposing reads (see the flag) ----
+  int wr[4], rdy[4], rdx = 0;
+  if constexpr (OI_WG_TR) {
+    const int p = lane & 31, gp = tr_g(p);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) wr[it] = 8 * (32 * p + ((8 * it + 2 * wave + h) ^ gp));   // granule `it`: features 32 it + 8 wave + 4 h ..
+    const int t = lane & 15, cb = (lane >> 4) & 1, hp = lane >> 5, r = t >> 2, tl = t & 3;
+    const int gr = tr_g(8 * hp + r);   // (g reads bits 0, 1, 3 of the point: the k-step and half bits 4, 2 stay immediates)
+#pragma unroll
+    for (int T = 0; T < 4; ++T) rdy[T] = 8 * (32 * (8 * hp + r) + ((8 * T + 4 * cb + tl) ^ gr));
+    rdx = wave == 0 ? rdy[0] : (wave == 1 ? rdy[1] : (wave == 2 ? rdy[2] : rdy[3]));
+    asm volatile("" : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2]), "+v"(wr[3]), "+v"(rdy[0]), "+v"(rdy[1]), "+v"(rdy[2]), "+v"(rdy[3]), "+v"(rdx));
+  }
+  auto put4 = [&](int plane, int it, const f32x4& v) {   // four features of this thread's point -> the hi (and lo) plane
+    if constexpr (BF) {
+      const bf16x2 a = {(__bf16)v[0], (__bf16)v[1]}, b = {(__bf16)v[2], (__bf16)v[3]};
+      *reinterpret_cast<u32x2*>(planes + plane * TR_PLANE + wr[it]) = u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+    } else {
+      unsigned h0, l0, h1, l1;
+      split_pair(v[0], v[1], h0, l0);
+      split_pair(v[2], v[3], h1, l1);
+      *reinterpret_cast<u32x2*>(planes + plane * TR_PLANE + wr[it]) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(planes + (plane + 1) * TR_PLANE + wr[it]) = u32x2{l0, l1};
+    }
+  };
+  auto tile_tr = [&](long long wt, Stage& st) {
+    __syncthreads();  // (A) the previous tile's fragment reads are done
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      f32x4 ph, vb4 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (FIRST) {
+        l0_phase_vb<FAST>(l0tab, st.pt[0], st.pt[1], grp_f0(4 * it + wave) + 4 * h, ph, vb4);
+      } else {
+        ph = WS::phase_of(st.ph4[it]);
+        if constexpr (!COL) {
+          if constexpr (VBQ) vb4 = unpack_q24(st.vb4[it]); else vb4 = WS::value(st.vb4[it]);
+        }
+      }
+      const float kv = (VBQ && !FIRST && !COL) ? st.vbinv * scy[0] : scy[0], cv = (VBQ && !FIRST && !COL) ? -1.5f * kv : 0.f;
+      f32x4 y0, y1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        y0[k] = COL ? __builtin_amdgcn_sinf(ph[k]) * scy[0] : fmaf(vb4[k], kv, cv) * __builtin_amdgcn_cosf(ph[k]);
+        if constexpr (npair == 2) y1[k] = __builtin_amdgcn_sinf(ph[k]) * scy[1];
+      }
+      put4(0, it, xval(st, 0, it));
+      put4(2, it, y0);
+      if constexpr (npair == 2) {
+        put4(4, it, xval(st, 1, it));
+        put4(6, it, y1);
+      }
+    }
+    __syncthreads();  // (B) the planes are complete
+    __builtin_amdgcn_sched_barrier(0);
+    if (wt + 2 < t_end) request(wt + 2, st);  // every register of the set is dead: two tiles are in flight from here on
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pr = 0; pr < npair; ++pr) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int base = pr * 4 * TR_PLANE + ks * 4096;
+        const f16x8 ah = tr_frag(planes, rdx, base);
+        f16x8 al;
+        if constexpr (!BF) al = tr_frag(planes, rdx, base + TR_PLANE);
+        if (pr == npair - 1) {   // the last pair's X is phibar_l (uvbar): its sum over the points is the bias gradient
+          const u32x4 uh = __builtin_bit_cast(u32x4, ah);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const unsigned eh = uh[d];   // (element copies first: hipcc 7.2 reads element 0 for every d when a vector-element
+            if constexpr (BF) {          //  lvalue is bit_cast directly -- see pack24f)
+              sub = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, eh), bf16x2{(__bf16)1.0f, (__bf16)1.0f}, sub, false);
+            } else {
+              const u32x4 ul = __builtin_bit_cast(u32x4, al);
+              const unsigned el = ul[d];
+              sub = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, eh), f16x2{(_Float16)1.0f, (_Float16)1.0f}, sub, false);
+              sub = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, el), f16x2{(_Float16)1.0f, (_Float16)1.0f}, sub, false);
+            }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const f16x8 bh = tr_frag(planes, rdy[t], base + 2 * TR_PLANE);
+          if constexpr (BF) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc[t], 0, 0, 0);
+          } else {
+            const f16x8 bl = tr_frag(planes, rdy[t], base + 3 * TR_PLANE);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
   if (t_begin < t_end) request(t_begin, stA);
   if (t_begin + 1 < t_end) request(t_begin + 1, stB);
   for (long long wt = t_begin; wt < t_end; wt += 2) {
-    tile(wt, stA);
-    if (wt + 1 < t_end) tile(wt + 1, stB);
+    if constexpr (OI_WG_TR) {
+      tile_tr(wt, stA);
+      if (wt + 1 < t_end) tile_tr(wt + 1, stB);
+    } else {
+      tile(wt, stA);
+      if (wt + 1 < t_end) tile(wt + 1, stB);
+    }
   }
 #ifdef OI_WG_PROF
   if (lane == 0 && !COL) {
@@ -1724,23 +1850,31 @@ mlp_wgrad_f16_kernel(const char* __restrict__ scratch, const float* __restrict__
                      size_t plain_offset, const float* __restrict__ gamma, const float* __restrict__ beta,
                      float* __restrict__ d_wmat, float* __restrict__ d_gamma, float* __restrict__ d_beta,
                      float* __restrict__ d_small, long long wt_per_elem, int tiles_per_chunk, int has_col) {
+#if OI_WG_TR
+  __shared__ __attribute__((aligned(16))) char planes[TR_PLANES * TR_PLANE];   // 64 KiB: two workgroups per CU
+  __shared__ __attribute__((aligned(16))) float l0tab[L0TAB_FLOATS];
+  float *sx = nullptr, *sy = nullptr;
+  SbPtr sb = nullptr;
+#else
   __shared__ __attribute__((aligned(16))) float sx[WG16_SLOT_FLOATS], sy[WG16_SLOT_FLOATS];
   __shared__ __attribute__((aligned(16))) float l0tab[L0TAB_FLOATS];
   // ONE copy for both pairs (barrier 4 separates pair 0's readers from pair 1's writers)
   __shared__ __attribute__((aligned(16))) f16x8 sb[2][4][2][64];
+  char* planes = nullptr;
+#endif
   const int m = blockIdx.y;
   // a compile-time split per kind of matrix: with `m` tested at run time hipcc turned per-element selects into branches
   if (m == 7) {
     if (has_col)
-      wgrad_f16_body<1, FAST, BF>(sx, sy, sb, l0tab, 7, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
+      wgrad_f16_body<1, FAST, BF>(sx, sy, sb, planes, l0tab, 7, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
                               d_small, wt_per_elem, tiles_per_chunk);
   } else if (m == 0) {
     l0tab_fill(l0tab, reinterpret_cast<const float*>(packed), gamma, beta, blockIdx.z, threadIdx.x);
     __syncthreads();
-    wgrad_f16_body<2, FAST, BF>(sx, sy, sb, l0tab, 0, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
+    wgrad_f16_body<2, FAST, BF>(sx, sy, sb, planes, l0tab, 0, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
                             d_small, wt_per_elem, tiles_per_chunk);
   } else {
-    wgrad_f16_body<0, FAST, BF>(sx, sy, sb, l0tab, m, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
+    wgrad_f16_body<0, FAST, BF>(sx, sy, sb, planes, l0tab, m, scratch, op_max, packed, plain_offset, gamma, d_wmat, d_gamma, d_beta,
                             d_small, wt_per_elem, tiles_per_chunk);
   }
 }
