@@ -1443,6 +1443,9 @@ __device__ unsigned long long oi_prof_bwd[16];
 #ifndef OI_WG_TR
 #define OI_WG_TR 1
 #endif
+#ifndef OI_WG_TR_SPREAD
+#define OI_WG_TR_SPREAD 1
+#endif
 constexpr int TR_PLANE = 8192;   // bytes of one limb plane: 32 points x 32 pieces of 8 bytes
 constexpr int TR_PLANES = 8;     // X0h X0l Y0h Y0l X1h X1l Y1h Y1l  (bf16 operands: the four hi planes)
 typedef __fp16 trh4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -1544,7 +1547,10 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
   // through a buffer descriptor over the wave tile (512 KiB): the tile base and the slot offsets travel in SGPRs, the lane
   // offset in ONE VGPR -- with flat pointers hipcc kept 20 address pairs live across the loop and spilled
   const int t16 = tid * (PK == 1 ? 12 : (PK == 2 ? 8 : 16));
-  auto request = [&](long long wt, Stage& st) {
+  // granules [it0, it1) of the tile (the per-lane scales and layer 0's point ride with granule 0): the transposing-read build
+  // issues a tile's requests in four parts BETWEEN its MFMA groups -- issued in one go after the stores they stalled the wave for
+  // 14 % of a tile (the vector-memory queue is in order and 6 bits deep), with the matrix cores idle meanwhile
+  auto request_part = [&](long long wt, Stage& st, int it0, int it1) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(scratch) + wt * (long long)(NSLOT_BWD * 16384), 0, NSLOT_BWD * 16384, 0x00020000);
     auto ld = [&](int slot, int it) -> Frag {   // granule q = it 256 + tid of the slot: group q / 64, lane q % 64
@@ -1559,6 +1565,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
     };
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
+      if (it < it0 || it >= it1) continue;
       if constexpr (!FIRST) {
         if constexpr (PHQ) st.ph4[it] = __builtin_amdgcn_raw_buffer_load_b96(rs, tid * 12, (S_PHI + m) * 16384 + it * 3072, OI_WGRAD_NT ? 2 : 0);
         else st.ph4[it] = ld(S_PHI + m, it);
@@ -1572,6 +1579,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
         st.xall[1][it] = ldx(S_U + m, it);
       }
     }
+    if (it0 != 0) return;
     if constexpr (VBQ && !FIRST && !COL)
       st.vbinv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * (tid & 63), (S_VB + m) * 16384 + XQ_SCALE_OFF,
                                                                                 OI_WGRAD_NT ? 2 : 0));
@@ -1588,6 +1596,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
                                                                                   OI_WGRAD_NT ? 2 : 0));
     }
   };
+  auto request = [&](long long wt, Stage& st) { request_part(wt, st, 0, 4); };
   // fragments of one pair out of the fp32 LDS copies: this wave's column tile of Y -> shared fp16 fragments sb[pr], its
   // own row strip of X -> registers
   auto extract = [&](int pr, f16x8 (&ah)[2], f16x8 (&al)[2], bool last_pair) {
@@ -1750,6 +1759,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
   };
   auto tile_tr = [&](long long wt, Stage& st) {
     __syncthreads();  // (A) the previous tile's fragment reads are done
+    WG_T(0);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       f32x4 ph, vb4 = {0.f, 0.f, 0.f, 0.f};
@@ -1775,14 +1785,28 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
         put4(6, it, y1);
       }
     }
+    WG_T(1);
     __syncthreads();  // (B) the planes are complete
-    __builtin_amdgcn_sched_barrier(0);
-    if (wt + 2 < t_end) request(wt + 2, st);  // every register of the set is dead: two tiles are in flight from here on
-    __builtin_amdgcn_sched_barrier(0);
+    WG_T(2);
+    // every register of the set is dead: the tile two ahead is requested from here on, a part per MFMA group (OI_WG_TR_SPREAD=0:
+    // all at once, in front of the groups)
+    const bool more = wt + 2 < t_end;
+    if (!OI_WG_TR_SPREAD) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) request(wt + 2, st);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    WG_T(3);
 #pragma unroll
     for (int pr = 0; pr < npair; ++pr) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+        if (OI_WG_TR_SPREAD) {
+          const int part = pr * 2 + ks, nparts = 2 * npair;   // 4 granules over the 2 or 4 groups
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) request_part(wt + 2, st, part * 4 / nparts, (part + 1) * 4 / nparts);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         const int base = pr * 4 * TR_PLANE + ks * 4096;
         const f16x8 ah = tr_frag(planes, rdx, base);
         f16x8 al;
@@ -1816,6 +1840,7 @@ __device__ __forceinline__ void wgrad_f16_body(float* sx, float* sy, SbPtr sb, c
         }
       }
     }
+    WG_T(4);
   };
   if (t_begin < t_end) request(t_begin, stA);
   if (t_begin + 1 < t_end) request(t_begin + 1, stB);

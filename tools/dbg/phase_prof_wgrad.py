@@ -28,6 +28,9 @@ raw.oi_prof_bwd_read(buf, 0)
 names = ["wait for the tile's loads + sin / cos", "barrier 1", "LDS writes pair 0", "barrier 2 + fragments pair 0",
          "barrier 3 + LDS writes pair 1 + next tile's requests", "MFMAs pair 0", "barrier 4 + fragments pair 1",
          "barrier 5 + MFMAs pair 1"]
+if os.environ.get("OI_WG_TR", "1") != "0":   # the transposing-read build (round 6): five phases
+    names = ["barrier A (the previous tile's reads; the MFMAs behind them)", "wait for the loads + unpack, sin / cos, split, 32 ds_write_b64",
+             "barrier B", "the tile two ahead: 19 buffer loads issued", "80 transposing reads + 48 MFMAs", "-", "-", "-"]
 nt = buf[13]
 print(f"wave-tiles {nt}, mean ticks per tile (layer matrices) {buf[12] / nt:.0f}")
 for i, nm in enumerate(names):
