@@ -319,9 +319,9 @@ def main():
     timer = KernelTimer()
     orig = A.sdf_mlp
 
-    def sdf_mlp_timed(pack, pts, gamma, beta, B_, want_grad, want_rgb, want_feat, scratch=None):
+    def sdf_mlp_timed(pack, pts, gamma, beta, B_, want_grad, want_rgb, want_feat, scratch=None, **kw):
         fn = timer.wrap(orig) if (want_grad and timer_on[0] and timer.due()) else orig
-        return fn(pack, pts, gamma, beta, B_, want_grad, want_rgb, want_feat, scratch)
+        return fn(pack, pts, gamma, beta, B_, want_grad, want_rgb, want_feat, scratch, **kw)
 
     timer_on = [False]
     A.sdf_mlp = sdf_mlp_timed
@@ -702,17 +702,18 @@ def build_line(args, value, dt, world, timer, d_img_s, train, distributed, bf16_
                        "parallelism": f"dp{world} (independent renders, no data-path collective)"},
             "d_images_per_s": d_img_s,
             "d_images_per_s_what": "ADADiscriminatorView forward, batch 1 per GPU, through oi_amd.graphed.GraphedDForward: at batch "
-                                   "<= 4 a plan held by the library (oi_disc_graph_*: four launches per image, image pointer and "
-                                   "augmentation matrices passed per call; OI_DISC_LAUNCH=graph replays them as one hipGraph), "
-                                   "augmentation parameters drawn per call on the host; d_images_per_s_eager = the module's own "
-                                   "forward, call by call",
+                                   "<= 4 a plan held by the library (oi_disc_graph_*: four launches per image, image pointer "
+                                   "passed per call; OI_DISC_LAUNCH=graph replays them as one hipGraph); d_images_per_s_eager = the "
+                                   "module's own forward (the reference's call), call by call.  Since round 6 both draw the "
+                                   "augmentation parameters INSIDE the library from one seed of numpy's stream per call "
+                                   "(oi_disc_graph_launch_ada): no numpy / Python arithmetic per image",
             "d_images_per_s_eager": getattr(args, "_d_images_per_s_eager", None),
             "training": train,
             "bf16_mode": bf16_mode,
             "roofline": {"bound": "mfma",
-                         "kernel": ("sdf_mlp_full3_kernel (register-resident: sdf + d sdf/dx + albedo at the fine samples; kernel_ms "
-                                    "also covers the call's first launch, film_blob_f3_kernel: ~6 us of per-element tables, so frac is "
-                                    "conservative by ~0.7 %)"
+                         "kernel": ("sdf_mlp_full3_kernel (register-resident: sdf + d sdf/dx + albedo at the fine samples; since round 6 "
+                                    "its per-element table blob is formed by the step's prep launch, so the HIP-event pair covers "
+                                    "this kernel alone -- with OI_STEP_TAIL=0 it also covers film_blob_f3_kernel, ~6 us)"
                                     if args.precision == "f16x3" else "sdf_mlp_kernel<full> (sdf + d sdf/dx + albedo at the fine samples)"),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None,

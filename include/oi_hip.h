@@ -122,6 +122,16 @@ size_t oi_mlp_scratch_bytes_prec(int B, long long n_per_elem, int prec);
 int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, const float* beta,
                    float* sdf, float* grad, float* rgb, float* feat, void* scratch,
                    int B, long long n_per_elem, int prec, int fast_trig, oi_stream_t stream);
+/* The same with `flags`.  OI_MLP_BLOB_READY (OI_PREC_F16X3 with grad != NULL only): the per-element table blobs the register-
+ * resident kernel stages from -- oi_mlp_f3_blob_bytes() bytes per batch element at byte oi_mlp_f3_blob_offset(B, n) of `scratch` --
+ * have already been written for THESE gamma / beta / packed by oi_prep_render (its `f3_packed` / `f3_blob` fields): the call then
+ * skips its own blob launch (one launch and its boundary less per render; the bytes are the same: csrc/f3_blob.h). */
+#define OI_MLP_BLOB_READY 1
+size_t oi_mlp_f3_blob_offset(int B, long long n_per_elem);
+size_t oi_mlp_f3_blob_bytes(void);
+int oi_sdf_mlp_fwd_ex(const float* pts, const void* packed, const float* gamma, const float* beta,
+                      float* sdf, float* grad, float* rgb, float* feat, void* scratch,
+                      int B, long long n_per_elem, int prec, int fast_trig, int flags, oi_stream_t stream);
 
 /* Backward of oi_sdf_mlp_fwd w.r.t. every parameter and the FiLM vectors -- including the second-order
  * terms that arise because d sdf/dx is a forward output (the reference: autograd with create_graph=True
@@ -234,6 +244,13 @@ typedef struct oi_prep_params {
   const float *kinv, *light_direction, *jitter;
   const float *style_w, *style_b, *z, *gw, *gb, *bw, *bb;
   float *pose_out, *rays_o, *rays_d, *near_, *far_, *light_dir, *z_coarse, *pts_coarse, *w_out, *gamma, *beta;
+  /* round 6.  jitter_normal != 0: `jitter` holds one STANDARD NORMAL draw per ray (the caller drew latents and jitter with one
+   * generator call); the kernel maps it to the uniform of renderer.py:372 through the normal CDF.  f3_packed / f3_blob (both or
+   * neither; NL must be 9): the OI_PREC_F16X3 packed image and where the FiLM workgroups write the per-element blobs of the
+   * register-resident MLP kernel (B x oi_mlp_f3_blob_bytes(); see oi_sdf_mlp_fwd_ex / OI_MLP_BLOB_READY). */
+  int jitter_normal;
+  const void* f3_packed;
+  void* f3_blob;
 } oi_prep_params;
 int oi_prep_render(const oi_prep_params* p, oi_stream_t stream);
 
@@ -566,6 +583,19 @@ int oi_disc_graph_create(oi_disc_graph** out, int aug, const float* f12, int mx0
                          float* workspace, unsigned* ticket, float* logits, int B, int C, int H, int W, int n_feat, int out_dim,
                          float slope);
 int oi_disc_graph_launch(oi_disc_graph* g, const float* x, const float* theta_host, oi_stream_t stream);
+/* The shipped discriminators (configs/train.yaml:78-102: img_size 128 = FIVE blocks C -> 32 -> 64 -> 128 -> 256 -> 512 -> out_dim) the
+ * same way (round 6): w0 [32][C][4][4] rides on the augmentation kernel, w1 [64][32][4][4] has a kernel of its own (32 input
+ * channels: arithmetic, not a weight stream), w2..w4 + head are the 64 x 64 network's conv 2..4: five launches (six with the canvas
+ * in memory).  x [B][C][128][128]; workspace: oi_disc_fwd_small128_workspace_floats.  The plan form is launched launch by launch
+ * only (oi_disc_graph_launch_eager / _launch_ada with eager != 0; oi_disc_graph_launch returns OI_ERR_UNSUPPORTED for it). */
+size_t oi_disc_fwd_small128_workspace_floats(int B, int C, int mx0, int mx1, int my0, int my1);
+int oi_disc_fwd_small128(const float* x, const float* theta_host, const float* theta_dev, const float* f12, int mx0, int mx1, int my0,
+                         int my1, const float* w0, const float* w1, const float* w2, const float* w3, const float* w4, const float* whead,
+                         const float* bhead, float* workspace, unsigned* ticket, float* logits, int B, int C, int n_feat, int out_dim,
+                         float slope, oi_stream_t stream);
+int oi_disc_graph_create128(oi_disc_graph** out, int aug, const float* f12, int mx0, int mx1, int my0, int my1, const float* w0,
+                            const float* w1, const float* w2, const float* w3, const float* w4, const float* whead, const float* bhead,
+                            float* workspace, unsigned* ticket, float* logits, int B, int C, int n_feat, int out_dim, float slope);
 /* the same launches issued one by one (no graph replay) from the object's stored arguments; `logits`: where this call's
  * [B][out_dim] result goes (NULL: the buffer given at creation) */
 int oi_disc_graph_launch_eager(oi_disc_graph* g, const float* x, const float* theta_host, float* logits, oi_stream_t stream);

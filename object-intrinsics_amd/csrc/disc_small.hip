@@ -257,7 +257,7 @@ d_aug_conv1_kernel(const float* __restrict__ src, const ThetaArg th, const float
   // Output in the layout the next layer reads with the input channel on the lane: y[b][oy][ox / 4][ch][ox % 4]
   constexpr int OT = DA_T / 2;
   const int Ho1 = H / 2, Wo1 = W / 2;
-  static_assert(OT * OT * 64 == 256, "one conv 1 output per thread (C1 = 64)");
+  static_assert(OT * OT * 64 == 256, "one conv 1 output per thread (C1 <= 64: 64 channels at 64 x 64, 32 at 128 x 128)");
   if (tid < C1 * OT * OT) {
     const int ch = tid / (OT * OT), py = (tid / OT) % OT, px = tid % OT;
     float acc = 0.f;
@@ -461,6 +461,70 @@ d_conv_small_kernel(const float* __restrict__ x, const float* __restrict__ w, fl
   }
 }
 
+// ---- the shipped 128 x 128 network's second block: 32 -> 64 channels, 64 x 64 -> 32 x 32 (round 6) ---------------------------
+// (configs/train.yaml:78-102: img_size 128 = five blocks 3 | 1 -> 32 -> 64 -> 128 -> 256 -> 512; the last three are the 64 x 64
+// network's conv 2..4 + head, the first rides on d_aug_conv1_kernel with C1 = 32.)  With 32 input channels the "input channel on
+// the lane" form of d_conv_small_kernel has half a wave of work per task; this layer is 33.5 M MACs per image over 128 KB of
+// weights -- arithmetic, not a weight stream: one workgroup per (output row, half of the output channels), the four input rows
+// under the output row and the 32 channels' weights staged in LDS once, a thread = one output channel x four consecutive
+// output pixels, 2048 FMAs per thread in a fixed (c_in, ky, kx) order.
+//   x A[B][64][16][32][4] -> y A[B][32][8][64][4] = lrelu(conv4x4 s2 p1 (x, w)), w [64][32][4][4]
+constexpr int DC32_ROW = 72;          // staged input row of one channel: x = -4 .. 67 (zero outside the image)
+constexpr int DC32_WST = 512 + 4;     // weights of one output channel (+ 4: the eight channels of a wave in distinct 16-byte slots)
+constexpr int DC32_LDS = (4 * 32 * DC32_ROW + 32 * DC32_WST) * 4;   // 102,912 bytes
+__global__ void __launch_bounds__(256) d_conv_c32_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                         float slope) {
+  extern __shared__ __attribute__((aligned(16))) float dc32_lds[];
+  float* in_l = dc32_lds;                       // [ky 4][c_in 32][DC32_ROW]
+  float* w_l = dc32_lds + 4 * 32 * DC32_ROW;    // [c_out 32][DC32_WST]
+  const int tid = threadIdx.x, oy = blockIdx.x, half = blockIdx.y, b = blockIdx.z;
+  // weights of this half's 32 output channels: 32 x 512 floats, float4 per thread and step
+  for (int i = tid; i < 32 * 128; i += 256) {
+    const int co = i >> 7, q = i & 127;
+    *reinterpret_cast<float4*>(w_l + co * DC32_WST + 4 * q) = *reinterpret_cast<const float4*>(w + ((size_t)(half * 32 + co) * 512 + 4 * q));
+  }
+  // input rows 2 oy - 1 .. 2 oy + 2: [row][xq 16][c 32][4] in memory -> [row][c][4 + 4 xq ..] in LDS; halo columns zero
+  for (int i = tid; i < 4 * 32 * 2; i += 256) {   // the two halo quads of every (row, channel)
+    const int r = i >> 6, c = (i >> 1) & 31, side = i & 1;
+    *reinterpret_cast<float4*>(in_l + (r * 32 + c) * DC32_ROW + (side ? 68 : 0)) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int i = tid; i < 4 * 16 * 32; i += 256) {
+    const int r = i >> 9, xq = (i >> 5) & 15, c = i & 31;
+    const int iy = 2 * oy - 1 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < 64) v = *reinterpret_cast<const float4*>(x + ((((size_t)b * 64 + iy) * 16 + xq) * 32 + c) * 4);
+    *reinterpret_cast<float4*>(in_l + (r * 32 + c) * DC32_ROW + 4 + 4 * xq) = v;
+  }
+  __syncthreads();
+  const int co = tid >> 3, xq = tid & 7;   // output pixels ox = 4 xq + j: input x = 8 xq + 2 j - 1 + kx  ->  staged index 8 xq + 2 j + 3 + kx
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* wp = w_l + co * DC32_WST;
+  const float* ip = in_l + 8 * xq;
+  for (int c = 0; c < 32; ++c) {
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const float4 wv = *reinterpret_cast<const float4*>(wp + c * 16 + ky * 4);
+      const float* row = ip + (ky * 32 + c) * DC32_ROW;
+      const float4 a0 = *reinterpret_cast<const float4*>(row), a1 = *reinterpret_cast<const float4*>(row + 4);
+      const float4 a2 = *reinterpret_cast<const float4*>(row + 8), a3 = *reinterpret_cast<const float4*>(row + 12);
+      const float v[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = fmaf(wv.x, v[2 * j + 3], acc[j]);
+        acc[j] = fmaf(wv.y, v[2 * j + 4], acc[j]);
+        acc[j] = fmaf(wv.z, v[2 * j + 5], acc[j]);
+        acc[j] = fmaf(wv.w, v[2 * j + 6], acc[j]);
+      }
+    }
+  }
+  float4 o;
+  o.x = acc[0] > 0.f ? acc[0] : acc[0] * slope;
+  o.y = acc[1] > 0.f ? acc[1] : acc[1] * slope;
+  o.z = acc[2] > 0.f ? acc[2] : acc[2] * slope;
+  o.w = acc[3] > 0.f ? acc[3] : acc[3] * slope;
+  *reinterpret_cast<float4*>(y + ((((size_t)b * 32 + oy) * 8 + xq) * 64 + half * 32 + co) * 4) = o;
+}
+
 }  // namespace
 
 // Does every tile's canvas footprint fit d_aug_conv1_kernel<true>'s LDS tile?  Conservative: over the 21 grid steps of a tile
@@ -487,29 +551,38 @@ extern "C" int oi_ada_pad_up2(const float* x, const float* f, float* canvas, int
 
 extern "C" {
 
-size_t oi_disc_fwd_small_workspace_floats(int B, int C, int mx0, int mx1, int my0, int my1) {
-  const size_t canvas = (size_t)B * C * (2 * (64 + my0 + my1)) * (2 * (64 + mx0 + mx1));
-  return (canvas + 63) / 64 * 64 + (size_t)B * (64 * 32 * 32 + 128 * 16 * 16 + 256 * 8 * 8) + (size_t)512 * DS_MAX_B * 8;
+}  // extern "C"
+
+// w0 != NULL: the 128 x 128 / five-block network (C -> 32 -> 64 -> 128 -> 256 -> 512 -> out_dim), else the 64 x 64 / four-block one
+static size_t small_workspace_floats(int B, int C, int R, int mx0, int mx1, int my0, int my1) {
+  const size_t canvas = (size_t)B * C * (2 * (R + my0 + my1)) * (2 * (R + mx0 + mx1));
+  return (canvas + 63) / 64 * 64 + (R == 128 ? (size_t)B * 32 * 64 * 64 : 0) + (size_t)B * (64 * 32 * 32 + 128 * 16 * 16 + 256 * 8 * 8) +
+         (size_t)512 * DS_MAX_B * 8;
 }
 
-int oi_disc_fwd_small(const float* x, const float* theta_host, const float* theta_dev, const float* f12, int mx0, int mx1, int my0,
-                      int my1, const float* w1, const float* w2, const float* w3, const float* w4, const float* whead,
-                      const float* bhead, float* workspace, unsigned* ticket, float* logits, int B, int C, int H, int W, int n_feat,
-                      int out_dim, float slope, oi_stream_t stream) {
+static int disc_fwd_small_impl(const float* x, const float* theta_host, const float* theta_dev, const float* f12, int mx0, int mx1, int my0,
+                               int my1, const float* w0, const float* w1, const float* w2, const float* w3, const float* w4, const float* whead,
+                               const float* bhead, float* workspace, unsigned* ticket, float* logits, int B, int C, int H, int W, int n_feat,
+                               int out_dim, float slope, oi_stream_t stream) {
   OI_REQUIRE(x && f12 && w1 && w2 && w3 && w4 && whead && workspace && ticket && logits, "oi_disc_fwd_small: null pointer");
   OI_REQUIRE(theta_host == nullptr || theta_dev == nullptr, "oi_disc_fwd_small: theta_host and theta_dev are alternatives");
-  if (!(B >= 1 && B <= DS_MAX_B && C >= 1 && C <= DS_MAX_C && H == 64 && W == 64 && n_feat == 512 && out_dim >= 1 && out_dim <= 8))
-    return oi::fail(OI_ERR_UNSUPPORTED, "oi_disc_fwd_small: only B <= %d, C <= %d, 64 x 64, n_feat 512, out_dim <= 8 (got B=%d C=%d %dx%d n_feat=%d out_dim=%d)",
-                    DS_MAX_B, DS_MAX_C, B, C, H, W, n_feat, out_dim);
+  const int R = w0 != nullptr ? 128 : 64;
+  if (!(B >= 1 && B <= DS_MAX_B && C >= 1 && C <= DS_MAX_C && H == R && W == R && n_feat == 512 && out_dim >= 1 && out_dim <= 8))
+    return oi::fail(OI_ERR_UNSUPPORTED, "oi_disc_fwd_small: only B <= %d, C <= %d, %d x %d, n_feat 512, out_dim <= 8 (got B=%d C=%d %dx%d n_feat=%d out_dim=%d)",
+                    DS_MAX_B, DS_MAX_C, R, R, B, C, H, W, n_feat, out_dim);
   hipStream_t st = oi::as_stream(stream);
   const bool aug = theta_host != nullptr || theta_dev != nullptr;
   float* canvas = workspace;
   const int Hp = H + my0 + my1, Wp = W + mx0 + mx1;
   const size_t canvas_n = aug ? (size_t)B * C * (2 * Hp) * (2 * Wp) : 0;
-  float* a1 = workspace + (canvas_n + 63) / 64 * 64;   // conv 1 out; dead after conv 2: conv 4's output lands here again
+  float* a0 = workspace + (canvas_n + 63) / 64 * 64;   // 128 x 128 only: block 1's output (32 channels, 64 x 64)
+  float* a1 = a0 + (R == 128 ? (size_t)B * 32 * 64 * 64 : 0);   // 64 channels, 32 x 32; dead after the next block: conv 4's output lands here again
   float* a2 = a1 + (size_t)B * 64 * 32 * 32;
   float* a3 = a2 + (size_t)B * 128 * 16 * 16;
   float* partials = a3 + (size_t)B * 256 * 8 * 8;
+  const float* wfirst = R == 128 ? w0 : w1;
+  float* afirst = R == 128 ? a0 : a1;
+  const int c_first = R == 128 ? 32 : 64;
   ThetaArg th = {};
   int rc = OI_OK;
   // the canvas built inside d_aug_conv1_kernel (one launch less) when the host can see that every tile's footprint fits
@@ -524,13 +597,19 @@ int oi_disc_fwd_small(const float* x, const float* theta_host, const float* thet
     }
   }
   if (fold)
-    hipLaunchKernelGGL(d_aug_conv1_kernel<true>, dim3(W / DA_T, H / DA_T, B), dim3(256), 0, st, x, th, theta_dev, 1, f12, w1, a1, C, H, W,
-                       2 * Hp, 2 * Wp, 64, slope, mx0, my0);
+    hipLaunchKernelGGL(d_aug_conv1_kernel<true>, dim3(W / DA_T, H / DA_T, B), dim3(256), 0, st, x, th, theta_dev, 1, f12, wfirst, afirst, C, H, W,
+                       2 * Hp, 2 * Wp, c_first, slope, mx0, my0);
   else
     hipLaunchKernelGGL(d_aug_conv1_kernel<false>, dim3(W / DA_T, H / DA_T, B), dim3(256), 0, st, aug ? canvas : x, th, theta_dev,
-                       aug ? 1 : 0, f12, w1, a1, C, H, W, 2 * Hp, 2 * Wp, 64, slope, mx0, my0);
+                       aug ? 1 : 0, f12, wfirst, afirst, C, H, W, 2 * Hp, 2 * Wp, c_first, slope, mx0, my0);
   rc = oi::check_launch("oi_disc_fwd_small(aug + conv1)");
   if (rc != OI_OK) return rc;
+  if (R == 128) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(d_conv_c32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DC32_LDS);
+    hipLaunchKernelGGL(d_conv_c32_kernel, dim3(32, 2, B), dim3(256), DC32_LDS, st, a0, w1, a1, slope);
+    rc = oi::check_launch("oi_disc_fwd_small(conv 32 -> 64)");
+    if (rc != OI_OK) return rc;
+  }
   hipLaunchKernelGGL((d_conv_small_kernel<64, 32, 8, 2, false>), dim3(128 / 2, 2), dim3(512), 0, st, a1, w2, a2, B, 128, slope, nullptr,
                      nullptr, 0, nullptr, nullptr, nullptr);
   rc = oi::check_launch("oi_disc_fwd_small(conv2)");
@@ -543,6 +622,32 @@ int oi_disc_fwd_small(const float* x, const float* theta_host, const float* thet
   hipLaunchKernelGGL((d_conv_small_kernel<256, 8, 4, 2, true>), dim3(512 / 2, 1), dim3(256), 0, st, a3, w4, a1, B, 512, slope, whead, bhead,
                      out_dim, partials, ticket, logits);
   return oi::check_launch("oi_disc_fwd_small(conv4 + head)");
+}
+
+extern "C" {
+
+size_t oi_disc_fwd_small_workspace_floats(int B, int C, int mx0, int mx1, int my0, int my1) {
+  return small_workspace_floats(B, C, 64, mx0, mx1, my0, my1);
+}
+size_t oi_disc_fwd_small128_workspace_floats(int B, int C, int mx0, int mx1, int my0, int my1) {
+  return small_workspace_floats(B, C, 128, mx0, mx1, my0, my1);
+}
+
+int oi_disc_fwd_small(const float* x, const float* theta_host, const float* theta_dev, const float* f12, int mx0, int mx1, int my0,
+                      int my1, const float* w1, const float* w2, const float* w3, const float* w4, const float* whead,
+                      const float* bhead, float* workspace, unsigned* ticket, float* logits, int B, int C, int H, int W, int n_feat,
+                      int out_dim, float slope, oi_stream_t stream) {
+  return disc_fwd_small_impl(x, theta_host, theta_dev, f12, mx0, mx1, my0, my1, nullptr, w1, w2, w3, w4, whead, bhead, workspace, ticket,
+                             logits, B, C, H, W, n_feat, out_dim, slope, stream);
+}
+
+int oi_disc_fwd_small128(const float* x, const float* theta_host, const float* theta_dev, const float* f12, int mx0, int mx1, int my0,
+                         int my1, const float* w0, const float* w1, const float* w2, const float* w3, const float* w4, const float* whead,
+                         const float* bhead, float* workspace, unsigned* ticket, float* logits, int B, int C, int n_feat, int out_dim,
+                         float slope, oi_stream_t stream) {
+  OI_REQUIRE(w0 != nullptr, "oi_disc_fwd_small128: null pointer");
+  return disc_fwd_small_impl(x, theta_host, theta_dev, f12, mx0, mx1, my0, my1, w0, w1, w2, w3, w4, whead, bhead, workspace, ticket, logits,
+                             B, C, 128, 128, n_feat, out_dim, slope, stream);
 }
 
 }  // extern "C"
@@ -574,6 +679,7 @@ struct oi_disc_graph {
   int aug = 0, B = 0, H = 0, W = 0, Hp = 0, Wp = 0;
   // everything oi_disc_fwd_small takes besides the image and the matrices (oi_disc_graph_launch_eager)
   const float *f12 = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr, *w4 = nullptr, *whead = nullptr, *bhead = nullptr;
+  const float* w0 = nullptr;   // the 128 x 128 network's first block (oi_disc_graph_create128); NULL: the 64 x 64 network
   float* workspace = nullptr;
   unsigned* ticket = nullptr;
   float* logits = nullptr;
@@ -610,9 +716,30 @@ int oi_disc_graph_create(oi_disc_graph** out, int aug, const float* f12, int mx0
   return OI_OK;   //  eagerly makes no capture -- and can therefore be created while its caller is capturing)
 }
 
+int oi_disc_graph_create128(oi_disc_graph** out, int aug, const float* f12, int mx0, int mx1, int my0, int my1, const float* w0,
+                            const float* w1, const float* w2, const float* w3, const float* w4, const float* whead, const float* bhead,
+                            float* workspace, unsigned* ticket, float* logits, int B, int C, int n_feat, int out_dim, float slope) {
+  OI_REQUIRE(out != nullptr && workspace != nullptr && ticket != nullptr && logits != nullptr && w0 && w1 && w2 && w3 && w4 && whead,
+             "oi_disc_graph_create128: null pointer");
+  OI_REQUIRE(!aug || f12 != nullptr, "oi_disc_graph_create128: augmentation without the filter taps");
+  *out = nullptr;
+  if (!(B >= 1 && B <= DS_MAX_B && C >= 1 && C <= DS_MAX_C && n_feat == 512 && out_dim >= 1 && out_dim <= 8))
+    return oi::fail(OI_ERR_UNSUPPORTED, "oi_disc_graph_create128: only B <= %d, C <= %d, n_feat 512, out_dim <= 8", DS_MAX_B, DS_MAX_C);
+  oi_disc_graph* g = new oi_disc_graph();
+  g->aug = aug ? 1 : 0;
+  g->B = B; g->H = 128; g->W = 128; g->Hp = 128 + my0 + my1; g->Wp = 128 + mx0 + mx1;
+  g->f12 = f12; g->w0 = w0; g->w1 = w1; g->w2 = w2; g->w3 = w3; g->w4 = w4; g->whead = whead; g->bhead = bhead;
+  g->workspace = workspace; g->ticket = ticket; g->logits = logits;
+  g->C = C; g->mx0 = mx0; g->mx1 = mx1; g->my0 = my0; g->my1 = my1; g->n_feat = n_feat; g->out_dim = out_dim; g->slope = slope;
+  *out = g;
+  return OI_OK;
+}
+
 // captures the variants (private stream, relaxed mode) on first use
 static int graph_capture(oi_disc_graph* g) {
   if (g->v[0].exec != nullptr) return OI_OK;
+  if (g->w0 != nullptr)
+    return oi::fail(OI_ERR_UNSUPPORTED, "oi_disc_graph_launch: the 128 x 128 plan is launched launch by launch (oi_disc_graph_launch_eager)");
   hipStream_t cs = nullptr;
   if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_disc_graph_launch: stream");
   int rc = OI_OK;
@@ -688,9 +815,9 @@ int oi_disc_graph_launch(oi_disc_graph* g, const float* x, const float* theta_ho
 int oi_disc_graph_launch_eager(oi_disc_graph* g, const float* x, const float* theta_host, float* logits, oi_stream_t stream) {
   OI_REQUIRE(g != nullptr && x != nullptr, "oi_disc_graph_launch_eager: null pointer");
   OI_REQUIRE((theta_host != nullptr) == (g->aug != 0), "oi_disc_graph_launch_eager: the object was created %s augmentation", g->aug ? "with" : "without");
-  return oi_disc_fwd_small(x, theta_host, nullptr, g->f12 != nullptr ? g->f12 : g->workspace, g->mx0, g->mx1, g->my0, g->my1, g->w1, g->w2,
-                           g->w3, g->w4, g->whead, g->bhead, g->workspace, g->ticket, logits != nullptr ? logits : g->logits, g->B, g->C,
-                           g->H, g->W, g->n_feat, g->out_dim, g->slope, stream);
+  return disc_fwd_small_impl(x, theta_host, nullptr, g->f12 != nullptr ? g->f12 : g->workspace, g->mx0, g->mx1, g->my0, g->my1, g->w0, g->w1,
+                             g->w2, g->w3, g->w4, g->whead, g->bhead, g->workspace, g->ticket, logits != nullptr ? logits : g->logits, g->B,
+                             g->C, g->H, g->W, g->n_feat, g->out_dim, g->slope, stream);
 }
 
 // ---- AugmentPipe's parameter draws for the shipped configuration (xint + scale), inside the library --------------------------

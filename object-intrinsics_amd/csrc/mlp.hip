@@ -25,6 +25,7 @@
 #include <algorithm>
 
 #include "mlp_common.h"
+#include "f3_blob.h"
 
 namespace {
 
@@ -987,7 +988,19 @@ size_t oi_mlp_scratch_bytes_prec(int B, long long n_per_elem, int prec) {
 int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf,
                    float* grad, float* rgb, float* feat, void* scratch, int B, long long n_per_elem, int prec,
                    int fast_trig, oi_stream_t stream) {
+  return oi_sdf_mlp_fwd_ex(pts, packed, gamma, beta, sdf, grad, rgb, feat, scratch, B, n_per_elem, prec, fast_trig, 0, stream);
+}
+
+size_t oi_mlp_f3_blob_offset(int B, long long n_per_elem) { return oimlp::full3_blob_offset(B, n_per_elem); }
+size_t oi_mlp_f3_blob_bytes(void) { return (size_t)oif3::F3_BLOB; }
+
+int oi_sdf_mlp_fwd_ex(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf,
+                      float* grad, float* rgb, float* feat, void* scratch, int B, long long n_per_elem, int prec,
+                      int fast_trig, int flags, oi_stream_t stream) {
   OI_REQUIRE(pts && packed && gamma && beta && sdf, "oi_sdf_mlp_fwd: null pointer");
+  OI_REQUIRE((flags & ~OI_MLP_BLOB_READY) == 0, "oi_sdf_mlp_fwd_ex: unknown flag bits %d", flags);
+  OI_REQUIRE(!(flags & OI_MLP_BLOB_READY) || (prec == OI_PREC_F16X3 && grad != nullptr),
+             "oi_sdf_mlp_fwd_ex: OI_MLP_BLOB_READY applies to the OI_PREC_F16X3 pass with the gradient");
   OI_REQUIRE(B > 0 && n_per_elem > 0, "oi_sdf_mlp_fwd: B=%d n=%lld", B, n_per_elem);
   OI_REQUIRE(grad != nullptr || rgb == nullptr, "oi_sdf_mlp_fwd: rgb requires grad");
   OI_REQUIRE(grad == nullptr || scratch != nullptr, "oi_sdf_mlp_fwd: grad requires scratch");
@@ -995,7 +1008,8 @@ int oi_sdf_mlp_fwd(const float* pts, const void* packed, const float* gamma, con
   // F16X3 with the gradient: the register-resident kernel (mlp_fwd3.hip); OI_FWD_V2=1 keeps the scratch-streaming v2
   static const bool use_v2 = [] { const char* v = getenv("OI_FWD_V2"); return v && v[0] == '1'; }();
   if (prec == OI_PREC_F16X3 && grad != nullptr && !use_v2)
-    return oimlp::launch_full3_f16x3(pts, packed, gamma, beta, sdf, grad, rgb, feat, scratch, B, n_per_elem, fast_trig, st);
+    return oimlp::launch_full3_f16x3(pts, packed, gamma, beta, sdf, grad, rgb, feat, scratch, B, n_per_elem, fast_trig,
+                                     (flags & OI_MLP_BLOB_READY) != 0, st);
   // BF16 with the gradient: the register-resident kernel of mlp_fwd3b.hip (no scratch stream)
   if (prec == OI_PREC_BF16 && grad != nullptr && !use_v2)
     return oimlp::launch_full3_bf16(pts, packed, gamma, beta, sdf, grad, rgb, feat, scratch, B, n_per_elem, fast_trig, st);

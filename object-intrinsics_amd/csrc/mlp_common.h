@@ -585,8 +585,9 @@ __device__ __forceinline__ void ring_sync() {
 
 // mlp_fwd3.hip: register-resident F16X3 forward with gradient (+ albedo); scratch = one 16 KiB slot per wave tile
 size_t full3_scratch_bytes(int B, long long n_per_elem);
+size_t full3_blob_offset(int B, long long n_per_elem);   // byte offset of the per-element blobs inside that scratch
 int launch_full3_f16x3(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf,
-                       float* grad, float* rgb, float* feat, void* scratch, int B, long long n, int fast_trig,
+                       float* grad, float* rgb, float* feat, void* scratch, int B, long long n, int fast_trig, bool blob_ready,
                        hipStream_t st);
 
 // mlp_fwd3b.hip: register-resident BF16 forward with gradient (+ albedo); no scratch

@@ -20,18 +20,21 @@
 #include <type_traits>
 
 #include "mlp_common.h"
+#include "f3_blob.h"
 
 namespace {
 
 using namespace oimlp;
+static_assert(oif3::FC == C && oif3::HB_SIG == H_SIG && oif3::HB_TABS_END == H_TABS_END && oif3::HB_BIAS == H_BIAS &&
+              oif3::HB_WSCALE == H_WSCALE && oif3::HB_NL_SDF == NL_SDF, "f3_blob.h mirrors the packed header's offsets");
 
 constexpr int F3_WAVES = 4;
 constexpr int F3_TILE = F3_WAVES * WAVE_PTS;  // 128 points per workgroup
 // LDS: FiLM rows [10][A 128 | B 128 | G 128] floats, small tables, double-buffered image ring
-constexpr int F3_FILM = 0;
-constexpr int F3_FILM_ROW = 3 * C * 4;                      // bytes per FiLM layer
-constexpr int F3_TABS = F3_FILM + 10 * F3_FILM_ROW;         // 15360
-constexpr int F3_GMAX = F3_TABS + H_TABS_END * 4;           // [16] max |G_l| per FiLM layer (9: max |G7 w_sigma|)
+using oif3::F3_FILM;       // 0
+using oif3::F3_FILM_ROW;   // 3 * C * 4 bytes per FiLM layer
+using oif3::F3_TABS;       // 15360
+using oif3::F3_GMAX;       // [16] max |G_l| per FiLM layer (9: max |G7 w_sigma|)
 // OI_F3_BLOB (round 5): everything in front of the image ring depends on the batch element only, so ONE launch per call
 // (film_blob_f3_kernel, a block per element) writes it as a 22 KiB blob and a tile's prologue is 22 LDS-DMA copies of 1 KiB
 // instead of ~25 dependent global loads per thread, 21 KB of ds_writes, the row maxima and two barriers -- 4,096 workgroups of
@@ -39,10 +42,9 @@ constexpr int F3_GMAX = F3_TABS + H_TABS_END * 4;           // [16] max |G_l| pe
 #ifndef OI_F3_BLOB
 #define OI_F3_BLOB 1
 #endif
-constexpr int F3_BLOB = 22528;
+using oif3::F3_BLOB;       // 22528
 constexpr int F3_WBUF = OI_F3_BLOB ? F3_BLOB : F3_GMAX + 64;  // 22,528 (21,696 without the blob)
 constexpr int F3_LDS = F3_WBUF + 2 * 65536;                 // 153,600 of the CU's 163,840 bytes
-static_assert(F3_GMAX + 64 <= F3_BLOB, "blob layout");
 
 // One parked 128-vector of this lane's point: [group g][k]  <->  act[4 g + k].  The values are pinned to the ACCUMULATOR
 // half of the register file through the "a" constraint: left to itself hipcc's allocator treats them as ordinary
@@ -913,35 +915,15 @@ sdf_mlp_full3_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 // The per-element blob of sdf_mlp_full3_kernel: LDS bytes [0, F3_BLOB) as the kernel's own staging loop formed them (the
 // phase in REVOLUTIONS: phi / 2pi = A * acc + B with A = gamma * 2^-k_image / 2pi, B = (gamma * bias + beta) / 2pi; G = gamma *
 // 2^-k_image; row 9 = G7 * w_sigma; the header tables; max |G_l| per layer and of row 9).  One block per batch element.
-__global__ void __launch_bounds__(256) film_blob_f3_kernel(const char* __restrict__ packed, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(128) film_blob_f3_kernel(const char* __restrict__ packed, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, char* __restrict__ blob) {
-  __shared__ float gl[10 * C];
-  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float red[8];
+  const int e = blockIdx.x, l = blockIdx.y, tid = threadIdx.x;   // a workgroup per (element, FiLM layer)
   const float* hdr = reinterpret_cast<const float*>(packed);
   float* out = reinterpret_cast<float*>(blob + (size_t)e * F3_BLOB);
-  float* tabs = out + F3_TABS / 4;
-  for (int i = tid; i < H_TABS_END; i += 256) tabs[i] = hdr[i];
-  float* film = out + F3_FILM / 4;
-  constexpr float INV_2PI = 0.15915494309189533577f;
-  for (int i = tid; i < 9 * C; i += 256) {
-    const int l = i / C, f = i % C;
-    const float gm = gamma[((size_t)e * 9 + l) * C + f];
-    const float wsc = l == 0 ? 1.f : hdr[H_WSCALE + (l < NL_SDF ? l - 1 : 14)];
-    const float G = gm * wsc;
-    film[l * (F3_FILM_ROW / 4) + f] = G * INV_2PI;
-    film[l * (F3_FILM_ROW / 4) + C + f] = fmaf(gm, hdr[H_BIAS + l * C + f], beta[((size_t)e * 9 + l) * C + f]) * INV_2PI;
-    film[l * (F3_FILM_ROW / 4) + 2 * C + f] = G;
-    gl[l * C + f] = G;
-    if (l == 7) {
-      film[9 * (F3_FILM_ROW / 4) + f] = G * hdr[H_SIG + f];
-      gl[9 * C + f] = G * hdr[H_SIG + f];
-    }
-  }
-  __syncthreads();
-  for (int l = wave; l < 10; l += 4) {
-    const float m = oi::wave_max(fmaxf(fabsf(gl[l * C + lane]), fabsf(gl[l * C + 64 + lane])));
-    if (lane == 0) out[F3_GMAX / 4 + l] = m;
-  }
+  // (oif3::blob_layer: the same code prep_render_kernel's FiLM workgroups run)
+  const float gm = tid < C ? gamma[((size_t)e * 9 + l) * C + tid] : 0.f, bt = tid < C ? beta[((size_t)e * 9 + l) * C + tid] : 0.f;
+  oif3::blob_layer(hdr, out, l, tid, gm, bt, red);
 }
 
 size_t full3_slot_bytes(int B, long long n_per_elem) {
@@ -951,13 +933,13 @@ size_t full3_slot_bytes(int B, long long n_per_elem) {
 
 template <bool FAST>
 int launch_full3(const float* pts, const char* pk, const float* gamma, const float* beta, float* sdf, float* grad,
-                 float* rgb, float* feat, char* scratch, int B, long long n, hipStream_t st) {
+                 float* rgb, float* feat, char* scratch, int B, long long n, bool blob_ready, hipStream_t st) {
   dim3 grid(oi::cdiv(n, F3_TILE), B), block(64 * F3_WAVES);
   auto k = sdf_mlp_full3_kernel<FAST>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, F3_LDS);
   char* blob = scratch + full3_slot_bytes(B, n);   // behind the feature slots
 #if OI_F3_BLOB
-  hipLaunchKernelGGL(film_blob_f3_kernel, dim3(B), dim3(256), 0, st, pk, gamma, beta, blob);
+  if (!blob_ready) hipLaunchKernelGGL(film_blob_f3_kernel, dim3(B, 9), dim3(128), 0, st, pk, gamma, beta, blob);
 #endif
   hipLaunchKernelGGL(k, grid, block, F3_LDS, st, pts, pk, gamma, beta, sdf, grad, rgb, feat, scratch, blob, n);
   return oi::check_launch("oi_sdf_mlp_fwd(full3)");
@@ -971,13 +953,15 @@ size_t full3_scratch_bytes(int B, long long n_per_elem) {   // feature slots + t
   return full3_slot_bytes(B, n_per_elem) + (size_t)B * F3_BLOB;
 }
 
+size_t full3_blob_offset(int B, long long n_per_elem) { return full3_slot_bytes(B, n_per_elem); }
+
 int launch_full3_f16x3(const float* pts, const void* packed, const float* gamma, const float* beta, float* sdf,
-                       float* grad, float* rgb, float* feat, void* scratch, int B, long long n, int fast_trig,
+                       float* grad, float* rgb, float* feat, void* scratch, int B, long long n, int fast_trig, bool blob_ready,
                        hipStream_t st) {
   const char* pk = reinterpret_cast<const char*>(packed);
   char* sc = reinterpret_cast<char*>(scratch);
-  return fast_trig ? launch_full3<true>(pts, pk, gamma, beta, sdf, grad, rgb, feat, sc, B, n, st)
-                   : launch_full3<false>(pts, pk, gamma, beta, sdf, grad, rgb, feat, sc, B, n, st);
+  return fast_trig ? launch_full3<true>(pts, pk, gamma, beta, sdf, grad, rgb, feat, sc, B, n, blob_ready, st)
+                   : launch_full3<false>(pts, pk, gamma, beta, sdf, grad, rgb, feat, sc, B, n, blob_ready, st);
 }
 
 }  // namespace oimlp

@@ -12,6 +12,7 @@
 // lanes (coalesced), the transmittance product and the CDF are wavefront shuffle scans, the
 // searchsorted / sort of the reference become binary searches over LDS-resident per-ray arrays.
 #include "oi_common.h"
+#include "f3_blob.h"
 
 namespace {
 
@@ -71,10 +72,17 @@ OI_RAY_FP_CONTRACT
   return r;
 }
 // coarse sample i of S on [near, far] (+ the per-ray jitter): renderer.py:359-360, 372-373
-__device__ __forceinline__ float coarse_z_at(float nr, float fr, int S, int i, const float* __restrict__ jitter, long long r) {
+__device__ __forceinline__ float coarse_z_at(float nr, float fr, int S, int i, const float* __restrict__ jitter, long long r,
+                                             bool jitter_normal = false) {
 OI_RAY_FP_CONTRACT
   float zv = nr + (fr - nr) * linspace_at(0.f, 1.f, S, i);
-  if (jitter != nullptr) zv = zv + (jitter[r] - 0.5f) * 2.0f / (float)S;
+  if (jitter != nullptr) {
+    float u = jitter[r];
+    // a standard normal draw (the caller's ONE generator call for latents + jitter) -> its CDF: uniform on (0, 1), kept below 1
+    // like torch.rand's [0, 1)
+    if (jitter_normal) u = fminf(0.5f * erfcf(-0.70710678118654752f * u), 0.99999994f);
+    zv = zv + (u - 0.5f) * 2.0f / (float)S;
+  }
   return zv;
 }
 __device__ __forceinline__ float along_ray(float o, float d, float z) {
@@ -127,7 +135,8 @@ __device__ __forceinline__ void style_film_block(const float* __restrict__ style
                                                  const float* __restrict__ gw, const float* __restrict__ gb,
                                                  const float* __restrict__ bw, const float* __restrict__ bb,
                                                  float* __restrict__ gamma, float* __restrict__ beta, int NL, int e, int l,
-                                                 float (*h)[64]) {
+                                                 float (*h)[64], const float* __restrict__ f3_hdr = nullptr,
+                                                 float* __restrict__ f3_blob = nullptr, float* f3_red = nullptr) {
   // (csrc/mlp.hip film_params_kernel, same operations in the same order; threads >= 128 only keep the barriers)
   const int t = threadIdx.x;
   if (z != nullptr) {
@@ -155,6 +164,7 @@ __device__ __forceinline__ void style_film_block(const float* __restrict__ style
     if (t < 64) h[0][t] = w_out[e * 64 + t];
     __syncthreads();
   }
+  float gm = 0.f, bt = 0.f;
   if (l < NL && t < 128) {
     const float* g = gw + ((size_t)l * 128 + t) * 64;
     const float* b = bw + ((size_t)l * 128 + t) * 64;
@@ -164,9 +174,14 @@ __device__ __forceinline__ void style_film_block(const float* __restrict__ style
       ag = fmaf(h[0][k], g[k], ag);
       ab = fmaf(h[0][k], b[k], ab);
     }
-    gamma[((size_t)e * NL + l) * 128 + t] = 15.0f * (ag + gb[l * 128 + t]) + 30.0f;
-    beta[((size_t)e * NL + l) * 128 + t] = 0.25f * (ab + bb[l * 128 + t]) + 0.0f;
+    gm = 15.0f * (ag + gb[l * 128 + t]) + 30.0f;
+    bt = 0.25f * (ab + bb[l * 128 + t]) + 0.0f;
+    gamma[((size_t)e * NL + l) * 128 + t] = gm;
+    beta[((size_t)e * NL + l) * 128 + t] = bt;
   }
+  // the per-element blob of the register-resident MLP kernel, this workgroup's layer of it (csrc/f3_blob.h): gamma_l / beta_l are
+  // in registers here -- film_blob_f3_kernel would read them back from memory in a launch of its own
+  if (f3_blob != nullptr && l < NL) oif3::blob_layer(f3_hdr, f3_blob + (size_t)e * (oif3::F3_BLOB / 4), l, t, gm, bt, f3_red);
 }
 
 __global__ void __launch_bounds__(256) prep_render_kernel(const oi_prep_params p) {
@@ -175,8 +190,9 @@ __global__ void __launch_bounds__(256) prep_render_kernel(const oi_prep_params p
   const int nl1 = p.NL > 0 ? p.NL : 1;
   const int n_film = p.B * nl1;
   if ((int)blockIdx.x < n_film) {
+    __shared__ float f3_red[8];
     style_film_block(p.style_w, p.style_b, p.z, p.w_out, p.gw, p.gb, p.bw, p.bb, p.gamma, p.beta, p.NL, blockIdx.x / nl1,
-                     blockIdx.x % nl1, h);
+                     blockIdx.x % nl1, h, reinterpret_cast<const float*>(p.f3_packed), reinterpret_cast<float*>(p.f3_blob), f3_red);
     return;
   }
   const int rb = blockIdx.x - n_film, t = threadIdx.x, R = p.R;
@@ -223,7 +239,7 @@ __global__ void __launch_bounds__(256) prep_render_kernel(const oi_prep_params p
     const int lr = i / S, k = i % S;
     const long long r = r0 + lr;
     if (r >= n) break;
-    const float zv = coarse_z_at(ray[lr][6], ray[lr][7], S, k, p.jitter, r);
+    const float zv = coarse_z_at(ray[lr][6], ray[lr][7], S, k, p.jitter, r, p.jitter_normal != 0);
     const long long o_ = r * S + k;
     p.z_coarse[o_] = zv;
 #pragma unroll
@@ -736,6 +752,8 @@ int oi_prep_render(const oi_prep_params* p, oi_stream_t stream) {
   OI_REQUIRE((p->light_dir == nullptr) == (p->light_direction == nullptr), "oi_prep_render: light_dir needs light_direction");
   OI_REQUIRE(p->NL == 0 || (p->gw && p->gb && p->bw && p->bb && p->gamma && p->beta), "oi_prep_render: null FiLM pointer");
   OI_REQUIRE(p->z == nullptr || (p->style_w && p->style_b), "oi_prep_render: z given without style weights");
+  OI_REQUIRE((p->f3_packed == nullptr) == (p->f3_blob == nullptr), "oi_prep_render: f3_packed and f3_blob come together");
+  OI_REQUIRE(p->f3_blob == nullptr || p->NL == 9, "oi_prep_render: the blob covers the 9 FiLM layers (NL=%d)", p->NL);
   const long long n = (long long)p->B * p->R * p->R;
   const int blocks = p->B * (p->NL > 0 ? p->NL : 1) + (int)oi::cdiv(n, PREP_RAYS);
   hipLaunchKernelGGL(prep_render_kernel, dim3(blocks), dim3(256), 0, oi::as_stream(stream), *p);

@@ -90,14 +90,14 @@ def style_mlp(style_module, z):
 # a3-a6: the MLP
 # ------------------------------------------------------------------------------------------
 
-def sdf_mlp(pack, pts, gamma, beta, B, want_grad, want_rgb, want_feat, scratch=None):
-    """-> (sdf (n,), grad (n,3)|None, rgb (n,3)|None, feat (n,128)|None)."""
+def sdf_mlp(pack, pts, gamma, beta, B, want_grad, want_rgb, want_feat, scratch=None, blob_ready=False):
+    """-> (sdf (n,), grad (n,3)|None, rgb (n,3)|None, feat (n,128)|None).  scratch / blob_ready: ops.sdf_mlp_fwd (no-grad path)."""
     if _needs_grad(pts, gamma, beta, *pack.param_lists()[0]):
         from .autograd_mlp import SdfMlpFunction
         return SdfMlpFunction.run(pack, pts, gamma, beta, B, want_grad, want_rgb, want_feat)
     with torch.no_grad():
         sdf, grad, rgb, feat, _ = ops.sdf_mlp_fwd(pts, pack.packed(), gamma, beta, B, pack.prec, pack.fast_trig,
-                                                  want_grad, want_rgb, want_feat, scratch)
+                                                  want_grad, want_rgb, want_feat, scratch, blob_ready)
     return sdf, grad, rgb, feat
 
 

@@ -19,6 +19,7 @@ LARGE_PATH = True   # batch >= 16 no-grad forwards take csrc/disc_large.hip when
 LARGE_MIN_BATCH = 16
 FAST_ADA = True     # ADADiscriminator.forward, shipped augmentation, batch <= 4: parameters drawn inside the library (False: numpy)
 SMALL_PATH = True   # batch <= 4 no-grad forwards of the 64 x 64 network take csrc/disc_small.hip (False: the general chain)
+SMALL_PATH_128 = True   # ... and of the shipped 128 x 128 / five-block network (round 6)
 
 
 class _ConvParam(nn.Module):
@@ -93,8 +94,13 @@ class DCDiscriminator(nn.Module):
         the general chain is taken instead; the plain entry with a device-resident matrix (`theta_dev`, what captured graphs use)
         refuses a FIRST call inside a capture (ops.disc_fwd_small)."""
         if not (SMALL_PATH and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 4 and x.shape[0] <= 4 and x.shape[1] <= 4
-                and tuple(x.shape[2:]) == (64, 64) and len(self.blocks) == 4 and self.blocks[0].weight.shape[0] == 64
-                and self.blocks[3].weight.shape[0] == 512 and self.out_dim <= 8):
+                and self.out_dim <= 8):
+            return False
+        # BASELINE's 64 x 64 network (four blocks 64 .. 512) or the shipped 128 x 128 one (five blocks 32 .. 512: configs/train.yaml:78-102)
+        hw, nb = tuple(x.shape[2:]), len(self.blocks)
+        if not ((hw == (64, 64) and nb == 4) or (hw == (128, 128) and nb == 5 and SMALL_PATH_128)):
+            return False
+        if [int(l.weight.shape[0]) for l in self.blocks] != ([64, 128, 256, 512] if nb == 4 else [32, 64, 128, 256, 512]):
             return False
         ws = [l.weight for l in self.blocks] + [self.conv_out.weight] + ([] if self.conv_out.bias is None else [self.conv_out.bias])
         if not (x.shape[1] == self.in_dim == self.blocks[0].weight.shape[1]

@@ -8,6 +8,7 @@ with no host synchronisation -- `it` is mirrored on the host, the light scalars 
 compositing kernel from device memory, stats stay on the device -- and the Phong maps come out of
 the same compositing launch instead of ~40 elementwise kernels over (N, T, 3) tensors."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -21,6 +22,10 @@ from .renderer import assemble_render_dict
 import weakref
 
 MAX_RAY_BATCH_SIZE = 128 * 128 * 1
+# round 6, the no-grad fused forward (OI_STEP_TAIL=0 switches both off: the round-5 launch sequence, 13 per step):
+ONE_DRAW = os.environ.get("OI_STEP_TAIL", "1") != "0"          # latents + per-ray jitter from ONE generator launch
+F3_BLOB_IN_PREP = os.environ.get("OI_STEP_TAIL", "1") != "0"   # the f16x3 kernel's per-element blobs formed by the prep launch
+_TORCH_RAND, _TORCH_RANDN = torch.rand, torch.randn           # (a caller that patches them replays recorded draws: see _prep_fused)
 _STAGE_RINGS = weakref.WeakKeyDictionary()
 
 
@@ -174,19 +179,39 @@ class Generator(nn.Module):
     def _prep_fused(self, bs, data):
         """No-grad forward with host-sampled poses: pose upload, rays, light direction, style MLP + FiLM parameters and the
         coarse samples in ONE launch (ops.prep_render); the torch draws keep their order (latent, then the per-ray jitter).
-        -> (prior, latent, rays, film, coarse)"""
+        -> (prior, latent, rays, film, coarse, f3_scratch)"""
         dev = self.it.device
         b2w_h, w2b_h, c2b_h, xy_h, bg_h = self._sample_prior_host(bs, data)
-        latent = self.sample_latent(bs, data)
         R, S = self.resolution, self.renderer.n_samples
         perturb = self.renderer.perturb if self.training else 0
-        jitter = torch.rand([bs * R * R, 1], device=dev) if perturb > 0 else None   # renderer.py:372
+        jitter_normal = False
+        if (ONE_DRAW and perturb > 0 and "sample_latent" not in self.__dict__ and type(self).sample_latent is Generator.sample_latent
+                and torch.rand is _TORCH_RAND and torch.randn is _TORCH_RANDN):
+            # ONE generator launch for the forward's two draws (latents, then one value per ray for the jitter -- the reference's
+            # order, generator.py:234 / renderer.py:372): standard normals; the prep kernel maps a ray's value to its uniform
+            # through the normal CDF.  (A caller that replays recorded draws -- F13 patches sample_latent / torch.rand -- keeps the
+            # two separate calls.)
+            buf = torch.randn(bs * self.z_dim + bs * R * R, device=dev)
+            latent = {"z": buf[:bs * self.z_dim].view(bs, self.z_dim)}
+            jitter, jitter_normal = buf[bs * self.z_dim:], True
+        else:
+            latent = self.sample_latent(bs, data)
+            jitter = torch.rand([bs * R * R, 1], device=dev) if perturb > 0 else None   # renderer.py:372
+        # f16x3: the per-element table blobs of the fine pass's MLP kernel are formed by this launch's FiLM workgroups (one
+        # launch and its boundary less per render): the fine pass's working memory is allocated here
+        pack, f3_scratch, f3_blob, f3_packed = self.renderer.pack, None, None, None
+        if F3_BLOB_IN_PREP and pack.prec == ops._l.OI_PREC_F16X3 and pack.color_network is not None:
+            I, K = self.renderer.n_importance, max(1, self.renderer.up_sample_steps)
+            T = S + (I // K) * K if I > 0 else S
+            f3_scratch, f3_blob = ops.f3_scratch_for(bs, R * R * T, dev)
+            f3_packed = pack.packed()
         pre = ops.prep_render(b2w_h, w2b_h, c2b_h, xy_h, bg_h, self._kinv(dev), R, S, jitter, self.light.param_direction,
-                              self.renderer.pack.film_stacked(differentiable=False), latent["z"])
+                              pack.film_stacked(differentiable=False), latent["z"], jitter_normal=jitter_normal,
+                              f3_packed=f3_packed, f3_blob=f3_blob)
         prior = self._prior_from_flat(pre["pose"], bs, True)
         rays = {"x_offset": self._xy_off[:, 0], "y_offset": self._xy_off[:, 1], "light_dir": pre["light_dir"],
                 "rays_o": pre["rays_o"], "rays_d": pre["rays_d"], "near": pre["near"], "far": pre["far"]}
-        return prior, latent, rays, (pre["w"], pre["gamma"], pre["beta"]), (pre["z_coarse"], pre["pts_coarse"])
+        return prior, latent, rays, (pre["w"], pre["gamma"], pre["beta"]), (pre["z_coarse"], pre["pts_coarse"]), f3_scratch
 
     def _camera_host(self):
         # host copies of the camera buffers, keyed on (address, version) of the device buffers: load_state_dict / .to()
@@ -257,8 +282,9 @@ class Generator(nn.Module):
         film = coarse = None
         fused = (not torch.is_grad_enabled() and self.it.is_cuda and bs <= PREP_MAX_B and bs * h * w <= MAX_RAY_BATCH_SIZE
                  and not any(k in data for k in ("b2w", "z", "w", "bg_color")))
+        f3_scratch = None
         if fused:
-            prior, latent, rays, film, coarse = self._prep_fused(bs, data)
+            prior, latent, rays, film, coarse, f3_scratch = self._prep_fused(bs, data)
             grad_light = False
         else:
             prior = self.sample_prior(bs, data)
@@ -308,7 +334,8 @@ class Generator(nn.Module):
                                              perturb_overwrite=-1 if self.training else 0,
                                              cos_anneal_ratio=cos_anneal_ratio, z=latent["z"], w=latent["w"],
                                              light=lpk, light_dir=ldir, bg=bg, film=film, coarse=coarse,
-                                             image_planar=(n_chunks == 1), outputs=want)
+                                             image_planar=(n_chunks == 1), outputs=want,
+                                             f3_scratch=f3_scratch if n_chunks == 1 else None)
             outs.append((s, c))
         if n_chunks == 1:
             s, c = outs[0]

@@ -351,7 +351,8 @@ class GraphedDForward:
         geom = aug is not None and _has_geometric(aug)
         H, W = x.shape[2:]
         return ops.DiscGraph(tuple(x.shape), x.device, [l.weight for l in d.blocks], d.conv_out.weight, d.conv_out.bias,
-                             f12=aug.Hz_geom if geom else None, margins=aug.static_margins(H, W) if geom else None), geom
+                             f12=aug.Hz_geom if geom else None, margins=aug.static_margins(H, W) if geom else None,
+                             launch="eager" if len(d.blocks) == 5 else None), geom   # (the 128 x 128 plan: launch by launch only)
 
     def capture(self, x):
         import numpy as np

@@ -14,6 +14,7 @@ _lock = threading.Lock()
 _lib = None
 
 OI_PREC_F32, OI_PREC_BF16X3, OI_PREC_BF16, OI_PREC_BF16X6, OI_PREC_F16X3 = 0, 1, 2, 3, 4
+OI_MLP_BLOB_READY = 1
 PRECISIONS = {"f32": OI_PREC_F32, "fp32": OI_PREC_F32, "bf16x3": OI_PREC_BF16X3, "bf16": OI_PREC_BF16,
               "bf16x6": OI_PREC_BF16X6, "f16x3": OI_PREC_F16X3}
 
@@ -41,7 +42,8 @@ class PrepParams(ctypes.Structure):
                 [(n, _i) for n in ("B", "R", "S", "NL")] +
                 [(n, _vp) for n in ("kinv", "light_direction", "jitter", "style_w", "style_b", "z", "gw", "gb", "bw", "bb",
                                     "pose_out", "rays_o", "rays_d", "near_", "far_", "light_dir", "z_coarse", "pts_coarse",
-                                    "w_out", "gamma", "beta")])
+                                    "w_out", "gamma", "beta")] +
+                [("jitter_normal", _i), ("f3_packed", _vp), ("f3_blob", _vp)])
 
 
 class CompositeGrads(ctypes.Structure):
@@ -63,6 +65,9 @@ _SIGS = {
     "oi_mlp_scratch_bytes": (_sz, [_i, _ll]),
     "oi_mlp_scratch_bytes_prec": (_sz, [_i, _ll, _i]),
     "oi_sdf_mlp_fwd": (_i, [_vp] * 9 + [_i, _ll, _i, _i, _vp]),
+    "oi_sdf_mlp_fwd_ex": (_i, [_vp] * 9 + [_i, _ll, _i, _i, _i, _vp]),
+    "oi_mlp_f3_blob_offset": (_sz, [_i, _ll]),
+    "oi_mlp_f3_blob_bytes": (_sz, []),
     "oi_selftest_sincos": (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
     "oi_selftest_q24": (_i, [_vp, _vp, _ll, _i, _vp]),
     "oi_selftest_cu_slots": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -109,6 +114,9 @@ _SIGS = {
     "oi_disc_fwd_large": (_i, [_vp] * 5 + [_sz, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "oi_disc_graph_create": (_i, [_vp, _i, _vp] + [_i] * 4 + [_vp] * 9 + [_i] * 6 + [_f]),
     "oi_disc_graph_launch": (_i, [_vp, _vp, _vp, _vp]),
+    "oi_disc_fwd_small128_workspace_floats": (_sz, [_i] * 6),
+    "oi_disc_fwd_small128": (_i, [_vp] * 4 + [_i] * 4 + [_vp] * 10 + [_i] * 4 + [_f, _vp]),
+    "oi_disc_graph_create128": (_i, [_vp, _i, _vp] + [_i] * 4 + [_vp] * 10 + [_i] * 4 + [_f]),
     "oi_disc_graph_launch_eager": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "oi_ada_theta_xint_scale": (_i, [ctypes.c_ulonglong] + [_i] * 7 + [_f] * 4 + [_vp, _vp]),
     "oi_disc_graph_launch_ada": (_i, [_vp, _vp, ctypes.c_ulonglong, _f, _f, _f, _f, _vp, _i, _vp]),

@@ -174,7 +174,8 @@ def film_params(style_w, style_b, gw, gb, bw, bb, z=None, w=None):
     return w_out, gamma, beta
 
 
-def prep_render(b2w, w2b, c2b, offs, bg, kinv, R, S, jitter, light_direction, film_P, z):
+def prep_render(b2w, w2b, c2b, offs, bg, kinv, R, S, jitter, light_direction, film_P, z, jitter_normal=False, f3_packed=None,
+                f3_blob=None):
     """ONE launch for everything a render needs before its first MLP pass (oi_prep_render): the pose block (numpy, host) goes
     BY VALUE in the kernel arguments; rays, near / far, light direction, coarse samples + points and the style MLP + FiLM
     parameters come back.  -> dict(pose (53 B: b2w | w2b | c2b | offs | bg blocks), rays_o, rays_d, near, far, light_dir, z_coarse, pts_coarse, w, gamma, beta)."""
@@ -200,6 +201,9 @@ def prep_render(b2w, w2b, c2b, offs, bg, kinv, R, S, jitter, light_direction, fi
     P.pose_out, P.rays_o, P.rays_d, P.near_, P.far_ = (_p(out[k]) for k in ("pose", "rays_o", "rays_d", "near", "far"))
     P.light_dir, P.z_coarse, P.pts_coarse = _p(out["light_dir"]), _p(out["z_coarse"]), _p(out["pts_coarse"])
     P.w_out, P.gamma, P.beta = _p(out["w"]), _p(out["gamma"]), _p(out["beta"])
+    P.jitter_normal = int(bool(jitter_normal))
+    if f3_blob is not None:   # the f16x3 kernel's per-element blobs, formed by the FiLM workgroups (oi_sdf_mlp_fwd_ex / OI_MLP_BLOB_READY)
+        P.f3_packed, P.f3_blob = _p(f3_packed), _p(f3_blob)
     _l.check(L.oi_prep_render(ctypes.byref(P), _stream()), "oi_prep_render")
     return out
 
@@ -255,8 +259,10 @@ def mlp_scratch_bytes(B, n_per_elem, prec=None):
 
 
 def sdf_mlp_fwd(pts, packed, gamma, beta, B, prec, fast_trig=False, want_grad=False, want_rgb=False,
-                want_feat=False, scratch=None):
-    """pts (B*n, 3) -> sdf (B*n,), grad (B*n,3)|None, rgb (B*n,3)|None, feat (B*n,128)|None, scratch."""
+                want_feat=False, scratch=None, blob_ready=False):
+    """pts (B*n, 3) -> sdf (B*n,), grad (B*n,3)|None, rgb (B*n,3)|None, feat (B*n,128)|None, scratch.
+    blob_ready: `scratch` (from f3_scratch_for) already holds the per-element blobs of the f16x3 kernel, written by
+    prep_render for these gamma / beta (oi_sdf_mlp_fwd_ex, OI_MLP_BLOB_READY)."""
     L = _l.load()
     pts = _c(pts)
     n_tot = pts.shape[0]
@@ -269,10 +275,24 @@ def sdf_mlp_fwd(pts, packed, gamma, beta, B, prec, fast_trig=False, want_grad=Fa
     if want_grad and scratch is None:
         scratch = torch.empty(L.oi_mlp_scratch_bytes_prec(B, n, prec), dtype=torch.uint8, device=pts.device)
     assert not want_rgb or want_grad
+    if blob_ready:
+        assert want_grad and prec == _l.OI_PREC_F16X3 and scratch.numel() >= L.oi_mlp_scratch_bytes_prec(B, n, prec)
+        _l.check(L.oi_sdf_mlp_fwd_ex(_p(pts), _p(packed), _p(gamma), _p(beta), _p(sdf), _p(grad), _p(rgb), _p(feat), _p(scratch), B, n,
+                                     prec, int(bool(fast_trig)), _l.OI_MLP_BLOB_READY, _stream()), "oi_sdf_mlp_fwd_ex")
+        return sdf, grad, rgb, feat, scratch
     _l.check(L.oi_sdf_mlp_fwd(_p(pts), _p(packed), _p(gamma), _p(beta), _p(sdf), _p(grad), _p(rgb), _p(feat),
                               _p(scratch) if want_grad else None, B, n, prec, int(bool(fast_trig)), _stream()),
              "oi_sdf_mlp_fwd")
     return sdf, grad, rgb, feat, scratch
+
+
+def f3_scratch_for(B, n, device):
+    """(scratch, blob view) of the f16x3 gradient pass over n points per element: the blob view is where oi_prep_render writes the
+    per-element blobs (its f3_blob field) that OI_MLP_BLOB_READY then promises."""
+    L = _l.load()
+    scratch = torch.empty(L.oi_mlp_scratch_bytes_prec(B, n, _l.OI_PREC_F16X3), dtype=torch.uint8, device=device)
+    off = L.oi_mlp_f3_blob_offset(B, n)
+    return scratch, scratch[off:off + B * L.oi_mlp_f3_blob_bytes()]
 
 
 def bwd_scratch_cap_bytes():
@@ -775,7 +795,8 @@ def disc_fwd_small(x, weights, whead, bhead, f12=None, theta_np=None, theta_dev=
     x = _c(x)
     B, C, H, W = x.shape
     mx0, my0, mx1, my1 = (int(v) for v in margins)
-    n = L.oi_disc_fwd_small_workspace_floats(B, C, mx0, mx1, my0, my1)
+    big = len(weights) == 5   # the shipped 128 x 128 / five-block network (oi_disc_fwd_small128)
+    n = (L.oi_disc_fwd_small128_workspace_floats if big else L.oi_disc_fwd_small_workspace_floats)(B, C, mx0, mx1, my0, my1)
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
     key = (x.device, _stream().value or 0)
     ticket = _DISC_TICKETS.get(key)
@@ -794,6 +815,12 @@ def disc_fwd_small(x, weights, whead, bhead, f12=None, theta_np=None, theta_dev=
         assert th_arr.size == 6 * B                                             # values into the kernel arguments
         th_host = th_arr.ctypes.data_as(ctypes.c_void_p)
     ws_ = [_c(w) for w in weights]
+    if big:
+        assert (H, W) == (128, 128)
+        _l.check(L.oi_disc_fwd_small128(_p(x), th_host, _p(_c(theta_dev)), _p(_c(f12)) if f12 is not None else _p(x), mx0, mx1, my0, my1,
+                                        *[_p(w) for w in ws_], _p(_c(whead)), _p(_c(bhead)), _p(ws), _vp(ticket.data_ptr()), _p(logits),
+                                        B, C, int(ws_[4].shape[0]), int(out_dim), float(slope), _stream()), "oi_disc_fwd_small128")
+        return logits
     _l.check(L.oi_disc_fwd_small(_p(x), th_host, _p(_c(theta_dev)), _p(_c(f12)) if f12 is not None else _p(x), mx0, mx1, my0, my1,
                                  *[_p(w) for w in ws_], _p(_c(whead)), _p(_c(bhead)), _p(ws), _vp(ticket.data_ptr()), _p(logits),
                                  B, C, H, W, int(ws_[3].shape[0]), int(out_dim), float(slope), _stream()), "oi_disc_fwd_small")
@@ -868,13 +895,24 @@ class DiscGraph:
         assert launch in ("eager", "graph"), launch
         self.eager = launch == "eager"
         mx0, my0, mx1, my1 = (int(v) for v in margins) if self.aug else (0, 0, 0, 0)
-        n = L.oi_disc_fwd_small_workspace_floats(B, C, mx0, mx1, my0, my1)
+        self.big = len(weights) == 5   # the shipped 128 x 128 / five-block network: launch by launch only (oi_disc_graph_create128)
+        if self.big and launch != "eager":
+            raise _l.OiHipError("ops.DiscGraph: the 128 x 128 plan is launched launch by launch (launch='eager')")
+        n = (L.oi_disc_fwd_small128_workspace_floats if self.big else L.oi_disc_fwd_small_workspace_floats)(B, C, mx0, mx1, my0, my1)
         self.ws = torch.empty(n, dtype=torch.float32, device=device)
         self.ticket = torch.zeros(4097, dtype=torch.int32, device=device)   # OI_TICKET_WORDS, this graph's own
         self.logits = torch.empty(B, whead.shape[0], dtype=torch.float32, device=device)
         # (the graph holds raw pointers: keep the tensors it was built from alive)
+        nb = len(weights)
         self.keep = [_c(w) for w in weights] + [_c(whead), _c(bhead), _c(f12) if f12 is not None else None]
         self.handle = ctypes.c_void_p()
+        if self.big:
+            assert (H, W) == (128, 128)
+            _l.check(L.oi_disc_graph_create128(ctypes.byref(self.handle), int(self.aug), _p(self.keep[nb + 2]), mx0, mx1, my0, my1,
+                                               *[_p(w) for w in self.keep[:5]], _p(self.keep[5]), _p(self.keep[6]), _p(self.ws),
+                                               _vp(self.ticket.data_ptr()), _p(self.logits), B, C, int(self.keep[4].shape[0]),
+                                               int(whead.shape[0]), float(slope)), "oi_disc_graph_create128")
+            return
         _l.check(L.oi_disc_graph_create(ctypes.byref(self.handle), int(self.aug), _p(self.keep[6]), mx0, mx1, my0, my1,
                                         *[_p(w) for w in self.keep[:4]], _p(self.keep[4]), _p(self.keep[5]), _p(self.ws),
                                         _vp(self.ticket.data_ptr()), _p(self.logits), B, C, H, W, int(self.keep[3].shape[0]),

@@ -61,8 +61,10 @@ class NeuSRenderer:
         return (z, mid) if with_mid else z
 
     def render_full(self, rays_o, rays_d, near, far, perturb_overwrite=-1, cos_anneal_ratio=0.0, z=None, w=None,
-                    light=None, light_dir=None, bg=None, outputs=None, film=None, image_planar=False, coarse=None):
-        """Shared implementation: returns (per-sample/per-ray dict, composite dict)."""
+                    light=None, light_dir=None, bg=None, outputs=None, film=None, image_planar=False, coarse=None,
+                    f3_scratch=None):
+        """Shared implementation: returns (per-sample/per-ray dict, composite dict).  f3_scratch: the fine pass's working memory
+        with the f16x3 kernel's per-element blobs already in it (ops.f3_scratch_for; written by the caller's prep launch)."""
         from .autograd import composite
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
         N = rays_o.shape[0]
@@ -83,7 +85,8 @@ class NeuSRenderer:
         else:  # no importance samples: the coarse list itself
             with torch.no_grad():
                 dists, mid_z, pts = ops.midpoints(rays_o, rays_d, zv, 2.0 / self.n_samples)
-        sdf, grad, rgb, _ = sdf_mlp(self.pack, pts.view(-1, 3), gamma, beta, B, True, True, False)
+        sdf, grad, rgb, _ = sdf_mlp(self.pack, pts.view(-1, 3), gamma, beta, B, True, True, False, scratch=f3_scratch,
+                                    blob_ready=f3_scratch is not None)
         dev = rays_o.device
         if light is None:
             light = torch.tensor([0.0, 0.0, 1.0], device=dev)

@@ -266,6 +266,9 @@ def test_generator_fused_prep_launch_matches_the_separate_launches(monkeypatch, 
     gen = build_generator(16, 16, 16, 1, "f16x3")
     gen = gen.train() if train else gen.eval()
 
+    monkeypatch.setattr(G, "ONE_DRAW", False)   # (the two generator calls of the separate chain; the one-launch draw of round 6 has
+    #                                              its own test: test_step_tail_blob_in_prep_bit_identical_and_one_draw_jitter)
+
     def run(fused):
         monkeypatch.setattr(G, "PREP_MAX_B", 8 if fused else 0)
         np.random.seed(5)
@@ -1068,3 +1071,64 @@ def test_ada_discriminator_eager_forward_draws_in_the_library(B, in_dim, out_dim
         d = D(x).clone()
         th_p = D.aug.theta_for(orig(x, 0.7), m, H, W)
         assert torch.equal(d, D._forward_small(x, f12=D.aug.Hz_geom, theta_np=th_p, margins=m))
+
+
+def test_step_tail_blob_in_prep_bit_identical_and_one_draw_jitter():
+    """Round 6, the no-grad fused forward (generator._prep_fused): (a) the per-element blobs of the f16x3 MLP kernel formed by the
+    prep launch's FiLM workgroups (oi_prep_render f3_blob + oi_sdf_mlp_fwd_ex OI_MLP_BLOB_READY) against the call's own blob
+    launch: every map of a seeded forward bit-identical, in eval and in training mode (two-call draws); (b) one generator launch
+    for latents + jitter: the prep kernel's normal -> uniform map equals the normal CDF evaluated by torch (same coarse samples to
+    two ulp of z), the jitter it implies is uniform on [0, 1) (mean / variance over 8,192 rays), and a forward drawn
+    that way renders the same distribution of maps (finite, silhouette fraction within 2 % of the two-call forward's)."""
+    import oi_amd.generator as GM
+    from oi_amd import ops
+    gen = build_generator(32, 16, 16, 1, "f16x3")
+    keys = ("image", "mask", "shading_map", "color_map", "weight_sum_map")
+
+    def forward(train, blob_in_prep, one_draw, seed=11):
+        gen.train(train)
+        GM.F3_BLOB_IN_PREP, GM.ONE_DRAW = blob_in_prep, one_draw
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        try:
+            with torch.no_grad():
+                out = gen(bs=2, it=0, data={})["box"]
+        finally:
+            GM.F3_BLOB_IN_PREP, GM.ONE_DRAW = True, True
+        return {k: out["render_out"][k].clone() for k in keys}, out["loss"]["eikonal"].clone()
+
+    for train in (False, True):
+        a, ea = forward(train, True, False)
+        b, eb = forward(train, False, False)
+        for k in keys:
+            assert torch.equal(a[k], b[k]), (train, k, maxdiff(a[k], b[k]))
+        assert torch.equal(ea, eb)
+    # (b) the kernel's map of a normal draw to the jitter
+    B, R, S = 2, 64, 16
+    N = B * R * R
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(N, device="cuda", generator=g)
+    u = (0.5 * torch.erfc(-x.double() * 0.5 ** 0.5)).clamp(max=0.99999994).float()
+    pose = gen.pose_prior(B).astype(np.float32)
+    cam = gen._camera_host()
+    w2b = np.linalg.inv(pose).astype(np.float32)
+    c2b = (w2b @ cam["c2w"]).astype(np.float32)
+    xy = gen._crop_offsets_host(pose, cam)
+    kw = dict(b2w=pose, w2b=w2b, c2b=c2b, offs=xy, bg=np.zeros((B, 3), np.float32), kinv=gen._kinv(x.device), R=R, S=S,
+              light_direction=gen.light.param_direction, film_P=gen.renderer.pack.film_stacked(differentiable=False),
+              z=torch.randn(B, 64, device="cuda", generator=g))
+    with torch.no_grad():
+        p_n = ops.prep_render(jitter=x, jitter_normal=True, **kw)
+        p_u = ops.prep_render(jitter=u, jitter_normal=False, **kw)
+        p_0 = ops.prep_render(jitter=None, **kw)
+    sec = 2.0 / S
+    assert maxdiff(p_n["z_coarse"], p_u["z_coarse"]) < 2e-6   # (z is ~11: one ulp is 9.5e-7; the two uniforms differ by an ulp of theirs)
+    jit = ((p_n["z_coarse"] - p_0["z_coarse"])[:, 0].double() / sec + 0.5).cpu().numpy()    # the uniform the kernel used
+    assert jit.min() >= -1e-4 and jit.max() <= 1 + 1e-4
+    assert abs(jit.mean() - 0.5) < 5 * (1 / 12 / N) ** 0.5 and abs(jit.var() - 1 / 12) < 5 * (1 / 180 / N) ** 0.5
+    # a forward drawn with one launch: same kind of picture
+    c, _ = forward(True, True, True)
+    d, _ = forward(True, True, False)
+    for k in keys:
+        assert bool(torch.isfinite(c[k]).all())
+    assert abs(float((c["mask"] > 0.5).float().mean()) - float((d["mask"] > 0.5).float().mean())) < 0.02
