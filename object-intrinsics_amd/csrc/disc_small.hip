@@ -465,27 +465,29 @@ d_conv_small_kernel(const float* __restrict__ x, const float* __restrict__ w, fl
 // (configs/train.yaml:78-102: img_size 128 = five blocks 3 | 1 -> 32 -> 64 -> 128 -> 256 -> 512; the last three are the 64 x 64
 // network's conv 2..4 + head, the first rides on d_aug_conv1_kernel with C1 = 32.)  With 32 input channels the "input channel on
 // the lane" form of d_conv_small_kernel has half a wave of work per task; this layer is 33.5 M MACs per image over 128 KB of
-// weights -- arithmetic, not a weight stream: one workgroup per (output row, half of the output channels), the four input rows
-// under the output row and the 32 channels' weights staged in LDS once, a thread = one output channel x four consecutive
-// output pixels, 2048 FMAs per thread in a fixed (c_in, ky, kx) order.
+// weights -- arithmetic, not a weight stream: one workgroup per (output row, quarter of the output channels), the four input rows
+// under the output row and the 16 channels' weights staged in LDS once, a thread = one output channel x two consecutive
+// output pixels, 1024 FMAs per thread in a fixed (c_in, ky, kx) order.  (Halves of the channels x four pixels per thread: 18.4 us;
+// this form: see DESIGN.)
 //   x A[B][64][16][32][4] -> y A[B][32][8][64][4] = lrelu(conv4x4 s2 p1 (x, w)), w [64][32][4][4]
 constexpr int DC32_ROW = 72;          // staged input row of one channel: x = -4 .. 67 (zero outside the image)
-constexpr int DC32_WST = 512 + 4;     // weights of one output channel (+ 4: the eight channels of a wave in distinct 16-byte slots)
-constexpr int DC32_LDS = (4 * 32 * DC32_ROW + 32 * DC32_WST) * 4;   // 102,912 bytes
+constexpr int DC32_WST = 512 + 4;     // weights of one output channel (+ 4: the four channels of a wave in distinct 16-byte slots)
+constexpr int DC32_CO = 16;           // output channels per workgroup: 32 rows x 4 quarters = 128 workgroups per image
+constexpr int DC32_LDS = (4 * 32 * DC32_ROW + DC32_CO * DC32_WST) * 4;   // 69,888 bytes
 __global__ void __launch_bounds__(256) d_conv_c32_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
                                                          float slope) {
   extern __shared__ __attribute__((aligned(16))) float dc32_lds[];
   float* in_l = dc32_lds;                       // [ky 4][c_in 32][DC32_ROW]
-  float* w_l = dc32_lds + 4 * 32 * DC32_ROW;    // [c_out 32][DC32_WST]
-  const int tid = threadIdx.x, oy = blockIdx.x, half = blockIdx.y, b = blockIdx.z;
-  // weights of this half's 32 output channels: 32 x 512 floats, float4 per thread and step
-  for (int i = tid; i < 32 * 128; i += 256) {
+  float* w_l = dc32_lds + 4 * 32 * DC32_ROW;    // [c_out 16][DC32_WST]
+  const int tid = threadIdx.x, oy = blockIdx.x, quarter = blockIdx.y, b = blockIdx.z;
+  // weights of this quarter's 16 output channels: 16 x 512 floats, float4 per thread and step
+  for (int i = tid; i < DC32_CO * 128; i += 256) {
     const int co = i >> 7, q = i & 127;
-    *reinterpret_cast<float4*>(w_l + co * DC32_WST + 4 * q) = *reinterpret_cast<const float4*>(w + ((size_t)(half * 32 + co) * 512 + 4 * q));
+    *reinterpret_cast<float4*>(w_l + co * DC32_WST + 4 * q) = *reinterpret_cast<const float4*>(w + ((size_t)(quarter * DC32_CO + co) * 512 + 4 * q));
   }
   // input rows 2 oy - 1 .. 2 oy + 2: [row][xq 16][c 32][4] in memory -> [row][c][4 + 4 xq ..] in LDS; halo columns zero
-  for (int i = tid; i < 4 * 32 * 2; i += 256) {   // the two halo quads of every (row, channel)
-    const int r = i >> 6, c = (i >> 1) & 31, side = i & 1;
+  {
+    const int r = tid >> 6, c = (tid >> 1) & 31, side = tid & 1;   // the two halo quads of every (row, channel): 256 of them
     *reinterpret_cast<float4*>(in_l + (r * 32 + c) * DC32_ROW + (side ? 68 : 0)) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int i = tid; i < 4 * 16 * 32; i += 256) {
@@ -496,20 +498,21 @@ __global__ void __launch_bounds__(256) d_conv_c32_kernel(const float* __restrict
     *reinterpret_cast<float4*>(in_l + (r * 32 + c) * DC32_ROW + 4 + 4 * xq) = v;
   }
   __syncthreads();
-  const int co = tid >> 3, xq = tid & 7;   // output pixels ox = 4 xq + j: input x = 8 xq + 2 j - 1 + kx  ->  staged index 8 xq + 2 j + 3 + kx
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // thread = output channel co x output pixels ox = 2 xh, 2 xh + 1: input x = 4 xh + 2 j - 1 + kx  ->  staged index 4 xh + 2 j + 3 + kx
+  const int co = tid >> 4, xh = tid & 15;
+  float acc[2] = {0.f, 0.f};
   const float* wp = w_l + co * DC32_WST;
-  const float* ip = in_l + 8 * xq;
+  const float* ip = in_l + 4 * xh;
   for (int c = 0; c < 32; ++c) {
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
       const float4 wv = *reinterpret_cast<const float4*>(wp + c * 16 + ky * 4);
       const float* row = ip + (ky * 32 + c) * DC32_ROW;
       const float4 a0 = *reinterpret_cast<const float4*>(row), a1 = *reinterpret_cast<const float4*>(row + 4);
-      const float4 a2 = *reinterpret_cast<const float4*>(row + 8), a3 = *reinterpret_cast<const float4*>(row + 12);
-      const float v[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+      const float4 a2 = *reinterpret_cast<const float4*>(row + 8);
+      const float v[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 2; ++j) {
         acc[j] = fmaf(wv.x, v[2 * j + 3], acc[j]);
         acc[j] = fmaf(wv.y, v[2 * j + 4], acc[j]);
         acc[j] = fmaf(wv.z, v[2 * j + 5], acc[j]);
@@ -517,12 +520,11 @@ __global__ void __launch_bounds__(256) d_conv_c32_kernel(const float* __restrict
       }
     }
   }
-  float4 o;
+  float2 o;
   o.x = acc[0] > 0.f ? acc[0] : acc[0] * slope;
   o.y = acc[1] > 0.f ? acc[1] : acc[1] * slope;
-  o.z = acc[2] > 0.f ? acc[2] : acc[2] * slope;
-  o.w = acc[3] > 0.f ? acc[3] : acc[3] * slope;
-  *reinterpret_cast<float4*>(y + ((((size_t)b * 32 + oy) * 8 + xq) * 64 + half * 32 + co) * 4) = o;
+  // y A[b][oy][ox / 4][channel][ox % 4]: ox = 2 xh + j
+  *reinterpret_cast<float2*>(y + ((((size_t)b * 32 + oy) * 8 + (xh >> 1)) * 64 + quarter * DC32_CO + co) * 4 + 2 * (xh & 1)) = o;
 }
 
 }  // namespace
@@ -606,7 +608,7 @@ static int disc_fwd_small_impl(const float* x, const float* theta_host, const fl
   if (rc != OI_OK) return rc;
   if (R == 128) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(d_conv_c32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DC32_LDS);
-    hipLaunchKernelGGL(d_conv_c32_kernel, dim3(32, 2, B), dim3(256), DC32_LDS, st, a0, w1, a1, slope);
+    hipLaunchKernelGGL(d_conv_c32_kernel, dim3(32, 64 / DC32_CO, B), dim3(256), DC32_LDS, st, a0, w1, a1, slope);
     rc = oi::check_launch("oi_disc_fwd_small(conv 32 -> 64)");
     if (rc != OI_OK) return rc;
   }

@@ -19,7 +19,8 @@ LARGE_PATH = True   # batch >= 16 no-grad forwards take csrc/disc_large.hip when
 LARGE_MIN_BATCH = 16
 FAST_ADA = True     # ADADiscriminator.forward, shipped augmentation, batch <= 4: parameters drawn inside the library (False: numpy)
 SMALL_PATH = True   # batch <= 4 no-grad forwards of the 64 x 64 network take csrc/disc_small.hip (False: the general chain)
-SMALL_PATH_128 = True   # ... and of the shipped 128 x 128 / five-block network (round 6)
+import os
+SMALL_PATH_128 = os.environ.get("OI_SMALL128", "1") != "0"   # ... and of the shipped 128 x 128 / five-block network (round 6)
 
 
 class _ConvParam(nn.Module):

@@ -1132,3 +1132,49 @@ def test_step_tail_blob_in_prep_bit_identical_and_one_draw_jitter():
     for k in keys:
         assert bool(torch.isfinite(c[k]).all())
     assert abs(float((c["mask"] > 0.5).float().mean()) - float((d["mask"] > 0.5).float().mean())) < 0.02
+
+
+@pytest.mark.parametrize("tag,B", [("v_", 1), ("v_", 2), ("m_", 1), ("m_", 2)])
+def test_shipped_128_discriminators_small_batch_forward_f14(tag, B, monkeypatch):
+    """Round 6: the batch <= 4 no-grad forward of csrc/disc_small.hip covers the SHIPPED discriminators (configs/train.yaml:78-102:
+    128 x 128, 3 | 1 -> 32 -> 64 -> 128 -> 256 -> 512 -> 7 | 1): oi_disc_fwd_small128 / oi_disc_graph_create128 -- the augmentation
+    kernel with 32 output channels, d_conv_c32_kernel for the 32 -> 64 block, then the 64 x 64 network's conv 2..4 + head.
+    (a) the reference's own logits (F14, ADA at the fixture's pinned percentile) at 2e-5; (b) the general chain it replaces at
+    2e-5, and really another path; (c) bit-reproducible; (d) the library-drawn augmentation (ADADiscriminator.forward's one-call
+    route) equals the explicit route for the same seed, bit for bit, and follows an in-place weight update."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oi_amd.discriminator as DM
+    from test_gpu_backward import _f14_net
+    g = load_golden("f14_discriminator_128")
+    D, wsd, pct = _f14_net(g, tag, B)
+    del D.aug.forward                        # (_f14_net pins the percentile through `forward`: here through sample_G_inv,
+    orig = D.aug.sample_G_inv                #  which keeps ADADiscriminator.forward on its small-batch branch)
+    D.aug.sample_G_inv = lambda im, _pct=None: orig(im, pct)
+    D = D.eval()
+    t = f"{tag}b{B}_"
+    x = g[t + "x"].cuda()
+    with torch.no_grad():
+        assert D._small_ok(x)
+        d = D(x).clone()
+        assert len(DM._SMALL_PLANS.get(D, {})) == 1 and next(iter(DM._SMALL_PLANS[D].values())).big
+        assert maxdiff(d.cpu(), g[t + "d"]) < 2e-5 * max(1.0, float(g[t + "d"].abs().max())), maxdiff(d.cpu(), g[t + "d"])
+        assert torch.equal(d, D(x))
+        monkeypatch.setattr(DM, "SMALL_PATH_128", False)
+        general = D(x).clone()
+        monkeypatch.setattr(DM, "SMALL_PATH_128", True)
+        assert maxdiff(d, general) < 2e-5 * max(1.0, float(general.abs().max())) and not torch.equal(d, general)
+        # (d) the one-call route with the draws made inside the library
+        del D.aug.sample_G_inv
+        H = W = 128
+        m = D.aug.static_margins(H, W)
+        np.random.seed(31)
+        a = D(x).clone()
+        assert DM._FAST_ADA.get(D) is not None
+        np.random.seed(31)
+        th = D.aug.theta_fast(B, H, W)
+        assert torch.equal(a, D._forward_small(x, f12=D.aug.Hz_geom, theta_np=th, margins=m))
+        D.blocks[1].weight.mul_(0.5)
+        np.random.seed(32); b = D(x).clone()
+        np.random.seed(32); th = D.aug.theta_fast(B, H, W)
+        assert torch.equal(b, D._forward_small(x, f12=D.aug.Hz_geom, theta_np=th, margins=m)) and maxdiff(a, b) > 1e-4
