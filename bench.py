@@ -602,6 +602,26 @@ def extras(args, gen, device):
                                                       "executed_mfma_frac_of_peak": 3 * bsz * d_flops / ms / 1e9 / 2500.0},
                                          "weight_read_hbm": {"achieved_GB_per_s": d_wbytes / ms / 1e6, "peak": 8000.0,
                                                              "frac": d_wbytes / ms / 1e6 / 8000.0}}}
+    # the shipped network (configs/train.yaml:78-102: 128^2, five blocks 3 -> 32 -> ... -> 512 -> 7) at batch 1: csrc/disc_small.hip since
+    # round 6 (oi_disc_fwd_small128), against the general layer-by-layer chain it took until then
+    import oi_amd.discriminator as _DM
+    disc128 = build_from_config(net("src.models.discriminator.ADADiscriminatorView",
+                                    aug=net("src.third_party.ada.augment.AugmentPipe", scale=1, xint=1), aug_p=1, img_size=128,
+                                    in_dim=3, last_bias=False, n_feat=512, out_dim=7, out_dim_latent=0, out_dim_position=6)).to(device).eval()
+    x128 = torch.rand(1, 3, 128, 128, device=device)
+    with torch.no_grad():
+        ms128 = _ev_time(lambda: disc128(x128, it=0), 30)
+        _DM.SMALL_PATH_128 = False
+        _DM._FAST_ADA.pop(disc128, None)
+        try:
+            ms128_general = _ev_time(lambda: disc128(x128, it=0), 30)
+        finally:
+            _DM.SMALL_PATH_128 = True
+    sweep["B1_128"] = {"ms": ms128, "images_per_s": 1e3 / ms128, "general_chain_ms": ms128_general,
+                       "what": "the SHIPPED 128^2 / five-block network at batch 1 (281.1 MFLOP per image): five launches of csrc/disc_small.hip; "
+                               "general_chain_ms = the same forward through the layer-by-layer chain of csrc/disc.hip",
+                       "roofline": {"mfma_fp32": {"achieved_TFLOP_per_s": 281.1e6 / ms128 / 1e9, "peak": 157.3, "frac": 281.1e6 / ms128 / 1e9 / 157.3}}}
+    del disc128, x128
     out["discriminator"] = {"what": "ADADiscriminatorView forward (ADA xint + scale, 5 conv4x4 s2 + head), 64^2; batch <= 4: csrc/disc_small.hip "
                                     "(four launches, fp32 VALU, weight-stream bound); batch >= 16: csrc/disc_large.hip (NHWC fp16 limb planes, "
                                     "packed weight images, f16x3 = 22-bit operands / fp32 accumulate on the matrix cores, fixed-order "

@@ -67,7 +67,7 @@ def describe(tag):
             s += f"; shipped configuration {e['training_shipped_config']['it_per_s']:.1f} it/s"
         if e.get("inference"):
             s += f"; inference {e['inference']['s_per_frame'] * 1e3:.2f} ms per frame"
-        for k in ("B1", "B4", "B64"):
+        for k in ("B1", "B4", "B64", "B1_128"):
             if (e.get("discriminator") or {}).get(k):
                 s += f"; D {k} {e['discriminator'][k]['ms'] * 1e3:.1f} us"
         c = d.get("cpu_baseline") or {}

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Runs ON the GPU box (gpurun): regenerates every file profiles/ holds for the default (f16x3) mode into gpurun_out/.
 #   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'
-# then copy gpurun_out/r5_* into profiles/.  Counter passes are separate runs (--pmc never combined with other traces).
+# then copy gpurun_out/r6_* into profiles/ and run tools/profiles_index.py r6 --write.  Counter passes are separate runs (--pmc never combined with other traces).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
-T=${OI_PROFILE_TAG:-r5}
+T=${OI_PROFILE_TAG:-r6}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # every profiled run under its own timeout: one hung step (seen once: the one-rank process-group run never returned) must not
