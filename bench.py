@@ -673,7 +673,7 @@ def csrc_digest():
     return mod._digest()
 
 
-TRAFFIC_FILE = "r5_traffic.json"
+TRAFFIC_FILE = "r*_traffic.json"   # the newest round's file whose digest matches the built sources
 
 
 def measured_traffic(args, precision=None):
@@ -681,17 +681,25 @@ def measured_traffic(args, precision=None):
     written by tools/traffic_json.py: FETCH_SIZE x2 -- the gfx950 correction of MI355X_MICROARCH.md -- + WRITE_SIZE).
     Counters cannot be collected from inside the timed process, so the figure is tied to the kernel sources by digest:
     a build whose csrc/ differs from the profiled one reports traffic = null instead of a stale number."""
-    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-    if not os.path.exists(path):
+    import glob
+    import re
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", TRAFFIC_FILE)),
+                   key=lambda p_: int(re.search(r"r(\d+)_traffic", p_).group(1)), reverse=True)
+    if not paths:
         return None, f"profiles/{TRAFFIC_FILE} missing"
-    rec = json.load(open(path))
     key = f"{precision or args.precision}:{args.batch}x{args.res}x{args.res}:{args.samples}+{args.importance}"
-    ent = rec.get("entries", {}).get(key)
-    if ent is None:
-        return None, f"no PMC record for {key}"
-    if rec.get("csrc_digest") != csrc_digest():
-        return None, f"csrc/ changed since the PMC passes of profiles/{TRAFFIC_FILE} were taken (re-run tools/refresh_profiles.sh)"
-    return float(ent["bytes_per_launch"]), ent["source"]
+    dig, why = csrc_digest(), None
+    for path in paths:   # newest round first
+        rec = json.load(open(path))
+        ent = rec.get("entries", {}).get(key)
+        name = os.path.basename(path)
+        if ent is None:
+            why = why or f"no PMC record for {key} in profiles/{name}"
+        elif rec.get("csrc_digest") != dig:
+            why = why or f"csrc/ changed since the PMC passes of profiles/{name} were taken (re-run tools/refresh_profiles.sh)"
+        else:
+            return float(ent["bytes_per_launch"]), ent["source"]
+    return None, why
 
 
 def build_line(args, value, dt, world, timer, d_img_s, train, distributed, bf16_mode=None, spread=None):
