@@ -751,8 +751,9 @@ def test_training_trajectory_f16x3_tracks_native_fp32():
 # bf16 operand mode (BASELINE configs[1]) over the same six iterations: per logged loss, <= 3x the worst |bf16 - f32| / max(1, |f32|)
 # measured on the MI355X (profiles/r6_gradient_margins.txt, rows training_trajectory_bf16_vs_f32)
 # The worst iteration's error depends on the draws of the run: two generator draw schemes were measured in round 6 (two launches /
-# one launch for latents + jitter: worst generator/loss 2.45e-4 / 8.7e-4 over the six iterations, generator/eikonal 6.5e-4 / see
-# profiles/r6_gradient_margins.txt); the bars are 3x the larger one, rounded.
+# one launch for latents + jitter).  Worst over the six iterations: generator/loss 2.45e-4 / 7.6e-4-8.7e-4, generator/eikonal 6.5e-4 /
+# 6.5e-4, discriminator/loss 2.45e-4 / 2.1e-4, discriminator/reg 5.8e-5 / 9.4e-5, mask_discriminator/loss 1.7e-4 / 6.9e-5
+# (profiles/r6_gradient_margins.txt holds the final scheme's); the bars are ~3x the larger one, rounded.
 BF16_TRAJ_TOL = {"generator/loss": 2.6e-3, "generator/eikonal": 2.6e-3, "discriminator/loss": 2.6e-3, "discriminator/reg": 5e-4,
                  "mask_discriminator/loss": 2e-3}
 
@@ -809,10 +810,11 @@ def _generator_fit(prec, steps=200, R=16):
     return torch.stack(losses).cpu().numpy()
 
 
-# measured on the MI355X (profiles/r6_gradient_margins.txt, rows generator_fit_200_adam_steps): final / first loss 0.049 (f32),
-# 0.062 (bf16); bf16 final / f32 final 1.26; the first step's losses agree to 1.2e-5
-FIT_DROP = 0.15         # both modes: mean loss of the last 10 steps < FIT_DROP x the first step's (3 x the measured 0.05)
-FIT_BF16_VS_F32 = 1.8   # bf16's final loss within this factor of fp32's, either way (measured 1.26)
+# measured on the MI355X with both draw schemes of round 6 (profiles/r6_gradient_margins.txt, rows generator_fit_200_adam_steps, holds
+# the final one's): final / first loss 0.049 / 0.072 (f32), 0.062 / 0.058 (bf16); bf16 final / f32 final 1.26 / 0.80 -- either mode
+# ends lower depending on the draws, neither is biased; the first step's losses agree to 1.2e-5
+FIT_DROP = 0.15         # both modes: mean loss of the last 10 steps < FIT_DROP x the first step's (2-3 x the measured 0.05-0.07)
+FIT_BF16_VS_F32 = 1.8   # bf16's final loss within this factor of fp32's, either way (measured 1.26 and 1 / 1.25)
 
 
 def test_generator_fit_converges_bf16_like_fp32():
