@@ -33,6 +33,13 @@ def _rays(N, seed):
     return ro, rd, near, far
 
 
+# per-ray outputs of ALL sampled rays (flipped importance samples included): <= 3x the worst error measured on the MI355X
+# (profiles/r6_gradient_margins.txt, rows full_size_all_rays_vs_fp32_oracle)
+# measured: colour 4.2e-7 .. 6.4e-7, opacity 8.6e-7 .. 1.27e-6 over the four cases (C4: 0.8 % of the sampled rays unmatched in z,
+# and their colour still agrees to 6.3e-7 -- a flipped sample carries almost no weight)
+ALL_RAYS_TOL = {1: {"color_fine": 2e-6, "weight_sum": 4e-6}, 4: {"color_fine": 2e-6, "weight_sum": 4e-6}}
+
+
 @pytest.mark.parametrize("name,B,R,S,I,K,precision", [("C2", 1, 64, 64, 64, 1, "f16x3"), ("C2", 1, 64, 64, 64, 1, "bf16x6"), ("C2", 1, 64, 64, 64, 1, "f32"),
                                                       ("C4", 1, 128, 128, 128, 4, "f16x3")])
 def test_full_size_render_properties(sdf_sd, col_sd, name, B, R, S, I, K, precision):
@@ -72,6 +79,15 @@ def test_full_size_render_properties(sdf_sd, col_sd, name, B, R, S, I, K, precis
     # evaluations; against fp64 the sdf-only kernel is off by 1.5e-6 at most, exactly like the native-fp32 mode --
     # tools/dbg/sdf_err.py); measured 2.1e-4 on the matched rays
     assert maxdiff(out["weights"].cpu()[idx][ok], ref["weights"][ok]) < (2e-4 if K == 1 else 3e-4)
+    # ... and EVERY sampled ray, matched or not, is compared where a flipped importance sample cannot hide (review, round 5: at C4
+    # one ray in ten may be placed differently and was then not compared at all): the per-ray outputs.  A flip moves one sample of
+    # 128 / 256 to a neighbouring section; the composited colour and opacity move by what that sample weighs.
+    e_col = maxdiff(out["color_fine"].cpu()[idx], ref["color_fine"])
+    e_ws = maxdiff(out["weight_sum"].cpu()[idx], ref["weight_sum"])
+    record_margin(f"full_size_all_rays_vs_fp32_oracle[{name}-{precision}]", "color_fine", e_col)
+    record_margin(f"full_size_all_rays_vs_fp32_oracle[{name}-{precision}]", "weight_sum", e_ws)
+    record_margin(f"full_size_all_rays_vs_fp32_oracle[{name}-{precision}]", "unmatched fraction", 1.0 - float(ok.float().mean()))
+    assert e_col < ALL_RAYS_TOL[K]["color_fine"] and e_ws < ALL_RAYS_TOL[K]["weight_sum"], (e_col, e_ws)
 
 
 @pytest.mark.parametrize("name,B,R,S,I,K", [("C2", 1, 64, 64, 64, 1)])
