@@ -752,8 +752,9 @@ def test_training_trajectory_f16x3_tracks_native_fp32():
 # measured on the MI355X (profiles/r6_gradient_margins.txt, rows training_trajectory_bf16_vs_f32)
 # The worst iteration's error depends on the draws of the run: two generator draw schemes were measured in round 6 (two launches /
 # one launch for latents + jitter).  Worst over the six iterations: generator/loss 2.45e-4 / 7.6e-4-8.7e-4, generator/eikonal 6.5e-4 /
-# 6.5e-4, discriminator/loss 2.45e-4 / 2.1e-4, discriminator/reg 5.8e-5 / 9.4e-5, mask_discriminator/loss 1.7e-4 / 6.9e-5
-# (profiles/r6_gradient_margins.txt holds the final scheme's); the bars are ~3x the larger one, rounded.
+# 6.5e-4, discriminator/loss 2.45e-4 / 1.9e-4-2.3e-4, discriminator/reg 5.8e-5 / 6.9e-5-9.4e-5, mask_discriminator/loss 1.7e-4 /
+# 6.9e-5-5.6e-4 (four runs of the final scheme: the split-K sums of the eager discriminator steps are not bit-stable);
+# profiles/r6_gradient_margins.txt holds one of them.  The bars are ~3x the largest value seen, rounded.
 BF16_TRAJ_TOL = {"generator/loss": 2.6e-3, "generator/eikonal": 2.6e-3, "discriminator/loss": 2.6e-3, "discriminator/reg": 5e-4,
                  "mask_discriminator/loss": 2e-3}
 
@@ -798,7 +799,7 @@ def _generator_fit(prec, steps=200, R=16):
     # the silhouette to fit: the initial one (28 % of a 16 x 16 crop) eroded by one pixel on every side
     target = (torch.nn.functional.avg_pool2d(m0, 3, stride=1, padding=1) > 0.98).float()
     assert 0.03 < float(target.mean()) < float(m0.mean()) - 0.03, (float(target.mean()), float(m0.mean()))
-    opt = FusedAdam(gen.parameters(), lr=1e-4, betas=(0.0, 0.9))
+    opt = FusedAdam(gen.parameters(), lr=2e-5, betas=(0.0, 0.9))   # the reference's generator optimiser (configs/train.yaml:133-139)
     losses = []
     for it in range(steps):
         opt.zero_grad(set_to_none=False)
@@ -810,21 +811,25 @@ def _generator_fit(prec, steps=200, R=16):
     return torch.stack(losses).cpu().numpy()
 
 
-# measured on the MI355X with both draw schemes of round 6 (profiles/r6_gradient_margins.txt, rows generator_fit_200_adam_steps, holds
-# the final one's): final / first loss 0.049 / 0.072 (f32), 0.062 / 0.058 (bf16); bf16 final / f32 final 1.26 / 0.80 -- either mode
-# ends lower depending on the draws, neither is biased; the first step's losses agree to 1.2e-5
-FIT_DROP = 0.15         # both modes: mean loss of the last 10 steps < FIT_DROP x the first step's (2-3 x the measured 0.05-0.07)
-FIT_BF16_VS_F32 = 1.8   # bf16's final loss within this factor of fp32's, either way (measured 1.26 and 1 / 1.25)
+# measured on the MI355X (tools/dbg/fit_curves.py, three runs per mode: the MLP backward adds its weight gradients with atomics, so
+# runs differ in the last bits and Adam with beta1 = 0 amplifies that; profiles/r6_gradient_margins.txt, rows
+# generator_fit_200_adam_steps): mean loss of the last 50 steps / first loss 0.019-0.020 in BOTH modes, bf16 / fp32 0.95-1.05, the
+# 20-step block means of the two modes within 10 % of each other all the way; the first step's losses agree to 1.2e-5.
+# (With lr = 1e-4 the same optimiser oscillates -- last-50 means 0.09-0.14 run to run in either mode --, with betas = (0.9, 0.999) the
+# two modes' curves agree to four digits and fall 1000 x: the reference's own setting is the one asserted.)
+FIT_DROP = 0.06         # both modes: mean loss of the last 50 steps < FIT_DROP x the first step's (3 x the measured 0.02)
+FIT_BF16_VS_F32 = 1.25  # bf16's final loss within this factor of fp32's, either way (measured 0.95-1.05)
 
 
 def test_generator_fit_converges_bf16_like_fp32():
-    """200 Adam steps of the generator alone on a fixed silhouette + eikonal objective from sphere_init (`_generator_fit`) in
-    native fp32 and in the bf16 operand mode: both reduce the loss by the stated factor and end within the stated factor of
-    each other.  bf16's per-tensor gradient errors (1-5 %, section 5 of DESIGN.md) are unbiased enough for Adam to converge to
-    the same place; if this ever fails, bench.py's `bf16_mode.training` must stop being quoted."""
+    """200 steps of the reference's generator optimiser (Adam, lr 2e-5, betas (0, 0.9)) on the generator alone, on a fixed
+    silhouette + eikonal objective from sphere_init (`_generator_fit`), in native fp32 and in the bf16 operand mode: both reduce
+    the loss by the stated factor and end within the stated factor of each other.  bf16's per-tensor gradient errors (1-5 %,
+    section 5 of DESIGN.md) are unbiased enough for Adam to converge to the same place; if this ever fails, bench.py's
+    `bf16_mode.training` must stop being quoted."""
     a, b = _generator_fit("f32"), _generator_fit("bf16")
     assert np.isfinite(a).all() and np.isfinite(b).all()
-    fa, fb = float(a[-10:].mean()), float(b[-10:].mean())
+    fa, fb = float(a[-50:].mean()), float(b[-50:].mean())
     record_margin("generator_fit_200_adam_steps", "f32 final / first", fa / float(a[0]))
     record_margin("generator_fit_200_adam_steps", "bf16 final / first", fb / float(b[0]))
     record_margin("generator_fit_200_adam_steps", "bf16 final / f32 final", fb / fa)
