@@ -276,7 +276,9 @@ def sdf_mlp_fwd(pts, packed, gamma, beta, B, prec, fast_trig=False, want_grad=Fa
         scratch = torch.empty(L.oi_mlp_scratch_bytes_prec(B, n, prec), dtype=torch.uint8, device=pts.device)
     assert not want_rgb or want_grad
     if blob_ready:
-        assert want_grad and prec == _l.OI_PREC_F16X3 and scratch.numel() >= L.oi_mlp_scratch_bytes_prec(B, n, prec)
+        # (== : the blob's offset inside the scratch depends on the point count the scratch was sized for -- f3_scratch_for(B, n))
+        assert want_grad and prec == _l.OI_PREC_F16X3 and scratch.numel() == L.oi_mlp_scratch_bytes_prec(B, n, prec), \
+            "blob_ready: the scratch was not made by f3_scratch_for for this (B, n)"
         _l.check(L.oi_sdf_mlp_fwd_ex(_p(pts), _p(packed), _p(gamma), _p(beta), _p(sdf), _p(grad), _p(rgb), _p(feat), _p(scratch), B, n,
                                      prec, int(bool(fast_trig)), _l.OI_MLP_BLOB_READY, _stream()), "oi_sdf_mlp_fwd_ex")
         return sdf, grad, rgb, feat, scratch
