@@ -71,7 +71,7 @@ constexpr int DS_TOTAL = 2440;
 // One workgroup (4 waves, one per SIMD, 512 registers each) per CU: the next layer's image and FiLM rows are requested
 // while the current layer computes, so a layer boundary costs a barrier and not an LDS-DMA round trip + the drain of
 // every scratch store in flight.
-constexpr int L_RACC = L_WBUF + 2 * 65536;  // per-workgroup reduction scratch: [8][128] floats
+constexpr int L_RACC = L_WBUF + 2 * 65536;  // per-workgroup reduction scratch: [RACC_ROWS][128] floats
 // Waves per workgroup of the sweep (one workgroup per CU either way: the two image slots fill the LDS).  4 = one wave per
 // SIMD with 512 registers; 8 = two waves per SIMD with 256 registers each (the co-resident wave fills the other's LDS /
 // MFMA-result / memory stalls and the VALU issues 1.45 x faster with two waves to pick from: tools/dbg/valu_issue.hip).
@@ -95,7 +95,25 @@ constexpr int BW_NW = OI_BWD_NW, BW_THREADS = 64 * BW_NW, BW_TILE = WAVE_PTS * B
 #ifndef OI_BWD_AC_REGS
 #define OI_BWD_AC_REGS (OI_BWD_NW == 4)
 #endif
-constexpr int L_FILM2 = L_RACC + 8 * C * 4;
+// Point sums of the colour head, of w_sigma and of layer 0 in rows of their own (1): every row is flushed ONCE, behind the last
+// barrier of the kernel -- the colour head's flush (two barriers and 900 atomics in the tile's first microseconds), the barrier
+// of the turn and layer 0's re-zeroing go away.  0: one set of 8 rows, flushed and re-zeroed where each user ends (round 5).
+// Persistent workgroups (1): one per CU (/ B) walks its share of the element's tiles -- tables, layer 0's FiLM rows and the zeroed
+// reduction rows are set up once, the rows are flushed once per workgroup (needs OI_BWD_LATE_FLUSH).  0 (default): one workgroup
+// per tile.  Measured, round 6: 2.78 / 2.83 ms persistent against 2.77 / 2.77 (same box, alternating) -- nothing sits between two
+// tiles of a CU that a loop would remove (the per-CU timelines of tools/dbg/phase_prof_bwd.py: a CU's tiles follow each other
+// within the profiling code's own cost), and tile lifetimes spread 0.55x .. 1.45x around their mean: the tiles wait on the
+// memory system they share, not on their own start.
+#ifndef OI_BWD_PERSIST
+#define OI_BWD_PERSIST 0
+#endif
+#ifndef OI_BWD_LATE_FLUSH
+#define OI_BWD_LATE_FLUSH 1
+#endif
+constexpr int RACC_ROWS = OI_BWD_LATE_FLUSH ? 16 : 8;
+constexpr int RR_COL = OI_BWD_LATE_FLUSH ? 8 : 0;    // the colour head's rows 2..7 -> RR_COL + 2 .. RR_COL + 7
+constexpr int RR_WSIG = OI_BWD_LATE_FLUSH ? 0 : 3;   // (layer 0: rows 1, 3, 4, 5)
+constexpr int L_FILM2 = L_RACC + RACC_ROWS * C * 4;
 constexpr int L_TOTAL_BWD = L_FILM2 + 1536;
 
 // Cache policy per slot family (aux operand of the buffer instructions; measured in oi_common.h's table):
@@ -364,7 +382,7 @@ struct RowSum {
 
 __device__ __forceinline__ void racc_zero(char* lds, int tid) {
   float* racc = reinterpret_cast<float*>(lds + L_RACC);
-  for (int i = tid; i < 8 * C; i += BW_THREADS) racc[i] = 0.f;
+  for (int i = tid; i < RACC_ROWS * C; i += BW_THREADS) racc[i] = 0.f;
 }
 // flush `rows` accumulator rows: row r goes to dst[r] (a global base pointer per row)
 __device__ __forceinline__ void racc_flush_row(char* lds, int row, float* dst, int stride, int tid) {
@@ -513,7 +531,8 @@ __device__ __forceinline__ void publish_max(float* op_max, int slot, float lane_
 #endif
 // -DOI_BWD_PROF: per-phase shader-clock accounting of the sweep (tools/dbg/phase_prof_bwd.py)
 #ifdef OI_BWD_PROF
-__device__ unsigned long long oi_prof_bwd[16];
+__device__ unsigned long long oi_prof_bwd[24];
+__device__ unsigned long long oi_prof_bwd_wg[4 * 4096];   // per workgroup: start, end (100 MHz), HW_ID, XCC_ID
 #define BW_T(i)                                                  \
   do {                                                           \
     const unsigned long long t_ = __builtin_readcyclecounter();  \
@@ -540,13 +559,25 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
                      long long n_per_elem, long long n_stride, long long pt_off) {
   // this launch covers points [pt_off, pt_off + n_per_elem) of every batch element; an element holds n_stride points
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, j = lane & 31;
   const int e = blockIdx.y;
   const float* hdr = reinterpret_cast<const float*>(packed);
   const char* mats = packed + H_BYTES;
   const bool has_col = rgb_fwd != nullptr && g_rgb != nullptr && feat_fwd != nullptr;
+  const int n_tiles = (int)((n_per_elem + BW_TILE - 1) / BW_TILE);   // of this launch, per batch element
+#if OI_BWD_PERSIST
+  static_assert(OI_BWD_LATE_FLUSH == 1, "persistent workgroups keep their point sums in LDS across tiles");
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  const bool first = tile == (int)blockIdx.x, last = tile + (int)gridDim.x >= n_tiles;
+#else
+  {
+  const int tile = blockIdx.x;
+  constexpr bool first = true, last = true;
+#endif
+  // (the thread index is taken anew per tile, through an empty asm: everything derived from it -- lane offsets, the per-lane
+  // addresses of the FiLM rows and tables -- would otherwise be hoisted out of the tile loop and kept, i.e. spilled, across it)
+  const int tid = late(threadIdx.x), lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, j = lane & 31;
 
   LaneOff o;
   o.h16 = 16 * h;
@@ -556,7 +587,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   asm volatile("" : "+v"(o.h16), "+v"(o.h64), "+v"(o.l16), "+v"(o.l16hi));
 
   const RowSum rs{reinterpret_cast<float*>(lds + L_RACC), lane};
-  const long long local = (long long)blockIdx.x * BW_TILE + wave * WAVE_PTS + j;
+  const long long local = (long long)tile * BW_TILE + wave * WAVE_PTS + j;
   const bool valid = local < n_per_elem;
   const long long pt = (long long)e * n_stride + pt_off + (valid ? local : n_per_elem - 1);
   const float vmask = valid ? 1.f : 0.f;  // tail points contribute nothing
@@ -572,7 +603,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   ws.l12 = (PK == 2 ? 8 : 12) * lane;
   asm volatile("" : "+v"(ws.l12));
   {
-    const long long wt = ((long long)e * gridDim.x + blockIdx.x) * BW_NW + wave;
+    const long long wt = ((long long)e * n_tiles + tile) * BW_NW + wave;
     ws.rs = __builtin_amdgcn_make_buffer_rsrc(scratch + wt * (long long)(NSLOT_BWD * 16384), 0, NSLOT_BWD * 16384,
                                               0x00020000);
   }
@@ -605,35 +636,83 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   // Everything the tile needs from memory before its first product is requested up front (round 2 paid four exposed
   // round trips in the colour head: tables, image 14, the per-point forward values, image 15): both colour images go to
   // the two image slots, the colour head's FiLM rows to FiLM slot 1 and layer 0's to slot 0.
-  if (has_col) {
-    stage_img(14, 0);
-    stage_img(15, 1);
-    stage_flm(8, 1);
-  }
-  {
-    float* tabs = reinterpret_cast<float*>(lds + L_TABS);
-    for (int i = tid; i < H_TABS_END; i += BW_THREADS) tabs[i] = hdr[i];
-    stage_flm(0, 0);
-    racc_zero(lds, tid);
-  }
 #ifdef OI_BWD_PROF
-  unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long pacc[20] = {0};
   unsigned long long tprev = __builtin_readcyclecounter();
   const unsigned long long tstart = tprev;
+  const unsigned long long rstart = wall_clock64();   // (100 MHz, shared by the chip: workgroup lifetimes against the launch's span)
 #endif
+  float act[64];  // up sweep: a_l;     down sweep: abar_{l+1} -> ubar_l -> abar_l
+  // The vector-memory counter retires in issue order, and the colour images are 128 KiB of LDS-DMA: every register load of the
+  // prologue is issued AHEAD of them (tables, both sets of FiLM rows, the point, its upstream gradients and forward values), so
+  // that the LDS copies of the tables wait for those loads only -- round 5 paid four dependent round trips here (DMA, rows, tables,
+  // point) before the first product.
+  // (tables, layer 0's rows and the zeroed reduction rows: the workgroup's first tile only -- the down sweep leaves layer 0's rows
+  // in FiLM slot 0 again)
+  FilmRegs fr8{}, fr1{}, fr0{};
+  constexpr int NTAB = (H_TABS_END + BW_THREADS - 1) / BW_THREADS;
+  float tabv[NTAB];
+  if (first) {
+    fr0 = load_flm(0);
+#pragma unroll
+    for (int i = 0; i < NTAB; ++i) tabv[i] = hdr[min(tid + i * BW_THREADS, H_TABS_END - 1)];
+  }
+  if (has_col) fr8 = load_flm(8);
   const float px = pts[pt * 3 + 0], py = pts[pt * 3 + 1], pz = pts[pt * 3 + 2];
   const float gs = (g_sdf ? g_sdf[pt] : 0.f) * vmask;
   float Gx = (g_grad ? g_grad[pt * 3 + 0] : 0.f) * vmask, Gy = (g_grad ? g_grad[pt * 3 + 1] : 0.f) * vmask,
         Gz = (g_grad ? g_grad[pt * 3 + 2] : 0.f) * vmask;
+  float fx = 0.f, fy = 0.f, fz = 0.f, rho[3] = {0.f, 0.f, 0.f};
+  if (has_col) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {  // a_8, as the forward wrote it (feat output): features grp_f0(g) + 4 h .. + 3
+      const f32x4 v = *reinterpret_cast<const f32x4*>(feat_fwd + pt * C + grp_f0(g) + 4 * h);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) act[4 * g + k] = v[k];
+    }
+    fx = grad_fwd[pt * 3 + 0]; fy = grad_fwd[pt * 3 + 1]; fz = grad_fwd[pt * 3 + 2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float rv = rgb_fwd[pt * 3 + k];
+      rho[k] = g_rgb[pt * 3 + k] * rv * (1.0f - rv) * vmask;  // through the sigmoid
+    }
+    stage_img(14, 0);
+    stage_img(15, 1);
+  }
+  if (first) {
+    float* tabs = reinterpret_cast<float*>(lds + L_TABS);
+#pragma unroll
+    for (int i = 0; i < NTAB; ++i)
+      if (tid + i * BW_THREADS < H_TABS_END) tabs[tid + i * BW_THREADS] = tabv[i];
+    store_flm(fr0, 0);
+    racc_zero(lds, tid);
+  }
+  if (has_col) store_flm(fr8, 1);
   __syncthreads();
 
-  float act[64];  // up sweep: a_l;     down sweep: abar_{l+1} -> ubar_l -> abar_l
   float gb[64];   // up sweep: gbar_l -> vbar_l -> gbar_{l+1};   down sweep: g_{l+1} -> v_l -> g_l
   f32x16 acc[4];
   // F16X3: the images carry a power-of-two scale 2^k_m (header H_WSCALE holds 2^-k_m); every product returns the factor
   // its accumulators still need (gemm2), adjoint vectors are normalised per point before the fp16 split.
   constexpr bool SC = PREC == OI_PREC_F16X3;
 
+  // the colour head's point sums, rows 2 / 6 / 7 of sums of phibar_v (not of uvbar = gamma_v phibar_v):
+  //   d gamma_v += sum_{j < 3} Wv[f][128 + j] R_j   (the GEMM adds the other 128 columns and bv),   dWv[f][128 + j] = gamma_v[f] R_j
+  // and rows 3..5 = d Wrgb; gv_row = gamma_v (its LDS copy while the head runs, the caller's array at the end of the kernel)
+  auto flush_colour = [&](const float* gv_row) {
+    if (const int t_ = late(tid); t_ < C) {
+      const float* racc = reinterpret_cast<const float*>(lds + L_RACC) + RR_COL * C;
+      const f32x4 wx = *reinterpret_cast<const f32x4*>(lds + L_TABS + H_TABV * 4 + t_ * 16);
+      atomicAdd(d_gamma + ((size_t)e * 9 + 8) * C + t_,
+                fmaf(wx[0], racc[6 * C + t_], fmaf(wx[1], racc[7 * C + t_], wx[2] * racc[2 * C + t_])));
+    }
+    racc_flush_row_scaled(lds, RR_COL + 2, gv_row, d_small + DS_WVX + 2, 3, tid);
+    racc_flush_row(lds, RR_COL + 3, d_small + DS_WRGB + 0 * C, 1, tid);
+    racc_flush_row(lds, RR_COL + 4, d_small + DS_WRGB + 1 * C, 1, tid);
+    racc_flush_row(lds, RR_COL + 5, d_small + DS_WRGB + 2 * C, 1, tid);
+    racc_flush_row_scaled(lds, RR_COL + 6, gv_row, d_small + DS_WVX + 0, 3, tid);
+    racc_flush_row_scaled(lds, RR_COL + 7, gv_row, d_small + DS_WVX + 1, 3, tid);
+  };
   // ================= colour head backward (first: its dL/dgrad term is part of gbar_0) =================
   OI_MARK("colour x1");
   // abar_8 contribution of the colour head: waits for the down sweep in registers (one wave per SIMD: the AGPR half has
@@ -644,25 +723,14 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   for (int k = 0; k < 64; ++k) ac[k] = 0.f;
 #endif
   if (has_col) {
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {  // a_8, as the forward wrote it (feat output): features grp_f0(g) + 4 h .. + 3
-      const f32x4 v = *reinterpret_cast<const f32x4*>(feat_fwd + pt * C + grp_f0(g) + 4 * h);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) act[4 * g + k] = v[k];
-    }
-    const float fx = grad_fwd[pt * 3 + 0], fy = grad_fwd[pt * 3 + 1], fz = grad_fwd[pt * 3 + 2];
-    float rho[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float rv = rgb_fwd[pt * 3 + k];
-      rho[k] = g_rgb[pt * 3 + k] * rv * (1.0f - rv) * vmask;  // through the sigmoid
-    }
     dma_sync();
+    BW_T(14);
     const LaneOff oc = layer_off(0, 1);  // image slot 0, FiLM slot 1
     acc_zero(acc);
     (void)gemm2<PREC, false>(lds, oc, act, acc, 1.f);
     __syncthreads();   // every wave is done with image slot 0:
     stage_img(0, 0);   // the up sweep's first image travels under the epilogue
+    BW_T(15);
     // uv -> phiv -> hv; then uvbar.  Point sums kept here: rows 3..5 dWrgb, rows 2 / 6 / 7 dWv[:, 130 / 128 / 129]; the FiLM and
     // bias gradients of the head come out of the weight-gradient GEMM (FiLM-scale identity), the part of it that belongs to
     // the three extra input columns is added at the flush below
@@ -711,9 +779,10 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         float row[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) row[i] = (r >= 3 && r <= 5) ? sc * hv16[i] : uv16[i] * sc;
-        rs.add(r, t, row);
+        rs.add(RR_COL + r, t, row);
       }
     }
+    BW_T(16);
     // contribution to dL/dgrad through the colour-head input
     dGx += __shfl_xor(dGx, 32, 64);
     dGy += __shfl_xor(dGy, 32, 64);
@@ -729,28 +798,19 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         atomicAdd(d_small + DS_BRGB + 2, b2);
       }
     }
-    __syncthreads();
-    // rows 2 / 6 / 7 hold sums of phibar_v (not of uvbar = gamma_v phibar_v):
-    //   d gamma_v += sum_{j < 3} Wv[f][128 + j] R_j   (the GEMM adds the other 128 columns and bv),   dWv[f][128 + j] = gamma_v[f] R_j
-    const float* gv_row = reinterpret_cast<const float*>(lds + L_FILM2);  // the head's rows sit in FiLM slot 1
-    if (const int t_ = late(tid); t_ < C) {
-      const float* racc = reinterpret_cast<const float*>(lds + L_RACC);
-      const f32x4 wx = *reinterpret_cast<const f32x4*>(lds + L_TABS + H_TABV * 4 + t_ * 16);
-      atomicAdd(d_gamma + ((size_t)e * 9 + 8) * C + t_,
-                fmaf(wx[0], racc[6 * C + t_], fmaf(wx[1], racc[7 * C + t_], wx[2] * racc[2 * C + t_])));
+    if constexpr (!OI_BWD_LATE_FLUSH) {
+      __syncthreads();
+      flush_colour(reinterpret_cast<const float*>(lds + L_FILM2));  // the head's rows sit in FiLM slot 1
+      __syncthreads();
+      racc_zero(lds, tid);
     }
-    racc_flush_row_scaled(lds, 2, gv_row, d_small + DS_WVX + 2, 3, tid);
-    racc_flush_row(lds, 3, d_small + DS_WRGB + 0 * C, 1, tid);
-    racc_flush_row(lds, 4, d_small + DS_WRGB + 1 * C, 1, tid);
-    racc_flush_row(lds, 5, d_small + DS_WRGB + 2 * C, 1, tid);
-    racc_flush_row_scaled(lds, 6, gv_row, d_small + DS_WVX + 0, 3, tid);
-    racc_flush_row_scaled(lds, 7, gv_row, d_small + DS_WVX + 1, 3, tid);
-    __syncthreads();
-    racc_zero(lds, tid);
+    BW_T(17);
     // abar_8 from the colour head: Wv[:, :128]^T uvbar   (transposed colour image, matrix 15: resident in slot 1 since the
     // prologue)
     acc_zero(acc);
+    fr1 = load_flm(1);  // layer 1's FiLM rows travel under the product
     const float fT = gemm2<PREC, true>(lds, layer_off(1, 1), act, acc, SC ? hdr[H_WSCALE + 15] : 1.f);
+    BW_T(18);
     if constexpr (SC) publish_max(op_max, OM_UV, mx_pv);  // (of the parked operand: phibar_v)
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -789,9 +849,12 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
   // ================= up sweep: recompute phi_l, carry gbar_l =================
   // FiLM rows of layer l live in FiLM slot l & 1, layer l's forward image in image slot (l - 1) & 1: both are requested one
   // layer ahead
-  if (!has_col) stage_img(0, 0);  // (with a colour head: requested right after its first product)
-  __syncthreads();                // the colour head is done with FiLM slot 1
-  stage_flm(1, 1);
+  if (!has_col) {
+    fr1 = load_flm(1);
+    stage_img(0, 0);  // (with a colour head: requested right after its first product)
+  }
+  __syncthreads();    // the colour head is done with FiLM slot 1
+  store_flm(fr1, 1);
   // layer 0 on the VALU: phi_0; vbar_0 = W0 gbar_0 (gbar_0 = dL/dgrad, a 3-vector); gbar_1 = vbar_0 c_0
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
@@ -895,7 +958,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       }
       if (!(OI_BWD_ABL & 4)) ws.store_phase(S_PHI + l, g, o.l16, ph);
       if constexpr (LAST)
-        if ((g & 3) == 3) rs.add(3, g >> 2, wsig_row);
+        if ((g & 3) == 3) rs.add(RR_WSIG, g >> 2, wsig_row);
       __builtin_amdgcn_sched_barrier(0);
     }
     BW_T(5);
@@ -909,8 +972,10 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     b = oi::wave_sum(b);
     if (lane == 0) atomicAdd(d_small + DS_BSIG, b);
   }
-  __syncthreads();
-  racc_flush_row(lds, 3, d_small + DS_WSIG, 1, tid);
+  if constexpr (!OI_BWD_LATE_FLUSH) {
+    __syncthreads();
+    racc_flush_row(lds, RR_WSIG, d_small + DS_WSIG, 1, tid);
+  }
 
   // ================= down sweep: g_l and abar_l together =================
   // The top layer (7) takes phi_7 / vbar_7 from the point vectors, g_8 = w_sigma from the tables and abar_8 = gs * w_sigma
@@ -950,7 +1015,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
     if constexpr (L0) OI_MARK("down0 x1"); else if constexpr (TOP) OI_MARK("down_top x1"); else OI_MARK("down_body x6");
     dma_sync();  // layer l's transposed image and FiLM rows have landed
     BW_T(7);
-    if constexpr (L0) {  // the reduction rows still hold the w_sigma sums of the up sweep (flushed many barriers ago)
+    if constexpr (L0 && !OI_BWD_LATE_FLUSH) {  // the reduction rows still hold the w_sigma sums of the up sweep (flushed many barriers ago)
       racc_zero(lds, tid);
       __syncthreads();
     }
@@ -1159,7 +1224,7 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
       load_vb_scale(S_VB + l - 1);
     }
     BW_T(10);
-    if constexpr (L0) {
+    if (L0 && last) {   // (a persistent workgroup: after its last tile)
       __syncthreads();
       // the rows hold sums of phibar_0 / (v_0 / gamma_0) terms, R1 = sum phibar_0, R_{3+j} = sum (phibar_0 x_j + v_0/gamma_0 G_j):
       //   d b_0 = gamma_0 R1,  d W0[:, j] = gamma_0 R_{3+j},  d beta_0 = R1,  d gamma_0 = sum_j W0[f][j] R_{3+j} + b_0[f] R1
@@ -1176,6 +1241,10 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
         atomicAdd(d_gamma + (size_t)e * 9 * C + t_,
                   fmaf(w[0], racc[3 * C + t_], fmaf(w[1], racc[4 * C + t_], fmaf(w[2], racc[5 * C + t_], hdr[H_BIAS + t_] * r1))));
       }
+      if constexpr (OI_BWD_LATE_FLUSH) {
+        racc_flush_row(lds, RR_WSIG, d_small + DS_WSIG, 1, tid);
+        if (has_col) flush_colour(gamma + ((size_t)e * 9 + 8) * C);
+      }
     }
     BW_T(11);
   };
@@ -1185,10 +1254,25 @@ mlp_bwd_sweep_kernel(const float* __restrict__ pts, const char* __restrict__ pac
 #ifdef OI_BWD_PROF
   if (lane == 0) {
     for (int i = 0; i < 12; ++i) atomicAdd(&oi_prof_bwd[i], pacc[i]);
+    for (int i = 14; i < 20; ++i) atomicAdd(&oi_prof_bwd[i], pacc[i]);
     atomicAdd(&oi_prof_bwd[12], __builtin_readcyclecounter() - tstart);
     atomicAdd(&oi_prof_bwd[13], 1ull);
+    if (wave == 0) {
+      const unsigned long long rend = wall_clock64();
+      atomicAdd(&oi_prof_bwd[20], rend - rstart);
+      atomicMax(&oi_prof_bwd[21], (1ull << 62) - rstart);
+      atomicMax(&oi_prof_bwd[22], rend);
+      const unsigned wg = tile + blockIdx.y * n_tiles;
+      if (wg < 4096) {
+        oi_prof_bwd_wg[4 * wg + 0] = rstart;
+        oi_prof_bwd_wg[4 * wg + 1] = rend;
+        oi_prof_bwd_wg[4 * wg + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        oi_prof_bwd_wg[4 * wg + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+      }
+    }
   }
 #endif
+  }  // tile
 }
 
 // Layer 0 is not parked by the sweep (see S_PHI): the weight-gradient kernels form phi_0 / (gamma vbar)_0 of matrix m = 0 from
@@ -1416,7 +1500,7 @@ __device__ __forceinline__ f32x4 ld_once(const f32x4* p) { return OI_WGRAD_NT ? 
 // -DOI_WG_PROF: per-phase shader-clock accounting of the weight-gradient GEMM (read with oi_prof_bwd_read, slots 0..7)
 #ifdef OI_WG_PROF
 #ifndef OI_BWD_PROF
-__device__ unsigned long long oi_prof_bwd[16];
+__device__ unsigned long long oi_prof_bwd[24];
 #endif
 #define WG_T(i)                                                  \
   do {                                                           \
@@ -1930,7 +2014,17 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
   for (long long t0 = 0; t0 < tiles_all; t0 += tiles_fit) {
     const long long nt = std::min(tiles_fit, tiles_all - t0);
     const long long off = t0 * BW_TILE, cn = std::min<long long>(nt * BW_TILE, n - off);
+#if OI_BWD_PERSIST
+    static const int cus = [] {
+      int dev = 0, n_ = 256;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&n_, hipDeviceAttributeMultiprocessorCount, dev);
+      return n_ > 0 ? n_ : 256;
+    }();
+    dim3 grid((unsigned)std::min<long long>(nt, std::max(1, cus / B)), B), block(256);
+#else
     dim3 grid((unsigned)nt, B), block(256);
+#endif
     if constexpr (PREC == OI_PREC_F16X3) {
       hipError_t e = oi::zero_async(op_max, OM_FLOATS, st);
       if (e != hipSuccess) return oi::fail(OI_ERR_LAUNCH, "oi_sdf_mlp_bwd: zero fill: %s", hipGetErrorString(e));
@@ -1939,7 +2033,7 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
                        rgb_fwd, feat_fwd, g_sdf, g_grad, g_rgb, g_feat, d_small, d_gamma, d_beta, tiles, op_max, cn, n, off);
     int rc = oi::check_launch("oi_sdf_mlp_bwd(sweep)");
     if (rc != OI_OK) return rc;
-    const long long wt_per_elem = (long long)grid.x * BW_NW, n_wt = (long long)B * wt_per_elem;
+    const long long wt_per_elem = nt * BW_NW, n_wt = (long long)B * wt_per_elem;
     // ~2048 workgroups in total; a chunk never straddles two batch elements (per-element FiLM gradients)
     const int chunk = (int)std::min<long long>(wt_per_elem, std::max<long long>(1, (n_wt * 8 + OI_WG_TARGET - 1) / OI_WG_TARGET));
     dim3 g2(oi::cdiv(wt_per_elem, chunk), 8, B);
@@ -1962,6 +2056,13 @@ int launch_bwd(const float* pts, const void* packed, const float* gamma, const f
 
 }  // namespace
 
+#ifdef OI_BWD_PROF
+extern "C" int oi_prof_bwd_read_wg(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(oi_prof_bwd_wg), sizeof(unsigned long long) * 4 * 4096);
+  return 0;
+}
+#endif
 #ifdef OI_WG_PROF
 extern "C" int oi_dbg_occupancy(int which) {
   int n = -1;
@@ -1973,9 +2074,9 @@ extern "C" int oi_dbg_occupancy(int which) {
 #if defined(OI_BWD_PROF) || defined(OI_WG_PROF)
 extern "C" int oi_prof_bwd_read(unsigned long long* out, int reset) {
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(oi_prof_bwd), sizeof(unsigned long long) * 16);
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(oi_prof_bwd), sizeof(unsigned long long) * 24);
   if (reset) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[24] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(oi_prof_bwd), z, sizeof(z));
   }
   return 0;

@@ -17,7 +17,7 @@ B, n = 1, 524288
 pts = (torch.rand(B * n, 3, device="cuda") * 2 - 1)
 w = torch.randn(B, 64, device="cuda").requires_grad_(True)
 raw = ctypes.CDLL(lib.LIB_PATH)
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 24)()
 for it in range(4):
     _, gamma, beta = pack.film(w=w)
     sdf, grad, rgb, _ = sdf_mlp(pack, pts, gamma, beta, B, True, True, False)
