@@ -621,6 +621,18 @@ void oi_disc_graph_destroy(oi_disc_graph* g);
 int oi_ada_geom_fwd(const float* x, const float* theta, const float* f, float* y, float* canvas, int B, int C, int H,
                     int W, int mx0, int mx1, int my0, int my1, oi_stream_t stream);
 
+/* The same map for AXIS-ALIGNED sampling matrices (theta[b][0][1] == theta[b][1][0] == 0 for every b: translations, isotropic /
+ * anisotropic scales, flips -- AugmentPipe without rotate / rotate90; the CALLER guarantees it, the kernel does not read those
+ * two entries), in ONE launch and without a canvas: the four stages are then separable, y_c = A_y x_c A_x^T with two H x H
+ * matrices per image that a workgroup builds in LDS (csrc/disc.hip, ada_sep_kernel).  Equal to oi_ada_geom_fwd up to fp32
+ * summation order (not bit-identical to it; deterministic).  Covered shapes: oi_ada_geom_sep_supported(C, H, W) != 0
+ * (1..3 channels of 64 x 64); anything else is OI_ERR_INVALID_ARG -- use oi_ada_geom_fwd.
+ * The matrices come from the device (theta) or from the HOST (theta_host, [B][2][3]: passed to the kernel by value, 64 images
+ * per launch -- a caller that drew them on the host, e.g. with oi_ada_theta_xint_scale, uploads nothing); exactly one of the two. */
+int oi_ada_geom_sep_supported(int C, int H, int W);
+int oi_ada_geom_sep_fwd(const float* x, const float* theta, const float* theta_host, const float* f, float* y, int B, int C, int H,
+                        int W, int mx0, int mx1, int my0, int my1, oi_stream_t stream);
+
 /* Stand-alone plugin ops, for a caller that keeps the reference's own Python layers and only swaps the compiled ops
  * (INTEGRATION.md 3).
  * oi_fused_bias_act = fused_bias_act(input, bias, refer, act, grad, alpha, scale) of stylesdf/op/fused_bias_act.cpp:11-20

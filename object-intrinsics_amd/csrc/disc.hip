@@ -677,6 +677,147 @@ ada_resample_down2_kernel(const float* __restrict__ canvas, const float* __restr
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The same augmentation for AXIS-ALIGNED sampling matrices (theta[1] = theta[3] = 0: integer / fractional translation, isotropic
+// or anisotropic scale, flips -- everything but the rotations), ONE launch and no canvas.  Each of the four stages is linear and,
+// without a rotation, separable (reflect pad, the two FIRs, and bilinear sampling with zero padding on an axis-aligned grid), so
+// the whole map is  y_c = A_y x_c A_x^T  with two H x H matrices per image: A = D S(theta) U P, D = /2 down-FIR (12 taps per
+// row), S = the 1-D bilinear sampling (2 per row), U = x2 up-FIR (6 per row), P = reflect pad (1 per row): 144 products per
+// row.  At batch 64 the two-launch form writes and re-reads an 86 MB canvas for 6 MB of images (23 + 26 us); this one reads the
+// images once.  A workgroup = (image, 16 output rows): builds A_x^T (64 x 64) and its 16 rows of A_y in LDS -- 1920 tasks (row,
+// down-FIR tap, bilinear corner) of six products each, formed and added as FIXED POINT with 64-bit LDS atomics (integer sums: the
+// order the threads arrive in does not matter, the result is bit-reproducible) -- then two small fp32 products on the matrix
+// cores.  Same products as the two-launch form in a different association: equal to it within rounding, not bit-identical.
+// ------------------------------------------------------------------------------------------
+#ifndef OI_AS_ABL   // timing ablations (results garbage): 1 = no matrix build, 2 = no first product, 4 = no second product, 8 = no zero fill
+#define OI_AS_ABL 0
+#endif
+#ifndef OI_AS_THREADS
+#define OI_AS_THREADS 1024
+#endif
+constexpr int AS_N = 64, AS_RB = 16, AS_THREADS = OI_AS_THREADS, AS_NW = AS_THREADS / 64, AS_MAX_C = 3;
+constexpr int AS_XS = 80, AS_ZS = 68;   // LDS row strides (floats) of MFMA B / A operands: the 64 lanes of a fragment read 64 banks
+// LDS (bytes): fixed-point A_x^T [src][out] | fixed-point A_y rows [src][16] | A_x^T | A_y rows | image [C][64] rows | Z [C * 16] rows | taps
+constexpr int AS_O_FX = 0, AS_O_FY = AS_O_FX + AS_N * AS_N * 8, AS_O_AX = AS_O_FY + AS_RB * AS_N * 8;
+constexpr int AS_O_AY = AS_O_AX + AS_N * AS_XS * 4, AS_O_X = AS_O_AY + AS_RB * AS_ZS * 4;
+constexpr int AS_O_Z = AS_O_X + AS_MAX_C * AS_N * AS_XS * 4, AS_O_F = AS_O_Z + AS_MAX_C * AS_RB * AS_ZS * 4;
+constexpr int AS_LDS_BYTES = AS_O_F + 2 * ADA_TAPS * 4;
+static_assert(AS_LDS_BYTES <= 160 * 1024, "ada_sep_kernel: LDS");
+
+// 1-D sampling coordinate on the canvas axis: affine_src with the other axis' coefficient zero, in ITS operations (the product
+// and the sum round separately there: the zero term sits between them) -- the same bits, so the same bilinear weights
+__device__ __forceinline__ float sep_coord(float ts, float tt, int g, int No, int Nc) {
+  const float n = (2.0f * g + 1.0f) / No - 1.0f;
+  float pr = ts * n;
+  asm volatile("" : "+v"(pr));   // (hipcc fuses __fadd_rn(__fmul_rn()) as well: the product must round on its own)
+  const float gg = pr + tt;
+  return ((gg + 1.0f) * Nc - 1.0f) * 0.5f;
+}
+// The build in integers: taps and bilinear weights as 2^-28 fixed point, a term = ((f_k w + 2^27) >> 28) x fr_q at 2^-56 in 64 bits
+// (each factor within 2^-29 of its fp32 value, rounded to nearest: 144 terms stay below fp32's own 2^-24).  Integer sums do not
+// depend on the order the threads add in, and an entry of A is rounded to fp32 ONCE, after its terms have cancelled.
+__device__ __forceinline__ int sep_fix28(float v) { return (int)rintf(v * 268435456.0f); }
+__device__ __forceinline__ float sep_from_fix(long long v) { return (float)((double)v * (1.0 / 72057594037927936.0)); }
+
+// the sampling matrices of up to AS_BYVAL images in the kernel arguments (a caller that drew them on the host: no upload)
+constexpr int AS_BYVAL = 64;
+struct AsTheta {
+  float t[AS_BYVAL][6];
+};
+
+template <int C, bool BYVAL>
+__global__ void __launch_bounds__(AS_THREADS)
+ada_sep_kernel(const float* __restrict__ x, const float* __restrict__ theta, const AsTheta thv, const float* __restrict__ f,
+               float* __restrict__ y, int mx0, int my0, int Wp, int Hp) {
+  extern __shared__ __attribute__((aligned(16))) char as_lds[];
+  unsigned long long* fxx = reinterpret_cast<unsigned long long*>(as_lds + AS_O_FX);   // [source x][output x]
+  unsigned long long* fxy = reinterpret_cast<unsigned long long*>(as_lds + AS_O_FY);   // [source y][row of the block]
+  float* axt = reinterpret_cast<float*>(as_lds + AS_O_AX);
+  float* ayb = reinterpret_cast<float*>(as_lds + AS_O_AY);
+  float* xs = reinterpret_cast<float*>(as_lds + AS_O_X);
+  float* zb = reinterpret_cast<float*>(as_lds + AS_O_Z);
+  int* fs = reinterpret_cast<int*>(as_lds + AS_O_F);   // down-FIR taps (flip_filter: the filter itself), 2^-28 fixed point
+  int* fr = fs + ADA_TAPS;                             // up-FIR taps: reversed, sqrt(gain) = 2 per axis
+  const int tid = threadIdx.x, b = blockIdx.y, rb = blockIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  // the image: requested first
+  constexpr int NX = C * AS_N * AS_N / (4 * AS_THREADS);   // b128 loads per thread
+  f32x4 xv[NX];
+  const float* xb = x + (size_t)b * C * AS_N * AS_N;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xv[i] = *reinterpret_cast<const f32x4*>(xb + 4 * (tid + i * AS_THREADS));
+  const float tsx = BYVAL ? thv.t[b][0] : theta[b * 6 + 0], ttx = BYVAL ? thv.t[b][2] : theta[b * 6 + 2];
+  const float tsy = BYVAL ? thv.t[b][4] : theta[b * 6 + 4], tty = BYVAL ? thv.t[b][5] : theta[b * 6 + 5];
+  if (tid < ADA_TAPS) {
+    fs[tid] = sep_fix28(f[tid]);
+    fr[tid] = sep_fix28(2.0f * f[ADA_TAPS - 1 - tid]);
+  }
+  for (int i = tid; i < ((OI_AS_ABL & 8) ? 0 : (AS_O_AX - AS_O_FX) / 16); i += AS_THREADS) reinterpret_cast<f32x4*>(as_lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  // the matrices: one task per (row, down-FIR tap k, bilinear corner c) = 6 products through the up-FIR and the reflect pad
+  constexpr int NTASK = (AS_N + AS_RB) * ADA_TAPS * 2;
+  for (int t_ = tid; t_ < ((OI_AS_ABL & 1) ? 0 : NTASK); t_ += AS_THREADS) {
+    // (the row on the lane: the 64-bit adds of a wave then go to different addresses -- with the taps on the lane up to 24 lanes
+    // met in one)
+    const int kc = t_ / (AS_N + AS_RB), row = t_ - kc * (AS_N + AS_RB), k = kc >> 1, c = kc & 1;
+    const bool isx = row < AS_N;
+    const int a = isx ? row : rb * AS_RB + (row - AS_N);
+    const int m0 = isx ? mx0 : my0, Np = isx ? Wp : Hp, Nc = 2 * Np;
+    const float ic = sep_coord(isx ? tsx : tsy, isx ? ttx : tty, 2 * a + k + 1, 2 * (AS_N + ADA_PAD), Nc);
+    const float fl = floorf(ic), tt_ = ic - fl;
+    const int u = (int)fl + c;
+    if (u < 0 || u >= Nc) continue;
+    const int wc = (int)(((long long)fs[k] * sep_fix28(c ? tt_ : 1.f - tt_) + (1ll << 27)) >> 28);
+    const int ku = u & 1, base = (u + ku) / 2 - 3;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int r = base + q;
+      if (r < 0 || r >= Np) continue;
+      const int sidx = reflect_idx(r - m0, AS_N);
+      atomicAdd(isx ? fxx + sidx * AS_N + a : fxy + sidx * AS_RB + (row - AS_N), (unsigned long long)((long long)wc * fr[ku + 2 * q]));
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < AS_N * AS_N; i += AS_THREADS) axt[(i >> 6) * AS_XS + (i & 63)] = sep_from_fix((long long)fxx[i]);
+  for (int i = tid; i < AS_RB * AS_N; i += AS_THREADS) ayb[(i & 15) * AS_ZS + (i >> 4)] = sep_from_fix((long long)fxy[i]);
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int e = 4 * (tid + i * AS_THREADS);   // element of [C][64][64]: row e / 64, column e % 64
+    *reinterpret_cast<f32x4*>(xs + (e >> 6) * AS_XS + (e & 63)) = xv[i];
+  }
+  __syncthreads();
+  // two small products on the matrix cores (exact fp32 operands, v_mfma_f32_16x16x4_f32: A lane = (row l % 16, k l / 16),
+  // B lane = (k l / 16, column l % 16), D lane = (rows 4 (l / 16) + r, column l % 16)); a wave takes tiles wave, wave + AS_NW, ..
+  const int l16 = lane & 15, kq = lane >> 4;
+  {  // Z_c = A_y[block] X_c: per channel 16 x 64, K = 64 source rows
+    float ay[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) ay[kk] = ayb[l16 * AS_ZS + 4 * kk + kq];
+    for (int p = wave; p < ((OI_AS_ABL & 2) ? 0 : C * 4); p += AS_NW) {
+      const int c = p >> 2, nt = p & 3;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ay[kk], xs[(c * AS_N + 4 * kk + kq) * AS_XS + 16 * nt + l16], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zb[(c * AS_RB + 4 * kq + r) * AS_ZS + 16 * nt + l16] = acc[r];
+    }
+  }
+  __syncthreads();
+  for (int p = wave; p < ((OI_AS_ABL & 4) ? 0 : C * 4); p += AS_NW) {   // Y = Z A_x^T: (C 16) x 64, K = 64 source columns
+    const int c = p >> 2, nt = p & 3;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zb[(c * AS_RB + l16) * AS_ZS + 4 * kk + kq], axt[(4 * kk + kq) * AS_XS + 16 * nt + l16],
+                                                 acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      y[(((size_t)b * C + c) * AS_N + rb * AS_RB + 4 * kq + r) * AS_N + 16 * nt + l16] = acc[r];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -713,6 +854,46 @@ int oi_ada_geom_fwd(const float* x, const float* theta, const float* f, float* y
   hipLaunchKernelGGL(ada_resample_down2_kernel, dim3(oi::cdiv(W, ADA_T), oi::cdiv(H, ADA_T), (unsigned)BC), dim3(256), 0, st,
                      canvas, theta, f, y, C, H, W, 2 * Hp, 2 * Wp);
   return oi::check_launch("oi_ada_geom_fwd(resample + downsample)");
+}
+
+int oi_ada_geom_sep_supported(int C, int H, int W) { return (C >= 1 && C <= AS_MAX_C && H == AS_N && W == AS_N) ? 1 : 0; }
+
+int oi_ada_geom_sep_fwd(const float* x, const float* theta, const float* theta_host, const float* f, float* y, int B, int C, int H,
+                        int W, int mx0, int mx1, int my0, int my1, oi_stream_t stream) {
+  OI_REQUIRE(x && f && y, "oi_ada_geom_sep_fwd: null pointer");
+  OI_REQUIRE((theta != nullptr) != (theta_host != nullptr), "oi_ada_geom_sep_fwd: the sampling matrices on the device OR on the host");
+  OI_REQUIRE(B > 0 && B <= 65535, "oi_ada_geom_sep_fwd: batch %d", B);
+  OI_REQUIRE(oi_ada_geom_sep_supported(C, H, W), "oi_ada_geom_sep_fwd: %d x %d x %d images (covered: 1..%d channels of %d x %d)", C, H, W,
+             AS_MAX_C, AS_N, AS_N);
+  OI_REQUIRE(mx0 >= 0 && mx1 >= 0 && my0 >= 0 && my1 >= 0 && mx0 < W && mx1 < W && my0 < H && my1 < H,
+             "oi_ada_geom_sep_fwd: reflect margins must be in [0, size)");
+  const int Hp = H + my0 + my1, Wp = W + mx0 + mx1;
+  hipStream_t st = oi::as_stream(stream);
+  constexpr int lds = AS_LDS_BYTES;
+  auto launch = [&](auto k, const float* xb, const float* th, const AsTheta& tv, float* yb, int nb) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(k, dim3(AS_N / AS_RB, nb), dim3(AS_THREADS), lds, st, xb, th, tv, f, yb, mx0, my0, Wp, Hp);
+  };
+  if (theta != nullptr) {
+    static const AsTheta none{};
+    if (C == 1) launch(ada_sep_kernel<1, false>, x, theta, none, y, B);
+    else if (C == 2) launch(ada_sep_kernel<2, false>, x, theta, none, y, B);
+    else launch(ada_sep_kernel<3, false>, x, theta, none, y, B);
+    return oi::check_launch("oi_ada_geom_sep_fwd");
+  }
+  for (int b0 = 0; b0 < B; b0 += AS_BYVAL) {   // the matrices by value: AS_BYVAL images per launch
+    const int nb = std::min(AS_BYVAL, B - b0);
+    AsTheta tv;
+    for (int i = 0; i < nb * 6; ++i) tv.t[i / 6][i % 6] = theta_host[(size_t)b0 * 6 + i];
+    const float* xb = x + (size_t)b0 * C * H * W;
+    float* yb = y + (size_t)b0 * C * H * W;
+    if (C == 1) launch(ada_sep_kernel<1, true>, xb, nullptr, tv, yb, nb);
+    else if (C == 2) launch(ada_sep_kernel<2, true>, xb, nullptr, tv, yb, nb);
+    else launch(ada_sep_kernel<3, true>, xb, nullptr, tv, yb, nb);
+    int rc = oi::check_launch("oi_ada_geom_sep_fwd");
+    if (rc != OI_OK) return rc;
+  }
+  return OI_OK;
 }
 
 int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,

@@ -268,7 +268,9 @@ class AugmentPipe(torch.nn.Module):
         mx0, my0, mx1, my1 = margins
         Hz_pad = self.Hz_geom.shape[0] // 4
         if FUSED and self.Hz_geom.shape[0] == 12 and B * C <= 65535:
-            return ada_geom(images, theta, self.Hz_geom, margins)   # the same four stages in two launches
+            # the same four stages in two launches -- or in one, when this pipe cannot draw a rotation (every theta it forms is
+            # then axis-aligned: xflip / xint / scale / aniso / xfrac only scale and shift the axes)
+            return ada_geom(images, theta, self.Hz_geom, margins, axis_aligned=self.rotate90 == 0 and self.rotate == 0)
         x = reflect_pad(images, mx0, mx1, my0, my1)
         x = upfirdn2d_separable(x, self.Hz_geom, up=2, pad=(6, 5, 6, 5), flip=False, gain=4.0)  # upsample2d
         Ho, Wo = (H + Hz_pad * 2) * 2, (W + Hz_pad * 2) * 2

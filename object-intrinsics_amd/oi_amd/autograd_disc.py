@@ -143,32 +143,33 @@ class _AdaGeom(torch.autograd.Function):
     backward an R1 penalty takes runs the two fused launches too, not six separate stages."""
 
     @staticmethod
-    def forward(ctx, x, theta, f1, margins):
+    def forward(ctx, x, theta, f1, margins, axis_aligned=False):
         ctx.save_for_backward(theta, f1)
-        ctx.margins = tuple(margins)
-        return ops.ada_geom_fwd(x, theta, f1, margins)
+        ctx.margins, ctx.axis_aligned = tuple(margins), bool(axis_aligned)
+        return ops.ada_geom_fwd(x, theta, f1, margins, axis_aligned)
 
     @staticmethod
     def backward(ctx, gy):
         theta, f1 = ctx.saved_tensors
-        return _AdaGeomAdjoint.apply(gy, theta, f1, ctx.margins), None, None, None
+        return _AdaGeomAdjoint.apply(gy, theta, f1, ctx.margins, ctx.axis_aligned), None, None, None, None
 
 
 class _AdaGeomAdjoint(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gy, theta, f1, margins):
+    def forward(ctx, gy, theta, f1, margins, axis_aligned=False):
         ctx.save_for_backward(theta, f1)
-        ctx.margins = tuple(margins)
+        ctx.margins, ctx.axis_aligned = tuple(margins), bool(axis_aligned)
         return _ada_geom_adjoint(gy, theta, f1, gy.shape[2], gy.shape[3], margins)
 
     @staticmethod
     def backward(ctx, ggx):
         theta, f1 = ctx.saved_tensors
-        return _AdaGeom.apply(ggx, theta, f1, ctx.margins), None, None, None
+        return _AdaGeom.apply(ggx, theta, f1, ctx.margins, ctx.axis_aligned), None, None, None, None
 
 
-def ada_geom(x, theta, f1, margins):
-    return _AdaGeom.apply(x, theta.detach(), f1, tuple(int(m) for m in margins))
+def ada_geom(x, theta, f1, margins, axis_aligned=False):
+    """`axis_aligned`: the caller's promise that no theta carries a rotation (the one-launch separable form, ops.ada_geom_fwd)."""
+    return _AdaGeom.apply(x, theta.detach(), f1, tuple(int(m) for m in margins), bool(axis_aligned))
 
 
 # ------------------------------------------------------------------------------------------

@@ -242,6 +242,16 @@ class ADADiscriminator(DCDiscriminator):
             # sampled as with margins fitted to the draw, augment.py:272-282)
             margins = aug.static_margins(H, W)
             return self._forward_small(x, f12=aug.Hz_geom, theta_np=aug.theta_for(G_inv, margins, H, W), margins=margins)
+        if (aug_theta is None and FAST_ADA and not torch.is_grad_enabled() and x.is_cuda and x.shape[0] >= LARGE_MIN_BATCH
+                and type(aug).forward is AugmentPipe.forward and aug.fast_draw_ok()):
+            # large no-grad batches of the shipped configuration: the parameters from one seed of numpy's stream, expanded inside
+            # the library (as the batch <= 4 path above), the sampling matrices in the arguments of ONE augmentation launch
+            # (numpy draws + matrix algebra + the upload of 64 matrices cost the host more than the GPU needs for the forward)
+            from . import ops
+            xf = x.float().contiguous()
+            if ops.ada_geom_sep_ok(xf):
+                B, _, H, W = xf.shape
+                return super().forward(ops.ada_geom_sep_host(xf, aug.theta_fast(B, H, W), aug.Hz_geom, aug.static_margins(H, W)), **kwargs)
         return super().forward(self.aug(x) if aug_theta is None else self.aug(x, theta=aug_theta), **kwargs)
 
 

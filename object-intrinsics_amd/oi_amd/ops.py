@@ -975,14 +975,42 @@ def ada_theta_xint_scale(seed, B, H, W, margins, p_xint, xint_max, p_scale, scal
     return (th, ts) if with_draws else th
 
 
-def ada_geom_fwd(x, theta, f12, margins):
-    """reflect pad + x2 up-FIR + affine resample + /2 down-FIR (AugmentPipe geometry) in two launches; see oi_ada_geom_fwd."""
+ADA_SEPARABLE = os.environ.get("OI_ADA_SEP", "1") != "0"   # axis-aligned matrices: the one-launch form (oi_ada_geom_sep_fwd)
+
+
+def ada_geom_sep_ok(x):
+    """The one-launch separable augmentation covers this image batch (1..3 channels of 64 x 64, fp32, on the GPU)."""
+    return (ADA_SEPARABLE and x.is_cuda and x.dim() == 4 and x.dtype is torch.float32 and x.shape[0] <= 65535
+            and bool(_l.load().oi_ada_geom_sep_supported(x.shape[1], x.shape[2], x.shape[3])))
+
+
+def ada_geom_sep_host(x, theta_np, f12, margins):
+    """oi_ada_geom_sep_fwd with AXIS-ALIGNED sampling matrices that live on the host ((B, 2, 3) float32 numpy: they travel in the
+    kernel arguments, nothing is uploaded).  No gradient."""
+    x, f12 = _c(x), _c(f12)
+    B, C, H, W = x.shape
+    mx0, my0, mx1, my1 = margins
+    th = np.ascontiguousarray(theta_np, np.float32)
+    assert th.shape == (B, 2, 3) and f12.numel() == 12
+    y = torch.empty_like(x)
+    _l.check(_l.load().oi_ada_geom_sep_fwd(_p(x), None, th.ctypes.data_as(_vp), _p(f12), _p(y), B, C, H, W, mx0, mx1, my0, my1,
+                                           _stream()), "oi_ada_geom_sep_fwd")
+    return y
+
+
+def ada_geom_fwd(x, theta, f12, margins, axis_aligned=False):
+    """reflect pad + x2 up-FIR + affine resample + /2 down-FIR (AugmentPipe geometry); see oi_ada_geom_fwd (two launches) and
+    oi_ada_geom_sep_fwd (one: `axis_aligned` is the caller's promise that no theta carries a rotation)."""
     L = _l.load()
     x, theta, f12 = _c(x), _c(theta), _c(f12)
     B, C, H, W = x.shape
     mx0, my0, mx1, my1 = margins
     assert f12.numel() == 12 and theta.shape == (B, 2, 3)
     y = torch.empty_like(x)
+    if axis_aligned and ADA_SEPARABLE and B <= 65535 and L.oi_ada_geom_sep_supported(C, H, W):
+        _l.check(L.oi_ada_geom_sep_fwd(_p(x), _p(theta), None, _p(f12), _p(y), B, C, H, W, mx0, mx1, my0, my1, _stream()),
+                 "oi_ada_geom_sep_fwd")
+        return y
     canvas = _new(x, B * C * 2 * (H + my0 + my1) * 2 * (W + mx0 + mx1))
     _l.check(L.oi_ada_geom_fwd(_p(x), _p(theta), _p(f12), _p(y), _p(canvas), B, C, H, W, mx0, mx1, my0, my1, _stream()),
              "oi_ada_geom_fwd")

@@ -8,7 +8,8 @@ import pytest
 import torch
 
 import oi_oracle as O
-from conftest import load_golden, maxdiff, sub_sd
+O_ref = O
+from conftest import load_golden, maxdiff, sub_sd, record_margin
 
 pytestmark = pytest.mark.gpu
 
@@ -672,6 +673,59 @@ def test_ada_geom_fused_matches_the_staged_chain(ops, B, C, R, static, monkeypat
         outs.append((y.detach(), gx.detach(), g2.detach()))
     for name, a, b in zip(("value", "gradient", "double backward"), outs[0], outs[1]):
         assert maxdiff(a, b) < 2e-6 * max(1.0, float(b.abs().max())), (name, maxdiff(a, b), float(b.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,static", [(2, 3, True), (5, 3, False), (3, 1, False), (64, 3, False)])
+def test_ada_geom_separable_matches_the_two_launch_form(ops, B, C, static, monkeypatch):
+    """oi_ada_geom_sep_fwd (one launch, y = A_y x A_x^T: what a pipe without rotations takes at 64 x 64) against oi_ada_geom_fwd
+    for flips, integer and fractional translations, isotropic and anisotropic scales, fitted and static margins: values, the
+    gradient to the images and the R1-style double backward (whose second pass is this forward again)."""
+    import oi_amd.augment as A
+    import oi_amd.ops as O
+    aug = A.AugmentPipe(xflip=1, xint=1, scale=1, aniso=1, xfrac=1).cuda()
+    np.random.seed(B * 11 + C)
+    R = 64
+    x = torch.rand(B, C, R, R, generator=torch.Generator().manual_seed(B)).cuda()
+    G = aug.sample_G_inv(x)
+    assert np.all(G[:, 0, 1] == 0) and np.all(G[:, 1, 0] == 0) and np.any(G[:, 0, 0] < 0) or B < 5   # (a flip among the draws)
+    margins = aug.static_margins(R, R) if static else aug.margins_for(G, R, R)
+    theta = torch.from_numpy(aug.theta_for(G, margins, R, R)).cuda()
+    assert float(theta[:, 0, 1].abs().max()) == 0.0 and float(theta[:, 1, 0].abs().max()) == 0.0
+    outs = []
+    for sep in (True, False):
+        monkeypatch.setattr(O, "ADA_SEPARABLE", sep)
+        xi = x.clone().requires_grad_()
+        y = aug.apply_theta(xi, theta, margins)
+        cot = torch.rand(y.shape, generator=torch.Generator().manual_seed(1)).cuda()
+        (gx,) = torch.autograd.grad((y * cot).sum(), xi, create_graph=True)
+        xi2 = x.clone().requires_grad_()
+        y2 = aug.apply_theta(xi2, theta, margins)
+        (g1,) = torch.autograd.grad(y2.square().sum(), xi2, create_graph=True)
+        (g2,) = torch.autograd.grad(g1.square().sum(), xi2)
+        outs.append((y.detach(), gx.detach(), g2.detach()))
+    if B <= 5:   # both against the staged chain in float64 (the oracle's own stages; its sampling coordinates are float64 too)
+        f64 = aug.Hz_geom.double().cpu()
+        mx0, my0, mx1, my1 = margins
+        xp = torch.nn.functional.pad(x.double().cpu(), [mx0, mx1, my0, my1], mode="reflect")
+        g = O_ref.affine_bilinear_sample(O_ref.upsample2d(xp, f64), theta.double().cpu(), 2 * (R + 6), 2 * (R + 6))
+        ref = O_ref.downsample2d(g, f64, down=2, padding=-6, flip=True)
+        for tag, got in (("separable", outs[0][0]), ("two-launch", outs[1][0])):
+            record_margin("ada_geom_vs_float64_stages", f"{tag} [{B}-{C}-{int(static)}]", maxdiff(got.cpu(), ref))
+            assert maxdiff(got.cpu(), ref) < 2e-5, (tag, maxdiff(got.cpu(), ref))
+    for name, a, b in zip(("value", "gradient", "double backward"), outs[0], outs[1]):
+        record_margin("ada_geom_separable_vs_two_launch", f"{name} [{B}-{C}-{int(static)}]", maxdiff(a, b) / max(1.0, float(b.abs().max())))
+        assert maxdiff(a, b) < 1.5e-6 * max(1.0, float(b.abs().max())), (name, maxdiff(a, b), float(b.abs().max()))   # (measured: <= 4.9e-7)
+    assert maxdiff(outs[0][0], outs[1][0]) > 0.0 or B == 0   # (two different kernels ran: not bit-identical by construction)
+    # a rotation in the pipe: the general form, whatever the switch says
+    monkeypatch.setattr(O, "ADA_SEPARABLE", True)
+    rot = A.AugmentPipe(xint=1, rotate=1).cuda()
+    Gr = rot.sample_G_inv(x)
+    mr = rot.margins_for(Gr, R, R)
+    tr = torch.from_numpy(rot.theta_for(Gr, mr, R, R)).cuda()
+    ya = rot.apply_theta(x, tr, mr)
+    monkeypatch.setattr(O, "ADA_SEPARABLE", False)
+    assert torch.equal(ya, rot.apply_theta(x, tr, mr))
 
 
 def test_gan_losses_fused_match_the_reference_composition():

@@ -1073,6 +1073,56 @@ def test_ada_discriminator_eager_forward_draws_in_the_library(B, in_dim, out_dim
         assert torch.equal(d, D._forward_small(x, f12=D.aug.Hz_geom, theta_np=th_p, margins=m))
 
 
+@pytest.mark.parametrize("B,in_dim,out_dim", [(64, 3, 7), (16, 1, 1)])
+def test_ada_discriminator_large_batch_forward_draws_in_the_library(B, in_dim, out_dim, monkeypatch):
+    """ADADiscriminator.forward without gradient at batch >= 16, the shipped xint + scale augmentation: parameters drawn inside the
+    library from one seed of numpy's stream, the matrices in the arguments of ONE augmentation launch (oi_ada_geom_sep_fwd), then
+    csrc/disc_large.hip.  (a) equal to the explicit route (the same seed's matrices, the two-launch augmentation, the same
+    network path) within the separable form's rounding; (b) against the fp64 oracle with the augmentation the library drew;
+    (c) FAST_ADA = False or a pinned debug_percentile takes the numpy route."""
+    import oi_amd.discriminator as DM
+    import oi_amd.ops as OPS
+    D = _ada_disc(in_dim, out_dim).cuda().eval()
+    with torch.no_grad():
+        for p_ in D.parameters():
+            p_.copy_((torch.rand_like(p_) * 2 - 1) * (6.0 / (1.04 * p_[0].numel())) ** 0.5)
+    H = W = 64
+    m = D.aug.static_margins(H, W)
+    x = torch.rand(B, in_dim, H, W, generator=torch.Generator().manual_seed(5)).cuda()
+    calls = []
+    real = OPS.ada_geom_sep_host
+    monkeypatch.setattr(OPS, "ada_geom_sep_host", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    np.random.seed(41)
+    with torch.no_grad():
+        got = D(x, it=0).clone()
+    assert calls == [1] and got.shape == (B, out_dim)
+    np.random.seed(41)
+    th, ts = D.aug.theta_fast(B, H, W, with_draws=True)
+    assert np.all(th[:, 0, 1] == 0) and np.all(th[:, 1, 0] == 0) and np.any(ts[:, 2] != 1)
+    with torch.no_grad():
+        xa = OPS.ada_geom_fwd(x, torch.from_numpy(th).cuda(), D.aug.Hz_geom, m)          # two launches, device matrices
+        want = DM.DCDiscriminator.forward(D, xa)
+    assert maxdiff(got, want) < 2e-5 * max(1.0, float(want.abs().max())), maxdiff(got, want)
+    if B <= 16:
+        dsd = {k: v.detach().double().cpu() for k, v in D.state_dict().items() if "aug." not in k}
+        t64, s64 = torch.from_numpy(ts[:, :2].astype(np.float64)), torch.from_numpy(ts[:, 2].astype(np.float64))
+        ref = O.dc_discriminator(dsd, O.ada_geometric(x.double().cpu(), O.ada_G_inv(B, H, W, t64, s64, dtype=torch.float64))[0])
+        assert maxdiff(got.cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max())), maxdiff(got.cpu(), ref)
+    with torch.no_grad():
+        monkeypatch.setattr(DM, "FAST_ADA", False)
+        np.random.seed(8); c = D(x).clone()
+        np.random.seed(8)
+        G = D.aug.sample_G_inv(x, None)
+        mf = D.aug.margins_for(G, H, W)
+        xa = OPS.ada_geom_fwd(x, torch.from_numpy(D.aug.theta_for(G, mf, H, W)).cuda(), D.aug.Hz_geom, mf)
+        assert calls == [1] and maxdiff(c, DM.DCDiscriminator.forward(D, xa)) < 2e-5 * max(1.0, float(c.abs().max()))
+        monkeypatch.setattr(DM, "FAST_ADA", True)
+        orig = D.aug.sample_G_inv
+        D.aug.sample_G_inv = lambda im, _pct=None: orig(im, 0.7)
+        D(x)
+        assert calls == [1]
+
+
 def test_step_tail_blob_in_prep_bit_identical_and_one_draw_jitter():
     """Round 6, the no-grad fused forward (generator._prep_fused): (a) the per-element blobs of the f16x3 MLP kernel formed by the
     prep launch's FiLM workgroups (oi_prep_render f3_blob + oi_sdf_mlp_fwd_ex OI_MLP_BLOB_READY) against the call's own blob
