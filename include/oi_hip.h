@@ -626,11 +626,17 @@ int oi_ada_geom_fwd(const float* x, const float* theta, const float* f, float* y
  * two entries), in ONE launch and without a canvas: the four stages are then separable, y_c = A_y x_c A_x^T with two H x H
  * matrices per image that a workgroup builds in LDS (csrc/disc.hip, ada_sep_kernel).  Equal to oi_ada_geom_fwd up to fp32
  * summation order (not bit-identical to it; deterministic).  Covered shapes: oi_ada_geom_sep_supported(C, H, W) != 0
- * (1..3 channels of 64 x 64); anything else is OI_ERR_INVALID_ARG -- use oi_ada_geom_fwd.
+ * (1..3 channels of 64 x 64 or 128 x 128; at 128 the matrices are accumulated in 32-bit fixed point); anything else is
+ * OI_ERR_INVALID_ARG -- use oi_ada_geom_fwd.
  * The matrices come from the device (theta) or from the HOST (theta_host, [B][2][3]: passed to the kernel by value, 64 images
  * per launch -- a caller that drew them on the host, e.g. with oi_ada_theta_xint_scale, uploads nothing); exactly one of the two. */
 int oi_ada_geom_sep_supported(int C, int H, int W);
 int oi_ada_geom_sep_fwd(const float* x, const float* theta, const float* theta_host, const float* f, float* y, int B, int C, int H,
+                        int W, int mx0, int mx1, int my0, int my1, oi_stream_t stream);
+/* The ADJOINT of that map, gx_c = A_y^T gy_c A_x (same arguments, same kernel with the matrices stored the other way round): the
+ * gradient of a loss with respect to the un-augmented images, one launch instead of the six adjoint stages
+ * (oi_upfirdn2d x 4, oi_affine_grid_sample_bwd, oi_reflect_pad_bwd); gx is written, not accumulated. */
+int oi_ada_geom_sep_adj(const float* gy, const float* theta, const float* theta_host, const float* f, float* gx, int B, int C, int H,
                         int W, int mx0, int mx1, int my0, int my1, oi_stream_t stream);
 
 /* Stand-alone plugin ops, for a caller that keeps the reference's own Python layers and only swaps the compiled ops

@@ -696,14 +696,26 @@ ada_resample_down2_kernel(const float* __restrict__ canvas, const float* __restr
 #ifndef OI_AS_THREADS
 #define OI_AS_THREADS 1024
 #endif
-constexpr int AS_N = 64, AS_RB = 16, AS_THREADS = OI_AS_THREADS, AS_NW = AS_THREADS / 64, AS_MAX_C = 3;
-constexpr int AS_XS = 80, AS_ZS = 68;   // LDS row strides (floats) of MFMA B / A operands: the 64 lanes of a fragment read 64 banks
-// LDS (bytes): fixed-point A_x^T [src][out] | fixed-point A_y rows [src][16] | A_x^T | A_y rows | image [C][64] rows | Z [C * 16] rows | taps
-constexpr int AS_O_FX = 0, AS_O_FY = AS_O_FX + AS_N * AS_N * 8, AS_O_AX = AS_O_FY + AS_RB * AS_N * 8;
-constexpr int AS_O_AY = AS_O_AX + AS_N * AS_XS * 4, AS_O_X = AS_O_AY + AS_RB * AS_ZS * 4;
-constexpr int AS_O_Z = AS_O_X + AS_MAX_C * AS_N * AS_XS * 4, AS_O_F = AS_O_Z + AS_MAX_C * AS_RB * AS_ZS * 4;
-constexpr int AS_LDS_BYTES = AS_O_F + 2 * ADA_TAPS * 4;
-static_assert(AS_LDS_BYTES <= 160 * 1024, "ada_sep_kernel: LDS");
+constexpr int AS_RB = 16, AS_THREADS = OI_AS_THREADS, AS_NW = AS_THREADS / 64, AS_MAX_C = 3;
+// Per image edge N (64: BASELINE's discriminators; 128: the shipped ones).  LDS row strides (floats) of the MFMA operands are
+// chosen so that the 64 lanes of a fragment read 64 banks: B operands [k][n] N + 16, A operands [m][k] N + 4.
+//   N = 64:  the matrices are accumulated as 2^-56 fixed point in 64 bits and converted into their own float arrays; the image
+//            is staged in LDS (61 KB);
+//   N = 128: 64-bit accumulators of A_x alone would be 128 KB: 32-bit, 2^-27 (each term rounded to nearest: 144 terms stay
+//            near fp32's own 2^-24), converted IN PLACE; the image is not staged -- the first product's B fragments come
+//            straight from memory (the eight row blocks of an image read the same 196 KB: L2).
+template <int N>
+struct AsCfg {
+  static constexpr bool WIDE = N == 64;                 // 64-bit fixed point, separate float arrays, image in LDS
+  static constexpr int XS = N + 16, ZS = N + 4;
+  static constexpr int FXS = WIDE ? N + 1 : XS;         // row stride of the fixed-point A_x (WIDE adjoint: rows on the lanes -> other banks)
+  static constexpr int FB = WIDE ? 8 : 4;               // bytes per accumulator
+  static constexpr int O_FX = 0, O_FY = O_FX + N * FXS * FB, O_FEND = O_FY + N * AS_RB * FB;
+  static constexpr int O_AX = WIDE ? O_FEND : O_FX, O_AY = WIDE ? O_AX + N * XS * 4 : O_FEND;
+  static constexpr int O_X = O_AY + AS_RB * ZS * 4, O_Z = O_X + (WIDE ? AS_MAX_C * N * XS * 4 : 0);
+  static constexpr int O_F = O_Z + AS_MAX_C * AS_RB * ZS * 4, LDS_BYTES = O_F + 2 * ADA_TAPS * 4;
+  static_assert(LDS_BYTES <= 160 * 1024 && O_FEND % 16 == 0, "ada_sep_kernel: LDS");
+};
 
 // 1-D sampling coordinate on the canvas axis: affine_src with the other axis' coefficient zero, in ITS operations (the product
 // and the sum round separately there: the zero term sits between them) -- the same bits, so the same bilinear weights
@@ -719,6 +731,8 @@ __device__ __forceinline__ float sep_coord(float ts, float tt, int g, int No, in
 // depend on the order the threads add in, and an entry of A is rounded to fp32 ONCE, after its terms have cancelled.
 __device__ __forceinline__ int sep_fix28(float v) { return (int)rintf(v * 268435456.0f); }
 __device__ __forceinline__ float sep_from_fix(long long v) { return (float)((double)v * (1.0 / 72057594037927936.0)); }
+__device__ __forceinline__ float sep_from_fix(int v) { return (float)v * (1.0f / 134217728.0f); }   // (|v| < 2^31: two roundings of
+                                                                                                    //  an entry, 2^-27 then fp32)
 
 // the sampling matrices of up to AS_BYVAL images in the kernel arguments (a caller that drew them on the host: no upload)
 constexpr int AS_BYVAL = 64;
@@ -726,45 +740,55 @@ struct AsTheta {
   float t[AS_BYVAL][6];
 };
 
-template <int C, bool BYVAL>
+// ADJ: the adjoint map gx_c = A_y^T gy_c A_x (the backward of the forward map, and -- the map being linear -- what the R1
+// penalty's second pass differentiates): the same kernel with the matrices stored the other way round; a workgroup's 16 rows of
+// A_y^T are 16 COLUMNS of A_y, so all N rows of A_y are walked and the terms that land in the block are kept.
+template <int N, int C, bool BYVAL, bool ADJ>
 __global__ void __launch_bounds__(AS_THREADS)
 ada_sep_kernel(const float* __restrict__ x, const float* __restrict__ theta, const AsTheta thv, const float* __restrict__ f,
                float* __restrict__ y, int mx0, int my0, int Wp, int Hp) {
+  using K = AsCfg<N>;
+  using FX = std::conditional_t<K::WIDE, unsigned long long, unsigned>;
+  using FXS_ = std::conditional_t<K::WIDE, long long, int>;
+  constexpr int XS = K::XS, ZS = K::ZS, LOGN = N == 64 ? 6 : 7;
   extern __shared__ __attribute__((aligned(16))) char as_lds[];
-  unsigned long long* fxx = reinterpret_cast<unsigned long long*>(as_lds + AS_O_FX);   // [source x][output x]
-  unsigned long long* fxy = reinterpret_cast<unsigned long long*>(as_lds + AS_O_FY);   // [source y][row of the block]
-  float* axt = reinterpret_cast<float*>(as_lds + AS_O_AX);
-  float* ayb = reinterpret_cast<float*>(as_lds + AS_O_AY);
-  float* xs = reinterpret_cast<float*>(as_lds + AS_O_X);
-  float* zb = reinterpret_cast<float*>(as_lds + AS_O_Z);
-  int* fs = reinterpret_cast<int*>(as_lds + AS_O_F);   // down-FIR taps (flip_filter: the filter itself), 2^-28 fixed point
+  FX* fxx = reinterpret_cast<FX*>(as_lds + K::O_FX);   // forward [source x][output x], adjoint [output x][source x]
+  FX* fxy = reinterpret_cast<FX*>(as_lds + K::O_FY);   // [k of the first product][row of the block]
+  float* axt = reinterpret_cast<float*>(as_lds + K::O_AX);
+  float* ayb = reinterpret_cast<float*>(as_lds + K::O_AY);
+  float* xs = reinterpret_cast<float*>(as_lds + K::O_X);
+  float* zb = reinterpret_cast<float*>(as_lds + K::O_Z);
+  int* fs = reinterpret_cast<int*>(as_lds + K::O_F);   // down-FIR taps (flip_filter: the filter itself), 2^-28 fixed point
   int* fr = fs + ADA_TAPS;                             // up-FIR taps: reversed, sqrt(gain) = 2 per axis
   const int tid = threadIdx.x, b = blockIdx.y, rb = blockIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  // the image: requested first
-  constexpr int NX = C * AS_N * AS_N / (4 * AS_THREADS);   // b128 loads per thread
+  const float* xb = x + (size_t)b * C * N * N;
+  // WIDE: the image is requested first
+  constexpr int NX = K::WIDE ? C * N * N / (4 * AS_THREADS) : 1;   // b128 loads per thread
   f32x4 xv[NX];
-  const float* xb = x + (size_t)b * C * AS_N * AS_N;
+  if constexpr (K::WIDE) {
 #pragma unroll
-  for (int i = 0; i < NX; ++i) xv[i] = *reinterpret_cast<const f32x4*>(xb + 4 * (tid + i * AS_THREADS));
+    for (int i = 0; i < NX; ++i) xv[i] = *reinterpret_cast<const f32x4*>(xb + 4 * (tid + i * AS_THREADS));
+  }
   const float tsx = BYVAL ? thv.t[b][0] : theta[b * 6 + 0], ttx = BYVAL ? thv.t[b][2] : theta[b * 6 + 2];
   const float tsy = BYVAL ? thv.t[b][4] : theta[b * 6 + 4], tty = BYVAL ? thv.t[b][5] : theta[b * 6 + 5];
   if (tid < ADA_TAPS) {
     fs[tid] = sep_fix28(f[tid]);
     fr[tid] = sep_fix28(2.0f * f[ADA_TAPS - 1 - tid]);
   }
-  for (int i = tid; i < ((OI_AS_ABL & 8) ? 0 : (AS_O_AX - AS_O_FX) / 16); i += AS_THREADS) reinterpret_cast<f32x4*>(as_lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < ((OI_AS_ABL & 8) ? 0 : (K::O_FEND - K::O_FX) / 16); i += AS_THREADS)
+    reinterpret_cast<f32x4*>(as_lds + K::O_FX)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   // the matrices: one task per (row, down-FIR tap k, bilinear corner c) = 6 products through the up-FIR and the reflect pad
-  constexpr int NTASK = (AS_N + AS_RB) * ADA_TAPS * 2;
+  constexpr int NROW = N + (ADJ ? N : AS_RB), NTASK = NROW * ADA_TAPS * 2;
   for (int t_ = tid; t_ < ((OI_AS_ABL & 1) ? 0 : NTASK); t_ += AS_THREADS) {
-    // (the row on the lane: the 64-bit adds of a wave then go to different addresses -- with the taps on the lane up to 24 lanes
+    // (the row on the lane: the adds of a wave then go to different addresses -- with the taps on the lane up to 24 lanes
     // met in one)
-    const int kc = t_ / (AS_N + AS_RB), row = t_ - kc * (AS_N + AS_RB), k = kc >> 1, c = kc & 1;
-    const bool isx = row < AS_N;
-    const int a = isx ? row : rb * AS_RB + (row - AS_N);
+    const int kc = t_ / NROW, row = t_ - kc * NROW, k = kc >> 1, c = kc & 1;
+    const bool isx = row < N;
+    const int a = isx ? row : (ADJ ? row - N : rb * AS_RB + (row - N));
     const int m0 = isx ? mx0 : my0, Np = isx ? Wp : Hp, Nc = 2 * Np;
-    const float ic = sep_coord(isx ? tsx : tsy, isx ? ttx : tty, 2 * a + k + 1, 2 * (AS_N + ADA_PAD), Nc);
+    const float ic = sep_coord(isx ? tsx : tsy, isx ? ttx : tty, 2 * a + k + 1, 2 * (N + ADA_PAD), Nc);
     const float fl = floorf(ic), tt_ = ic - fl;
     const int u = (int)fl + c;
     if (u < 0 || u >= Nc) continue;
@@ -774,48 +798,129 @@ ada_sep_kernel(const float* __restrict__ x, const float* __restrict__ theta, con
     for (int q = 0; q < 6; ++q) {
       const int r = base + q;
       if (r < 0 || r >= Np) continue;
-      const int sidx = reflect_idx(r - m0, AS_N);
-      atomicAdd(isx ? fxx + sidx * AS_N + a : fxy + sidx * AS_RB + (row - AS_N), (unsigned long long)((long long)wc * fr[ku + 2 * q]));
+      const int sidx = reflect_idx(r - m0, N);
+      FX* dst;
+      if constexpr (ADJ) {
+        const int i = sidx - rb * AS_RB;
+        if (!isx && (i < 0 || i >= AS_RB)) continue;
+        dst = isx ? fxx + a * K::FXS + sidx : fxy + a * AS_RB + i;
+      } else {
+        dst = isx ? fxx + sidx * (K::WIDE ? N : XS) + a : fxy + sidx * AS_RB + (row - N);
+      }
+      const long long term = (long long)wc * fr[ku + 2 * q];   // 2^-56
+      if constexpr (K::WIDE) atomicAdd(dst, (FX)term);
+      else atomicAdd(dst, (FX)(int)((term + (1ll << 28)) >> 29));   // 2^-27, to nearest
     }
   }
   __syncthreads();
-  for (int i = tid; i < AS_N * AS_N; i += AS_THREADS) axt[(i >> 6) * AS_XS + (i & 63)] = sep_from_fix((long long)fxx[i]);
-  for (int i = tid; i < AS_RB * AS_N; i += AS_THREADS) ayb[(i & 15) * AS_ZS + (i >> 4)] = sep_from_fix((long long)fxy[i]);
+  // the second product's B operand [k][n]: forward k = source, adjoint k = output
+  if constexpr (K::WIDE) {
+    for (int i = tid; i < N * N; i += AS_THREADS)
+      axt[(i >> LOGN) * XS + (i & (N - 1))] = sep_from_fix((FXS_)fxx[(i >> LOGN) * (ADJ ? K::FXS : N) + (i & (N - 1))]);
+  } else {
+    for (int i = tid; i < N * N; i += AS_THREADS) {   // in place: the thread that reads a word writes it
+      const int o = (i >> LOGN) * XS + (i & (N - 1));
+      axt[o] = sep_from_fix((FXS_)fxx[o]);
+    }
+  }
+  for (int i = tid; i < AS_RB * N; i += AS_THREADS) ayb[(i & 15) * ZS + (i >> 4)] = sep_from_fix((FXS_)fxy[i]);
+  if constexpr (K::WIDE) {
 #pragma unroll
-  for (int i = 0; i < NX; ++i) {
-    const int e = 4 * (tid + i * AS_THREADS);   // element of [C][64][64]: row e / 64, column e % 64
-    *reinterpret_cast<f32x4*>(xs + (e >> 6) * AS_XS + (e & 63)) = xv[i];
+    for (int i = 0; i < NX; ++i) {
+      const int e = 4 * (tid + i * AS_THREADS);   // element of [C][N][N]: row e / N, column e % N
+      *reinterpret_cast<f32x4*>(xs + (e >> LOGN) * XS + (e & (N - 1))) = xv[i];
+    }
   }
   __syncthreads();
   // two small products on the matrix cores (exact fp32 operands, v_mfma_f32_16x16x4_f32: A lane = (row l % 16, k l / 16),
   // B lane = (k l / 16, column l % 16), D lane = (rows 4 (l / 16) + r, column l % 16)); a wave takes tiles wave, wave + AS_NW, ..
   const int l16 = lane & 15, kq = lane >> 4;
-  {  // Z_c = A_y[block] X_c: per channel 16 x 64, K = 64 source rows
-    float ay[16];
+  constexpr int KS = N / 4, NT = N / 16;
+  {  // Z_c = A_y[block] X_c: per channel 16 x N, K = N source rows
+    float ay[KS];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) ay[kk] = ayb[l16 * AS_ZS + 4 * kk + kq];
-    for (int p = wave; p < ((OI_AS_ABL & 2) ? 0 : C * 4); p += AS_NW) {
-      const int c = p >> 2, nt = p & 3;
+    for (int kk = 0; kk < KS; ++kk) ay[kk] = ayb[l16 * ZS + 4 * kk + kq];
+    for (int p = wave; p < ((OI_AS_ABL & 2) ? 0 : C * NT); p += AS_NW) {
+      const int c = p / NT, nt = p - c * NT;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (K::WIDE) {
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ay[kk], xs[(c * AS_N + 4 * kk + kq) * AS_XS + 16 * nt + l16], acc, 0, 0, 0);
+        for (int kk = 0; kk < KS; ++kk)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ay[kk], xs[(c * N + 4 * kk + kq) * XS + 16 * nt + l16], acc, 0, 0, 0);
+      } else {
+        float bv[KS];   // every load of the tile in flight before the first product
 #pragma unroll
-      for (int r = 0; r < 4; ++r) zb[(c * AS_RB + 4 * kq + r) * AS_ZS + 16 * nt + l16] = acc[r];
+        for (int kk = 0; kk < KS; ++kk) bv[kk] = xb[(size_t)(c * N + 4 * kk + kq) * N + 16 * nt + l16];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ay[kk], bv[kk], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zb[(c * AS_RB + 4 * kq + r) * ZS + 16 * nt + l16] = acc[r];
     }
   }
   __syncthreads();
-  for (int p = wave; p < ((OI_AS_ABL & 4) ? 0 : C * 4); p += AS_NW) {   // Y = Z A_x^T: (C 16) x 64, K = 64 source columns
-    const int c = p >> 2, nt = p & 3;
+  for (int p = wave; p < ((OI_AS_ABL & 4) ? 0 : C * NT); p += AS_NW) {   // Y = Z A_x^T: (C 16) x N, K = N
+    const int c = p / NT, nt = p - c * NT;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk)
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zb[(c * AS_RB + l16) * AS_ZS + 4 * kk + kq], axt[(4 * kk + kq) * AS_XS + 16 * nt + l16],
+    for (int kk = 0; kk < KS; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zb[(c * AS_RB + l16) * ZS + 4 * kk + kq], axt[(4 * kk + kq) * XS + 16 * nt + l16],
                                                  acc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      y[(((size_t)b * C + c) * AS_N + rb * AS_RB + 4 * kq + r) * AS_N + 16 * nt + l16] = acc[r];
+      y[(((size_t)b * C + c) * N + rb * AS_RB + 4 * kq + r) * N + 16 * nt + l16] = acc[r];
   }
+}
+
+template <int N>
+int ada_sep_launch_n(const char* who, bool adj, const float* x, const float* theta, const float* theta_host, const float* f,
+                            float* y, int B, int C, int mx0, int my0, int Wp, int Hp, hipStream_t st) {
+  constexpr int lds = AsCfg<N>::LDS_BYTES;
+  auto launch = [&](auto k, const float* xb, const float* th, const AsTheta& tv, float* yb, int nb) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(k, dim3(N / AS_RB, nb), dim3(AS_THREADS), lds, st, xb, th, tv, f, yb, mx0, my0, Wp, Hp);
+  };
+  auto pick = [&](auto byval, const float* xb, const float* th, const AsTheta& tv, float* yb, int nb) {
+    constexpr bool BV = decltype(byval)::value;
+    if (adj) {
+      if (C == 1) launch(ada_sep_kernel<N, 1, BV, true>, xb, th, tv, yb, nb);
+      else if (C == 2) launch(ada_sep_kernel<N, 2, BV, true>, xb, th, tv, yb, nb);
+      else launch(ada_sep_kernel<N, 3, BV, true>, xb, th, tv, yb, nb);
+    } else {
+      if (C == 1) launch(ada_sep_kernel<N, 1, BV, false>, xb, th, tv, yb, nb);
+      else if (C == 2) launch(ada_sep_kernel<N, 2, BV, false>, xb, th, tv, yb, nb);
+      else launch(ada_sep_kernel<N, 3, BV, false>, xb, th, tv, yb, nb);
+    }
+  };
+  if (theta != nullptr) {
+    static const AsTheta none{};
+    pick(std::false_type{}, x, theta, none, y, B);
+    return oi::check_launch(who);
+  }
+  for (int b0 = 0; b0 < B; b0 += AS_BYVAL) {   // the matrices by value: AS_BYVAL images per launch
+    const int nb = std::min(AS_BYVAL, B - b0);
+    AsTheta tv;
+    for (int i = 0; i < nb * 6; ++i) tv.t[i / 6][i % 6] = theta_host[(size_t)b0 * 6 + i];
+    pick(std::true_type{}, x + (size_t)b0 * C * N * N, nullptr, tv, y + (size_t)b0 * C * N * N, nb);
+    int rc = oi::check_launch(who);
+    if (rc != OI_OK) return rc;
+  }
+  return OI_OK;
+}
+
+int ada_sep_launch(const char* who, bool adj, const float* x, const float* theta, const float* theta_host, const float* f,
+                          float* y, int B, int C, int H, int W, int mx0, int mx1, int my0, int my1, oi_stream_t stream) {
+  OI_REQUIRE(x && f && y, "%s: null pointer", who);
+  OI_REQUIRE((theta != nullptr) != (theta_host != nullptr), "%s: the sampling matrices on the device OR on the host", who);
+  OI_REQUIRE(B > 0 && B <= 65535, "%s: batch %d", who, B);
+  OI_REQUIRE(oi_ada_geom_sep_supported(C, H, W), "%s: %d x %d x %d images (covered: 1..%d channels of 64 x 64 or 128 x 128)", who, C, H,
+             W, AS_MAX_C);
+  OI_REQUIRE(mx0 >= 0 && mx1 >= 0 && my0 >= 0 && my1 >= 0 && mx0 < W && mx1 < W && my0 < H && my1 < H,
+             "%s: reflect margins must be in [0, size)", who);
+  const int Hp = H + my0 + my1, Wp = W + mx0 + mx1;
+  hipStream_t st = oi::as_stream(stream);
+  return H == 64 ? ada_sep_launch_n<64>(who, adj, x, theta, theta_host, f, y, B, C, mx0, my0, Wp, Hp, st)
+                 : ada_sep_launch_n<128>(who, adj, x, theta, theta_host, f, y, B, C, mx0, my0, Wp, Hp, st);
 }
 
 }  // namespace
@@ -856,44 +961,16 @@ int oi_ada_geom_fwd(const float* x, const float* theta, const float* f, float* y
   return oi::check_launch("oi_ada_geom_fwd(resample + downsample)");
 }
 
-int oi_ada_geom_sep_supported(int C, int H, int W) { return (C >= 1 && C <= AS_MAX_C && H == AS_N && W == AS_N) ? 1 : 0; }
+int oi_ada_geom_sep_supported(int C, int H, int W) { return (C >= 1 && C <= AS_MAX_C && H == W && (H == 64 || H == 128)) ? 1 : 0; }
 
 int oi_ada_geom_sep_fwd(const float* x, const float* theta, const float* theta_host, const float* f, float* y, int B, int C, int H,
                         int W, int mx0, int mx1, int my0, int my1, oi_stream_t stream) {
-  OI_REQUIRE(x && f && y, "oi_ada_geom_sep_fwd: null pointer");
-  OI_REQUIRE((theta != nullptr) != (theta_host != nullptr), "oi_ada_geom_sep_fwd: the sampling matrices on the device OR on the host");
-  OI_REQUIRE(B > 0 && B <= 65535, "oi_ada_geom_sep_fwd: batch %d", B);
-  OI_REQUIRE(oi_ada_geom_sep_supported(C, H, W), "oi_ada_geom_sep_fwd: %d x %d x %d images (covered: 1..%d channels of %d x %d)", C, H, W,
-             AS_MAX_C, AS_N, AS_N);
-  OI_REQUIRE(mx0 >= 0 && mx1 >= 0 && my0 >= 0 && my1 >= 0 && mx0 < W && mx1 < W && my0 < H && my1 < H,
-             "oi_ada_geom_sep_fwd: reflect margins must be in [0, size)");
-  const int Hp = H + my0 + my1, Wp = W + mx0 + mx1;
-  hipStream_t st = oi::as_stream(stream);
-  constexpr int lds = AS_LDS_BYTES;
-  auto launch = [&](auto k, const float* xb, const float* th, const AsTheta& tv, float* yb, int nb) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k, dim3(AS_N / AS_RB, nb), dim3(AS_THREADS), lds, st, xb, th, tv, f, yb, mx0, my0, Wp, Hp);
-  };
-  if (theta != nullptr) {
-    static const AsTheta none{};
-    if (C == 1) launch(ada_sep_kernel<1, false>, x, theta, none, y, B);
-    else if (C == 2) launch(ada_sep_kernel<2, false>, x, theta, none, y, B);
-    else launch(ada_sep_kernel<3, false>, x, theta, none, y, B);
-    return oi::check_launch("oi_ada_geom_sep_fwd");
-  }
-  for (int b0 = 0; b0 < B; b0 += AS_BYVAL) {   // the matrices by value: AS_BYVAL images per launch
-    const int nb = std::min(AS_BYVAL, B - b0);
-    AsTheta tv;
-    for (int i = 0; i < nb * 6; ++i) tv.t[i / 6][i % 6] = theta_host[(size_t)b0 * 6 + i];
-    const float* xb = x + (size_t)b0 * C * H * W;
-    float* yb = y + (size_t)b0 * C * H * W;
-    if (C == 1) launch(ada_sep_kernel<1, true>, xb, nullptr, tv, yb, nb);
-    else if (C == 2) launch(ada_sep_kernel<2, true>, xb, nullptr, tv, yb, nb);
-    else launch(ada_sep_kernel<3, true>, xb, nullptr, tv, yb, nb);
-    int rc = oi::check_launch("oi_ada_geom_sep_fwd");
-    if (rc != OI_OK) return rc;
-  }
-  return OI_OK;
+  return ada_sep_launch("oi_ada_geom_sep_fwd", false, x, theta, theta_host, f, y, B, C, H, W, mx0, mx1, my0, my1, stream);
+}
+
+int oi_ada_geom_sep_adj(const float* gy, const float* theta, const float* theta_host, const float* f, float* gx, int B, int C, int H,
+                        int W, int mx0, int mx1, int my0, int my1, oi_stream_t stream) {
+  return ada_sep_launch("oi_ada_geom_sep_adj", true, gy, theta, theta_host, f, gx, B, C, H, W, mx0, mx1, my0, my1, stream);
 }
 
 int oi_conv4x4_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int H, int W, int Cout,

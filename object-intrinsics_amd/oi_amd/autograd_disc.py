@@ -159,6 +159,8 @@ class _AdaGeomAdjoint(torch.autograd.Function):
     def forward(ctx, gy, theta, f1, margins, axis_aligned=False):
         ctx.save_for_backward(theta, f1)
         ctx.margins, ctx.axis_aligned = tuple(margins), bool(axis_aligned)
+        if axis_aligned and ops.ada_geom_sep_ok(gy):
+            return ops.ada_geom_adj_sep(gy, theta, f1, margins)   # one launch: A_y^T gy A_x
         return _ada_geom_adjoint(gy, theta, f1, gy.shape[2], gy.shape[3], margins)
 
     @staticmethod

@@ -107,6 +107,7 @@ _SIGS = {
     "oi_ada_geom_fwd": (_i, [_vp] * 5 + [_i] * 8 + [_vp]),
     "oi_ada_geom_sep_supported": (_i, [_i] * 3),
     "oi_ada_geom_sep_fwd": (_i, [_vp] * 5 + [_i] * 8 + [_vp]),
+    "oi_ada_geom_sep_adj": (_i, [_vp] * 5 + [_i] * 8 + [_vp]),
     "oi_ada_pad_up2": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "oi_disc_fwd_small_workspace_floats": (_sz, [_i] * 6),
     "oi_disc_fwd_small": (_i, [_vp] * 4 + [_i] * 4 + [_vp] * 9 + [_i] * 6 + [_f, _vp]),

@@ -998,6 +998,17 @@ def ada_geom_sep_host(x, theta_np, f12, margins):
     return y
 
 
+def ada_geom_adj_sep(gy, theta, f12, margins):
+    """A^T gy for AXIS-ALIGNED device matrices in one launch (oi_ada_geom_sep_adj); the caller checked ada_geom_sep_ok(gy)."""
+    gy, theta, f12 = _c(gy), _c(theta), _c(f12)
+    B, C, H, W = gy.shape
+    mx0, my0, mx1, my1 = margins
+    gx = torch.empty_like(gy)
+    _l.check(_l.load().oi_ada_geom_sep_adj(_p(gy), _p(theta), None, _p(f12), _p(gx), B, C, H, W, mx0, mx1, my0, my1, _stream()),
+             "oi_ada_geom_sep_adj")
+    return gx
+
+
 def ada_geom_fwd(x, theta, f12, margins, axis_aligned=False):
     """reflect pad + x2 up-FIR + affine resample + /2 down-FIR (AugmentPipe geometry); see oi_ada_geom_fwd (two launches) and
     oi_ada_geom_sep_fwd (one: `axis_aligned` is the caller's promise that no theta carries a rotation)."""

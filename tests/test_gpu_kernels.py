@@ -676,16 +676,16 @@ def test_ada_geom_fused_matches_the_staged_chain(ops, B, C, R, static, monkeypat
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,C,static", [(2, 3, True), (5, 3, False), (3, 1, False), (64, 3, False)])
-def test_ada_geom_separable_matches_the_two_launch_form(ops, B, C, static, monkeypatch):
-    """oi_ada_geom_sep_fwd (one launch, y = A_y x A_x^T: what a pipe without rotations takes at 64 x 64) against oi_ada_geom_fwd
+@pytest.mark.parametrize("B,C,static,R", [(2, 3, True, 64), (5, 3, False, 64), (3, 1, False, 64), (64, 3, False, 64), (2, 3, True, 128),
+                                          (3, 1, False, 128)])
+def test_ada_geom_separable_matches_the_two_launch_form(ops, B, C, static, R, monkeypatch):
+    """oi_ada_geom_sep_fwd (one launch, y = A_y x A_x^T: what a pipe without rotations takes at 64 x 64 and 128 x 128) against oi_ada_geom_fwd
     for flips, integer and fractional translations, isotropic and anisotropic scales, fitted and static margins: values, the
     gradient to the images and the R1-style double backward (whose second pass is this forward again)."""
     import oi_amd.augment as A
     import oi_amd.ops as O
     aug = A.AugmentPipe(xflip=1, xint=1, scale=1, aniso=1, xfrac=1).cuda()
     np.random.seed(B * 11 + C)
-    R = 64
     x = torch.rand(B, C, R, R, generator=torch.Generator().manual_seed(B)).cuda()
     G = aug.sample_G_inv(x)
     assert np.all(G[:, 0, 1] == 0) and np.all(G[:, 1, 0] == 0) and np.any(G[:, 0, 0] < 0) or B < 5   # (a flip among the draws)
@@ -711,10 +711,11 @@ def test_ada_geom_separable_matches_the_two_launch_form(ops, B, C, static, monke
         g = O_ref.affine_bilinear_sample(O_ref.upsample2d(xp, f64), theta.double().cpu(), 2 * (R + 6), 2 * (R + 6))
         ref = O_ref.downsample2d(g, f64, down=2, padding=-6, flip=True)
         for tag, got in (("separable", outs[0][0]), ("two-launch", outs[1][0])):
-            record_margin("ada_geom_vs_float64_stages", f"{tag} [{B}-{C}-{int(static)}]", maxdiff(got.cpu(), ref))
-            assert maxdiff(got.cpu(), ref) < 2e-5, (tag, maxdiff(got.cpu(), ref))
+            record_margin("ada_geom_vs_float64_stages", f"{tag} [{B}-{C}-{int(static)}-{R}]", maxdiff(got.cpu(), ref))
+            # (fp32 sampling coordinates on a canvas of up to 2 (3 R - 2) pixels: 1.3e-5 measured at 64, 2.7e-5 at 128, both forms)
+            assert maxdiff(got.cpu(), ref) < 2e-5 * R / 64, (tag, maxdiff(got.cpu(), ref))
     for name, a, b in zip(("value", "gradient", "double backward"), outs[0], outs[1]):
-        record_margin("ada_geom_separable_vs_two_launch", f"{name} [{B}-{C}-{int(static)}]", maxdiff(a, b) / max(1.0, float(b.abs().max())))
+        record_margin("ada_geom_separable_vs_two_launch", f"{name} [{B}-{C}-{int(static)}-{R}]", maxdiff(a, b) / max(1.0, float(b.abs().max())))
         assert maxdiff(a, b) < 1.5e-6 * max(1.0, float(b.abs().max())), (name, maxdiff(a, b), float(b.abs().max()))   # (measured: <= 4.9e-7)
     assert maxdiff(outs[0][0], outs[1][0]) > 0.0 or B == 0   # (two different kernels ran: not bit-identical by construction)
     # a rotation in the pipe: the general form, whatever the switch says
