@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = sys.argv[1] if len(sys.argv) > 1 else "/tmp/oi_margins.json"
 env = dict(os.environ, OI_MARGIN_OUT=out)
-sel = "full_size_render_properties or mlp_backward or f6 or f7 or f9 or f14 or c2_size or c4_size or composite_backward or bf16 or color_network or reference_style"
+sel = "full_size_render_properties or mlp_backward or f6 or f7 or f9 or f14 or c2_size or c4_size or composite_backward or bf16 or color_network or reference_style or ada_geom_separable"
 r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-q", "-m", "gpu", "-k", sel, "-p",
                     "no:cacheprovider"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 print(r.stdout.strip().splitlines()[-1])

@@ -63,7 +63,7 @@ python $R/tools/traffic_json.py $O/${T}_pmc_fetch_f16x3.txt $O/${T}_pmc_write_f1
 # the batch-64 discriminator forward (csrc/disc_large.hip): one step's timeline + kernel stats
 rm -rf /tmp/p_d64; $RP --kernel-trace --stats --output-format csv -d /tmp/p_d64 -- python $R/tools/dbg/prof_disc64.py > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/p_d64 $O/${T}_kernel_stats_disc_b64.txt > /dev/null
-python $R/tools/dbg/timeline.py /tmp/p_d64 $O/${T}_timeline_disc_b64.txt ada_pad_up2_kernel > /dev/null
+python $R/tools/dbg/timeline.py /tmp/p_d64 $O/${T}_timeline_disc_b64.txt ada_sep_kernel > /dev/null
 # the stand-alone albedo head (oi_color_head_fwd / _bwd) at the C2 point count
 timeout 300 python $R/tools/dbg/time_color_head.py > $O/${T}_color_head.txt 2>/dev/null
 # the same dominant kernel at the C4 per-GPU size (128^2 rays, 128 + 128 samples, 4 up-sampling steps: eight times the points)
