@@ -729,6 +729,29 @@ def test_ada_geom_separable_matches_the_two_launch_form(ops, B, C, static, R, mo
     assert torch.equal(ya, rot.apply_theta(x, tr, mr))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,C,B", [(64, 1, 70), (128, 3, 3)])
+def test_ada_geom_separable_host_matrices_equal_device_matrices(ops, R, C, B):
+    """oi_ada_geom_sep_fwd with the sampling matrices by value (64 images per launch: batch 70 = two launches) against the same
+    matrices read from device memory: the same kernel arithmetic, bit-identical; the adjoint entry satisfies <A x, g> = <x, A^T g>."""
+    import oi_amd.augment as A
+    import oi_amd.ops as OPS
+    aug = A.AugmentPipe(xint=1, scale=1).cuda()
+    np.random.seed(R + B)
+    x = torch.rand(B, C, R, R, generator=torch.Generator().manual_seed(2)).cuda()
+    m = aug.static_margins(R, R)
+    th = aug.theta_fast(B, R, R)
+    y_host = OPS.ada_geom_sep_host(x, th, aug.Hz_geom, m)
+    thd = torch.from_numpy(th).cuda()
+    y_dev = OPS.ada_geom_fwd(x, thd, aug.Hz_geom, m, axis_aligned=True)
+    assert torch.equal(y_host, y_dev)
+    g = torch.rand(y_dev.shape, generator=torch.Generator().manual_seed(3)).cuda()
+    gx = OPS.ada_geom_adj_sep(g, thd, aug.Hz_geom, m)
+    lhs, rhs = float((y_dev.double() * g.double()).sum()), float((x.double() * gx.double()).sum())
+    assert abs(lhs - rhs) < 2e-6 * abs(lhs), (lhs, rhs)
+    assert torch.equal(gx, OPS.ada_geom_adj_sep(g, thd, aug.Hz_geom, m))   # (fixed-point build: bit-reproducible)
+
+
 def test_gan_losses_fused_match_the_reference_composition():
     """oi_gan_losses_fwd / _bwd (one launch each way) against GANLoss + compute_grad2 + PositionLoss summed as the trainer
     sums them (src/loss/gan.py:5-22, 39-49; src/loss/position.py:4-18; gan_pose_trainer.py:163-190), through a toy
