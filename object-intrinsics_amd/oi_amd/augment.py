@@ -281,7 +281,8 @@ class AugmentPipe(torch.nn.Module):
     def forward(self, images, debug_percentile=None, theta=None):
         """`theta`: (B, 2, 3) device tensor built by the caller with `theta_for(sample_G_inv(...), static_margins(H, W), H, W)`
         -- the shape-static form used under hipGraph capture (oi_amd.graphed.GraphedDStep); default: the reference's
-        flow with margins fitted to the sampled transform."""
+        flow with margins fitted to the sampled transform.  A pipe without `rotate` / `rotate90` takes the one-launch separable
+        kernel, which does not read theta[:, 0, 1] / theta[:, 1, 0]: a caller-built `theta` must come from THIS pipe's draws."""
         assert isinstance(images, torch.Tensor) and images.ndim == 4
         B, C, H, W = images.shape
         if theta is not None:
