@@ -31,7 +31,7 @@ MODULE_KEYS = ("generator", "discriminator", "mask_discriminator")
 #   OI_TRAIN_D_STEPS=serial: one stream, the reference's order (render, step, render, step).
 # Same arithmetic and the same order of host-side draws in all three (the steps draw nothing from torch's generator).
 D_STEPS_MODE = os.environ.get("OI_TRAIN_D_STEPS", "concurrent")
-CONCURRENT_MAX_PIXELS = 2 * 64 * 64
+CONCURRENT_MAX_PIXELS = int(os.environ.get("OI_TRAIN_CONCURRENT_MAX_PIXELS", 2 * 128 * 128))
 assert D_STEPS_MODE in ("concurrent", "overlap", "serial"), D_STEPS_MODE
 DATA_KEYS = {"generator": ["image"], "discriminator": ["image"], "mask_discriminator": ["mask"]}
 
@@ -127,8 +127,10 @@ class Trainer:
         # discriminator's backward and its `sync(); opt.step()` so that, under FlatGradDDP, the 11 MB gradient exchange on
         # the communication stream overlaps it.  Same arithmetic and same RNG draw order as the reference's sequence
         # (gan_pose_trainer.py:84-90): the render only reads generator state.
-        # (side by side only while the steps are chains of launches too small to fill the chip -- up to 64 x 64 x 2 pixels per
-        #  batch; at the shipped 128 x 128 crop the same A/B measured 7.32 -> 7.51 ms per iteration: those steps are throughput-bound)
+        # (side by side while the steps are chains of launches too small to fill the chip -- up to 128 x 128 x 2 pixels per batch,
+        #  OI_TRAIN_CONCURRENT_MAX_PIXELS.  At the shipped 128 x 128 crop the same A/B first measured a LOSS, 7.32 -> 7.51 ms per
+        #  iteration, with the two-launch augmentation and its six-launch adjoint in every pass; with the one-launch forms it is a
+        #  gain: 6.55-6.75 -> 6.38-6.49 ms, three alternating pairs on one box)
         small = data["image"].shape[0] * data["image"].shape[-2] * data["image"].shape[-1] <= CONCURRENT_MAX_PIXELS
         if self._graphed is not None and D_STEPS_MODE == "concurrent" and small and data["image"].is_cuda:
             # inputs of the discriminator's step staged (and its augmentation drawn: the host's draw order stays render, step,
