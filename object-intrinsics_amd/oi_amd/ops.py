@@ -992,6 +992,8 @@ def ada_geom_sep_host(x, theta_np, f12, margins):
     mx0, my0, mx1, my1 = margins
     th = np.ascontiguousarray(theta_np, np.float32)
     assert th.shape == (B, 2, 3) and f12.numel() == 12
+    if np.any(th[:, 0, 1] != 0) or np.any(th[:, 1, 0] != 0):   # (the kernel does not read them: it would silently drop a rotation)
+        raise ValueError("ada_geom_sep_host: a sampling matrix with off-diagonal entries (rotation) -- use ada_geom_fwd")
     y = torch.empty_like(x)
     _l.check(_l.load().oi_ada_geom_sep_fwd(_p(x), None, th.ctypes.data_as(_vp), _p(f12), _p(y), B, C, H, W, mx0, mx1, my0, my1,
                                            _stream()), "oi_ada_geom_sep_fwd")

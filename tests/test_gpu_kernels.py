@@ -750,6 +750,10 @@ def test_ada_geom_separable_host_matrices_equal_device_matrices(ops, R, C, B):
     lhs, rhs = float((y_dev.double() * g.double()).sum()), float((x.double() * gx.double()).sum())
     assert abs(lhs - rhs) < 2e-6 * abs(lhs), (lhs, rhs)
     assert torch.equal(gx, OPS.ada_geom_adj_sep(g, thd, aug.Hz_geom, m))   # (fixed-point build: bit-reproducible)
+    bad = th.copy()
+    bad[0, 0, 1] = 1e-3
+    with pytest.raises(ValueError):
+        OPS.ada_geom_sep_host(x, bad, aug.Hz_geom, m)
 
 
 def test_gan_losses_fused_match_the_reference_composition():
